@@ -1,0 +1,429 @@
+"""NumPy/SciPy restatement of the runia_core scoring hot path (TEST INFRASTRUCTURE).
+
+Every function cites the reference file:line it follows (paths relative to
+``/root/reference/runia_core/`` unless absolute).  Third-party kernels that are
+absent from the image are restated from their published algorithm and pinned by
+the reference's own golden vectors (see ``oracle/__init__.py``).
+
+Only ``tests/``, ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline``
+leg may import this module.
+"""
+from __future__ import annotations
+
+import math
+from typing import Tuple
+
+import numpy as np
+from scipy.linalg import pinvh
+from scipy.spatial import cKDTree
+from scipy.special import digamma, logsumexp, softmax
+
+__all__ = [
+    "get_h",
+    "single_image_entropy_calculation",
+    "get_dl_h_z",
+    "kl_entropy_per_dim_vectorized",
+    "kl_entropy_joint_vectorized",
+    "dropblock_block_mask",
+    "mc_stack",
+    "pca_transform",
+    "empirical_precision",
+    "md_setup",
+    "md_score",
+    "md_score_reference_form",
+    "mahalanobis_setup",
+    "mahalanobis_score",
+    "mahalanobis_score_reference_form",
+    "energy_score",
+    "msp_score",
+    "normalizer",
+    "knn_kth_score",
+    "kde_score",
+    "method_threshold",
+    "binary_clf_curve",
+    "auroc_fpr95_aupr",
+    "larem_pipeline",
+    "FLT_MAX",
+]
+
+_trap = np.trapezoid if hasattr(np, "trapezoid") else np.trapz
+FLT_MAX = float(np.finfo(np.float32).max)  # 3.4028234663852886e38, faiss fill value
+
+
+# --------------------------------------------------------------------------
+# a2  Kozachenko-Leonenko kNN entropy  (evaluation/entropy.py:20-93)
+# --------------------------------------------------------------------------
+def get_h(x: np.ndarray, k: int = 1, norm: str = "max", min_dist: float = 0.0) -> float:
+    """``entropy_estimators.continuous.get_h`` (entropy-estimators==0.0.1,
+    /root/reference/requirements.txt:3), call sites evaluation/entropy.py:35,68,79.
+
+    Published algorithm: build a k-d tree on the n samples, query k+1 neighbours
+    (the query point itself is in the set) under the chosen norm, take the k-th
+    non-self distance, clip to ``min_dist``, and return
+    ``psi(n) - psi(k) + log_c_d + (d/n) * sum(log(2*eps))`` in nats with
+    ``log_c_d = 0`` for the max norm.
+    """
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x.reshape(-1, 1)
+    n, d = x.shape
+    if norm == "max":
+        p = np.inf
+        log_c_d = 0.0
+    elif norm == "euclidean":
+        p = 2
+        log_c_d = (d / 2.0) * math.log(math.pi) - math.lgamma(d / 2.0 + 1)
+    else:
+        raise NotImplementedError("Variable 'norm' either 'max' or 'euclidean'")
+    tree = cKDTree(x)
+    distances, _ = tree.query(x, k + 1, eps=0, p=p)
+    distances = distances[:, -1].copy()
+    distances[distances < min_dist] = min_dist
+    sum_log_dist = np.sum(np.log(2 * distances))
+    return float(-digamma(k) + digamma(n) + log_c_d + (d / float(n)) * sum_log_dist)
+
+
+def single_image_entropy_calculation(sample: np.ndarray, neighbors: int) -> np.ndarray:
+    """evaluation/entropy.py:20-38 — per-dimension entropy of one image's MC samples."""
+    return np.asarray(
+        [get_h(sample[:, j], k=neighbors, norm="max", min_dist=1e-5) for j in range(sample.shape[1])]
+    )
+
+
+def _neighbors(mcd_samples_nro: int) -> int:
+    # evaluation/entropy.py:66
+    return 5 if mcd_samples_nro > 5 else mcd_samples_nro - 1
+
+
+def get_dl_h_z(dl_z_samples: np.ndarray, mcd_samples_nro: int = 32) -> Tuple[np.ndarray, np.ndarray]:
+    """evaluation/entropy.py:41-93 in its reference algorithmic form (one k-d tree
+    per (image, dim) plus one joint tree per image).  Returns ``(N,1)`` joint and
+    ``(N,D)`` per-dimension entropies, float64."""
+    z = np.asarray(dl_z_samples)
+    n_img = int(z.shape[0] / mcd_samples_nro)
+    blocks = np.split(z, n_img)
+    k = _neighbors(mcd_samples_nro)
+    h_mvn = np.array([get_h(s, k=k, norm="max", min_dist=1e-5) for s in blocks])
+    h_mvn = np.expand_dims(h_mvn, axis=1)
+    h_z = np.asarray([single_image_entropy_calculation(s, k) for s in blocks])
+    return h_mvn, h_z
+
+
+def kl_entropy_per_dim_vectorized(z: np.ndarray, n_mc: int, k: int | None = None) -> np.ndarray:
+    """Vectorised equivalent of the per-dimension loop (evaluation/entropy.py:77-82):
+    1-D k-th-NN distance by sorting the n_mc values of each (image, dim) column.
+    Used for sizes where the k-d-tree form takes too long; checked against
+    :func:`get_dl_h_z` in tests."""
+    z = np.asarray(z, dtype=np.float64)
+    n_img = z.shape[0] // n_mc
+    d = z.shape[1]
+    if k is None:
+        k = _neighbors(n_mc)
+    v = np.sort(z.reshape(n_img, n_mc, d), axis=1)  # ascending along samples
+    # distances |v_i - v_j| for all pairs, k-th smallest non-self per i
+    diff = np.abs(v[:, :, None, :] - v[:, None, :, :])  # (N, n, n, D)
+    diff.sort(axis=2)
+    eps = np.maximum(diff[:, :, k, :], 1e-5)  # index 0 is self (0.0)
+    const = digamma(n_mc) - digamma(k)
+    return const + np.log(2.0 * eps).sum(axis=1) / n_mc
+
+
+def kl_entropy_joint_vectorized(z: np.ndarray, n_mc: int, k: int | None = None) -> np.ndarray:
+    """Vectorised equivalent of the joint call (evaluation/entropy.py:67-69):
+    Chebyshev distance in D dims."""
+    z = np.asarray(z, dtype=np.float64)
+    n_img = z.shape[0] // n_mc
+    d = z.shape[1]
+    if k is None:
+        k = _neighbors(n_mc)
+    v = z.reshape(n_img, n_mc, d)
+    out = np.empty((n_img, 1))
+    const = digamma(n_mc) - digamma(k)
+    for i in range(n_img):
+        cheb = np.abs(v[i][:, None, :] - v[i][None, :, :]).max(axis=2)  # (n, n)
+        cheb.sort(axis=1)
+        eps = np.maximum(cheb[:, k], 1e-5)
+        out[i, 0] = const + (d / n_mc) * np.log(2.0 * eps).sum()
+    return out
+
+
+# --------------------------------------------------------------------------
+# a1  MC-dropout latent stacking (feature_extraction/abstract_classes.py:81-101)
+#     PARITY UNPINNED for the mask path (dropblock==0.3.0 absent, see __init__).
+# --------------------------------------------------------------------------
+def dropblock_block_mask(rand: np.ndarray, drop_prob: float, block_size: int) -> np.ndarray:
+    """``dropblock.DropBlock2D`` block mask (dropblock==0.3.0,
+    /root/reference/requirements.txt:2; call sites
+    feature_extraction/abstract_classes.py:74-79,93).  ``rand`` is the uniform
+    draw ``torch.rand(B,H,W)``; returns ``1 - maxpool(rand < gamma)`` with kernel
+    ``block_size``, stride 1, padding ``block_size//2`` and the last row/column
+    cropped when ``block_size`` is even."""
+    rand = np.asarray(rand, dtype=np.float32)
+    gamma = np.float32(drop_prob / (block_size**2))
+    mask = (rand < gamma).astype(np.float32)
+    b, h, w = mask.shape
+    pad = block_size // 2
+    padded = np.zeros((b, h + 2 * pad, w + 2 * pad), dtype=np.float32)
+    padded[:, pad : pad + h, pad : pad + w] = mask
+    oh = h + 2 * pad - block_size + 1
+    ow = w + 2 * pad - block_size + 1
+    pooled = np.zeros((b, oh, ow), dtype=np.float32)
+    for dy in range(block_size):
+        for dx in range(block_size):
+            pooled = np.maximum(pooled, padded[:, dy : dy + oh, dx : dx + ow])
+    if block_size % 2 == 0:
+        pooled = pooled[:, :-1, :-1]
+    return (1.0 - pooled).astype(np.float32)
+
+
+def mc_stack(x: np.ndarray, rand: np.ndarray, drop_prob: float, block_size: int) -> np.ndarray:
+    """``MCSamplerModule.forward`` for ``layer_type="Conv"``
+    (feature_extraction/abstract_classes.py:91-101 + ``fullmean``,
+    feature_extraction/utils.py:88-92).  ``x`` is ``(1,C,H,W)`` f32, ``rand`` is
+    ``(n_mc,H,W)`` — the uniform draw of each drop layer in ``ModuleList`` order.
+    Returns ``(n_mc, C)`` f32."""
+    x = np.asarray(x, dtype=np.float32)
+    assert x.ndim == 4 and x.shape[0] == 1
+    n_mc = rand.shape[0]
+    out = np.empty((n_mc, x.shape[1]), dtype=np.float32)
+    if drop_prob == 0.0:
+        m = x.mean(axis=3, dtype=np.float32).mean(axis=2, dtype=np.float32)
+        out[:] = m
+        return out
+    bm = dropblock_block_mask(rand, drop_prob, block_size)  # (n_mc,H,W)
+    for s in range(n_mc):
+        scale = np.float32(bm[s].size) / np.float32(bm[s].sum(dtype=np.float32))
+        y = x[0] * bm[s][None] * scale  # (C,H,W) f32
+        out[s] = y.mean(axis=2, dtype=np.float32).mean(axis=1, dtype=np.float32)
+    return out
+
+
+# --------------------------------------------------------------------------
+# a4  PCA transform (dimensionality_reduction.py:75-87 -> sklearn PCA.transform)
+# --------------------------------------------------------------------------
+def pca_transform(
+    x: np.ndarray,
+    components: np.ndarray,
+    mean: np.ndarray,
+    explained_variance: np.ndarray,
+    whiten: bool = True,
+) -> np.ndarray:
+    """sklearn ``_BasePCA.transform`` closed form
+    (site-packages/sklearn/decomposition/_base.py:146-164):
+    ``Y = X @ C.T - mean @ C.T`` then ``Y /= max(sqrt(var), eps)`` when whitening."""
+    x = np.asarray(x, dtype=np.float64)
+    y = x @ components.T
+    y -= mean.reshape(1, -1) @ components.T
+    if whiten:
+        scale = np.sqrt(explained_variance)
+        min_scale = np.finfo(scale.dtype).eps
+        scale = np.where(scale < min_scale, min_scale, scale)
+        y /= scale
+    return y
+
+
+# --------------------------------------------------------------------------
+# a5  LaREM = MDLatentSpace (inference/postprocessors.py:181-244)
+# --------------------------------------------------------------------------
+def empirical_precision(x: np.ndarray) -> np.ndarray:
+    """``EmpiricalCovariance(assume_centered=False).fit(X).precision_``:
+    ``pinvh(np.cov(X.T, bias=1))`` (sklearn/covariance/_empirical_covariance.py)."""
+    x = np.asarray(x)
+    cov = np.cov(x.T, bias=1)
+    cov = np.atleast_2d(cov)
+    return pinvh(cov, check_finite=False)
+
+
+def md_setup(ind_train_data: np.ndarray):
+    """inference/postprocessors.py:210-222. Returns (feats_mean (1,D), centered, precision)."""
+    assert ind_train_data.ndim == 2
+    feats_mean = np.mean(ind_train_data, 0, keepdims=True)
+    centered = ind_train_data - feats_mean
+    precision = empirical_precision(centered)
+    return feats_mean, centered, precision
+
+
+def md_score_reference_form(test_data, feats_mean, precision) -> np.ndarray:
+    """inference/postprocessors.py:241-242 verbatim shape: full N x N product, then diag."""
+    diff = test_data - feats_mean
+    return -np.diag(np.matmul(np.matmul(diff, precision), np.transpose(diff)))
+
+
+def md_score(test_data, feats_mean, precision) -> np.ndarray:
+    """Row-wise form of the same quadratic form (O(N D^2) instead of O(N^2 D))."""
+    diff = np.asarray(test_data - feats_mean, dtype=np.float64)
+    return -np.einsum("ij,ij->i", diff @ precision, diff)
+
+
+# --------------------------------------------------------------------------
+# a6  class-conditional Mahalanobis (inference/funcs.py:33-102)
+# --------------------------------------------------------------------------
+def mahalanobis_setup(train_feats: np.ndarray, train_labels: np.ndarray, num_classes: int):
+    """inference/funcs.py:52-66."""
+    class_mean = []
+    centered = []
+    for c in range(num_classes):
+        cs = train_feats[train_labels == c]
+        class_mean.append(cs.mean(0))
+        centered.append(cs - class_mean[c].reshape(1, -1))
+    class_mean = np.stack(class_mean)
+    precision = empirical_precision(np.concatenate(centered).astype(np.float32))
+    return class_mean, precision
+
+
+def mahalanobis_score_reference_form(feats, class_mean, precision, num_classes) -> np.ndarray:
+    """inference/funcs.py:88-100 verbatim shape: Python double loop."""
+    out = []
+    for f in feats:
+        cs = np.zeros((1, num_classes))
+        for c in range(num_classes):
+            t = f - class_mean[c].reshape(1, -1)
+            cs[:, c] = np.diag(-np.matmul(np.matmul(t, precision), t.T))
+        cs[np.isnan(cs)] = -np.inf
+        out.append(np.max(cs, axis=1))
+    return np.concatenate(out)
+
+
+def mahalanobis_score(feats, class_mean, precision, num_classes) -> np.ndarray:
+    """Vectorised over rows; keeps the dtype of ``feats - class_mean[c]``
+    (f32 when both are f32, inference/funcs.py:92) before the f64 quadratic form."""
+    n = feats.shape[0]
+    cs = np.empty((n, num_classes))
+    for c in range(num_classes):
+        t = feats - class_mean[c].reshape(1, -1)
+        cs[:, c] = -np.einsum("ij,ij->i", np.matmul(t, precision), t)
+    cs[np.isnan(cs)] = -np.inf
+    return cs.max(axis=1)
+
+
+# --------------------------------------------------------------------------
+# a7  Energy / MSP (inference/postprocessors.py:549, 606)
+# --------------------------------------------------------------------------
+def energy_score(logits: np.ndarray) -> np.ndarray:
+    return logsumexp(logits, axis=1)
+
+
+def msp_score(logits: np.ndarray) -> np.ndarray:
+    return np.max(softmax(logits, axis=1), axis=1)
+
+
+# --------------------------------------------------------------------------
+# a8  kNN (inference/postprocessors.py:395-421, 842-880; inference/funcs.py:105-115)
+# --------------------------------------------------------------------------
+def normalizer(x: np.ndarray) -> np.ndarray:
+    """inference/funcs.py:115."""
+    return x / (np.linalg.norm(x, ord=2, axis=-1, keepdims=True) + 1e-10)
+
+
+def knn_kth_score(bank_normed: np.ndarray, queries: np.ndarray, k: int, chunk: int = 256) -> np.ndarray:
+    """``faiss.IndexFlatL2.add(bank); search(normalizer(q), k)`` then ``-D[:, -1]``
+    (faiss-gpu==1.7.2, /root/reference/requirements.txt:4; call sites
+    inference/postprocessors.py:396-397,419,850-851,878).  Published behaviour:
+    squared L2 in float32, results sorted ascending, tail filled with FLT_MAX when
+    ``k > ntotal``.  The reference searches one query at a time, for which faiss
+    accumulates ``sum((q-b)^2)`` directly (no norm expansion)."""
+    bank = np.ascontiguousarray(bank_normed, dtype=np.float32)
+    m = bank.shape[0]
+    n = queries.shape[0]
+    out = np.empty(n, dtype=np.float32)
+    if k > m:
+        out[:] = -np.float32(FLT_MAX)
+        return out
+    for s in range(0, n, chunk):
+        q = normalizer(queries[s : s + chunk])
+        q = np.ascontiguousarray(np.asarray(q).astype(np.float32))
+        d = ((q[:, None, :] - bank[None, :, :]) ** 2).sum(axis=2, dtype=np.float32)
+        out[s : s + chunk] = -np.partition(d, k - 1, axis=1)[:, k - 1]
+    return out
+
+
+# --------------------------------------------------------------------------
+# a9  LaRED = KDELatentSpace (inference/postprocessors.py:78-178)
+# --------------------------------------------------------------------------
+def kde_score(train: np.ndarray, x: np.ndarray, bandwidth: float = 1.0, chunk: int = 512) -> np.ndarray:
+    """sklearn ``KernelDensity(kernel="gaussian", bandwidth=h).fit(train).score_samples(x)``
+    closed form (exact because rtol=atol=0):
+    ``logsumexp_i(-|x-x_i|^2 / 2h^2) - log(N) - D*log(h) - (D/2)*log(2*pi)``."""
+    train = np.asarray(train, dtype=np.float64)
+    x = np.asarray(x, dtype=np.float64)
+    n_train, d = train.shape
+    out = np.empty(x.shape[0])
+    log_norm = -math.log(n_train) - d * math.log(bandwidth) - 0.5 * d * math.log(2 * math.pi)
+    for s in range(0, x.shape[0], chunk):
+        xs = x[s : s + chunk]
+        d2 = ((xs[:, None, :] - train[None, :, :]) ** 2).sum(axis=2)
+        out[s : s + chunk] = logsumexp(-0.5 * d2 / (bandwidth * bandwidth), axis=1) + log_norm
+    return out
+
+
+# --------------------------------------------------------------------------
+# a10 threshold (inference/abstract_classes.py:408-424)
+# --------------------------------------------------------------------------
+def method_threshold(scores: np.ndarray, z_score_percentile: float = 1.645) -> float:
+    mean = float(np.mean(scores))
+    std = float(np.std(scores))
+    return mean - (z_score_percentile * std)
+
+
+# --------------------------------------------------------------------------
+# f2  metrics after the path (evaluation/metrics.py:37-100; torchmetrics==1.8.2
+#     binary auroc / roc / precision_recall_curve, /root/reference/requirements.txt)
+# --------------------------------------------------------------------------
+def binary_clf_curve(preds: np.ndarray, target: np.ndarray):
+    """torchmetrics ``_binary_clf_curve``: sort by score descending, keep the last
+    index of each run of equal scores, cumulative true / false positives."""
+    order = np.argsort(-preds, kind="stable")
+    preds = preds[order]
+    target = target[order]
+    distinct = np.nonzero(preds[1:] - preds[:-1])[0]
+    idx = np.concatenate([distinct, [target.size - 1]])
+    tps = np.cumsum(target)[idx]
+    fps = 1 + idx - tps
+    return fps, tps, preds[idx]
+
+
+def auroc_fpr95_aupr(ind_scores: np.ndarray, ood_scores: np.ndarray):
+    """evaluation/metrics.py:61-81.  InD = positive class.  torchmetrics applies a
+    sigmoid when any score is outside [0,1] (monotone, but saturates), and returns
+    float32 curves; both are reproduced.  Returns (auroc, fpr@95, aupr) as floats."""
+    scores = np.concatenate([np.ravel(ind_scores), np.ravel(ood_scores)]).astype(np.float64)
+    labels = np.concatenate(
+        [np.ones(np.size(ind_scores), dtype=np.int64), np.zeros(np.size(ood_scores), dtype=np.int64)]
+    )
+    if not np.all((scores >= 0) & (scores <= 1)):
+        with np.errstate(over="ignore"):
+            scores = 1.0 / (1.0 + np.exp(-scores))
+    fps, tps, _ = binary_clf_curve(scores, labels)
+    # roc: leading (0,0), float32 ratios
+    tps_r = np.concatenate([[0], tps]).astype(np.float32)
+    fps_r = np.concatenate([[0], fps]).astype(np.float32)
+    fpr = fps_r / fps_r[-1]
+    tpr = tps_r / tps_r[-1]
+    # torchmetrics: torch.trapz on the float32 curves (sum order matters at 1e-7)
+    import torch
+
+    auroc = float(torch.trapz(torch.from_numpy(tpr), torch.from_numpy(fpr)).item())
+    fpr95 = float(fpr[np.where(tpr >= 0.95)[0][0]])
+    tps32 = tps.astype(np.float32)
+    fps32 = fps.astype(np.float32)
+    precision = tps32 / (tps32 + fps32)
+    recall = tps32 / tps32[-1]
+    precision = np.concatenate([precision[::-1], np.ones(1, dtype=np.float32)])
+    recall = np.concatenate([recall[::-1], np.zeros(1, dtype=np.float32)])
+    # sklearn.metrics.auc: trapezoid, sign by monotonic direction (recall decreasing)
+    aupr = float(-_trap(precision, recall))
+    return auroc, fpr95, aupr
+
+
+# --------------------------------------------------------------------------
+# a11 LaREM pipeline on pre-stacked MC samples (inference/image_level.py:115-119)
+# --------------------------------------------------------------------------
+def larem_pipeline(z, n_mc, pca_components, pca_mean, pca_var, md_mean, md_precision, faithful=False):
+    """``get_dl_h_z -> apply_pca_transform -> MDLatentSpace.postprocess`` on
+    ``z (N*n_mc, D)``; returns ``(scores (N,), h_z (N,D))``."""
+    if faithful:
+        _, h = get_dl_h_z(z, n_mc)
+    else:
+        h = kl_entropy_per_dim_vectorized(z, n_mc)
+    y = pca_transform(h, pca_components, pca_mean, pca_var, whiten=True)
+    return md_score(y, md_mean, md_precision), h

@@ -1,0 +1,52 @@
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def load_npz(name):
+    return np.load(os.path.join(GOLDEN, name))
+
+
+@pytest.fixture(scope="session")
+def ref_vectors():
+    """Golden numbers hard-coded in the reference's own unit tests
+    (tools/extract_test_vectors.py)."""
+    with open(os.path.join(GOLDEN, "reference_test_vectors.json")) as f:
+        return json.load(f)
+
+
+def generate_test_data(num_samples=10, feature_dim=32, num_classes=10, seed=42):
+    """Seeded input recipe of /root/reference/tests/unit_test_postprocessors.py:66-100
+    (data recipe only: the reference goldens are defined on these inputs)."""
+    import torch
+
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    features = np.random.randn(num_samples, feature_dim).astype(np.float32)
+    labels = np.random.randint(0, num_classes, num_samples)
+    for i in range(num_classes):
+        m = labels == i
+        if np.any(m):
+            features[m] += np.random.randn(feature_dim) * 0.5
+    logits = np.random.randn(num_samples, num_classes).astype(np.float32)
+    return features, labels, logits
+
+
+def rel_err(got, ref):
+    """Parity criterion of BASELINE.md section 5: |d| <= tol * max(1, |ref|)."""
+    got = np.asarray(got, dtype=np.float64)
+    ref = np.asarray(ref, dtype=np.float64)
+    return float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))) if ref.size else 0.0

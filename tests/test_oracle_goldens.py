@@ -1,0 +1,298 @@
+"""Pin the CPU oracle: (a) the golden vectors hard-coded in the reference's own
+unit tests, (b) fixtures produced by the reference's hot-path files imported by
+path in the build container (tools/make_goldens.py).  CPU only."""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from conftest import generate_test_data, load_npz, rel_err
+
+
+def _lists(ref_vectors, key):
+    return [np.array(l["values"]) for l in ref_vectors[key]["lists"]]
+
+
+def _scalars(ref_vectors, key):
+    return [s["value"] for s in ref_vectors[key]["scalars"]]
+
+
+# ---------------- a2 entropy ----------------------------------------------------
+def test_entropy_single_image_reference_golden(ref_vectors):
+    # /root/reference/tests/unit_test_feature_extraction.py:175-211 (SEED=1, 3 MC, 20 dims)
+    np.random.seed(1)
+    sample = np.random.rand(3, 20)
+    got = oracle.single_image_entropy_calculation(sample, 2)
+    (exp,) = _lists(ref_vectors, "entropy_single_image")
+    assert got.shape == (20,)
+    assert np.allclose(got, exp, atol=1e-6)
+    assert np.abs(got - exp).max() < 1e-8
+
+
+def test_entropy_get_dl_h_z_reference_golden(ref_vectors):
+    # /root/reference/tests/unit_test_feature_extraction.py:213-247
+    torch.manual_seed(1)
+    z = torch.rand(3 * 200, 20).numpy()
+    h_mvn, h_z = oracle.get_dl_h_z(z, 3)
+    (exp,) = _lists(ref_vectors, "entropy_get_dl_h_z")
+    assert h_z.shape == (200, 20) and h_mvn.shape == (200, 1)
+    assert np.allclose(h_z[0], exp, atol=1e-6)
+    assert np.abs(h_z[0] - exp).max() < 1e-8
+
+
+def test_entropy_degenerate_reference_golden(ref_vectors):
+    # /root/reference/tests/integration_tests.py:216-277: all-equal column, n=3,k=2
+    exp = _lists(ref_vectors, "entropy_degenerate")[0]
+    z = np.ones((3, 20), dtype=np.float32) * 0.25
+    _, h = oracle.get_dl_h_z(z, 3)
+    assert np.allclose(h[0], exp, atol=1e-6)
+    assert abs(h[0, 0] - (-10.319778284410283)) < 1e-12
+
+
+@pytest.mark.parametrize("n_mc,d", [(16, 37), (3, 20), (6, 11), (5, 8), (2, 5), (32, 9)])
+def test_entropy_vectorized_equals_tree_form(n_mc, d):
+    rng = np.random.default_rng(n_mc * 100 + d)
+    z = rng.standard_normal((7 * n_mc, d)).astype(np.float32)
+    z[n_mc : 2 * n_mc, 0] = 0.5  # constant column -> min_dist clip
+    z[0:n_mc:2, 1] = z[1, 1]  # ties
+    h_mvn, h = oracle.get_dl_h_z(z, n_mc)
+    hv = oracle.kl_entropy_per_dim_vectorized(z, n_mc)
+    jv = oracle.kl_entropy_joint_vectorized(z, n_mc)
+    assert np.abs(h - hv).max() < 1e-12
+    assert np.abs(h_mvn - jv).max() < 1e-10
+
+
+# ---------------- a4 PCA ---------------------------------------------------------
+def test_pca_transform_reference_golden(ref_vectors):
+    g = load_npz("ref_pca.npz")
+    tr0, comp0 = _lists(ref_vectors, "pca_ds_split")
+    (ood0,) = _lists(ref_vectors, "pca_transform")
+    # fitted state exported from sklearn through the reference helper reproduces the
+    # reference's hard-coded numbers (tests/unit_test_dim_reduction.py:24-107)
+    assert abs((g["unit_train_transformed"][0] - tr0).sum()) < 1e-7
+    assert abs((g["unit_components"][0] + comp0).sum()) < 1e-7
+    got = oracle.pca_transform(g["unit_ood"], g["unit_components"], g["unit_mean"], g["unit_var"])
+    assert abs((got[0] - ood0).sum()) < 1e-7
+    assert np.abs(got - g["unit_ood_transformed"]).max() < 1e-13
+    got = oracle.pca_transform(g["unit_ind"], g["unit_components"], g["unit_mean"], g["unit_var"])
+    assert np.abs(got - g["unit_train_transformed"]).max() < 1e-12
+
+
+def test_pca_transform_d512_fixture():
+    g = load_npz("ref_pca.npz")
+    got = oracle.pca_transform(g["d512_test"], g["d512_components"], g["d512_mean"], g["d512_var"])
+    assert rel_err(got, g["d512_test_transformed"]) < 1e-12
+
+
+# ---------------- a5 MD / LaREM ---------------------------------------------------
+def test_md_unit_reference_golden(ref_vectors):
+    tr, _, _ = generate_test_data(seed=42)
+    te, _, _ = generate_test_data(seed=43)
+    mean, centered, prec = oracle.md_setup(tr)
+    (exp,) = _lists(ref_vectors, "md_unit")
+    got = oracle.md_score_reference_form(te, mean, prec)
+    assert abs((exp - got).sum()) < 1e-6  # the reference's own assertion
+    assert rel_err(got, exp) < 1e-9
+    assert rel_err(oracle.md_score(te, mean, prec), exp) < 1e-9
+    g = load_npz("ref_md.npz")
+    assert np.array_equal(g["unit_train"], tr) and np.array_equal(g["unit_test"], te)
+    assert rel_err(prec, g["unit_precision"]) < 1e-9
+    assert rel_err(got, g["unit_scores"]) < 1e-10
+
+
+def test_larem_baselines_reference_golden(ref_vectors):
+    # /root/reference/tests/unit_test_baselines.py:463-530
+    np.random.seed(1)
+    feats = np.random.rand(200, 20)
+    mean, _, prec = oracle.md_setup(feats)
+    prec0, scores20 = _lists(ref_vectors, "larem_baselines")
+    assert np.allclose(prec[0], prec0, atol=1e-6)
+    got = oracle.md_score(feats, mean, prec)
+    assert np.allclose(got[:20], scores20, atol=1e-6)
+    g = load_npz("ref_md.npz")
+    assert rel_err(got, g["baselines_scores"]) < 1e-11
+
+
+def test_md_d256_fixture():
+    g = load_npz("ref_md.npz")
+    got = oracle.md_score(g["d256_test"], g["d256_mean"], g["d256_precision"])
+    assert rel_err(got, g["d256_scores"]) < 1e-11
+
+
+# ---------------- a6 Mahalanobis ----------------------------------------------------
+def test_mahalanobis_unit_reference_golden(ref_vectors):
+    tr, lab, _ = generate_test_data(seed=42)
+    te, _, _ = generate_test_data(seed=43)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cm, prec = oracle.mahalanobis_setup(tr, lab, 10)
+        got = -oracle.mahalanobis_score_reference_form(te, cm, prec, 10)  # flip_sign=True
+        got_v = -oracle.mahalanobis_score(te, cm, prec, 10)
+    (exp,) = _lists(ref_vectors, "mahalanobis_unit")
+    assert abs((exp - got).sum()) < 1e-6
+    assert rel_err(got, exp) < 1e-6
+    assert rel_err(got_v, got) < 1e-12
+    g = load_npz("ref_mahalanobis.npz")
+    assert rel_err(got, g["unit_scores"]) < 1e-9
+
+
+def test_mahalanobis_d96_fixture():
+    g = load_npz("ref_mahalanobis.npz")
+    cm, prec = oracle.mahalanobis_setup(g["d96_train"], g["d96_labels"], 7)
+    assert rel_err(cm, g["d96_class_mean"]) < 1e-7
+    assert rel_err(prec, g["d96_precision"]) < 1e-9
+    got = oracle.mahalanobis_score(g["d96_test"], g["d96_class_mean"], g["d96_precision"], 7)
+    assert rel_err(got, g["d96_scores"]) < 1e-12
+    got64 = oracle.mahalanobis_score(
+        g["d96_test"].astype(np.float64), g["d96_f64_class_mean"], g["d96_f64_precision"], 7
+    )
+    assert rel_err(got64, g["d96_f64_scores"]) < 1e-12
+
+
+# ---------------- a7 Energy / MSP ----------------------------------------------------
+def test_energy_unit_reference_golden(ref_vectors):
+    _, _, te = generate_test_data(seed=43)
+    (exp,) = _lists(ref_vectors, "energy_unit")
+    got = -oracle.energy_score(te)  # flip_sign=True
+    assert got.dtype == np.float32
+    assert abs((exp - got).sum()) < 1e-6
+    assert rel_err(got, exp) < 1e-6
+
+
+def test_energy_msp_fixtures():
+    g = load_npz("ref_energy_msp.npz")
+    for nm in ("c1000", "c10"):
+        assert np.array_equal(oracle.energy_score(g[f"{nm}_logits"]), g[f"{nm}_energy_scores"])
+        assert np.array_equal(oracle.msp_score(g[f"{nm}_logits"]), g[f"{nm}_msp_scores"])
+        thr = oracle.method_threshold(oracle.energy_score(g[f"{nm}_logits"][:64]))
+        assert abs(thr - float(g[f"{nm}_energy_threshold"])) < 1e-12
+
+
+# ---------------- a8 kNN --------------------------------------------------------------
+def test_knn_k_larger_than_bank_reference_golden(ref_vectors):
+    tr, _, _ = generate_test_data(seed=42)
+    te, _, _ = generate_test_data(seed=43)
+    bank = np.array([oracle.normalizer(f) for f in tr])
+    got = oracle.knn_kth_score(bank, te, 50)
+    (exp,) = _lists(ref_vectors, "knn_latent_unit")
+    assert np.array_equal(got.astype(np.float64), exp)
+
+
+def _all_baselines_inputs():
+    # input recipe of /root/reference/tests/unit_test_baselines.py:199-246
+    torch.manual_seed(1)
+    np.random.seed(1)
+    np.random.rand(20, 20)
+    np.random.rand(20)
+    f32 = lambda: np.float32(np.random.random((200, 20)))  # noqa: E731
+    return dict(tr_f=f32(), tr_l=f32(), va_f=f32(), va_l=f32(), ood_f=f32(), ood_l=f32())
+
+
+def test_all_baselines_means_reference_golden(ref_vectors):
+    d = _all_baselines_inputs()
+    sc = _scalars(ref_vectors, "all_baselines_means")
+    msp, knn, energy, mdist = sc[0], sc[1], sc[2], sc[8]
+    assert abs(oracle.msp_score(d["ood_l"]).mean() - msp) < 1e-6
+    assert abs(oracle.energy_score(d["ood_l"]).mean() - energy) < 1e-6
+    bank = np.ascontiguousarray(oracle.normalizer(d["tr_f"]).astype(np.float32))
+    assert abs(oracle.knn_kth_score(bank, d["ood_f"], 10).mean() - knn) < 1e-6
+    labels = np.argmax(d["tr_l"], axis=-1)
+    import warnings
+
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        cm, prec = oracle.mahalanobis_setup(d["tr_f"], labels, 20)
+        got = oracle.mahalanobis_score(d["ood_f"], cm, prec, 20)
+    assert abs(got.mean() - mdist) < 1e-6
+
+
+# ---------------- a9 KDE ---------------------------------------------------------------
+def test_kde_reference_goldens(ref_vectors):
+    tr, _, _ = generate_test_data(seed=42)
+    te, _, _ = generate_test_data(seed=43)
+    (exp,) = _lists(ref_vectors, "kde_unit")
+    got = oracle.kde_score(tr, te)
+    assert abs((exp - got).sum()) < 1e-6
+    assert rel_err(got, exp) < 1e-10
+    np.random.seed(1)
+    feats = np.random.rand(200, 20)
+    (exp20,) = _lists(ref_vectors, "lared_baselines")
+    assert np.allclose(oracle.kde_score(feats, feats)[:20], exp20, atol=1e-6)
+    g = load_npz("ref_kde.npz")
+    assert rel_err(oracle.kde_score(g["d12_train"], g["d12_test"]), g["d12_scores"]) < 1e-10
+
+
+def test_kde_reference_tree_residue_quirk():
+    """sklearn's KD-tree KDE (what the reference calls) loses the density to the
+    floating-point residue of its log-space bounds for D >~ 20: it can only
+    OVER-estimate.  The oracle is the exact definition; rows where sklearn is
+    converged agree, the others are strictly larger in the reference."""
+    g = load_npz("ref_kde.npz")
+    exact = oracle.kde_score(g["quirk64_train"], g["quirk64_test"])
+    ref = g["quirk64_scores"]
+    assert np.all(ref >= exact - 1e-8)
+    assert (np.abs(ref - exact) > 1e-3).any()  # the quirk is real at D=64
+
+
+# ---------------- a10 threshold ----------------------------------------------------------
+def test_threshold_fixture():
+    g = load_npz("ref_threshold.npz")
+    assert oracle.method_threshold(g["scores"]) == float(g["thr"])
+    assert oracle.method_threshold(g["scores"], 1.0) == float(g["thr1"])
+
+
+# ---------------- f2 metrics ---------------------------------------------------------------
+def test_metrics_reference_goldens(ref_vectors):
+    # /root/reference/tests/unit_test_metrics.py:21-29
+    np.random.seed(1)
+    ind = 0.5 + np.random.randn(1000)
+    ood = -0.5 + np.random.randn(1000)
+    fpr95, aupr, auroc = _scalars(ref_vectors, "metrics_hz")
+    a, f, p = oracle.auroc_fpr95_aupr(ind, ood)
+    assert abs(a - auroc) < 1e-7 and abs(f - fpr95) < 1e-7 and abs(p - aupr) < 1e-7
+
+
+def test_metrics_postprocessors_reference_goldens(ref_vectors):
+    # /root/reference/tests/unit_test_metrics.py:31-80: KDE and MD end to end
+    np.random.seed(1)
+    valid = 0.5 + np.random.randn(1000, 20)
+    train = 0.5 + np.random.randn(1000, 20)
+    np.random.randint(5, size=1000)
+    np.random.randint(5, size=1000)
+    np.random.randint(5, size=1000)
+    ood = -0.5 + np.random.randn(1000, 20)
+    kde_auroc, kde_aupr, kde_fpr, md_auroc, md_aupr, md_fpr = _scalars(ref_vectors, "metrics_postprocessors")
+    mean, _, prec = oracle.md_setup(train)
+    a, f, p = oracle.auroc_fpr95_aupr(oracle.md_score(valid, mean, prec), oracle.md_score(ood, mean, prec))
+    assert abs(a - md_auroc) < 1e-7 and abs(f - md_fpr) < 1e-7 and abs(p - md_aupr) < 1e-7
+    a, f, p = oracle.auroc_fpr95_aupr(oracle.kde_score(train, valid), oracle.kde_score(train, ood))
+    assert abs(a - kde_auroc) < 1e-7 and abs(f - kde_fpr) < 1e-7 and abs(p - kde_aupr) < 1e-7
+
+
+# ---------------- a1 mc_stack (restatement self-consistency; parity unpinned) -------------
+def test_mc_stack_matches_torch_composition():
+    """dropblock is absent; check the restatement against the same algebra written
+    with torch ops (max_pool2d) as the published DropBlock2D does it."""
+    import torch.nn.functional as F
+
+    torch.manual_seed(3)
+    for (c, h, w, bs, p) in [(8, 4, 4, 2, 0.5), (5, 8, 8, 3, 0.3), (4, 7, 5, 4, 0.6), (3, 8, 8, 8, 0.5)]:
+        x = torch.relu(torch.randn(1, c, h, w))
+        rand = torch.rand(6, h, w)
+        gamma = p / bs**2
+        mask = (rand < gamma).float()
+        bm = F.max_pool2d(mask[:, None], kernel_size=(bs, bs), stride=(1, 1), padding=bs // 2)
+        if bs % 2 == 0:
+            bm = bm[:, :, :-1, :-1]
+        bm = 1 - bm.squeeze(1)
+        exp = []
+        for s in range(6):
+            y = x * bm[s][None, None] * (bm[s].numel() / bm[s].sum())
+            exp.append(y.mean(dim=3, keepdim=True).mean(dim=2, keepdim=True).reshape(1, -1))
+        exp = torch.cat(exp).numpy()
+        got = oracle.mc_stack(x.numpy(), rand.numpy(), p, bs)
+        ok = np.isfinite(exp)
+        assert np.allclose(got[ok], exp[ok], rtol=2e-6, atol=1e-7)
+        assert np.array_equal(np.isfinite(got), ok)
