@@ -1,0 +1,149 @@
+/*
+ * runia_hip.h — C ABI of the MI355X (gfx950) scoring library `librunia_hip.so`.
+ *
+ * This is the drop-in boundary for the post-hoc OOD scoring hot path of
+ * CEA-LIST/runia_core (reference paths below are relative to
+ * /root/reference/runia_core/).  The reference is pure Python: each entry point
+ * replaces one host numerical call (NumPy / SciPy / scikit-learn / faiss /
+ * entropy_estimators) that the reference makes on this path, and is what a
+ * `ctypes` stub in the reference would bind.
+ *
+ * Conventions (last row):
+ *   - every pointer is a DEVICE pointer (HBM) unless the name says `host`;
+ *   - matrices are row-major and dense unless a leading dimension is given;
+ *   - `stream` is a hipStream_t passed as void*; calls are stream-ordered,
+ *     never synchronise, never allocate, and are re-entrant;
+ *   - return value: 0 on success, negative RUNIA_E_* code otherwise
+ *     (`runia_error_string` gives the text).
+ */
+#ifndef RUNIA_HIP_H
+#define RUNIA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RUNIA_OK 0
+#define RUNIA_E_INVALID (-1)   /* bad shape / null pointer / unsupported size */
+#define RUNIA_E_LAUNCH (-2)    /* hipGetLastError() after the launch was not hipSuccess */
+#define RUNIA_E_NODEVICE (-3)  /* no HIP device visible */
+#define RUNIA_E_WORKSPACE (-4) /* caller-provided workspace too small */
+
+typedef void* runia_stream_t;
+
+/* ---- library ------------------------------------------------------------ */
+int runia_abi_version(void);
+const char* runia_error_string(int code);
+/* number of visible HIP devices (0 when none; never fails) */
+int runia_device_count(void);
+
+/* ---- a1  MC-dropout latent stacking ------------------------------------- *
+ * Replaces MCSamplerModule.forward (feature_extraction/abstract_classes.py:81-101)
+ * = n_mc x DropBlock2D (dropblock==0.3.0) + get_mean_or_fullmean_ls_sample("fullmean")
+ * (feature_extraction/utils.py:88-92), for a batch of N latent maps.
+ *   x     [N, C, H, W] f32 (NCHW)
+ *   rand  uniform draws of the drop layers, [n_mc, H, W] per image; image i reads
+ *         rand + i*rand_image_stride (stride 0 = the same draws for every image)
+ *   out   [N*n_mc, C] f32, image-major (the n_mc rows of one image are contiguous)
+ * drop_prob == 0 -> plain full mean replicated n_mc times (DropBlock identity). */
+int runia_mc_stack_f32(const float* x, const float* rand, int64_t rand_image_stride, float* out,
+                       int64_t N, int C, int H, int W, int n_mc, double drop_prob, int block_size,
+                       runia_stream_t stream);
+
+/* ---- a2  Kozachenko-Leonenko kNN entropy --------------------------------- *
+ * Replaces the loops of get_dl_h_z / single_image_entropy_calculation
+ * (evaluation/entropy.py:20-93) over entropy_estimators.continuous.get_h(col, k,
+ * norm="max", min_dist).
+ *   z  [N*n_mc, D] f32 image-major;  h  [N, D] f64;  h_mvn [N] f64
+ * 2 <= n_mc <= 64, 1 <= k < n_mc. */
+int runia_kl_entropy_per_dim_f32(const float* z, double* h, int64_t N, int n_mc, int64_t D, int k,
+                                 double min_dist, runia_stream_t stream);
+int runia_kl_entropy_joint_f32(const float* z, double* h_mvn, int64_t N, int n_mc, int64_t D, int k,
+                               double min_dist, runia_stream_t stream);
+
+/* ---- dense f64 weights, packed once at setup ------------------------------ *
+ * The f64 contractions (PCA projection, quadratic forms) read their constant
+ * right-hand matrix B [K, n] (row-major, ld = ldb) from a fragment-ordered copy
+ * so that every MFMA operand load is one coalesced 512-byte wave access.
+ * `runia_packed_weights_bytes` gives the size of that copy. */
+size_t runia_packed_weights_bytes(int64_t K, int64_t n);
+int runia_pack_weights_f64(const double* B, int64_t ldb, int64_t K, int64_t n, double* packed,
+                           runia_stream_t stream);
+
+/* ---- a4  PCA transform ---------------------------------------------------- *
+ * Replaces apply_pca_transform (dimensionality_reduction.py:75-87) = sklearn
+ * PCA.transform:  Y = X @ C.T - mean @ C.T;  Y /= scale  (when whiten != 0).
+ *   x [N, D] (f64 or f32), packed_ct = pack(C.T [D, n]), bias [n] = mean @ C.T,
+ *   scale [n] = max(sqrt(explained_variance_), eps), y [N, n] f64. */
+int runia_pca_transform_f64(const double* x, const double* packed_ct, const double* bias,
+                            const double* scale, double* y, int64_t N, int64_t D, int64_t n,
+                            int whiten, runia_stream_t stream);
+int runia_pca_transform_f32in(const float* x, const double* packed_ct, const double* bias,
+                              const double* scale, double* y, int64_t N, int64_t D, int64_t n,
+                              int whiten, runia_stream_t stream);
+
+/* ---- a5  LaREM = MDLatentSpace.postprocess -------------------------------- *
+ * Replaces -np.diag(diff @ P @ diff.T) (inference/postprocessors.py:241-242).
+ *   x [N, n], mean [n], packed_p = pack(P [n, n]), score [N] f64.
+ * `diff` follows NumPy's dtype rules: f32 - f32 is rounded to f32 before the f64
+ * quadratic form (the reference's own unit test feeds f32 features); every other
+ * combination subtracts in f64 (an f32 mean against f64 rows is widened by the caller). */
+int runia_md_score_f64(const double* x, const double* mean, const double* packed_p, double* score,
+                       int64_t N, int64_t n, runia_stream_t stream);
+int runia_md_score_f32(const float* x, const float* mean, const double* packed_p, double* score,
+                       int64_t N, int64_t n, runia_stream_t stream);
+int runia_md_score_f32x_f64mean(const float* x, const double* mean, const double* packed_p,
+                                double* score, int64_t N, int64_t n, runia_stream_t stream);
+
+/* ---- a6  class-conditional Mahalanobis ------------------------------------ *
+ * Replaces mahalanobis_postprocess (inference/funcs.py:69-102): for each row and
+ * class c, t = x - mu_c (in the dtype of the inputs), s_c = -t P t^T in f64,
+ * NaN -> -inf, max over classes.
+ *   x [N, D] f32 (…_f32) or f64 (…_f64); class_mean [C, D] same dtype as x;
+ *   packed_p = pack(P [D, D]); mu_p [C, D] f64 = class_mean @ P; score [N] f64.
+ *   workspace: holds G = X P for a chunk of rows (runia_mahalanobis_workspace_bytes;
+ *   any size >= one row works, rows are processed in chunks that fit). */
+size_t runia_mahalanobis_workspace_bytes(int64_t N, int64_t D);
+int runia_mahalanobis_score_f32(const float* x, const float* class_mean, const double* packed_p,
+                                const double* mu_p, double* score, void* workspace,
+                                size_t workspace_bytes, int64_t N, int64_t D, int C,
+                                runia_stream_t stream);
+int runia_mahalanobis_score_f64(const double* x, const double* class_mean, const double* packed_p,
+                                const double* mu_p, double* score, void* workspace,
+                                size_t workspace_bytes, int64_t N, int64_t D, int C,
+                                runia_stream_t stream);
+
+/* ---- a7  Energy / MSP ------------------------------------------------------ *
+ * Replaces scipy.special.logsumexp(x, axis=1) and np.max(softmax(x, axis=1), axis=1)
+ * (inference/postprocessors.py:549, 606).  logits [N, C] f32; outputs [N] f32;
+ * either output pointer may be NULL. */
+int runia_row_lse_msp_f32(const float* logits, float* lse, float* msp, int64_t N, int64_t C,
+                          runia_stream_t stream);
+
+/* ---- a8  kNN ---------------------------------------------------------------- *
+ * normalizer (inference/funcs.py:105-115): y = x / (||x||_2 + 1e-10), f32. */
+int runia_l2_normalize_f32(const float* x, float* y, int64_t N, int64_t D, runia_stream_t stream);
+/* faiss.IndexFlatL2(D).add(bank); search(q, k) -> -D[:, -1]
+ * (inference/postprocessors.py:396-397,419,850-851,878).  q [N, D] and bank [M, D]
+ * are already normalised f32; score [N] f32 = -(k-th smallest squared L2), or
+ * -FLT_MAX when k > M.  `workspace` holds the distance tiles
+ * (runia_knn_workspace_bytes). */
+size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k);
+int runia_knn_kth_f32(const float* q, const float* bank, float* score, void* workspace,
+                      size_t workspace_bytes, int64_t N, int64_t M, int64_t D, int k,
+                      runia_stream_t stream);
+
+/* ---- a9  LaRED = KernelDensity.score_samples (gaussian) --------------------- *
+ * Replaces DetectorKDE.get_density_scores (inference/postprocessors.py:118-128):
+ * logsumexp_i(-|x - t_i|^2 / (2 h^2)) - log(M) - D log(h) - (D/2) log(2 pi).
+ *   train [M, D] f64, x [N, D] f64, score [N] f64 */
+int runia_kde_score_f64(const double* train, const double* x, double* score, int64_t M, int64_t N,
+                        int64_t D, double bandwidth, runia_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RUNIA_HIP_H */

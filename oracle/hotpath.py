@@ -192,8 +192,8 @@ def mc_stack(x: np.ndarray, rand: np.ndarray, drop_prob: float, block_size: int)
         return out
     bm = dropblock_block_mask(rand, drop_prob, block_size)  # (n_mc,H,W)
     for s in range(n_mc):
-        scale = np.float32(bm[s].size) / np.float32(bm[s].sum(dtype=np.float32))
-        y = x[0] * bm[s][None] * scale  # (C,H,W) f32
+        # published order: out = x * bm; out = out * bm.numel() / bm.sum()   (all f32)
+        y = (x[0] * bm[s][None]) * np.float32(bm[s].size) / np.float32(bm[s].sum(dtype=np.float32))
         out[s] = y.mean(axis=2, dtype=np.float32).mean(axis=1, dtype=np.float32)
     return out
 

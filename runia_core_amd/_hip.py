@@ -1,0 +1,326 @@
+"""ctypes binding of ``librunia_hip.so`` (C ABI in ``include/runia_hip.h``).
+
+PyTorch is plumbing here: it owns device memory and the HIP stream; every
+numerical stage of the scoring path is a kernel of the shared library.  There is
+NO CPU fallback: without the library or without a GPU the wrappers raise.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+from typing import Optional
+
+import numpy as np
+import torch  # imported before the library so that both share one HIP runtime
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librunia_hip.so")
+_lib: Optional[ctypes.CDLL] = None
+
+# name -> (restype, argtypes); mirrors include/runia_hip.h one to one
+_SIGNATURES = {
+    "runia_abi_version": (c_int, []),
+    "runia_error_string": (c_char_p, [c_int]),
+    "runia_device_count": (c_int, []),
+    "runia_mc_stack_f32": (
+        c_int,
+        [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p],
+    ),
+    "runia_kl_entropy_per_dim_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_double, c_void_p]),
+    "runia_kl_entropy_joint_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_double, c_void_p]),
+    "runia_packed_weights_bytes": (c_size_t, [c_int64, c_int64]),
+    "runia_pack_weights_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
+    "runia_pca_transform_f64": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p],
+    ),
+    "runia_pca_transform_f32in": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p],
+    ),
+    "runia_md_score_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "runia_md_score_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "runia_md_score_f32x_f64mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "runia_mahalanobis_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "runia_mahalanobis_score_f32": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int, c_void_p],
+    ),
+    "runia_mahalanobis_score_f64": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int, c_void_p],
+    ),
+    "runia_row_lse_msp_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "runia_l2_normalize_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "runia_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    "runia_knn_kth_f32": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int64, c_int, c_void_p],
+    ),
+    "runia_kde_score_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p]),
+}
+
+
+class RuniaHipError(RuntimeError):
+    pass
+
+
+def library_path() -> str:
+    return _LIB_PATH
+
+
+def load_library() -> ctypes.CDLL:
+    """Load the shared library and declare every C-ABI signature.  Works without a GPU."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuniaHipError(
+                f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950).  runia_core_amd has no CPU fallback."
+            )
+        lib = ctypes.CDLL(_LIB_PATH)
+        for name, (res, args) in _SIGNATURES.items():
+            fn = getattr(lib, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = lib
+    return _lib
+
+
+def exported_symbols():
+    return sorted(_SIGNATURES)
+
+
+def require_gpu() -> torch.device:
+    """The scoring path is HIP-only.  Fail loudly when it cannot run."""
+    lib = load_library()
+    if not torch.cuda.is_available() or lib.runia_device_count() < 1:
+        raise RuniaHipError(
+            "runia_core_amd: no HIP device visible (torch.cuda.is_available() is False). "
+            "The scoring hot path runs only as HIP kernels on MI355X; there is no CPU fallback."
+        )
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def _check(rc: int, what: str) -> None:
+    if rc != 0:
+        msg = load_library().runia_error_string(rc).decode()
+        raise RuniaHipError(f"{what} failed: {msg} (code {rc})")
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def to_device(a, dtype: torch.dtype) -> torch.Tensor:
+    """Host ndarray / tensor -> contiguous device tensor of ``dtype`` (H2D copy if needed)."""
+    dev = require_gpu()
+    if isinstance(a, np.ndarray):
+        t = torch.from_numpy(np.ascontiguousarray(a))
+    elif isinstance(a, torch.Tensor):
+        t = a.detach()
+    else:
+        t = torch.as_tensor(np.asarray(a))
+    return t.to(device=dev, dtype=dtype, non_blocking=False).contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# stage wrappers: device tensors in, device tensors out, stream-ordered, no sync
+# --------------------------------------------------------------------------------------
+def mc_stack(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob: float, block_size: int) -> torch.Tensor:
+    """x [N,C,H,W] f32, rand [n_mc,H,W] (shared) or [N,n_mc,H,W] f32 -> [N*n_mc, C] f32."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    stride = 0
+    if rand is not None:
+        assert rand.is_cuda and rand.dtype == torch.float32
+        rand = rand.contiguous()
+        if rand.dim() == 4:
+            assert rand.shape == (n, n_mc, h, w)
+            stride = n_mc * h * w
+        else:
+            assert rand.shape == (n_mc, h, w)
+    out = torch.empty((n * n_mc, c), dtype=torch.float32, device=x.device)
+    done = 0
+    while done < n:  # grid.y limit of the kernel
+        m = min(65535, n - done)
+        rp = None if rand is None else rand.data_ptr() + (done * stride * 4)
+        _check(
+            lib.runia_mc_stack_f32(
+                x.data_ptr() + done * c * h * w * 4, rp, stride, out.data_ptr() + done * n_mc * c * 4,
+                m, c, h, w, n_mc, float(drop_prob), int(block_size), _stream(),
+            ),
+            "runia_mc_stack_f32",
+        )
+        done += m
+    return out
+
+
+def kl_entropy_per_dim(z: torch.Tensor, n_mc: int, k: int, min_dist: float = 1e-5) -> torch.Tensor:
+    """z [N*n_mc, D] f32 -> h [N, D] f64."""
+    lib = load_library()
+    require_gpu()
+    assert z.is_cuda and z.dtype == torch.float32 and z.dim() == 2
+    z = z.contiguous()
+    n = z.shape[0] // n_mc
+    d = z.shape[1]
+    h = torch.empty((n, d), dtype=torch.float64, device=z.device)
+    _check(
+        lib.runia_kl_entropy_per_dim_f32(z.data_ptr(), h.data_ptr(), n, n_mc, d, k, min_dist, _stream()),
+        "runia_kl_entropy_per_dim_f32",
+    )
+    return h
+
+
+def kl_entropy_joint(z: torch.Tensor, n_mc: int, k: int, min_dist: float = 1e-5) -> torch.Tensor:
+    """z [N*n_mc, D] f32 -> h_mvn [N] f64."""
+    lib = load_library()
+    require_gpu()
+    assert z.is_cuda and z.dtype == torch.float32 and z.dim() == 2
+    z = z.contiguous()
+    n = z.shape[0] // n_mc
+    d = z.shape[1]
+    h = torch.empty((n,), dtype=torch.float64, device=z.device)
+    _check(
+        lib.runia_kl_entropy_joint_f32(z.data_ptr(), h.data_ptr(), n, n_mc, d, k, min_dist, _stream()),
+        "runia_kl_entropy_joint_f32",
+    )
+    return h
+
+
+def pack_weights(b: torch.Tensor) -> torch.Tensor:
+    """B [K, n] f64 (device) -> fragment-ordered copy for the f64 MFMA kernels."""
+    lib = load_library()
+    require_gpu()
+    assert b.is_cuda and b.dtype == torch.float64 and b.dim() == 2
+    b = b.contiguous()
+    k, n = b.shape
+    nbytes = lib.runia_packed_weights_bytes(k, n)
+    packed = torch.empty((nbytes // 8,), dtype=torch.float64, device=b.device)
+    _check(lib.runia_pack_weights_f64(b.data_ptr(), n, k, n, packed.data_ptr(), _stream()), "runia_pack_weights_f64")
+    return packed
+
+
+def pca_transform(x: torch.Tensor, packed_ct: torch.Tensor, bias: torch.Tensor, scale: Optional[torch.Tensor], n: int) -> torch.Tensor:
+    """x [N, D] f64/f32 -> y [N, n] f64."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.float64)
+    x = x.contiguous()
+    nrow, d = x.shape
+    y = torch.empty((nrow, n), dtype=torch.float64, device=x.device)
+    fn = lib.runia_pca_transform_f32in if x.dtype == torch.float32 else lib.runia_pca_transform_f64
+    _check(
+        fn(x.data_ptr(), packed_ct.data_ptr(), bias.data_ptr(), _ptr(scale), y.data_ptr(), nrow, d, n,
+           0 if scale is None else 1, _stream()),
+        "runia_pca_transform",
+    )
+    return y
+
+
+def md_score(x: torch.Tensor, mean: torch.Tensor, packed_p: torch.Tensor) -> torch.Tensor:
+    """x [N, n] (f64 or f32), mean [n] (f64 or f32) -> score [N] f64 = -(x-mean) P (x-mean)^T,
+    with ``x - mean`` formed under NumPy's dtype rules (f32 only when both are f32)."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.float64)
+    x = x.contiguous()
+    nrow, n = x.shape
+    if x.dtype == torch.float64:
+        mean = mean.to(torch.float64)
+        fn = lib.runia_md_score_f64
+    elif mean.dtype == torch.float32:
+        fn = lib.runia_md_score_f32
+    else:
+        mean = mean.to(torch.float64)
+        fn = lib.runia_md_score_f32x_f64mean
+    mean = mean.contiguous()
+    s = torch.empty((nrow,), dtype=torch.float64, device=x.device)
+    _check(fn(x.data_ptr(), mean.data_ptr(), packed_p.data_ptr(), s.data_ptr(), nrow, n, _stream()), "runia_md_score")
+    return s
+
+
+def mahalanobis_score(x: torch.Tensor, class_mean: torch.Tensor, packed_p: torch.Tensor, mu_p: torch.Tensor) -> torch.Tensor:
+    """x [N, D], class_mean [C, D] (both f32 or both f64) -> score [N] f64."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dim() == 2 and x.dtype == class_mean.dtype
+    x = x.contiguous()
+    nrow, d = x.shape
+    c = class_mean.shape[0]
+    s = torch.empty((nrow,), dtype=torch.float64, device=x.device)
+    ws_bytes = lib.runia_mahalanobis_workspace_bytes(nrow, d)
+    ws = torch.empty((max(ws_bytes, 8) // 8,), dtype=torch.float64, device=x.device)
+    fn = lib.runia_mahalanobis_score_f32 if x.dtype == torch.float32 else lib.runia_mahalanobis_score_f64
+    _check(
+        fn(x.data_ptr(), class_mean.data_ptr(), packed_p.data_ptr(), mu_p.data_ptr(), s.data_ptr(),
+           ws.data_ptr(), ws_bytes, nrow, d, c, _stream()),
+        "runia_mahalanobis_score",
+    )
+    return s
+
+
+def row_lse_msp(logits: torch.Tensor, want_lse: bool = True, want_msp: bool = False):
+    """logits [N, C] f32 -> (lse [N] f32 | None, msp [N] f32 | None)."""
+    lib = load_library()
+    require_gpu()
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2
+    logits = logits.contiguous()
+    n, c = logits.shape
+    lse = torch.empty((n,), dtype=torch.float32, device=logits.device) if want_lse else None
+    msp = torch.empty((n,), dtype=torch.float32, device=logits.device) if want_msp else None
+    _check(lib.runia_row_lse_msp_f32(logits.data_ptr(), _ptr(lse), _ptr(msp), n, c, _stream()), "runia_row_lse_msp_f32")
+    return lse, msp
+
+
+def l2_normalize(x: torch.Tensor) -> torch.Tensor:
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _check(lib.runia_l2_normalize_f32(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], _stream()), "runia_l2_normalize_f32")
+    return y
+
+
+def knn_kth(q: torch.Tensor, bank: torch.Tensor, k: int) -> torch.Tensor:
+    """q [N, D], bank [M, D] (both L2-normalised f32) -> -(k-th smallest squared L2) [N] f32."""
+    lib = load_library()
+    require_gpu()
+    assert q.is_cuda and bank.is_cuda and q.dtype == torch.float32 and bank.dtype == torch.float32
+    q = q.contiguous()
+    bank = bank.contiguous()
+    n, d = q.shape
+    m = bank.shape[0]
+    s = torch.empty((n,), dtype=torch.float32, device=q.device)
+    ws_bytes = lib.runia_knn_workspace_bytes(n, m, d, k)
+    ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=q.device)
+    _check(
+        lib.runia_knn_kth_f32(q.data_ptr(), bank.data_ptr(), s.data_ptr(), ws.data_ptr(), ws_bytes, n, m, d, int(k), _stream()),
+        "runia_knn_kth_f32",
+    )
+    return s
+
+
+def kde_score(train: torch.Tensor, x: torch.Tensor, bandwidth: float = 1.0) -> torch.Tensor:
+    """train [M, D] f64, x [N, D] f64 -> gaussian-KDE log-density [N] f64."""
+    lib = load_library()
+    require_gpu()
+    assert train.is_cuda and x.is_cuda and train.dtype == torch.float64 and x.dtype == torch.float64
+    train = train.contiguous()
+    x = x.contiguous()
+    m, d = train.shape
+    n = x.shape[0]
+    s = torch.empty((n,), dtype=torch.float64, device=x.device)
+    _check(
+        lib.runia_kde_score_f64(train.data_ptr(), x.data_ptr(), s.data_ptr(), m, n, d, float(bandwidth), _stream()),
+        "runia_kde_score_f64",
+    )
+    return s

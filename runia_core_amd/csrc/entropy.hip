@@ -1,0 +1,306 @@
+// a2: Kozachenko-Leonenko kNN entropy of MC-dropout samples.
+// Replaces the per-image / per-dimension loops of get_dl_h_z
+// (reference evaluation/entropy.py:41-93) over entropy_estimators.continuous.get_h
+// (k-d tree query of k+1 neighbours, max-norm, min_dist clip, psi(n)-psi(k)+(d/n)*sum log(2 eps)).
+//
+// 1-D case: the k-th nearest-neighbour distance of the element at sorted rank i is
+//   min_{j=0..k} max(v[i]-v[i-j], v[i+k-j]-v[i])      (out of range -> +inf)
+// so each (image, dim) column is a register sort of n_mc floats plus a k+1-wide
+// window scan; differences are taken in f64 (exact for f32 inputs, as in the
+// reference which promotes to f64 before the tree query).  sum_i log(2 eps_i) is
+// evaluated as log(prod mantissas) + ln2 * sum exponents: one f64 log per column.
+//
+// HBM-bound by design: 4*n_mc bytes in, 8 bytes out per column; loads are 16 B per
+// lane (4 adjacent dims), 1 KiB contiguous per wave instruction.
+#include "common.hpp"
+
+namespace {
+
+constexpr double kInf = __builtin_inf();
+
+template <int NP>
+__device__ __forceinline__ void bitonic_sort_asc(float (&v)[NP]) {
+#pragma unroll
+  for (int k = 2; k <= NP; k <<= 1) {
+#pragma unroll
+    for (int j = k >> 1; j > 0; j >>= 1) {
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int l = i ^ j;
+        if (l > i) {
+          const bool up = ((i & k) == 0);
+          const float a = v[i], b = v[l];
+          const float lo = fminf(a, b), hi = fmaxf(a, b);
+          v[i] = up ? lo : hi;
+          v[l] = up ? hi : lo;
+        }
+      }
+    }
+  }
+}
+
+// sum_i log(2*max(eps_i, min_dist)) for one sorted column (entries >= n are +inf pads)
+template <int NP, int K>
+__device__ __forceinline__ double column_log_sum(const float (&vs)[NP], int n, double min_dist) {
+  double v[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) v[i] = (double)vs[i];
+  double mant = 1.0;
+  int esum = 0;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if (i < n) {
+      double e = kInf;
+#pragma unroll
+      for (int j = 0; j <= K; ++j) {
+        const int li = i - j, ri = i + (K - j);
+        double L, R;
+        if (j == 0) L = 0.0; else if (li >= 0) L = v[i] - v[li]; else L = kInf;
+        if (K - j == 0) R = 0.0; else if (ri < NP) R = v[ri] - v[i]; else R = kInf;
+        e = fmin(e, fmax(L, R));
+      }
+      e = fmax(e, min_dist);
+      int ex;
+      const double m = frexp(2.0 * e, &ex);
+      mant *= m;
+      esum += ex;
+    }
+  }
+  return log(mant) + (double)esum * 0.69314718055994530942;
+}
+
+// VEC adjacent dims per thread (VEC = 4 -> float4 loads, VEC = 1 -> scalar)
+template <int NP, int K, int VEC>
+__global__ __launch_bounds__(256) void entropy_per_dim_kernel(const float* __restrict__ z,
+                                                               double* __restrict__ h, int64_t N, int n,
+                                                               int64_t D, double min_dist,
+                                                               double const_term, double inv_n) {
+  const int64_t DV = D / VEC;
+  const int64_t total = N * DV;
+  for (int64_t g = (int64_t)blockIdx.x * 256 + threadIdx.x; g < total; g += (int64_t)gridDim.x * 256) {
+    const int64_t img = g / DV;
+    const int64_t c = g - img * DV;
+    const float* base = z + (img * n) * D + c * VEC;
+    float v[VEC][NP];
+#pragma unroll
+    for (int s = 0; s < NP; ++s) {
+      if (s < n) {
+        if constexpr (VEC == 4) {
+          const float4 t = *reinterpret_cast<const float4*>(base + (int64_t)s * D);
+          v[0][s] = t.x; v[1][s] = t.y; v[2][s] = t.z; v[3][s] = t.w;
+        } else {
+          v[0][s] = base[(int64_t)s * D];
+        }
+      } else {
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) v[q][s] = INFINITY;
+      }
+    }
+    double out[VEC];
+#pragma unroll
+    for (int q = 0; q < VEC; ++q) {
+      bitonic_sort_asc<NP>(v[q]);
+      out[q] = const_term + inv_n * column_log_sum<NP, K>(v[q], n, min_dist);
+    }
+    double* dst = h + img * D + c * VEC;
+    if constexpr (VEC == 4) {
+      reinterpret_cast<double2*>(dst)[0] = make_double2(out[0], out[1]);
+      reinterpret_cast<double2*>(dst)[1] = make_double2(out[2], out[3]);
+    } else {
+      dst[0] = out[0];
+    }
+  }
+}
+
+// Any 2 <= n <= 64, any 1 <= k < n: thread-private column in LDS, insertion sort.
+__global__ __launch_bounds__(64) void entropy_per_dim_generic_kernel(const float* __restrict__ z,
+                                                                      double* __restrict__ h, int64_t N,
+                                                                      int n, int64_t D, int k,
+                                                                      double min_dist, double const_term,
+                                                                      double inv_n) {
+  __shared__ float col[64][64];  // [sample][thread]
+  const int t = threadIdx.x;
+  const int64_t total = N * D;
+  for (int64_t g = (int64_t)blockIdx.x * 64 + t; g < total; g += (int64_t)gridDim.x * 64) {
+    const int64_t img = g / D;
+    const int64_t c = g - img * D;
+    const float* base = z + (img * n) * D + c;
+    for (int s = 0; s < n; ++s) {  // insertion sort while loading
+      const float x = base[(int64_t)s * D];
+      int p = s;
+      while (p > 0 && col[p - 1][t] > x) {
+        col[p][t] = col[p - 1][t];
+        --p;
+      }
+      col[p][t] = x;
+    }
+    double mant = 1.0;
+    int esum = 0;
+    for (int i = 0; i < n; ++i) {
+      const double vi = (double)col[i][t];
+      double e = kInf;
+      for (int j = 0; j <= k; ++j) {
+        const int li = i - j, ri = i + (k - j);
+        const double L = (j == 0) ? 0.0 : (li >= 0 ? vi - (double)col[li][t] : kInf);
+        const double R = (k - j == 0) ? 0.0 : (ri < n ? (double)col[ri][t] - vi : kInf);
+        e = fmin(e, fmax(L, R));
+      }
+      e = fmax(e, min_dist);
+      int ex;
+      mant *= frexp(2.0 * e, &ex);
+      esum += ex;
+      if ((i & 15) == 15) {  // keep the mantissa product far from underflow
+        int e2;
+        mant = frexp(mant, &e2);
+        esum += e2;
+      }
+    }
+    h[img * D + c] = const_term + inv_n * (log(mant) + (double)esum * 0.69314718055994530942);
+  }
+}
+
+// Joint (D-dimensional, Chebyshev) entropy: one workgroup per image.  Each lane owns
+// sample pairs (a<b); the image's samples are staged through LDS in chunks of dims.
+constexpr int kJointChunk = 128;  // dims per staged chunk
+__global__ __launch_bounds__(256) void entropy_joint_kernel(const float* __restrict__ z,
+                                                             double* __restrict__ h_mvn, int64_t N, int n,
+                                                             int64_t D, int k, double min_dist,
+                                                             double const_term, double d_over_n) {
+  __shared__ float tile[64][kJointChunk + 1];
+  __shared__ double dist[64][65];
+  const int tid = threadIdx.x;
+  const int npairs = n * (n - 1) / 2;
+  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
+    const float* base = z + img * n * D;
+    // pairs owned by this thread: p = tid, tid+256, ... (at most 8 for n = 64)
+    double best[8];
+#pragma unroll
+    for (int q = 0; q < 8; ++q) best[q] = 0.0;
+    for (int64_t d0 = 0; d0 < D; d0 += kJointChunk) {
+      const int w = (int)((D - d0 < kJointChunk) ? (D - d0) : kJointChunk);
+      __syncthreads();
+      for (int i = tid; i < n * w; i += 256) {
+        const int s = i / w, j = i - s * w;
+        tile[s][j] = base[(int64_t)s * D + d0 + j];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const int p = tid + 256 * q;
+        if (p < npairs) {
+          // decode pair index -> (a, b), a < b
+          int a = 0, rem = p;
+          while (rem >= n - 1 - a) { rem -= n - 1 - a; ++a; }
+          const int b = a + 1 + rem;
+          double m = best[q];
+          for (int j = 0; j < w; ++j) m = fmax(m, fabs((double)tile[a][j] - (double)tile[b][j]));
+          best[q] = m;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 8; ++q) {
+      const int p = tid + 256 * q;
+      if (p < npairs) {
+        int a = 0, rem = p;
+        while (rem >= n - 1 - a) { rem -= n - 1 - a; ++a; }
+        const int b = a + 1 + rem;
+        dist[a][b] = best[q];
+        dist[b][a] = best[q];
+      }
+    }
+    __syncthreads();
+    // sample i: k-th smallest distance to the others (selection by counting, n <= 64)
+    double logsum = 0.0;
+    if (tid < n) {
+      const int i = tid;
+      double kth = kInf;
+      for (int c = 0; c < n; ++c) {
+        if (c == i) continue;
+        const double dc = dist[i][c];
+        int less = 0, leq = 0;
+        for (int o = 0; o < n; ++o) {
+          if (o == i) continue;
+          const double d_o = dist[i][o];
+          less += (d_o < dc);
+          leq += (d_o <= dc);
+        }
+        if (less < k && k <= leq) kth = dc;  // dc is the k-th order statistic (1-based)
+      }
+      logsum = log(2.0 * fmax(kth, min_dist));
+    }
+    // reduce over the first wave (n <= 64 lanes)
+    if (tid < 64) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) logsum += shfl_xor_f64(logsum, o);
+      if (tid == 0) h_mvn[img] = const_term + d_over_n * logsum;
+    }
+    __syncthreads();
+  }
+}
+
+int next_pow2(int n) {
+  int p = 4;
+  while (p < n) p <<= 1;
+  return p;
+}
+
+double digamma_diff(int n, int k) {  // psi(n) - psi(k) = sum_{j=k}^{n-1} 1/j for integers
+  double s = 0.0;
+  for (int j = n - 1; j >= k; --j) s += 1.0 / (double)j;
+  return s;
+}
+
+template <int NP, int K>
+void launch_per_dim(const float* z, double* h, int64_t N, int n, int64_t D, double min_dist, double ct,
+                    double inv_n, hipStream_t s) {
+  const bool vec = (NP <= 16) && ((D & 3) == 0) && ((((uintptr_t)z) & 15) == 0) && ((((uintptr_t)h) & 15) == 0);
+  if constexpr (NP <= 16) {
+    if (vec) {
+      entropy_per_dim_kernel<NP, K, 4><<<runia_stream_grid(N * (D / 4), 256), 256, 0, s>>>(
+          z, h, N, n, D, min_dist, ct, inv_n);
+      return;
+    }
+  }
+  entropy_per_dim_kernel<NP, K, 1><<<runia_stream_grid(N * D, 256), 256, 0, s>>>(z, h, N, n, D, min_dist,
+                                                                                  ct, inv_n);
+}
+
+}  // namespace
+
+extern "C" int runia_kl_entropy_per_dim_f32(const float* z, double* h, int64_t N, int n_mc, int64_t D, int k,
+                                            double min_dist, runia_stream_t stream) {
+  if (N < 0 || D <= 0 || n_mc < 2 || n_mc > 64 || k < 1 || k >= n_mc || (N > 0 && (!z || !h)))
+    return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  hipStream_t s = as_stream(stream);
+  const double ct = digamma_diff(n_mc, k);
+  const double inv_n = 1.0 / (double)n_mc;
+  const int np = next_pow2(n_mc);
+  bool done = true;
+  if (np == 4 && k == 1) launch_per_dim<4, 1>(z, h, N, n_mc, D, min_dist, ct, inv_n, s);
+  else if (np == 4 && k == 2) launch_per_dim<4, 2>(z, h, N, n_mc, D, min_dist, ct, inv_n, s);
+  else if (np == 4 && k == 3) launch_per_dim<4, 3>(z, h, N, n_mc, D, min_dist, ct, inv_n, s);
+  else if (np == 8 && k == 4) launch_per_dim<8, 4>(z, h, N, n_mc, D, min_dist, ct, inv_n, s);
+  else if (np == 8 && k == 5) launch_per_dim<8, 5>(z, h, N, n_mc, D, min_dist, ct, inv_n, s);
+  else if (np == 16 && k == 5) launch_per_dim<16, 5>(z, h, N, n_mc, D, min_dist, ct, inv_n, s);
+  else if (np == 32 && k == 5) launch_per_dim<32, 5>(z, h, N, n_mc, D, min_dist, ct, inv_n, s);
+  else if (np == 64 && k == 5) launch_per_dim<64, 5>(z, h, N, n_mc, D, min_dist, ct, inv_n, s);
+  else done = false;
+  if (!done)
+    entropy_per_dim_generic_kernel<<<runia_stream_grid(N * D, 64), 64, 0, s>>>(z, h, N, n_mc, D, k, min_dist,
+                                                                               ct, inv_n);
+  return runia_check_launch();
+}
+
+extern "C" int runia_kl_entropy_joint_f32(const float* z, double* h_mvn, int64_t N, int n_mc, int64_t D,
+                                          int k, double min_dist, runia_stream_t stream) {
+  if (N < 0 || D <= 0 || n_mc < 2 || n_mc > 64 || k < 1 || k >= n_mc || (N > 0 && (!z || !h_mvn)))
+    return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  const double ct = digamma_diff(n_mc, k);
+  const double d_over_n = (double)D / (double)n_mc;
+  entropy_joint_kernel<<<runia_stream_grid(N, 1), 256, 0, as_stream(stream)>>>(z, h_mvn, N, n_mc, D, k,
+                                                                               min_dist, ct, d_over_n);
+  return runia_check_launch();
+}

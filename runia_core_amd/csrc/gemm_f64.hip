@@ -1,0 +1,358 @@
+// f64 dense contractions of the scoring path on the CDNA4 matrix cores
+// (v_mfma_f64_16x16x4_f64):
+//   a4  PCA transform     Y = X @ C.T - mean @ C.T ; Y /= scale   (reference dimensionality_reduction.py:86)
+//   a5  LaREM / MD score  -diag(diff @ P @ diff.T)                 (reference inference/postprocessors.py:241-242)
+//   a6  Mahalanobis       max_c -(x-mu_c) P (x-mu_c)^T             (reference inference/funcs.py:88-100)
+//
+// Layout.  The right-hand matrix B [K, n] is constant after setup(), so it is repacked
+// once into MFMA fragment order: for k-step pair s2 (8 k values) and 16-column tile ct,
+//   packed[((s2*NT + ct)*64 + lane)*2 + h] = B[8*s2 + 4*h + (lane>>4)][16*ct + (lane&15)]
+// (zero padded to K%8==0, n%256==0).  One wave-wide 16-byte load then yields the B operand
+// of two MFMA k-steps, fully coalesced (1 KiB per instruction, 4 KiB per wave per k-step pair)
+// and served by the XCD L2 (the whole matrix is <= a few MiB).
+// The left-hand rows stream from HBM exactly once: a 32-row x 32-k chunk is staged into LDS
+// (pitch 34 doubles => conflict-free ds_read_b64 of the A fragment) while the previous chunk
+// is being multiplied.  A workgroup (4 waves) owns 32 rows x 256 columns; wave w owns the
+// 64-column slice w, i.e. 2 x 4 accumulator tiles (64 VGPRs).
+//
+// f64 MFMA fragment maps (guide section 3): A lane l -> A[l&15][l>>4]; B lane l -> B[l>>4][l&15];
+// C/D lane l, reg r -> C[(l>>4) + 4r][l&15].
+#include "common.hpp"
+
+namespace {
+
+constexpr int BM = 32;        // rows per workgroup
+constexpr int KC = 32;        // k values per staged chunk
+constexpr int APITCH = 34;    // doubles; 34 mod 32 == 2 -> 16 rows x 2 k hit 32 distinct bank pairs
+constexpr int BN = 256;       // columns per workgroup pass (4 waves x 4 tiles x 16)
+
+enum Epilogue { EPI_PCA = 0, EPI_ROWDOT = 1, EPI_STORE = 2 };
+
+struct GemmArgs {
+  const void* x;        // [N, K] rows (TA), ld = ldx
+  int64_t ldx;
+  const double* packed; // packed B
+  int64_t N, K, n;
+  // prologue
+  const void* sub;      // optional [K] (TS): a = x - sub[k]; subtraction in f32 when TA = TS = float (NumPy dtype rules)
+  // EPI_PCA
+  const double* bias;   // [n]
+  const double* scale;  // [n] or null
+  // outputs
+  double* out;          // EPI_PCA / EPI_STORE: [N, n] (ld = n); EPI_ROWDOT: [N]
+};
+
+__global__ __launch_bounds__(256) void pack_weights_kernel(const double* __restrict__ B, int64_t ldb,
+                                                            int64_t K, int64_t n, double* __restrict__ packed,
+                                                            int64_t NT, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int h = (int)(i & 1);
+    const int lane = (int)((i >> 1) & 63);
+    const int64_t t = i >> 7;  // s2*NT + ct
+    const int64_t ct = t % NT, s2 = t / NT;
+    const int64_t k = 8 * s2 + 4 * h + (lane >> 4);
+    const int64_t c = 16 * ct + (lane & 15);
+    packed[i] = (k < K && c < n) ? B[k * ldb + c] : 0.0;
+  }
+}
+
+// x - sub with NumPy's promotion: f32 - f32 stays f32 (then promoted), anything else is f64
+template <typename TA, typename TS>
+__device__ __forceinline__ double sub_promote(TA x, TS m) {
+  if constexpr (sizeof(TA) == 4 && sizeof(TS) == 4) return (double)(x - m);
+  else return (double)x - (double)m;
+}
+
+template <typename TA, typename TS>
+__device__ __forceinline__ void load_a_regs(const GemmArgs& g, int64_t r0, int64_t kc, int tid, double (&r)[4]) {
+  const int row = tid >> 3;          // 0..31
+  const int kk = (tid & 7) * 4;      // 0,4,...,28
+  const int64_t gr = r0 + row;
+  const int64_t gk = kc + kk;
+  const TA* x = reinterpret_cast<const TA*>(g.x);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    double v = 0.0;
+    if (gr < g.N && gk + q < g.K) {
+      const TA xv = x[gr * g.ldx + gk + q];
+      v = g.sub ? sub_promote<TA, TS>(xv, reinterpret_cast<const TS*>(g.sub)[gk + q]) : (double)xv;
+    }
+    r[q] = v;
+  }
+}
+
+template <typename TA, typename TS, int EPI>
+__global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
+  __shared__ double lds_a[2][BM][APITCH];
+  __shared__ double lds_part[4][BM];
+  const int tid = threadIdx.x;
+  const int lane = tid & 63;
+  const int wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int64_t n_pad = (g.n + BN - 1) / BN * BN;
+  const int64_t NT = n_pad / 16;
+  const int64_t K_pad = (g.K + 7) / 8 * 8;
+  const int64_t nchunks = (K_pad + KC - 1) / KC;
+  const int64_t r0 = (int64_t)blockIdx.x * BM;
+
+  double rowdot[2][4];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rowdot[a][r] = 0.0;
+
+  for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
+    const int64_t ctbase = cb * 16 + wave * 4;
+    const bool active = (ctbase * 16 < g.n);  // wave-uniform: this wave's 64 columns hold real data
+    d4 acc[2][4];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+
+    double areg[4];
+    load_a_regs<TA, TS>(g, r0, 0, tid, areg);
+    int buf = 0;
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+      {
+        const int row = tid >> 3, kk = (tid & 7) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) lds_a[buf][row][kk + q] = areg[q];
+      }
+      __syncthreads();
+      if (ch + 1 < nchunks) load_a_regs<TA, TS>(g, r0, (ch + 1) * KC, tid, areg);
+      if (active) {
+        const int64_t s2_base = ch * (KC / 8);
+        const int steps2 = (int)(((K_pad - ch * KC) < KC ? (K_pad - ch * KC) : KC) / 8);
+#pragma unroll
+        for (int s2 = 0; s2 < KC / 8; ++s2) {
+          if (s2 < steps2) {
+            double2 b[4];
+#pragma unroll
+            for (int c = 0; c < 4; ++c)
+              b[c] = reinterpret_cast<const double2*>(g.packed)[((s2_base + s2) * NT + ctbase + c) * 64 + lane];
+#pragma unroll
+            for (int h = 0; h < 2; ++h) {
+              const double a0 = lds_a[buf][li][8 * s2 + 4 * h + lg];
+              const double a1 = lds_a[buf][16 + li][8 * s2 + 4 * h + lg];
+#pragma unroll
+              for (int c = 0; c < 4; ++c) {
+                const double bv = h ? b[c].y : b[c].x;
+                acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][c], 0, 0, 0);
+                acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][c], 0, 0, 0);
+              }
+            }
+          }
+        }
+      }
+      buf ^= 1;
+    }
+
+    // ---- epilogue for this 256-column block ----
+    if (active) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int64_t col = (ctbase + c) * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t row = r0 + 16 * a + lg + 4 * r;
+            if (row < g.N && col < g.n) {
+              const double v = acc[a][c][r];
+              if constexpr (EPI == EPI_PCA) {
+                double y = v - g.bias[col];
+                if (g.scale) y = y / g.scale[col];
+                g.out[row * g.n + col] = y;
+              } else if constexpr (EPI == EPI_STORE) {
+                g.out[row * g.n + col] = v;
+              } else {  // EPI_ROWDOT: sum_j (d P)_j d_j with d = x - sub
+                const TA* x = reinterpret_cast<const TA*>(g.x);
+                const TA xv = x[row * g.ldx + col];
+                const double d = g.sub ? sub_promote<TA, TS>(xv, reinterpret_cast<const TS*>(g.sub)[col]) : (double)xv;
+                rowdot[a][r] += v * d;
+              }
+            }
+          }
+        }
+      }
+    }
+    __syncthreads();  // all waves done with the last chunk before the next block restages LDS
+  }
+
+  if constexpr (EPI == EPI_ROWDOT) {
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = rowdot[a][r];
+        v += shfl_xor_f64(v, 1);
+        v += shfl_xor_f64(v, 2);
+        v += shfl_xor_f64(v, 4);
+        v += shfl_xor_f64(v, 8);
+        if (li == 0) lds_part[wave][16 * a + lg + 4 * r] = v;
+      }
+    __syncthreads();
+    if (tid < BM) {
+      const int64_t row = r0 + tid;
+      if (row < g.N)
+        g.out[row] = -(((lds_part[0][tid] + lds_part[1][tid]) + lds_part[2][tid]) + lds_part[3][tid]);
+    }
+  }
+}
+
+template <typename TA, int EPI, typename TS = double>
+int launch_gemm(const GemmArgs& g, hipStream_t s) {
+  const int64_t tiles = (g.N + BM - 1) / BM;
+  if (tiles > 0x7fffffff) return RUNIA_E_INVALID;
+  gemm_rows_kernel<TA, TS, EPI><<<(unsigned)tiles, 256, 0, s>>>(g);
+  return runia_check_launch();
+}
+
+// ---- Mahalanobis class terms: one wave per row over G = X P ---------------------------
+// s_c = -(t P t^T), t = fl(x - mu_c) in the input dtype.  With a = x - mu_c exact in f64 and
+// t = a + e:  t P t^T = sum_j (G_j - (mu_c P)_j) * (2 t_j - a_j) + O(e^2)   (P symmetric).
+template <typename TX>
+__global__ __launch_bounds__(256) void maha_class_kernel(const TX* __restrict__ x, const TX* __restrict__ mu,
+                                                          const double* __restrict__ G,
+                                                          const double* __restrict__ muP,
+                                                          double* __restrict__ score, int64_t rows, int64_t D,
+                                                          int C) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < rows; row += (int64_t)gridDim.x * 4) {
+    const TX* xr = x + row * D;
+    const double* gr = G + row * D;
+    double best = -kInfD();
+    for (int c = 0; c < C; ++c) {
+      const TX* m = mu + (int64_t)c * D;
+      const double* q = muP + (int64_t)c * D;
+      double acc = 0.0;
+      for (int64_t j = lane; j < D; j += 64) {
+        const TX xv = xr[j], mv = m[j];
+        const double a = (double)xv - (double)mv;
+        const double t = (double)(TX)(xv - mv);
+        acc += (gr[j] - q[j]) * (2.0 * t - a);
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += shfl_xor_f64(acc, o);
+      double sc = -acc;
+      if (sc != sc) sc = -kInfD();  // NaN (class without training samples) -> -inf
+      best = fmax(best, sc);
+    }
+    if (lane == 0) score[row] = best;
+  }
+}
+
+}  // namespace
+
+extern "C" size_t runia_packed_weights_bytes(int64_t K, int64_t n) {
+  if (K <= 0 || n <= 0) return 0;
+  const int64_t n_pad = (n + BN - 1) / BN * BN;
+  const int64_t K_pad = (K + 7) / 8 * 8;
+  return (size_t)(n_pad * K_pad) * sizeof(double);
+}
+
+extern "C" int runia_pack_weights_f64(const double* B, int64_t ldb, int64_t K, int64_t n, double* packed,
+                                      runia_stream_t stream) {
+  if (!B || !packed || K <= 0 || n <= 0 || ldb < n) return RUNIA_E_INVALID;
+  const int64_t n_pad = (n + BN - 1) / BN * BN;
+  const int64_t K_pad = (K + 7) / 8 * 8;
+  const int64_t total = n_pad * K_pad;
+  pack_weights_kernel<<<runia_stream_grid(total, 256), 256, 0, as_stream(stream)>>>(B, ldb, K, n, packed,
+                                                                                     n_pad / 16, total);
+  return runia_check_launch();
+}
+
+static int pca_impl(const void* x, bool f32in, const double* packed_ct, const double* bias, const double* scale,
+                    double* y, int64_t N, int64_t D, int64_t n, int whiten, runia_stream_t stream) {
+  if (N < 0 || D <= 0 || n <= 0 || (N > 0 && (!x || !y)) || !packed_ct || !bias || (whiten && !scale))
+    return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  GemmArgs g{};
+  g.x = x; g.ldx = D; g.packed = packed_ct; g.N = N; g.K = D; g.n = n;
+  g.sub = nullptr; g.bias = bias; g.scale = whiten ? scale : nullptr; g.out = y;
+  return f32in ? launch_gemm<float, EPI_PCA>(g, as_stream(stream))
+               : launch_gemm<double, EPI_PCA>(g, as_stream(stream));
+}
+
+extern "C" int runia_pca_transform_f64(const double* x, const double* packed_ct, const double* bias,
+                                       const double* scale, double* y, int64_t N, int64_t D, int64_t n,
+                                       int whiten, runia_stream_t stream) {
+  return pca_impl(x, false, packed_ct, bias, scale, y, N, D, n, whiten, stream);
+}
+extern "C" int runia_pca_transform_f32in(const float* x, const double* packed_ct, const double* bias,
+                                         const double* scale, double* y, int64_t N, int64_t D, int64_t n,
+                                         int whiten, runia_stream_t stream) {
+  return pca_impl(x, true, packed_ct, bias, scale, y, N, D, n, whiten, stream);
+}
+
+template <typename TA, typename TS>
+static int md_impl(const TA* x, const TS* mean, const double* packed_p, double* score, int64_t N, int64_t n,
+                   runia_stream_t stream) {
+  if (N < 0 || n <= 0) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!x || !score || !mean || !packed_p) return RUNIA_E_INVALID;
+  GemmArgs g{};
+  g.x = x; g.ldx = n; g.packed = packed_p; g.N = N; g.K = n; g.n = n;
+  g.sub = mean; g.bias = nullptr; g.scale = nullptr; g.out = score;
+  return launch_gemm<TA, EPI_ROWDOT, TS>(g, as_stream(stream));
+}
+
+extern "C" int runia_md_score_f64(const double* x, const double* mean, const double* packed_p, double* score,
+                                  int64_t N, int64_t n, runia_stream_t stream) {
+  return md_impl<double, double>(x, mean, packed_p, score, N, n, stream);
+}
+extern "C" int runia_md_score_f32(const float* x, const float* mean, const double* packed_p, double* score,
+                                  int64_t N, int64_t n, runia_stream_t stream) {
+  return md_impl<float, float>(x, mean, packed_p, score, N, n, stream);
+}
+extern "C" int runia_md_score_f32x_f64mean(const float* x, const double* mean, const double* packed_p,
+                                           double* score, int64_t N, int64_t n, runia_stream_t stream) {
+  return md_impl<float, double>(x, mean, packed_p, score, N, n, stream);
+}
+
+extern "C" size_t runia_mahalanobis_workspace_bytes(int64_t N, int64_t D) {
+  if (N <= 0 || D <= 0) return 0;
+  // G = X P for a chunk of rows; chunk capped at 64 Ki rows so that the buffer stays L2/MALL friendly
+  const int64_t rows = N < 65536 ? N : 65536;
+  return (size_t)(rows * D) * sizeof(double);
+}
+
+template <typename TX>
+static int maha_impl(const TX* x, const TX* class_mean, const double* packed_p, const double* mu_p,
+                     double* score, void* workspace, size_t workspace_bytes, int64_t N, int64_t D, int C,
+                     runia_stream_t stream) {
+  if (N < 0 || D <= 0 || C <= 0 || (N > 0 && (!x || !score)) || !class_mean || !packed_p || !mu_p)
+    return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  const int64_t cap_rows = (int64_t)(workspace_bytes / ((size_t)D * sizeof(double)));
+  if (!workspace || cap_rows < 1) return RUNIA_E_WORKSPACE;
+  double* G = reinterpret_cast<double*>(workspace);
+  for (int64_t r0 = 0; r0 < N; r0 += cap_rows) {
+    const int64_t rows = (N - r0 < cap_rows) ? (N - r0) : cap_rows;
+    GemmArgs g{};
+    g.x = x + r0 * D; g.ldx = D; g.packed = packed_p; g.N = rows; g.K = D; g.n = D;
+    g.sub = nullptr; g.bias = nullptr; g.scale = nullptr; g.out = G;
+    int rc = launch_gemm<TX, EPI_STORE>(g, as_stream(stream));
+    if (rc != RUNIA_OK) return rc;
+    maha_class_kernel<TX><<<runia_stream_grid(rows, 4), 256, 0, as_stream(stream)>>>(
+        x + r0 * D, class_mean, G, mu_p, score + r0, rows, D, C);
+    rc = runia_check_launch();
+    if (rc != RUNIA_OK) return rc;
+  }
+  return RUNIA_OK;
+}
+
+extern "C" int runia_mahalanobis_score_f32(const float* x, const float* class_mean, const double* packed_p,
+                                           const double* mu_p, double* score, void* workspace,
+                                           size_t workspace_bytes, int64_t N, int64_t D, int C,
+                                           runia_stream_t stream) {
+  return maha_impl<float>(x, class_mean, packed_p, mu_p, score, workspace, workspace_bytes, N, D, C, stream);
+}
+extern "C" int runia_mahalanobis_score_f64(const double* x, const double* class_mean, const double* packed_p,
+                                           const double* mu_p, double* score, void* workspace,
+                                           size_t workspace_bytes, int64_t N, int64_t D, int C,
+                                           runia_stream_t stream) {
+  return maha_impl<double>(x, class_mean, packed_p, mu_p, score, workspace, workspace_bytes, N, D, C, stream);
+}

@@ -1,0 +1,172 @@
+// Row-streaming kernels (HBM-bound): Energy / MSP and the kNN normaliser.
+//   a7: scipy.special.logsumexp / softmax-max (reference inference/postprocessors.py:549,606)
+//   a8: normalizer (reference inference/funcs.py:105-115)
+#include "common.hpp"
+
+namespace {
+
+// scipy.special.logsumexp: a_max = max(row) (0 when not finite); out = log(sum(exp(a - a_max))) + a_max
+// scipy.special.softmax max: exp(a_max - a_max) / sum(exp(a - a_max)) = 1 / sum
+// An infinite row maximum is reset to 0 by logsumexp only; softmax keeps it and
+// therefore yields NaN (inf - inf), which is reproduced here.
+__device__ __forceinline__ void finish_row(float m_raw, float m, float s, float* lse, float* msp,
+                                           int64_t row) {
+  if (lse) lse[row] = logf(s) + m;
+  if (msp) msp[row] = (m_raw == INFINITY || m_raw == -INFINITY) ? NAN : 1.0f / s;
+}
+
+// ---- C <= 64: one row per lane, tile staged through LDS with coalesced loads ----
+constexpr int kSmallRows = 256;  // rows per workgroup tile
+
+__global__ __launch_bounds__(256) void lse_small_kernel(const float* __restrict__ x, float* lse,
+                                                         float* msp, int64_t N, int C) {
+  extern __shared__ float tile[];  // kSmallRows * C floats
+  const int tid = threadIdx.x;
+  for (int64_t r0 = (int64_t)blockIdx.x * kSmallRows; r0 < N; r0 += (int64_t)gridDim.x * kSmallRows) {
+    const int rows = (int)((N - r0 < kSmallRows) ? (N - r0) : kSmallRows);
+    const int total = rows * C;
+    const float* src = x + r0 * C;
+    __syncthreads();
+    if ((((uintptr_t)src) & 15) == 0) {
+      const int n4 = total >> 2;
+      const float4* s4 = reinterpret_cast<const float4*>(src);
+      float4* t4 = reinterpret_cast<float4*>(tile);
+      for (int i = tid; i < n4; i += 256) t4[i] = s4[i];
+      for (int i = (n4 << 2) + tid; i < total; i += 256) tile[i] = src[i];
+    } else {
+      for (int i = tid; i < total; i += 256) tile[i] = src[i];
+    }
+    __syncthreads();
+    if (tid < rows) {
+      const float* row = tile + tid * C;
+      // rotate the start column per lane so that lanes of one LDS access group hit
+      // different banks when C shares a factor with the bank count
+      int j0 = tid % C;
+      float m = -INFINITY;
+      int j = j0;
+      for (int t = 0; t < C; ++t) {
+        m = fmaxf(m, row[j]);
+        j = (j + 1 == C) ? 0 : j + 1;
+      }
+      // fmaxf drops NaN, expf(NaN) then poisons the sum as NumPy's max/exp do
+      const float m_raw = m;
+      if (m == INFINITY || m == -INFINITY) m = 0.f;
+      float s = 0.f;
+      j = j0;
+      for (int t = 0; t < C; ++t) {
+        s += expf(row[j] - m);
+        j = (j + 1 == C) ? 0 : j + 1;
+      }
+      finish_row(m_raw, m, s, lse, msp, r0 + tid);
+    }
+  }
+}
+
+// ---- C > 64: one wave per row; the row stays in registers when it fits ----
+template <int NCH>  // float4 chunks per lane; NCH == 0 -> re-read the row (any C)
+__global__ __launch_bounds__(256) void lse_wave_kernel(const float* __restrict__ x, float* lse,
+                                                        float* msp, int64_t N, int64_t C) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t wave_stride = (int64_t)gridDim.x * 4;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += wave_stride) {
+    const float* p = x + row * C;
+    float m = -INFINITY, s = 0.f, m_raw;
+    if constexpr (NCH > 0) {
+      const float4* p4 = reinterpret_cast<const float4*>(p);
+      const int n4 = (int)(C >> 2);
+      float4 v[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int i = lane + 64 * c;
+        v[c] = (i < n4) ? p4[i] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+      }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) m = fmaxf(m, fmaxf(fmaxf(v[c].x, v[c].y), fmaxf(v[c].z, v[c].w)));
+      m = wave_max_f32(m);
+      m_raw = m;
+      if (m == INFINITY || m == -INFINITY) m = 0.f;
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        s += (expf(v[c].x - m) + expf(v[c].y - m)) + (expf(v[c].z - m) + expf(v[c].w - m));
+    } else {
+      for (int64_t i = lane; i < C; i += 64) m = fmaxf(m, p[i]);
+      m = wave_max_f32(m);
+      m_raw = m;
+      if (m == INFINITY || m == -INFINITY) m = 0.f;
+      for (int64_t i = lane; i < C; i += 64) s += expf(p[i] - m);
+    }
+    s = wave_sum_f32(s);
+    if (lane == 0) finish_row(m_raw, m, s, lse, msp, row);
+  }
+}
+
+// ---- normalizer: y = x / (||x||_2 + 1e-10), f32, one wave per row ----
+__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x,
+                                                            float* __restrict__ y, int64_t N, int64_t D) {
+  const int lane = threadIdx.x & 63;
+  const int wave = threadIdx.x >> 6;
+  const int64_t wave_stride = (int64_t)gridDim.x * 4;
+  const bool vec = ((D & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)y) & 15) == 0);
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += wave_stride) {
+    const float* p = x + row * D;
+    float* q = y + row * D;
+    float ss = 0.f;
+    if (vec) {
+      const float4* p4 = reinterpret_cast<const float4*>(p);
+      const int64_t n4 = D >> 2;
+      for (int64_t i = lane; i < n4; i += 64) {
+        float4 v = p4[i];
+        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      }
+      ss = wave_sum_f32(ss);
+      const float den = sqrtf(ss) + 1e-10f;
+      float4* q4 = reinterpret_cast<float4*>(q);
+      for (int64_t i = lane; i < n4; i += 64) {
+        float4 v = p4[i];
+        q4[i] = make_float4(v.x / den, v.y / den, v.z / den, v.w / den);
+      }
+    } else {
+      for (int64_t i = lane; i < D; i += 64) ss += p[i] * p[i];
+      ss = wave_sum_f32(ss);
+      const float den = sqrtf(ss) + 1e-10f;
+      for (int64_t i = lane; i < D; i += 64) q[i] = p[i] / den;
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int runia_row_lse_msp_f32(const float* logits, float* lse, float* msp, int64_t N, int64_t C,
+                                     runia_stream_t stream) {
+  if (N < 0 || C <= 0) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!logits || (!lse && !msp)) return RUNIA_E_INVALID;
+  hipStream_t s = as_stream(stream);
+  if (C <= 64) {
+    const size_t shmem = (size_t)kSmallRows * C * sizeof(float);
+    lse_small_kernel<<<runia_stream_grid(N, kSmallRows), 256, shmem, s>>>(logits, lse, msp, N, (int)C);
+    return runia_check_launch();
+  }
+  const unsigned grid = runia_stream_grid(N, 4);
+  const bool vec = ((C & 3) == 0) && ((((uintptr_t)logits) & 15) == 0);
+  const int64_t n4 = C >> 2;
+  if (vec && n4 <= 64)
+    lse_wave_kernel<1><<<grid, 256, 0, s>>>(logits, lse, msp, N, C);
+  else if (vec && n4 <= 128)
+    lse_wave_kernel<2><<<grid, 256, 0, s>>>(logits, lse, msp, N, C);
+  else if (vec && n4 <= 256)
+    lse_wave_kernel<4><<<grid, 256, 0, s>>>(logits, lse, msp, N, C);
+  else if (vec && n4 <= 512)
+    lse_wave_kernel<8><<<grid, 256, 0, s>>>(logits, lse, msp, N, C);
+  else
+    lse_wave_kernel<0><<<grid, 256, 0, s>>>(logits, lse, msp, N, C);
+  return runia_check_launch();
+}
+
+extern "C" int runia_l2_normalize_f32(const float* x, float* y, int64_t N, int64_t D, runia_stream_t stream) {
+  if (N < 0 || D <= 0 || (N > 0 && (!x || !y))) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  l2_normalize_kernel<<<runia_stream_grid(N, 4), 256, 0, as_stream(stream)>>>(x, y, N, D);
+  return runia_check_launch();
+}
