@@ -1,0 +1,107 @@
+"""PCA helpers with the reference's signatures
+(``runia_core/dimensionality_reduction.py``: ``apply_pca_ds`` :26-49,
+``apply_pca_ds_split`` :52-72, ``apply_pca_transform`` :75-87).
+
+Fitting stays the scikit-learn call the reference makes (setup time);
+the per-row transform is the f64-MFMA kernel ``runia_pca_transform_*``.  A fitted
+sklearn ``PCA`` is read through its public attributes, so PCA objects created by
+user code drop in unchanged.
+"""
+from __future__ import annotations
+
+import weakref
+from typing import Tuple
+
+import numpy as np
+import torch
+
+from . import _hip
+
+__all__ = ["apply_pca_ds", "apply_pca_ds_split", "apply_pca_transform", "DevicePCA"]
+
+
+class DevicePCA:
+    """Device-resident copy of a fitted PCA: packed ``components_.T``, ``mean_ @ components_.T``
+    and the whitening scale ``max(sqrt(explained_variance_), eps)`` (sklearn ``_BasePCA.transform``)."""
+
+    def __init__(self, components: np.ndarray, mean, explained_variance: np.ndarray, whiten: bool):
+        components = np.asarray(components, dtype=np.float64)
+        self.n_components, self.n_features = components.shape
+        self.whiten = bool(whiten)
+        if mean is None:
+            bias = np.zeros(self.n_components)
+        else:
+            bias = (np.asarray(mean, dtype=np.float64).reshape(1, -1) @ components.T).ravel()
+        self.packed_ct = _hip.pack_weights(_hip.to_device(np.ascontiguousarray(components.T), torch.float64))
+        self.bias = _hip.to_device(bias, torch.float64)
+        self.scale = None
+        if self.whiten:
+            scale = np.sqrt(np.asarray(explained_variance, dtype=np.float64))
+            min_scale = np.finfo(scale.dtype).eps
+            scale = np.where(scale < min_scale, min_scale, scale)
+            self.scale = _hip.to_device(scale, torch.float64)
+
+    @classmethod
+    def from_sklearn(cls, pca) -> "DevicePCA":
+        return cls(pca.components_, getattr(pca, "mean_", None), pca.explained_variance_, getattr(pca, "whiten", False))
+
+    def transform_device(self, x: torch.Tensor) -> torch.Tensor:
+        if x.shape[1] != self.n_features:
+            raise ValueError(
+                f"X has {x.shape[1]} features, but PCA is expecting {self.n_features} features as input."
+            )
+        return _hip.pca_transform(x, self.packed_ct, self.bias, self.scale, self.n_components)
+
+
+_device_pca_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
+
+
+def device_pca_for(pca_transform) -> DevicePCA:
+    if isinstance(pca_transform, DevicePCA):
+        return pca_transform
+    try:
+        cached = _device_pca_cache.get(pca_transform)
+    except TypeError:
+        cached = None
+    if cached is None:
+        cached = DevicePCA.from_sklearn(pca_transform)
+        try:
+            _device_pca_cache[pca_transform] = cached
+        except TypeError:
+            pass
+    return cached
+
+
+def apply_pca_ds(train_samples: np.ndarray, test_samples: np.ndarray, nro_components: int = 16,
+                 svd_solver: str = "randomized", whiten: bool = True):
+    """Fit on ``train_samples``; return (train reduced, test reduced, fitted PCA)."""
+    from sklearn.decomposition import PCA
+
+    pca_dim_red = PCA(n_components=nro_components, svd_solver=svd_solver, whiten=whiten)
+    train_ds = pca_dim_red.fit_transform(train_samples)
+    test_ds = apply_pca_transform(test_samples, pca_dim_red)
+    return train_ds, test_ds, pca_dim_red
+
+
+def apply_pca_ds_split(samples: np.ndarray, nro_components: int = 16, svd_solver: str = "randomized",
+                       whiten: bool = True) -> Tuple[np.ndarray, "PCA"]:  # noqa: F821
+    """Fit a PCA on one dataset split; return (reduced samples, fitted sklearn PCA)."""
+    from sklearn.decomposition import PCA
+
+    pca_dim_red = PCA(n_components=nro_components, svd_solver=svd_solver, whiten=whiten)
+    dataset_dim_red = pca_dim_red.fit_transform(samples)
+    return dataset_dim_red, pca_dim_red
+
+
+def apply_pca_transform(samples: np.ndarray, pca_transform) -> np.ndarray:
+    """Project new samples with an already fitted PCA (sklearn ``PCA`` or :class:`DevicePCA`) on the GPU."""
+    dp = device_pca_for(pca_transform)
+    if isinstance(samples, torch.Tensor):
+        x = samples
+    else:
+        x = np.asarray(samples)
+        if x.ndim != 2:
+            raise ValueError(f"Expected 2D array, got {x.ndim}D array instead")
+    dtype = torch.float32 if (getattr(x, "dtype", None) in (np.float32, torch.float32)) else torch.float64
+    xd = _hip.to_device(x, dtype)
+    return dp.transform_device(xd).cpu().numpy()

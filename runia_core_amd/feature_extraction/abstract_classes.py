@@ -1,0 +1,70 @@
+"""``MCSamplerModule`` with the reference's constructor, attributes and output
+(reference ``runia_core/feature_extraction/abstract_classes.py:33-101``).
+
+The n_mc ``DropBlock2D`` layers + ``fullmean`` of the reference collapse into one
+kernel (``runia_mc_stack_f32``).  Parity mode keeps the reference's random stream:
+one ``torch.rand(1, H, W)`` per drop layer, in ``ModuleList`` order, on the CPU
+default generator (what ``dropblock==0.3.0`` does), uploaded as 16*H*W floats.
+"""
+from __future__ import annotations
+
+import torch
+
+from .. import _hip
+
+__all__ = ["MCSamplerModule", "DropBlockSpec"]
+
+
+class DropBlockSpec(torch.nn.Module):
+    """Parameter-free record of one DropBlock2D layer (``drop_prob``, ``block_size``).
+    Identity in eval mode, as the upstream layer."""
+
+    def __init__(self, block_size: int, drop_prob: float):
+        super().__init__()
+        self.block_size = block_size
+        self.drop_prob = drop_prob
+
+    def extra_repr(self) -> str:
+        return f"drop_prob={self.drop_prob}, block_size={self.block_size}"
+
+
+class MCSamplerModule(torch.nn.Module):
+    """Monte-Carlo DropBlock sampling of a latent map.
+
+    Args:
+        mc_samples: number of MC samples
+        block_size: DropBlock size
+        drop_prob: DropBlock probability
+        layer_type: ``"Conv"``, ``"FC"`` or ``"RPN"``
+    """
+
+    def __init__(self, mc_samples: int, block_size: int, drop_prob: float, layer_type: str = "Conv"):
+        super().__init__()
+        assert layer_type in ("Conv", "FC", "RPN")
+        self.layer_type = layer_type
+        self.mc_samples = mc_samples
+        self.block_size = block_size
+        self.drop_prob = drop_prob
+        self.drop_blocks = torch.nn.ModuleList(
+            [DropBlockSpec(block_size=block_size, drop_prob=drop_prob) for _ in range(self.mc_samples)]
+        )
+
+    def draw(self, batch: int, h: int, w: int, device, generator=None) -> torch.Tensor:
+        """Uniform draws of the drop layers: ``(batch, mc_samples, h, w)``; image-major, one
+        ``torch.rand(1, h, w)`` per layer on the CPU generator exactly as upstream draws them."""
+        draws = [torch.rand(1, h, w, generator=generator) for _ in range(batch * self.mc_samples)]
+        return torch.cat(draws).reshape(batch, self.mc_samples, h, w).to(device)
+
+    def forward(self, latent_rep: torch.Tensor, rand: torch.Tensor = None) -> torch.Tensor:
+        """``(N, C, H, W)`` -> ``(N * mc_samples, C)`` (the reference is called with N = 1).
+        ``rand`` optionally supplies the uniform draws (device tensor)."""
+        if self.layer_type != "Conv":
+            raise NotImplementedError("MCSamplerModule: only layer_type='Conv' is on the MI355X hot path")
+        assert latent_rep.dim() == 4, "latent representation must be (N, C, H, W)"
+        x = _hip.to_device(latent_rep, torch.float32)
+        n, _, h, w = x.shape
+        active = self.training and self.drop_prob != 0.0
+        if active and rand is None:
+            rand = self.draw(n, h, w, x.device)
+        return _hip.mc_stack(x, rand if active else None, self.mc_samples, self.drop_prob if active else 0.0,
+                             self.block_size)

@@ -1,0 +1,66 @@
+"""Device-resident LaREM row pipeline (additive API).
+
+``LaRExInference.get_score`` in the reference handles one image per call and goes
+device -> host between the sampler and the entropy stage
+(``runia_core/inference/image_level.py:96-120``, ``evaluation/entropy.py:58``).
+``LaREMPipeline`` is the batched form of exactly the same chain
+``mc_sampler -> get_dl_h_z(.)[1] -> apply_pca_transform -> MDLatentSpace.postprocess``
+with every intermediate kept in HBM; batch-1 results are identical to the per-image API.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import _hip
+from ..dimensionality_reduction import DevicePCA, device_pca_for
+from ..evaluation.entropy import MIN_DIST, neighbors_for
+
+__all__ = ["LaREMPipeline"]
+
+
+class LaREMPipeline:
+    """Fitted state on the device + ``score_*`` entry points.
+
+    Args:
+        postprocessor: a set-up ``MDLatentSpace`` (LaREM)
+        pca_transform: fitted sklearn ``PCA`` / ``DevicePCA`` or ``None``
+        mcd_samples_nro: MC samples per image
+        drop_block_prob, drop_block_size: DropBlock parameters of the sampler
+    """
+
+    def __init__(self, postprocessor, pca_transform, mcd_samples_nro: int, drop_block_prob: float = 0.0,
+                 drop_block_size: int = 1):
+        self.postprocessor = postprocessor
+        self.pca: Optional[DevicePCA] = device_pca_for(pca_transform) if pca_transform is not None else None
+        self.n_mc = int(mcd_samples_nro)
+        self.k = neighbors_for(self.n_mc)
+        self.drop_prob = float(drop_block_prob)
+        self.block_size = int(drop_block_size)
+
+    # -- stages ---------------------------------------------------------------------
+    def stack(self, latents: Tensor, rand: Optional[Tensor]) -> Tensor:
+        """``(N, C, H, W)`` f32 -> MC samples ``(N * n_mc, C)`` f32."""
+        return _hip.mc_stack(latents, rand, self.n_mc, self.drop_prob if rand is not None else 0.0, self.block_size)
+
+    def entropy(self, z: Tensor) -> Tensor:
+        return _hip.kl_entropy_per_dim(z, self.n_mc, self.k, MIN_DIST)
+
+    def score_entropies(self, h: Tensor) -> Tensor:
+        y = self.pca.transform_device(h) if self.pca is not None else h
+        return self.postprocessor.postprocess_device(y)
+
+    # -- chains ---------------------------------------------------------------------
+    def score_samples(self, z: Tensor) -> Tensor:
+        """Pre-stacked MC samples ``(N * n_mc, D)`` f32 (device) -> scores ``(N,)`` f64 (device)."""
+        return self.score_entropies(self.entropy(z))
+
+    def score_latents(self, latents: Tensor, rand: Optional[Tensor]) -> Tensor:
+        """Hooked activations ``(N, C, H, W)`` + uniform draws ``(N, n_mc, H, W)`` -> scores ``(N,)``."""
+        return self.score_samples(self.stack(latents, rand))
+
+    def score_samples_host(self, z: np.ndarray) -> np.ndarray:
+        return self.score_samples(_hip.to_device(z, torch.float32)).cpu().numpy()

@@ -1,0 +1,358 @@
+"""Postprocessor registry and the hot-path postprocessors on the GPU.
+
+Mirrors the reference's ``runia_core/inference/postprocessors.py``: registry
+:43-75; latent-space family ``KDE`` :131-178, ``MD`` (LaREM) :181-244, ``KNN``
+:360-423 (ctor ``(cfg=None)``); logits/features family ``energy`` :495-551,
+``msp`` :554-608, ``knn`` :789-883, ``mahalanobis`` :886-980 (ctor
+``(flip_sign, ..., cfg=None)``).  Same names, kwargs, public fitted attributes,
+output dtypes, assertion / error / warning texts.  ``setup`` fits on the host with
+the library call the reference makes; ``postprocess`` runs as HIP kernels and
+raises when no GPU is present (no CPU fallback).
+
+Every class additionally offers ``postprocess_device(tensor) -> tensor`` (additive):
+device rows in, device scores out, no host round trip.
+"""
+from __future__ import annotations
+
+import warnings
+from typing import Dict, List, Union
+
+import numpy as np
+import torch
+from torch import Tensor
+
+from .. import _hip
+from .abstract_classes import OodPostprocessor, Postprocessor
+from .funcs import MahalanobisState, _maha_dtype, mahalanobis_preprocess, normalizer
+
+__all__ = ["postprocessors_dict", "postprocessor_input_dict", "register_postprocessor"]
+
+_VALID_INPUT_TYPES = ("latent_space_means", "features", "logits")
+postprocessors_dict: Dict[str, Postprocessor] = {}
+postprocessor_input_dict: Dict[str, List[str]] = {}
+
+
+def register_postprocessor(postprocessor_name: str, postprocessor_input: List[str]):
+    """Class decorator: enter the class in ``postprocessors_dict`` and record which inputs it consumes."""
+
+    def decorator(cls):
+        for input_type in postprocessor_input:
+            assert (
+                input_type in _VALID_INPUT_TYPES
+            ), f"Invalid input type {input_type}. Specify at least one of {_VALID_INPUT_TYPES}."
+        postprocessors_dict[postprocessor_name] = cls
+        postprocessor_input_dict[postprocessor_name] = postprocessor_input
+        __all__.append(cls.__name__)
+        return cls
+
+    return decorator
+
+
+def _np_dtype_to_torch(a) -> torch.dtype:
+    return torch.float32 if getattr(a, "dtype", None) in (np.float32, torch.float32) else torch.float64
+
+
+# --------------------------------------------------------------------------------------
+# latent-space family
+# --------------------------------------------------------------------------------------
+class DetectorKDE:
+    """Gaussian kernel density estimate of the training embeddings (LaRED).  Holds the
+    training set on the device; ``get_density_scores`` is the exact log-density
+    ``logsumexp_i(-|x-x_i|^2 / 2h^2) - log N - D log h - (D/2) log 2 pi``."""
+
+    def __init__(self, train_embeddings, save_path=None, kernel="gaussian", bandwidth=1.0) -> None:
+        if kernel != "gaussian":
+            raise NotImplementedError("DetectorKDE on MI355X implements the gaussian kernel (the reference default)")
+        self.kernel = kernel
+        self.bandwidth = bandwidth
+        self.train_embeddings = train_embeddings
+        self.save_path = save_path
+        self.density = self.density_fit()
+
+    def density_fit(self):
+        self._train_dev = None  # uploaded on first use so that setup works without a GPU
+        return self
+
+    def _train(self) -> Tensor:
+        if self._train_dev is None:
+            self._train_dev = _hip.to_device(np.asarray(self.train_embeddings), torch.float64)
+        return self._train_dev
+
+    def score_samples_device(self, x: Tensor) -> Tensor:
+        return _hip.kde_score(self._train(), x.to(torch.float64), float(self.bandwidth))
+
+    def get_density_scores(self, test_embeddings):
+        x = _hip.to_device(np.asarray(test_embeddings), torch.float64)
+        return self.score_samples_device(x).cpu().numpy()
+
+
+@register_postprocessor("KDE", postprocessor_input=["latent_space_means"])
+class KDELatentSpace(Postprocessor):
+    """LaRED: kernel-density score of latent representations."""
+
+    def __init__(self, cfg=None):
+        super().__init__(cfg)
+        self.detector = None
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs) -> None:
+        assert ind_train_data.ndim == 2, "ind_feats must be 2 dimensional"
+        if not self._setup_flag:
+            self.detector = DetectorKDE(train_embeddings=ind_train_data)
+            self._setup_flag = True
+        else:
+            warnings.warn("KDEPostprocessor already trained")
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        assert test_data.ndim == 2, "ood_feats must be 2 dimensional"
+        return self.detector.get_density_scores(test_data)
+
+    def postprocess_device(self, test_data: Tensor) -> Tensor:
+        return self.detector.score_samples_device(test_data)
+
+
+@register_postprocessor("MD", postprocessor_input=["latent_space_means"])
+class MDLatentSpace(Postprocessor):
+    """LaREM: Mahalanobis distance score ``-(x - mu) P (x - mu)^T`` of latent representations."""
+
+    def __init__(self, cfg=None):
+        super().__init__(cfg)
+        self.feats_mean = None
+        self.precision = None
+        self.centered_data = None
+        self._dev = None
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs) -> None:
+        assert ind_train_data.ndim == 2, "ind_feats must be 2 dimensional"
+        if not self._setup_flag:
+            from sklearn.covariance import EmpiricalCovariance
+
+            self.feats_mean = np.mean(ind_train_data, 0, keepdims=True)
+            self.centered_data = ind_train_data - self.feats_mean
+            estimator = EmpiricalCovariance(assume_centered=False)
+            estimator.fit(self.centered_data)
+            self.precision = estimator.precision_
+            self._dev = None
+            self._setup_flag = True
+        else:
+            warnings.warn("MDPostprocessor already trained")
+
+    def _device_state(self):
+        if self._dev is None:
+            packed = _hip.pack_weights(_hip.to_device(np.asarray(self.precision, dtype=np.float64), torch.float64))
+            self._dev = {"packed_p": packed, "mean": {}}
+        return self._dev
+
+    def _mean(self, dtype: torch.dtype) -> Tensor:
+        st = self._device_state()
+        if dtype not in st["mean"]:
+            st["mean"][dtype] = _hip.to_device(np.asarray(self.feats_mean).ravel(), dtype)
+        return st["mean"][dtype]
+
+    def postprocess_device(self, test_data: Tensor) -> Tensor:
+        """Device rows ``(N, D)`` f64/f32 -> device scores ``(N,)`` f64."""
+        st = self._device_state()
+        mean_dtype = torch.float32 if np.asarray(self.feats_mean).dtype == np.float32 else torch.float64
+        return _hip.md_score(test_data, self._mean(mean_dtype), st["packed_p"])
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        assert test_data.ndim == 2, "test_feats must be 2 dimensional"
+        x = _hip.to_device(test_data, _np_dtype_to_torch(test_data))
+        return self.postprocess_device(x).cpu().numpy()
+
+
+@register_postprocessor("KNN", postprocessor_input=["latent_space_means"])
+class KNNLatentSpace(Postprocessor):
+    """k-th nearest-neighbour distance score on L2-normalised latent representations."""
+
+    def __init__(self, cfg=None):
+        super().__init__(cfg)
+        try:
+            self.K = cfg.k_neighbors
+        except AttributeError:
+            self.K = 50
+        self.activation_log = None
+        self.index = None
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs) -> None:
+        assert ind_train_data.ndim == 2, "ind_train_feats must be 2 dimensional"
+        if not self._setup_flag:
+            self.activation_log = np.array([_normalize_host(feat) for feat in ind_train_data])
+            self.index = FlatL2Bank(ind_train_data.shape[1])
+            self.index.add(self.activation_log)
+            self._setup_flag = True
+        else:
+            warnings.warn("KNNPostprocessor already trained")
+
+    def postprocess_device(self, test_data: Tensor) -> Tensor:
+        return self.index.kth_score_device(_hip.l2_normalize(test_data.to(torch.float32)), self.K)
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        assert test_data.ndim == 2, "test_feats must be 2 dimensional"
+        return self.index.kth_score(test_data, self.K)
+
+
+def _normalize_host(x):
+    # bank construction happens once in setup(); NumPy dtype rules as in the reference's normalizer
+    return x / (np.linalg.norm(x, ord=2, axis=-1, keepdims=True) + 1e-10)
+
+
+class FlatL2Bank:
+    """Exact squared-L2 bank (the role ``faiss.IndexFlatL2`` plays in the reference): ``add`` stores
+    f32 rows, ``search`` returns sorted distances like faiss, ``kth_score`` is the fused hot path."""
+
+    def __init__(self, d: int):
+        self.d = d
+        self.ntotal = 0
+        self._host = np.zeros((0, d), dtype=np.float32)
+        self._dev = None
+
+    def add(self, x: np.ndarray) -> None:
+        x = np.ascontiguousarray(np.asarray(x).astype(np.float32))
+        assert x.ndim == 2 and x.shape[1] == self.d
+        self._host = np.concatenate([self._host, x]) if self.ntotal else x
+        self.ntotal = self._host.shape[0]
+        self._dev = None
+
+    def _bank(self) -> Tensor:
+        if self._dev is None:
+            self._dev = _hip.to_device(self._host, torch.float32)
+        return self._dev
+
+    def kth_score_device(self, q_normed: Tensor, k: int) -> Tensor:
+        return _hip.knn_kth(q_normed, self._bank(), k)
+
+    def kth_score(self, feats: np.ndarray, k: int) -> np.ndarray:
+        """``-D[:, -1]`` of ``search(normalizer(feats), k)`` for every row, f32."""
+        q = _hip.l2_normalize(_hip.to_device(np.asarray(feats), torch.float32))
+        return self.kth_score_device(q, k).cpu().numpy()
+
+
+# --------------------------------------------------------------------------------------
+# logits / features family
+# --------------------------------------------------------------------------------------
+def _logits_to_device(test_data) -> Tensor:
+    return _hip.to_device(test_data, torch.float32)
+
+
+def _restore_dtype(scores: Tensor, src) -> np.ndarray:
+    out = scores.cpu().numpy()
+    want = np.asarray(src).dtype if not isinstance(src, Tensor) else np.float32
+    # scipy keeps the input dtype (f32 logits -> f32 scores; f64 logits -> f64)
+    return out.astype(want, copy=False) if want in (np.float32, np.float64) else out
+
+
+@register_postprocessor("energy", postprocessor_input=["logits"])
+class Energy(OodPostprocessor):
+    """Energy score: ``logsumexp(logits, axis=1)``."""
+
+    def _score(self, data) -> np.ndarray:
+        if isinstance(data, Tensor):
+            data = data.detach()
+        lse, _ = _hip.row_lse_msp(_logits_to_device(data), True, False)
+        return _restore_dtype(lse, data)
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs):
+        ind_scores = self.flip_sign_fn(self._score(ind_train_data))
+        self.set_threshold(ind_scores)
+
+    def postprocess_device(self, logits: Tensor) -> Tensor:
+        lse, _ = _hip.row_lse_msp(logits, True, False)
+        return -lse if self.flip_sign else lse
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        assert self._setup_flag, "setup() must be called before postprocess()"
+        return self.flip_sign_fn(self._score(test_data))
+
+
+@register_postprocessor("msp", postprocessor_input=["logits"])
+class MSP(OodPostprocessor):
+    """Maximum softmax probability."""
+
+    def _score(self, data) -> np.ndarray:
+        if isinstance(data, Tensor):
+            data = data.detach()
+        _, msp = _hip.row_lse_msp(_logits_to_device(data), False, True)
+        return _restore_dtype(msp, data)
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs):
+        ind_scores = self.flip_sign_fn(self._score(ind_train_data))
+        self.set_threshold(ind_scores)
+
+    def postprocess_device(self, logits: Tensor) -> Tensor:
+        _, msp = _hip.row_lse_msp(logits, False, True)
+        return -msp if self.flip_sign else msp
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        assert self._setup_flag, "setup() must be called before postprocess()"
+        return self.flip_sign_fn(self._score(test_data))
+
+
+@register_postprocessor("knn", postprocessor_input=["features"])
+class KNN(OodPostprocessor):
+    """k-th nearest-neighbour distance on L2-normalised features (flat exact index)."""
+
+    def __init__(self, flip_sign: bool, k_neighbors: int, cfg=None):
+        super().__init__(flip_sign, cfg)
+        self.k_neighbors = k_neighbors
+        self.gmm = None
+        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        self.index = None
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs):
+        assert "valid_feats" in kwargs, "valid_feats must be provided for KNN setup"
+        train = np.asarray(ind_train_data)
+        bank = _hip.l2_normalize(_hip.to_device(train, torch.float32)).cpu().numpy()
+        self.index = FlatL2Bank(train.shape[1])
+        self.index.add(bank)
+        ind_scores = self.postprocess(kwargs["valid_feats"])
+        ind_scores = self.flip_sign_fn(ind_scores)
+        self.set_threshold(ind_scores)
+
+    def postprocess_device(self, feats: Tensor) -> Tensor:
+        s = self.index.kth_score_device(_hip.l2_normalize(feats.to(torch.float32)), self.k_neighbors)
+        return -s if self.flip_sign else s
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        if isinstance(test_data, Tensor):
+            test_data = test_data.detach().cpu().numpy()
+        scores = self.index.kth_score(np.asarray(test_data), self.k_neighbors)
+        return self.flip_sign_fn(scores)
+
+
+@register_postprocessor("mahalanobis", postprocessor_input=["features"])
+class Mahalanobis(OodPostprocessor):
+    """Class-conditional Mahalanobis distance with a shared precision matrix."""
+
+    def __init__(self, flip_sign: bool, num_classes: int, cfg=None):
+        super().__init__(flip_sign, cfg)
+        self.num_classes = num_classes
+        self.class_mean = None
+        self.precision = None
+        self._state = None
+
+    def _scores(self, feats) -> np.ndarray:
+        if self._state is None:
+            self._state = MahalanobisState(self.class_mean[: self.num_classes], self.precision)
+        x = _hip.to_device(feats, _maha_dtype(feats, self.class_mean))
+        return self._state.score_device(x).cpu().numpy()
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs):
+        assert "train_labels" in kwargs, "train_labels must be provided for Mahalanobis"
+        assert "valid_feats" in kwargs, "valid_feats must be provided for Mahalanobis"
+        ind_data_dict = {"train features": ind_train_data, "train labels": kwargs["train_labels"]}
+        self.class_mean, self.precision = mahalanobis_preprocess(ind_data=ind_data_dict, num_classes=self.num_classes)
+        self._state = None
+        ind_scores = self.flip_sign_fn(self._scores(kwargs["valid_feats"]))
+        self.set_threshold(ind_scores)
+
+    def postprocess_device(self, feats: Tensor) -> Tensor:
+        if self._state is None:
+            self._state = MahalanobisState(self.class_mean[: self.num_classes], self.precision)
+        s = self._state.score_device(feats)
+        return -s if self.flip_sign else s
+
+    def postprocess(self, test_data: Union[np.ndarray, Tensor], **kwargs) -> np.ndarray:
+        assert self._setup_flag, "setup() must be called before postprocess()"
+        if isinstance(test_data, Tensor):
+            test_data = test_data.cpu().numpy()
+        return self.flip_sign_fn(self._scores(test_data))

@@ -1,0 +1,287 @@
+"""GPU parity of the drop-in classes (the reference's own test cases re-run through
+runia_core_amd) against the reference's golden numbers, the by-path fixtures and the oracle."""
+import warnings
+
+import numpy as np
+import pytest
+import torch
+
+import oracle
+import runia_core_amd as rc
+from conftest import generate_test_data, load_npz, rel_err
+from runia_core_amd.inference import (
+    KNN,
+    MSP,
+    Energy,
+    KDELatentSpace,
+    KNNLatentSpace,
+    LaREMPipeline,
+    Mahalanobis,
+    MDLatentSpace,
+    postprocessors_dict,
+)
+from test_oracle_goldens import _all_baselines_inputs
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-5
+
+
+def _list(ref_vectors, key, i=0):
+    return np.array(ref_vectors[key]["lists"][i]["values"])
+
+
+def test_md_unit_golden(ref_vectors):
+    # /root/reference/tests/unit_test_postprocessors.py:205-233
+    tr, _, _ = generate_test_data(seed=42)
+    te, _, _ = generate_test_data(seed=43)
+    md = MDLatentSpace()
+    md.setup(tr)
+    s = md.postprocess(te)
+    assert isinstance(s, np.ndarray) and s.dtype == np.float64 and len(s) == 10 and np.all(np.isfinite(s))
+    exp = _list(ref_vectors, "md_unit")
+    assert abs((exp - s).sum()) < 1e-6
+    assert rel_err(s, exp) < 1e-8
+
+
+def test_larem_lared_baselines_goldens(ref_vectors):
+    # /root/reference/tests/unit_test_baselines.py:463-568
+    np.random.seed(1)
+    f = np.random.rand(200, 20)
+    md = MDLatentSpace()
+    md.setup(f)
+    assert np.allclose(md.precision[0], _list(ref_vectors, "larem_baselines", 0), atol=1e-6)
+    s = md.postprocess(f)
+    assert s.shape == (200,) and np.allclose(s[:20], _list(ref_vectors, "larem_baselines", 1), atol=1e-6)
+    kde = KDELatentSpace()
+    kde.setup(f)
+    s = kde.postprocess(f)
+    assert s.shape == (200,) and np.allclose(s[:20], _list(ref_vectors, "lared_baselines"), atol=1e-6)
+
+
+def test_kde_unit_golden(ref_vectors):
+    tr, _, _ = generate_test_data(seed=42)
+    te, _, _ = generate_test_data(seed=43)
+    kde = KDELatentSpace()
+    kde.setup(tr)
+    s = kde.postprocess(te)
+    assert abs((_list(ref_vectors, "kde_unit") - s).sum()) < 1e-6
+
+
+def test_knn_latent_k_gt_bank_golden(ref_vectors):
+    tr, _, _ = generate_test_data(seed=42)
+    te, _, _ = generate_test_data(seed=43)
+    knn = KNNLatentSpace()
+    knn.setup(tr)
+    s = knn.postprocess(te)
+    assert s.dtype == np.float32 and np.all(np.isfinite(s))
+    assert abs((_list(ref_vectors, "knn_latent_unit") - s).sum()) < 1e-6
+
+
+def test_energy_msp_goldens(ref_vectors):
+    _, _, trl = generate_test_data(seed=42)
+    _, _, tel = generate_test_data(seed=43)
+    e = Energy(flip_sign=True)
+    e.setup(trl)
+    assert e._setup_flag and e.threshold is not None
+    s = e.postprocess(tel)
+    assert s.dtype == np.float32
+    assert abs((_list(ref_vectors, "energy_unit") - s).sum()) < 1e-6
+    st = e.postprocess(torch.Tensor(tel))  # tensor input
+    assert np.array_equal(s, st)
+    g = load_npz("ref_energy_msp.npz")
+    assert abs(e.threshold - float(g["unit_energy_threshold"])) < 1e-5
+    m = MSP(flip_sign=True)
+    m.setup(trl)
+    assert rel_err(m.postprocess(tel), g["unit_msp_scores"]) < TOL
+    assert abs(m.threshold - float(g["unit_msp_threshold"])) < 1e-5
+
+
+def test_mahalanobis_goldens(ref_vectors):
+    tr, lab, _ = generate_test_data(seed=42)
+    va, _, _ = generate_test_data(seed=44)
+    te, _, _ = generate_test_data(seed=43)
+    m = Mahalanobis(flip_sign=True, num_classes=10)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        m.setup(tr, train_labels=lab, valid_feats=va)
+    assert m._setup_flag and m.class_mean is not None and m.precision is not None and m.threshold is not None
+    s = m.postprocess(te)
+    assert s.dtype == np.float64
+    assert abs((_list(ref_vectors, "mahalanobis_unit") - s).sum()) < 1e-6
+    assert np.allclose(s, m.postprocess(torch.Tensor(te)))
+    g = load_npz("ref_mahalanobis.npz")
+    assert rel_err(s, g["unit_scores"]) < 1e-8
+    assert abs(m.threshold - float(g["unit_threshold"])) < 1e-6
+    m = Mahalanobis(flip_sign=False, num_classes=7)
+    m.setup(g["d96_train"], train_labels=g["d96_labels"], valid_feats=g["d96_train"][:100])
+    assert rel_err(m.postprocess(g["d96_test"]), g["d96_scores"]) < 1e-9
+    assert abs(m.threshold - float(g["d96_threshold"])) < 1e-8
+
+
+def test_all_baselines_means(ref_vectors):
+    # /root/reference/tests/unit_test_baselines.py:199-268 (msp, knn, energy, mdist)
+    d = _all_baselines_inputs()
+    sc = [s["value"] for s in ref_vectors["all_baselines_means"]["scalars"]]
+    p = MSP(flip_sign=False)
+    p.setup(ind_train_data=d["tr_l"])
+    assert abs(p.postprocess(test_data=d["ood_l"]).mean() - sc[0]) < 1e-6
+    p = KNN(flip_sign=False, k_neighbors=10)
+    p.setup(ind_train_data=d["tr_f"], valid_feats=d["va_f"])
+    assert abs(p.postprocess(test_data=d["ood_f"]).mean() - sc[1]) < 1e-6
+    p = Energy(flip_sign=False)
+    p.setup(ind_train_data=d["tr_l"])
+    assert abs(p.postprocess(test_data=d["ood_l"]).mean() - sc[2]) < 1e-6
+    p = Mahalanobis(flip_sign=False, num_classes=20)
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        p.setup(ind_train_data=d["tr_f"], train_labels=np.argmax(d["tr_l"], axis=-1), valid_feats=d["va_f"])
+        assert abs(p.postprocess(test_data=d["ood_f"]).mean() - sc[8]) < 1e-6
+
+
+def test_entropy_api_goldens(ref_vectors):
+    # /root/reference/tests/unit_test_feature_extraction.py:175-247
+    np.random.seed(1)
+    sample = np.random.rand(3, 20)
+    h = rc.single_image_entropy_calculation(sample, 2)
+    assert h.shape == (20,)
+    # the golden is defined on f64 draws; the device path (like the reference's own
+    # tensor path) carries MC samples in f32 -> compare at the f32-input level
+    assert np.allclose(h, _list(ref_vectors, "entropy_single_image"), atol=1e-5)
+    assert np.abs(h - oracle.single_image_entropy_calculation(sample.astype(np.float32), 2)).max() < 1e-12
+    torch.manual_seed(1)
+    z = torch.rand(3 * 200, 20)
+    h_mvn, h_z = rc.get_dl_h_z(z, 3, parallel_run=True)
+    assert h_z.shape == (200, 20) and h_mvn.shape == (200, 1) and h_z.dtype == np.float64
+    assert np.allclose(h_z[0], _list(ref_vectors, "entropy_get_dl_h_z"), atol=1e-6)
+    o_mvn, o_z = oracle.get_dl_h_z(z.numpy(), 3)
+    assert np.abs(h_z - o_z).max() < 1e-12 and np.abs(h_mvn - o_mvn).max() < 1e-10
+    h_mvn2, h_z2 = rc.get_dl_h_z(z.numpy(), 3)
+    assert np.array_equal(h_z, h_z2) and np.array_equal(h_mvn, h_mvn2)
+    with pytest.raises(ValueError):
+        rc.get_dl_h_z(np.zeros((7, 4), dtype=np.float32), 3)
+
+
+def test_pca_api_goldens(ref_vectors):
+    # /root/reference/tests/unit_test_dim_reduction.py:24-107
+    np.random.seed(1)
+    ind = 0.5 + np.random.randn(1000, 20)
+    ood = -0.5 + np.random.randn(1000, 20)
+    tr, pca = rc.apply_pca_ds_split(ind, 10)
+    assert abs((tr[0] - _list(ref_vectors, "pca_ds_split", 0)).sum()) < 1e-7
+    assert abs((pca.components_[0] + _list(ref_vectors, "pca_ds_split", 1)).sum()) < 1e-7
+    y = rc.apply_pca_transform(ood, pca)
+    assert y.shape == (1000, 10) and y.dtype == np.float64
+    assert abs((y[0] - _list(ref_vectors, "pca_transform")).sum()) < 1e-7
+    assert rel_err(y, pca.transform(ood)) < 1e-12
+    # fit_transform rows == transform of the same rows (sklearn identity) through the kernel
+    assert rel_err(rc.apply_pca_transform(ind, pca), tr) < 1e-9
+
+
+def test_metrics_postprocessors_goldens(ref_vectors):
+    # /root/reference/tests/unit_test_metrics.py:31-80 through the harness calling convention
+    np.random.seed(1)
+    valid = 0.5 + np.random.randn(1000, 20)
+    train = 0.5 + np.random.randn(1000, 20)
+    vl = np.random.randint(5, size=1000)
+    tl = np.random.randint(5, size=1000)
+    np.random.randint(5, size=1000)
+    ood = -0.5 + np.random.randn(1000, 20)
+    gold = [s["value"] for s in ref_vectors["metrics_postprocessors"]["scalars"]]
+    for name, (auroc, aupr, fpr) in (("KDE", gold[:3]), ("MD", gold[3:])):
+        p = postprocessors_dict[name](cfg=None)
+        p._setup_flag = False
+        p.setup(train, ind_train_labels=tl)
+        ind_s = p.postprocess(valid, pred_labels=vl)
+        ood_s = p.postprocess(ood, pred_labels=vl)
+        r = rc.evaluation.get_auroc_results(f"test {name}", ind_s, ood_s)
+        assert abs(r["auroc"].values[0] - auroc) < 1e-7
+        assert abs(r["aupr"].values[0] - aupr) < 1e-7
+        assert abs(r["fpr@95"].values[0] - fpr) < 1e-7
+
+
+class _ToyNet(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.conv = torch.nn.Conv2d(1, 20, 5)
+        self.fc = torch.nn.Linear(20, 10)
+
+    def forward(self, x):
+        f = torch.relu(torch.nn.functional.max_pool2d(self.conv(x), 3))
+        return self.fc(f.mean(dim=(2, 3)))
+
+
+def test_larex_inference_end_to_end():
+    """LaRExInference.get_score (image_level.py:96-120 of the reference) on a toy backbone,
+    against the oracle fed with the same hooked activation and the same CPU-generator draws."""
+    torch.manual_seed(1)
+    np.random.seed(1)
+    model = _ToyNet().eval()
+    hook = rc.Hook(model.conv)
+    feats = np.random.rand(200, 20)
+    red, pca = rc.apply_pca_ds_split(feats, 8)
+    md = MDLatentSpace()
+    md.setup(red)
+    inf = rc.LaRExInference(model=model, postprocessor=md, mcd_sampler=rc.MCSamplerModule, pca_transform=pca,
+                            mcd_samples_nro=16, drop_block_prob=0.5, drop_block_size=4, layer_type="Conv")
+    assert inf.mc_sampler.training and len(inf.mc_sampler.drop_blocks) == 16 and inf.device.type == "cuda"
+    img = torch.randn(1, 1, 28, 28)
+    torch.manual_seed(123)
+    out, score = inf.get_score(img, layer_hook=hook)
+    assert out.shape == (1, 10) and isinstance(score, np.ndarray) and score.shape == (1,) and score.dtype == np.float64
+    # oracle on the same activation and the same random stream
+    latent = hook.output.detach().cpu().numpy()
+    torch.manual_seed(123)
+    rand = torch.cat([torch.rand(1, latent.shape[2], latent.shape[3]) for _ in range(16)]).numpy()
+    z = oracle.mc_stack(latent, rand, 0.5, 4)
+    z_dev = inf.mc_sampler(hook.output, rand=torch.from_numpy(rand).cuda()[None]).cpu().numpy()
+    assert np.allclose(z_dev, z, rtol=3e-6, atol=1e-7)
+    # downstream stages from the device's own samples: f64-exact chain
+    _, h = oracle.get_dl_h_z(z_dev, 16)
+    y = oracle.pca_transform(h, pca.components_, pca.mean_, pca.explained_variance_)
+    exp = oracle.md_score(y, md.feats_mean, md.precision)
+    assert rel_err(score, exp) < 1e-9
+    # batched additive API == per-image API
+    torch.manual_seed(123)
+    s2 = inf.get_scores_from_latents(hook.output)
+    assert np.array_equal(s2, score)
+    # LaRD path (no MC, no entropy)
+    md2 = MDLatentSpace()
+    md2.setup(np.random.rand(100, 20))
+    lard = rc.LaRDInference(model, md2, pca_transform=None, layer_type="Conv")
+    out, s = lard.get_score(img, hook)
+    red_rows = latent.mean(axis=3, dtype=np.float32).mean(axis=2, dtype=np.float32)
+    assert rel_err(s, oracle.md_score(red_rows.astype(np.float64), md2.feats_mean, md2.precision)) < 1e-5
+
+
+def test_pipeline_full_size_properties():
+    """cfg2 at full size (N=10 000 x 16 x 512 -> PCA-256 -> LaREM): size-independent properties."""
+    torch.manual_seed(0)
+    n, n_mc, d, k = 10000, 16, 512, 256
+    g = torch.Generator(device="cuda").manual_seed(5)
+    base = torch.randn(n, 1, d, device="cuda", generator=g) + 2
+    z = (base * (1 + 0.1 * torch.randn(n, n_mc, d, device="cuda", generator=g))).reshape(n * n_mc, d).contiguous()
+    gp = load_npz("ref_pca.npz")
+    gm = load_npz("ref_md.npz")
+    from runia_core_amd.dimensionality_reduction import DevicePCA
+
+    md = MDLatentSpace()
+    md.feats_mean, md.precision, md._setup_flag = gm["d256_mean"], gm["d256_precision"], True
+    pipe = LaREMPipeline(md, DevicePCA(gp["d512_components"], gp["d512_mean"], gp["d512_var"], True), n_mc)
+    s = pipe.score_samples(z)
+    assert s.shape == (n,) and bool(torch.isfinite(s).all()) and bool((s <= 0).all())
+    # (1) permuting the MC samples of an image does not change its score (order statistics)
+    perm = torch.randperm(n_mc, device="cuda")
+    zp = z.reshape(n, n_mc, d)[:, perm, :].reshape(n * n_mc, d).contiguous()
+    assert torch.equal(pipe.score_samples(zp), s)
+    # (2) rows are independent: scoring a slice equals the slice of the scores (sharding property)
+    assert torch.equal(pipe.score_samples(z[3000 * n_mc : 5000 * n_mc]), s[3000:5000])
+    # (3) a bounded sample against the oracle
+    idx = slice(0, 64 * n_mc)
+    exp, _ = oracle.larem_pipeline(z[idx].cpu().numpy(), n_mc, gp["d512_components"], gp["d512_mean"], gp["d512_var"],
+                                   gm["d256_mean"], gm["d256_precision"])
+    assert rel_err(s[:64].cpu().numpy(), exp) < 1e-9
+    # (4) translating all samples of an image by a constant leaves the entropies unchanged up to f32 input rounding;
+    #     scaling by 2 adds exactly log(2) to every per-dimension entropy
+    h = pipe.entropy(z[: 32 * n_mc])
+    h2 = pipe.entropy((z[: 32 * n_mc] * 2).contiguous())
+    assert float((h2 - h - np.log(2.0)).abs().max()) < 1e-12
