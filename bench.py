@@ -1,0 +1,224 @@
+#!/usr/bin/env python3
+"""Headline benchmark: OOD scores/sec on the LaREM-16MC / PCA-256 hot path (BASELINE.json configs[1]).
+
+One "step" = one pass of the scoring hot path over the 10 000 test images of the workload,
+inputs resident in HBM:  hooked latent maps (N,512,4,4) f32 + DropBlock draws (N,16,4,4)
+  -> MC-dropout latent stacking -> per-dimension KL entropy -> PCA 512->256 (whitened)
+  -> LaREM (Mahalanobis) score -> [N>1: one RCCL all_gather of the score shards].
+Weak scaling: every rank scores its own 10 000-image shard (rows are independent).
+
+Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel,
+timed with HIP events on the launch stream inside the timed region) and `cpu_baseline`
+(the CPU oracle timed on a bounded sample; reported baseline, never the thing measured).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+N_MC, C, H, W, N_PCA = 16, 512, 4, 4, 256
+DROP_PROB, BLOCK = 0.5, 2
+HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def synth_latents(n, seed, shift, device, scale=1.0):
+    """cfg2-synth: X ~ ReLU(N(shift,1)) on (n,512,4,4); draws U(0,1) on (n,16,4,4).
+    Draws whose block mask would drop the whole 4x4 map (sum(bm)=0 -> inf/NaN in the reference
+    as well) are replaced by "no seed" so that every score is finite."""
+    g0 = torch.Generator(device=device).manual_seed(77)  # per-channel scale: a property of the "layer", same for all sets
+    chan = torch.rand(1, C, 1, 1, device=device, generator=g0) * 1.5 + 0.25
+    g = torch.Generator(device=device).manual_seed(seed)
+    x = torch.relu(torch.randn(n, C, H, W, device=device, generator=g) * (chan * scale) + shift).contiguous()
+    rand = torch.rand(n, N_MC, H, W, device=device, generator=g)
+    mask = (rand < DROP_PROB / BLOCK**2).float().reshape(n * N_MC, 1, H, W)
+    bm = 1 - torch.nn.functional.max_pool2d(mask, BLOCK, 1, BLOCK // 2)[:, :, :-1, :-1]
+    dead = bm.sum(dim=(1, 2, 3)) == 0
+    rand.reshape(n * N_MC, H, W)[dead] = 1.0
+    return x, rand.contiguous()
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--images", type=int, default=10000, help="test images per GPU (workload: 10 000)")
+    ap.add_argument("--train-images", type=int, default=4096)
+    ap.add_argument("--ood-scale", type=float, default=1.03)
+    ap.add_argument("--cpu-sample", type=int, default=1280, help="images timed on the CPU oracle")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--path", choices=["auto", "unfused", "fused"], default="auto")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+
+    import runia_core_amd as rc
+    from runia_core_amd import _hip
+    from runia_core_amd.inference import LaREMPipeline, MDLatentSpace
+
+    _hip.require_gpu()
+
+    # ---------------- setup (untimed): fit PCA-256 + LaREM on in-distribution entropies ----------
+    probe = LaREMPipeline(None, None, N_MC, DROP_PROB, BLOCK)
+    xtr, rtr = synth_latents(args.train_images, 1234, 0.0, device)
+    h_train = probe.entropy(probe.stack(xtr, rtr)).cpu().numpy()
+    del xtr, rtr
+    np.random.seed(1234)  # sklearn's randomized SVD draws from the global NumPy state
+    red, pca = rc.apply_pca_ds_split(h_train, N_PCA)
+    md = MDLatentSpace()
+    md.setup(red)
+    pipe = LaREMPipeline(md, pca, N_MC, DROP_PROB, BLOCK)
+    fused = hasattr(pipe, "score_latents_fused") and args.path in ("auto", "fused")
+
+    n = args.images
+    x, rand = synth_latents(n, 1235 + rank, 0.0, device)  # this rank's shard
+    gathered = torch.empty(world * n, dtype=torch.float64, device=device) if world > 1 else None
+
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(i=None):
+        z = pipe.stack(x, rand)
+        if i is not None:
+            ev[i][0].record()
+        if fused:
+            s = pipe.score_samples_fused(z)
+        else:
+            h = pipe.entropy(z)
+        if i is not None:
+            ev[i][1].record()
+        if not fused:
+            s = pipe.score_entropies(h)
+        if world > 1:
+            dist.all_gather_into_tensor(gathered, s)
+            return gathered
+        return s
+
+    for _ in range(args.warmup):
+        step()
+    # keep the interpreter's cyclic GC out of the timed region (a gen-2 pass over the torch/sklearn heap
+    # costs tens of ms, i.e. far more than the 10-step GPU work it would be charged to)
+    import gc
+
+    gc.collect()
+    gc.disable()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        scores = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if os.environ.get("RUNIA_BENCH_DEBUG"):
+        print("step gaps ms:", [round(ev[i][0].elapsed_time(ev[i + 1][0]), 3) for i in range(args.steps - 1)],
+              file=sys.stderr)
+    gc.enable()
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    ms_per_step = 1e3 * elapsed / args.steps
+    value = world * n * args.steps / elapsed
+
+    # ---------------- roofline of the dominant kernel ------------------------------------------
+    if fused:
+        kname, bytes_per_img = "larem_fused_kernel", N_MC * C * 4 + 8
+    else:
+        kname, bytes_per_img = "entropy_per_dim_kernel", N_MC * C * 4 + C * 8  # 32 768 B in + 4 096 B out
+    achieved = bytes_per_img * n / (kernel_ms * 1e-3) / 1e9
+    traffic = None
+    pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(pmc_file):
+        try:
+            traffic = json.load(open(pmc_file)).get(kname, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = {
+        "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+        "algorithmic_bytes_per_launch": bytes_per_img * n, "avg_launch_ms": round(kernel_ms, 4),
+    }
+
+    # ---------------- parity on a bounded sample + CPU baseline (oracle = checker / baseline only) --
+    out = {
+        "metric": "OOD scores/sec, LaREM 16-MC PCA-256 (ResNet-18 layer4 latent 512x4x4)",
+        "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": "f64", "data": "synthetic",
+        "config": {"workload": "CIFAR10 ResNet-18 LaREM: 16 MC samples, 512-d latent -> PCA-256, 10000 test images per GPU",
+                   "images_per_gpu": n, "mc_samples": N_MC, "latent": [C, H, W], "pca_components": N_PCA,
+                   "path": "fused" if fused else "unfused", "input_dtype": "f32"},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        import oracle  # checker / CPU baseline only
+
+        m = min(args.cpu_sample, n)
+        xs, rs = x[:m].cpu().numpy(), rand[:m].cpu().numpy()
+        xo, ro = synth_latents(m, 999, 0.0, device, args.ood_scale)  # wider activations -> OOD sample for the AUROC check
+        gpu_ind = scores[:m].cpu().numpy()
+        gpu_ood = (pipe.score_samples_fused(pipe.stack(xo, ro)) if fused else pipe.score_latents(xo, ro)).cpu().numpy()
+        comp, mean, var = pca.components_, pca.mean_, pca.explained_variance_
+        t0 = time.perf_counter()
+        z = np.concatenate([oracle.mc_stack(xs[i : i + 1], rs[i], DROP_PROB, BLOCK) for i in range(m)])
+        _, h = oracle.get_dl_h_z(z, N_MC)  # the reference's algorithmic form: one k-d tree per (image, dim)
+        y = oracle.pca_transform(h, comp, mean, var)
+        cpu_ind = oracle.md_score(y, md.feats_mean, md.precision)
+        cpu_s = time.perf_counter() - t0
+        # downstream parity from the device's own MC samples (f64-exact chain) and end-to-end from latents
+        z_dev = pipe.stack(x[:m], rand[:m]).cpu().numpy()
+        exact, _ = oracle.larem_pipeline(z_dev, N_MC, comp, mean, var, md.feats_mean, md.precision)
+        zo = np.concatenate([oracle.mc_stack(xo[i : i + 1].cpu().numpy(), ro[i].cpu().numpy(), DROP_PROB, BLOCK) for i in range(m)])
+        cpu_ood, _ = oracle.larem_pipeline(zo, N_MC, comp, mean, var, md.feats_mean, md.precision)
+        rel = lambda a, b: float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b))))  # noqa: E731
+        a_gpu = oracle.auroc_fpr95_aupr(gpu_ind, gpu_ood)
+        a_cpu = oracle.auroc_fpr95_aupr(cpu_ind, cpu_ood)
+        out["cpu_baseline"] = {
+            "value": round(m / cpu_s, 2), "unit": "images/s", "cores": 1, "kind": "port",
+            "sample": f"{m} of the {n} workload images, same inputs; oracle mc_stack + per-(image,dim) k-d-tree entropy "
+                      f"(reference form) + PCA + LaREM, {cpu_s:.1f} s; host has {os.cpu_count()} cores",
+        }
+        out["parity"] = {
+            "max_rel_err_from_device_samples": rel(gpu_ind, exact), "max_rel_err_from_latents": rel(gpu_ind, cpu_ind),
+            "auroc_gpu": a_gpu[0], "auroc_oracle": a_cpu[0], "fpr95_gpu": a_gpu[1], "fpr95_oracle": a_cpu[1],
+            "sample_images": m,
+        }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -53,32 +53,125 @@ __global__ __launch_bounds__(256) void mc_stack_kernel(const float* __restrict__
     bm[i] = keep;
   }
   __syncthreads();
-  // 2) per-layer rescale numel / sum(bm): one wave per layer
+  // 2) per-layer mask sum: one wave per layer
   {
     const int lane = tid & 63, wave = tid >> 6;
     for (int s = wave; s < n_mc; s += 4) {
       float acc = 0.f;
       for (int p = lane; p < HW; p += 64) acc += bm[s * HW + p];
       acc = wave_sum_f32(acc);  // exact: small integer counts
-      if (lane == 0) scale[s] = (float)HW / acc;
+      if (lane == 0) scale[s] = acc;
     }
   }
   __syncthreads();
-  // 3) masked means, one channel per thread
+  // 3) masked means, one channel per thread; upstream order ((x*bm)*numel)/sum -> mean W -> mean H
   const int c = blockIdx.x * 256 + tid;
   if (c >= C) return;
   const float* xc = x + (img * C + c) * (int64_t)HW;
-  const float invW = 1.0f / (float)W, invH = 1.0f / (float)H;
   float* o = out + img * n_mc * (int64_t)C + c;
   for (int s = 0; s < n_mc; ++s) {
     const float* b = bm + s * HW;
+    const float den = scale[s];
     float col = 0.f;
     for (int y = 0; y < H; ++y) {
       float rowsum = 0.f;
-      for (int xw = 0; xw < W; ++xw) rowsum += xc[y * W + xw] * b[y * W + xw];
-      col += rowsum * invW;
+      for (int xw = 0; xw < W; ++xw) {
+        const float q = (xc[y * W + xw] * (float)HW) / den;
+        rowsum += (b[y * W + xw] != 0.f) ? q : 0.f;
+      }
+      col += rowsum / (float)W;
     }
-    o[(int64_t)s * C] = (col * invH) * scale[s];
+    o[(int64_t)s * C] = (den == 0.f) ? NAN : col / (float)H;
+  }
+}
+
+
+// ---- register-resident form for small maps (H*W <= 64): the thread's whole map lives in VGPRs,
+// the block masks are 64-bit words broadcast from LDS, and every element follows the upstream
+// operation order  y = ((x * bm) * numel) / sum(bm)  -> mean over W -> mean over H  in f32.
+// The per-element division by the (integer-valued) mask sum is a reciprocal product with one
+// Newton correction (q + r*fma(-s, q, u)), 3 VALU ops instead of the ~10 of a full IEEE divide.
+__device__ __forceinline__ float div_newton(float u, float den, float r) {
+  const float q = u * r;
+  const float e = fmaf(-den, q, u);
+  return fmaf(e, r, q);
+}
+
+template <int HT, int WT>
+__global__ __launch_bounds__(256) void mc_stack_small_kernel(const float* __restrict__ x,
+                                                              const float* __restrict__ rnd, int64_t rand_stride,
+                                                              float* __restrict__ out, int C, int n_mc,
+                                                              float gamma, int block_size, int identity) {
+  constexpr int HW = HT * WT;
+  __shared__ unsigned long long keep_bits[kMaxMC];
+  __shared__ float msum[kMaxMC], mrcp[kMaxMC];
+  const int tid = threadIdx.x;
+  const int64_t img = blockIdx.y;
+  const int pad = block_size / 2;
+  // 1) one thread per drop layer builds its keep mask (HW <= 64 bits)
+  if (tid < n_mc) {
+    unsigned long long bits = ~0ull >> (64 - HW);
+    if (!identity) {
+      const float* r = rnd + img * rand_stride + (int64_t)tid * HW;
+      bits = 0ull;
+      for (int p = 0; p < HW; ++p) {
+        const int y = p / WT, xw = p - y * WT;
+        bool dropped = false;
+        for (int dy = 0; dy < block_size && !dropped; ++dy) {
+          const int yy = y - pad + dy;
+          if (yy < 0 || yy >= HT) continue;
+          for (int dx = 0; dx < block_size; ++dx) {
+            const int xx = xw - pad + dx;
+            if (xx < 0 || xx >= WT) continue;
+            if (r[yy * WT + xx] < gamma) { dropped = true; break; }
+          }
+        }
+        if (!dropped) bits |= (1ull << p);
+      }
+    }
+    keep_bits[tid] = bits;
+    const float cnt = (float)__popcll(bits);
+    msum[tid] = cnt;
+    mrcp[tid] = 1.0f / cnt;
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + tid;
+  if (c >= C) return;
+  const float* xc = x + (img * C + c) * (int64_t)HW;
+  float u[HW];
+  if constexpr (HW % 4 == 0) {
+#pragma unroll
+    for (int p = 0; p < HW / 4; ++p) {
+      const float4 v = reinterpret_cast<const float4*>(xc)[p];
+      u[4 * p] = v.x; u[4 * p + 1] = v.y; u[4 * p + 2] = v.z; u[4 * p + 3] = v.w;
+    }
+  } else {
+#pragma unroll
+    for (int p = 0; p < HW; ++p) u[p] = xc[p];
+  }
+#pragma unroll
+  for (int p = 0; p < HW; ++p) u[p] *= (float)HW;  // (x * bm) * numel; exact for power-of-two maps
+  constexpr bool w_pow2 = (WT & (WT - 1)) == 0, h_pow2 = (HT & (HT - 1)) == 0;
+  const float rW = 1.0f / (float)WT, rH = 1.0f / (float)HT;
+  float* o = out + img * n_mc * (int64_t)C + c;
+  for (int s = 0; s < n_mc; ++s) {
+    const unsigned long long bits = keep_bits[s];
+    const float den = msum[s], r = mrcp[s];
+    float col = 0.f;
+#pragma unroll
+    for (int y = 0; y < HT; ++y) {
+      float rowsum = 0.f;
+#pragma unroll
+      for (int xw = 0; xw < WT; ++xw) {
+        const int p = y * WT + xw;
+        const float q = div_newton(u[p], den, r);
+        rowsum += ((bits >> p) & 1ull) ? q : 0.f;
+      }
+      col += w_pow2 ? rowsum * rW : div_newton(rowsum, (float)WT, rW);
+    }
+    float res = h_pow2 ? col * rH : div_newton(col, (float)HT, rH);
+    if (den == 0.f) res = NAN;  // every position dropped: 0 * numel / 0 upstream
+    o[(int64_t)s * C] = res;
   }
 }
 
@@ -99,6 +192,18 @@ extern "C" int runia_mc_stack_f32(const float* x, const float* rnd, int64_t rand
   const size_t shmem = ((size_t)n_mc * H * W + n_mc) * sizeof(float);
   if (shmem > 64 * 1024) return RUNIA_E_INVALID;
   dim3 grid((C + 255) / 256, (unsigned)N);
+  const bool x16 = ((((uintptr_t)x) & 15) == 0);
+#define RUNIA_MC_SMALL(HH, WW)                                                                              \
+  if (H == HH && W == WW && (x16 || (HH * WW) % 4 != 0)) {                                                  \
+    mc_stack_small_kernel<HH, WW><<<grid, 256, 0, as_stream(stream)>>>(x, rnd, rand_image_stride, out, C,  \
+                                                                       n_mc, gamma, block_size, identity); \
+    return runia_check_launch();                                                                            \
+  }
+  RUNIA_MC_SMALL(2, 2)
+  RUNIA_MC_SMALL(4, 4)
+  RUNIA_MC_SMALL(7, 7)
+  RUNIA_MC_SMALL(8, 8)
+#undef RUNIA_MC_SMALL
   mc_stack_kernel<<<grid, 256, shmem, as_stream(stream)>>>(x, rnd, rand_image_stride, out, C, H, W, n_mc,
                                                           gamma, block_size, identity);
   return runia_check_launch();

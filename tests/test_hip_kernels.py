@@ -277,7 +277,8 @@ def test_kde_goldens(hip):
 
 # ---------------- a1 mc_stack ------------------------------------------------------------------------------
 @pytest.mark.parametrize("c,h,w,bs,p,n_mc,n", [(512, 4, 4, 2, 0.5, 16, 5), (20, 8, 8, 8, 0.5, 3, 2), (37, 7, 5, 3, 0.3, 6, 3),
-                                               (300, 8, 8, 4, 0.4, 16, 2), (64, 4, 4, 2, 0.0, 4, 2)])
+                                               (300, 8, 8, 4, 0.4, 16, 2), (64, 4, 4, 2, 0.0, 4, 2), (70, 7, 7, 3, 0.4, 8, 3),
+                                               (33, 2, 2, 1, 0.5, 5, 4), (40, 16, 16, 5, 0.3, 4, 2), (512, 4, 4, 2, 0.9, 16, 40)])
 def test_mc_stack_vs_oracle(hip, c, h, w, bs, p, n_mc, n):
     torch.manual_seed(c + h)
     x = torch.relu(torch.randn(n, c, h, w))
@@ -288,7 +289,7 @@ def test_mc_stack_vs_oracle(hip, c, h, w, bs, p, n_mc, n):
             exp = oracle.mc_stack(x[i : i + 1].numpy(), rand[i].numpy(), p, bs)
         ok = np.isfinite(exp)
         assert np.array_equal(np.isfinite(got[i]), ok)
-        assert np.allclose(got[i][ok], exp[ok], rtol=3e-6, atol=1e-7)
+        assert np.allclose(got[i][ok], exp[ok], rtol=4e-7, atol=1e-9)
     # shared draws for the whole batch (rand_image_stride = 0)
     if p > 0:
         got_s = hip.mc_stack(x.cuda(), rand[0].cuda(), n_mc, p, bs).cpu().numpy().reshape(n, n_mc, c)
