@@ -57,7 +57,6 @@ def main():
     ap.add_argument("--ood-scale", type=float, default=1.03)
     ap.add_argument("--cpu-sample", type=int, default=1280, help="images timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--path", choices=["auto", "unfused", "fused"], default="auto")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -91,7 +90,7 @@ def main():
     md = MDLatentSpace()
     md.setup(red)
     pipe = LaREMPipeline(md, pca, N_MC, DROP_PROB, BLOCK)
-    fused = hasattr(pipe, "score_latents_fused") and args.path in ("auto", "fused")
+    fused = _hip.mc_entropy_supported(H, W, N_MC, pipe.k)
 
     n = args.images
     x, rand = synth_latents(n, 1235 + rank, 0.0, device)  # this rank's shard
@@ -100,17 +99,12 @@ def main():
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
     def step(i=None):
-        z = pipe.stack(x, rand)
         if i is not None:
             ev[i][0].record()
-        if fused:
-            s = pipe.score_samples_fused(z)
-        else:
-            h = pipe.entropy(z)
+        h = pipe.entropy_from_latents(x, rand)  # K1: sampler + entropy (dominant kernel)
         if i is not None:
             ev[i][1].record()
-        if not fused:
-            s = pipe.score_entropies(h)
+        s = pipe.score_entropies(h)             # K2: PCA + LaREM
         if world > 1:
             dist.all_gather_into_tensor(gathered, s)
             return gathered
@@ -153,10 +147,9 @@ def main():
     value = world * n * args.steps / elapsed
 
     # ---------------- roofline of the dominant kernel ------------------------------------------
-    if fused:
-        kname, bytes_per_img = "larem_fused_kernel", N_MC * C * 4 + 8
-    else:
-        kname, bytes_per_img = "entropy_per_dim_kernel", N_MC * C * 4 + C * 8  # 32 768 B in + 4 096 B out
+    # algorithmic bytes of K1 per image ("with MC stacking from latent"): the latent map
+    # C*H*W*4, the draws n_mc*H*W*4, and the C entropies written as f64
+    kname, bytes_per_img = "mc_entropy_kernel", C * H * W * 4 + N_MC * H * W * 4 + C * 8
     achieved = bytes_per_img * n / (kernel_ms * 1e-3) / 1e9
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -179,7 +172,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "CIFAR10 ResNet-18 LaREM: 16 MC samples, 512-d latent -> PCA-256, 10000 test images per GPU",
                    "images_per_gpu": n, "mc_samples": N_MC, "latent": [C, H, W], "pca_components": N_PCA,
-                   "path": "fused" if fused else "unfused", "input_dtype": "f32"},
+                   "launches_per_step": 2 if fused else 4, "input_dtype": "f32"},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:
@@ -189,7 +182,7 @@ def main():
         xs, rs = x[:m].cpu().numpy(), rand[:m].cpu().numpy()
         xo, ro = synth_latents(m, 999, 0.0, device, args.ood_scale)  # wider activations -> OOD sample for the AUROC check
         gpu_ind = scores[:m].cpu().numpy()
-        gpu_ood = (pipe.score_samples_fused(pipe.stack(xo, ro)) if fused else pipe.score_latents(xo, ro)).cpu().numpy()
+        gpu_ood = pipe.score_latents(xo, ro).cpu().numpy()
         comp, mean, var = pca.components_, pca.mean_, pca.explained_variance_
         t0 = time.perf_counter()
         z = np.concatenate([oracle.mc_stack(xs[i : i + 1], rs[i], DROP_PROB, BLOCK) for i in range(m)])

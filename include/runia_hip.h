@@ -143,6 +143,28 @@ int runia_knn_kth_f32(const float* q, const float* bank, float* score, void* wor
 int runia_kde_score_f64(const double* train, const double* x, double* score, int64_t M, int64_t N,
                         int64_t D, double bandwidth, runia_stream_t stream);
 
+/* ---- a11 fused LaREM row pipeline ------------------------------------------- *
+ * LaRExInference.get_score after the backbone (inference/image_level.py:115-119) as two
+ * launches per batch.
+ * (1) runia_mc_entropy_f32 = MCSamplerModule.forward fused with the per-dimension loop of
+ *     get_dl_h_z: latent maps x [N, C, H, W] f32 + DropBlock draws (layout as
+ *     runia_mc_stack_f32) -> entropies h [N, C] f64; the MC samples never leave registers.
+ *     z_out (optional, may be NULL): [N*n_mc, C] f32 copy of the samples, drop layers in
+ *     mask-sum order (entropy is invariant to their order).  Shapes outside
+ *     runia_mc_entropy_supported() return RUNIA_E_INVALID: use the two unfused calls.
+ * (2) runia_pca_md_score_f64 = apply_pca_transform + MDLatentSpace.postprocess:
+ *     h [N, D] f64 -> score [N] f64; packed_ct/bias/scale as runia_pca_transform_f64
+ *     (packed_ct NULL = no PCA, n == D), md_mean [n], packed_p = pack(P [n, n]);
+ *     y_out (optional) receives the projected rows [N, n]. */
+int runia_mc_entropy_supported(int H, int W, int n_mc, int k);
+int runia_mc_entropy_f32(const float* x, const float* rand, int64_t rand_image_stride, double* h,
+                         float* z_out, int64_t N, int C, int H, int W, int n_mc, double drop_prob,
+                         int block_size, int k, double min_dist, runia_stream_t stream);
+int runia_pca_md_score_f64(const double* h, const double* packed_ct, const double* bias,
+                           const double* scale, const double* md_mean, const double* packed_p,
+                           double* score, double* y_out, int64_t N, int64_t D, int64_t n,
+                           runia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -58,6 +58,17 @@ _SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int64, c_int, c_void_p],
     ),
     "runia_kde_score_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p]),
+    "runia_mc_entropy_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "runia_mc_entropy_f32": (
+        c_int,
+        [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_int,
+         c_double, c_void_p],
+    ),
+    "runia_pca_md_score_f64": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
+         c_void_p],
+    ),
 }
 
 
@@ -324,3 +335,60 @@ def kde_score(train: torch.Tensor, x: torch.Tensor, bandwidth: float = 1.0) -> t
         "runia_kde_score_f64",
     )
     return s
+
+
+def mc_entropy_supported(h: int, w: int, n_mc: int, k: int) -> bool:
+    return bool(load_library().runia_mc_entropy_supported(int(h), int(w), int(n_mc), int(k)))
+
+
+def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob: float, block_size: int, k: int,
+               min_dist: float = 1e-5, want_samples: bool = False):
+    """Fused sampler + entropy: x [N,C,H,W] f32 (+ draws) -> h [N, C] f64 (and optionally the MC samples)."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    x = x.contiguous()
+    n, c, hh, ww = x.shape
+    stride = 0
+    if rand is not None:
+        assert rand.is_cuda and rand.dtype == torch.float32
+        rand = rand.contiguous()
+        if rand.dim() == 4:
+            assert rand.shape == (n, n_mc, hh, ww)
+            stride = n_mc * hh * ww
+        else:
+            assert rand.shape == (n_mc, hh, ww)
+    h = torch.empty((n, c), dtype=torch.float64, device=x.device)
+    z = torch.empty((n * n_mc, c), dtype=torch.float32, device=x.device) if want_samples else None
+    done = 0
+    while done < n:
+        m = min(65535, n - done)
+        rp = None if rand is None else rand.data_ptr() + done * stride * 4
+        zp = None if z is None else z.data_ptr() + done * n_mc * c * 4
+        _check(
+            lib.runia_mc_entropy_f32(x.data_ptr() + done * c * hh * ww * 4, rp, stride, h.data_ptr() + done * c * 8, zp,
+                                     m, c, hh, ww, n_mc, float(drop_prob), int(block_size), int(k), float(min_dist),
+                                     _stream()),
+            "runia_mc_entropy_f32",
+        )
+        done += m
+    return (h, z) if want_samples else h
+
+
+def pca_md_score(h: torch.Tensor, packed_ct: Optional[torch.Tensor], bias: Optional[torch.Tensor],
+                 scale: Optional[torch.Tensor], md_mean: torch.Tensor, packed_p: torch.Tensor, n: int,
+                 want_projection: bool = False):
+    """Fused PCA transform + LaREM score: h [N, D] f64 -> score [N] f64 (projected rows stay on chip)."""
+    lib = load_library()
+    require_gpu()
+    assert h.is_cuda and h.dtype == torch.float64 and h.dim() == 2
+    h = h.contiguous()
+    nrow, d = h.shape
+    s = torch.empty((nrow,), dtype=torch.float64, device=h.device)
+    y = torch.empty((nrow, n), dtype=torch.float64, device=h.device) if want_projection else None
+    _check(
+        lib.runia_pca_md_score_f64(h.data_ptr(), _ptr(packed_ct), _ptr(bias), _ptr(scale), md_mean.data_ptr(),
+                                   packed_p.data_ptr(), s.data_ptr(), _ptr(y), nrow, d, n, _stream()),
+        "runia_pca_md_score_f64",
+    )
+    return (s, y) if want_projection else s

@@ -1,0 +1,433 @@
+// Fused LaREM row pipeline (a11): LaRExInference.get_score after the backbone
+// (reference inference/image_level.py:115-119) as two launches per batch instead of
+// ~100 tiny ones per image:
+//
+//   K1  mc_entropy   hooked latent maps (N,C,H,W) + DropBlock draws -> per-dimension entropies H (N,C) f64
+//                    = MCSamplerModule.forward (feature_extraction/abstract_classes.py:81-101) fused with
+//                      the per-dimension loop of get_dl_h_z (evaluation/entropy.py:77-82).  One thread owns
+//                      one (image, channel): its H*W map stays in VGPRs, the n_mc MC samples are produced,
+//                      sorted and reduced to one entropy without ever leaving registers.  VALU-bound.
+//   K2  pca_md       H (N,D) f64 -> LaREM score (N) = apply_pca_transform (dimensionality_reduction.py:86)
+//                    + MDLatentSpace.postprocess (inference/postprocessors.py:241-242).  Both contractions run
+//                    on the f64 matrix cores; the projected rows never leave LDS.
+//
+// Sample order inside an image is irrelevant to the entropy (order statistics), so K1 visits the drop
+// layers sorted by their mask sum and recomputes the per-element quotients (x*numel)/sum only when the sum
+// changes (wave-uniform branch): same bits as the upstream op order, ~1/3 fewer VALU ops.
+#include "common.hpp"
+#include "entropy_core.hpp"
+
+namespace {
+
+using namespace runia_entropy;
+
+constexpr int kMaxMC = 64;
+
+__device__ __forceinline__ float div_newton(float u, float den, float r) {
+  const float q = u * r;
+  const float e = fmaf(-den, q, u);
+  return fmaf(e, r, q);
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: latent map -> MC samples -> entropy.   grid = (ceil(C/256), N)
+// ------------------------------------------------------------------------------------------
+template <int HT, int WT, int NP, int K>
+__global__ __launch_bounds__(256) void mc_entropy_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ rnd, int64_t rand_stride,
+                                                          double* __restrict__ h, float* __restrict__ z_out, int C,
+                                                          int n_mc, float gamma, int block_size, int identity,
+                                                          double min_dist, double const_term, double inv_n) {
+  constexpr int HW = HT * WT;
+  __shared__ unsigned long long keep_bits[kMaxMC], sbits[kMaxMC];
+  __shared__ float msum[kMaxMC], sden[kMaxMC], srcp[kMaxMC];
+  const int tid = threadIdx.x;
+  const int64_t img = blockIdx.y;
+  const int pad = block_size / 2;
+  // Block masks.  The image's n_mc*HW uniform draws are pulled into LDS with one coalesced pass, then one
+  // thread per (drop layer, position) evaluates its max-pool window and ORs its keep bit into the layer's
+  // 64-bit mask.  (A serial per-layer loop over global memory here costs ~20 us of dependent-load latency
+  // per workgroup.)
+  __shared__ float draws[kMaxMC * HW];
+  __shared__ unsigned keep_lo[kMaxMC], keep_hi[kMaxMC];
+  if (tid < n_mc) { keep_lo[tid] = 0u; keep_hi[tid] = 0u; }
+  if (!identity) {
+    const float* r = rnd + img * rand_stride;
+    for (int i = tid; i < n_mc * HW; i += 256) draws[i] = r[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < n_mc * HW; i += 256) {
+    const int s = i / HW, p = i - s * HW;
+    bool dropped = false;
+    if (!identity) {
+      const int y = p / WT, xw = p - y * WT;
+      for (int dy = 0; dy < block_size; ++dy) {
+        const int yy = y - pad + dy;
+        if (yy < 0 || yy >= HT) continue;
+        for (int dx = 0; dx < block_size; ++dx) {
+          const int xx = xw - pad + dx;
+          if (xx < 0 || xx >= WT) continue;
+          dropped = dropped || (draws[s * HW + yy * WT + xx] < gamma);
+        }
+      }
+    }
+    if (!dropped) {
+      if (p < 32) atomicOr(&keep_lo[s], 1u << p);
+      else atomicOr(&keep_hi[s], 1u << (p - 32));
+    }
+  }
+  __syncthreads();
+  if (tid < n_mc) {
+    const unsigned long long bits = ((unsigned long long)keep_hi[tid] << 32) | keep_lo[tid];
+    keep_bits[tid] = bits;
+    msum[tid] = (float)__popcll(bits);
+  }
+  __syncthreads();
+  if (tid < n_mc) {  // counting sort of the drop layers by mask sum (stable)
+    const float mine = msum[tid];
+    int rank = 0;
+    for (int j = 0; j < n_mc; ++j) {
+      const float o = msum[j];
+      rank += (o < mine) || (o == mine && j < tid);
+    }
+    sbits[rank] = keep_bits[tid];
+    sden[rank] = mine;
+    srcp[rank] = 1.0f / mine;
+  }
+  __syncthreads();
+  const int c = blockIdx.x * 256 + tid;
+  float u[HW];
+  {
+    // 16-byte loads at a 4*HW-byte lane stride: measured faster than staging the block's contiguous run
+    // through LDS (214 vs 271 us at N = 10 000, profiles/README.md) - the kernel is VALU-bound, not HBM-bound
+    if (c >= C) return;
+    const float* xc = x + (img * C + c) * (int64_t)HW;
+    if constexpr (HW % 4 == 0) {
+#pragma unroll
+      for (int p = 0; p < HW / 4; ++p) {
+        const float4 v = reinterpret_cast<const float4*>(xc)[p];
+        u[4 * p] = v.x; u[4 * p + 1] = v.y; u[4 * p + 2] = v.z; u[4 * p + 3] = v.w;
+      }
+    } else {
+#pragma unroll
+      for (int p = 0; p < HW; ++p) u[p] = xc[p];
+    }
+  }
+#pragma unroll
+  for (int p = 0; p < HW; ++p) u[p] *= (float)HW;
+  constexpr bool w_pow2 = (WT & (WT - 1)) == 0, h_pow2 = (HT & (HT - 1)) == 0;
+  const float rW = 1.0f / (float)WT, rH = 1.0f / (float)HT;
+  float z[NP];
+  float q[HW];
+  float cur_den = -1.f;
+  bool bad = false;
+#pragma unroll
+  for (int s = 0; s < NP; ++s) {
+    if (s < n_mc) {
+      const float den = sden[s];
+      if (den != cur_den) {  // wave-uniform: every thread of the block works on the same image
+        const float r = srcp[s];
+#pragma unroll
+        for (int p = 0; p < HW; ++p) q[p] = div_newton(u[p], den, r);
+        cur_den = den;
+      }
+      const unsigned long long bits = sbits[s];  // wave-uniform (LDS broadcast)
+      float col = 0.f;
+#pragma unroll
+      for (int y = 0; y < HT; ++y) {
+        float rowsum = 0.f;
+#pragma unroll
+        for (int xw = 0; xw < WT; ++xw) {
+          const int p = y * WT + xw;
+          rowsum += ((bits >> p) & 1ull) ? q[p] : 0.f;  // wave-uniform predicate (s_bitcmp + v_cndmask)
+        }
+        col += w_pow2 ? rowsum * rW : div_newton(rowsum, (float)WT, rW);
+      }
+      z[s] = h_pow2 ? col * rH : div_newton(col, (float)HT, rH);
+      bad = bad || (den == 0.f);
+    } else {
+      z[s] = INFINITY;
+    }
+  }
+  if (z_out) {  // optional copy of the MC samples (drop-layer order is the mask-sum order; tests only)
+#pragma unroll
+    for (int s = 0; s < NP; ++s)
+      if (s < n_mc) z_out[(img * n_mc + s) * (int64_t)C + c] = bad && sden[s] == 0.f ? NAN : z[s];
+  }
+  bitonic_sort_asc<NP>(z);
+  double res = const_term + inv_n * column_log_sum<NP, K>(z, n_mc, min_dist);
+  if (bad) res = NAN;  // a fully dropped map is 0*numel/0 = NaN upstream
+  h[img * C + c] = res;
+}
+
+// ------------------------------------------------------------------------------------------
+// K2: H -> PCA (optional) -> LaREM score.  One workgroup = BM rows; both contractions on f64 MFMA.
+// Packed weights layout: see gemm_f64.hip.
+// ------------------------------------------------------------------------------------------
+constexpr int KC = 32;
+constexpr int APITCH = 34;
+constexpr int BN = 256;
+
+struct PcaMdArgs {
+  const double* h;         // [N, D]
+  const double* packed_ct; // pack(C.T [D, n]) or null (no PCA: n == D)
+  const double* bias;      // [n]
+  const double* scale;     // [n] or null
+  const double* md_mean;   // [n]
+  const double* packed_p;  // pack(P [n, n])
+  double* score;           // [N]
+  double* y_out;           // optional [N, n]: the projected rows (tests)
+  int64_t N, D, n;
+};
+
+template <int RT>  // row tiles of 16 per workgroup (BM = 16*RT)
+__global__ __launch_bounds__(256) void pca_md_kernel(PcaMdArgs g) {
+  constexpr int BM = 16 * RT;
+  extern __shared__ double lds[];
+  // layout: lds_a [2][BM][APITCH] | lds_y [BM][ypitch] | part [4][BM]
+  const int64_t n_pad = (g.n + BN - 1) / BN * BN;
+  const int ypitch = (int)n_pad + 2;  // == 2 mod 32 -> conflict-free A-fragment reads
+  double* lds_a = lds;
+  double* lds_y = lds + 2 * BM * APITCH;
+  double* part = lds_y + (size_t)BM * ypitch;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int li = lane & 15, lg = lane >> 4;
+  const int64_t NT = n_pad / 16;
+  const int64_t r0 = (int64_t)blockIdx.x * BM;
+
+  // ---------------- phase A: d = (H C^T - bias) / scale - md_mean  -> lds_y ----------------
+  if (g.packed_ct) {
+    const int64_t K_pad = (g.D + 7) / 8 * 8;
+    const int64_t nchunks = (K_pad + KC - 1) / KC;
+    constexpr int PER_T = BM * KC / 256;  // doubles staged per thread per chunk (4 or 2)
+    for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
+      const int64_t ctbase = cb * 16 + wave * 4;
+      const bool active = (ctbase * 16 < g.n);
+      d4 acc[RT][4];
+#pragma unroll
+      for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+      double areg[PER_T];
+      auto load_a = [&](int64_t kc) {
+        const int row = (tid * PER_T) / KC, kk = (tid * PER_T) % KC;
+        const int64_t gr = r0 + row;
+#pragma unroll
+        for (int q = 0; q < PER_T; ++q) {
+          const int64_t gk = kc + kk + q;
+          areg[q] = (gr < g.N && gk < g.D) ? g.h[gr * g.D + gk] : 0.0;
+        }
+      };
+      load_a(0);
+      int buf = 0;
+      for (int64_t ch = 0; ch < nchunks; ++ch) {
+        {
+          const int row = (tid * PER_T) / KC, kk = (tid * PER_T) % KC;
+#pragma unroll
+          for (int q = 0; q < PER_T; ++q) lds_a[(buf * BM + row) * APITCH + kk + q] = areg[q];
+        }
+        __syncthreads();
+        if (ch + 1 < nchunks) load_a((ch + 1) * KC);
+        if (active) {
+          const int64_t s2_base = ch * (KC / 8);
+          const int steps2 = (int)(((K_pad - ch * KC) < KC ? (K_pad - ch * KC) : KC) / 8);
+#pragma unroll
+          for (int s2 = 0; s2 < KC / 8; ++s2) {
+            if (s2 < steps2) {
+              double2 b[4];
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                b[c] = reinterpret_cast<const double2*>(g.packed_ct)[((s2_base + s2) * NT + ctbase + c) * 64 + lane];
+#pragma unroll
+              for (int hh = 0; hh < 2; ++hh) {
+                double av[RT];
+#pragma unroll
+                for (int a = 0; a < RT; ++a) av[a] = lds_a[(buf * BM + 16 * a + li) * APITCH + 8 * s2 + 4 * hh + lg];
+#pragma unroll
+                for (int c = 0; c < 4; ++c) {
+                  const double bv = hh ? b[c].y : b[c].x;
+#pragma unroll
+                  for (int a = 0; a < RT; ++a)
+                    acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv, acc[a][c], 0, 0, 0);
+                }
+              }
+            }
+          }
+        }
+        buf ^= 1;
+      }
+      // epilogue: sklearn transform then the LaREM centring, kept in LDS
+#pragma unroll
+      for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int64_t col = (ctbase + c) * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int row = 16 * a + lg + 4 * r;
+            double d = 0.0;
+            if (active && col < g.n) {
+              double y = acc[a][c][r] - g.bias[col];
+              if (g.scale) y = y / g.scale[col];
+              if (g.y_out && r0 + row < g.N) g.y_out[(r0 + row) * g.n + col] = y;
+              d = y - g.md_mean[col];
+            }
+            lds_y[row * ypitch + col] = d;  // zero padding beyond n keeps phase B exact
+          }
+        }
+      __syncthreads();
+    }
+  } else {
+    // no PCA: d = h - md_mean straight into lds_y (n == D)
+    for (int i = tid; i < BM * (int)n_pad; i += 256) {
+      const int row = i / (int)n_pad, col = i - row * (int)n_pad;
+      double d = 0.0;
+      if (r0 + row < g.N && col < g.n) d = g.h[(r0 + row) * g.D + col] - g.md_mean[col];
+      lds_y[row * ypitch + col] = d;
+    }
+    __syncthreads();
+  }
+
+  // ---------------- phase B: score = -sum_j (d P)_j d_j, A fragments straight from lds_y ------
+  double rowdot[RT][4];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rowdot[a][r] = 0.0;
+  const int64_t Kp = (g.n + 7) / 8 * 8;
+  for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
+    const int64_t ctbase = cb * 16 + wave * 4;
+    if (ctbase * 16 < g.n) {
+      d4 acc[RT][4];
+#pragma unroll
+      for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int64_t s2 = 0; s2 < Kp / 8; ++s2) {
+        double2 b[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          b[c] = reinterpret_cast<const double2*>(g.packed_p)[(s2 * NT + ctbase + c) * 64 + lane];
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          double av[RT];
+#pragma unroll
+          for (int a = 0; a < RT; ++a) av[a] = lds_y[(16 * a + li) * ypitch + 8 * s2 + 4 * hh + lg];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const double bv = hh ? b[c].y : b[c].x;
+#pragma unroll
+            for (int a = 0; a < RT; ++a)
+              acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv, acc[a][c], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int col = (int)((ctbase + c) * 16) + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) rowdot[a][r] += acc[a][c][r] * lds_y[(16 * a + lg + 4 * r) * ypitch + col];
+        }
+    }
+  }
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = rowdot[a][r];
+      v += shfl_xor_f64(v, 1);
+      v += shfl_xor_f64(v, 2);
+      v += shfl_xor_f64(v, 4);
+      v += shfl_xor_f64(v, 8);
+      if (li == 0) part[wave * BM + 16 * a + lg + 4 * r] = v;
+    }
+  __syncthreads();
+  if (tid < BM) {
+    const int64_t row = r0 + tid;
+    if (row < g.N) g.score[row] = -(((part[tid] + part[BM + tid]) + part[2 * BM + tid]) + part[3 * BM + tid]);
+  }
+}
+
+double digamma_diff(int n, int k) {
+  double s = 0.0;
+  for (int j = n - 1; j >= k; --j) s += 1.0 / (double)j;
+  return s;
+}
+
+template <int RT>
+int launch_pca_md(const PcaMdArgs& g, hipStream_t s) {
+  constexpr int BM = 16 * RT;
+  const int64_t n_pad = (g.n + BN - 1) / BN * BN;
+  const size_t shmem = ((size_t)2 * BM * APITCH + (size_t)BM * (n_pad + 2) + 4 * BM) * sizeof(double);
+  if (shmem > 160 * 1024) return RUNIA_E_INVALID;
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pca_md_kernel<RT>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
+      return RUNIA_E_LAUNCH;
+    attr_set = true;
+  }
+  const int64_t tiles = (g.N + BM - 1) / BM;
+  pca_md_kernel<RT><<<(unsigned)tiles, 256, shmem, s>>>(g);
+  return runia_check_launch();
+}
+
+}  // namespace
+
+extern "C" int runia_pca_md_score_f64(const double* h, const double* packed_ct, const double* bias,
+                                      const double* scale, const double* md_mean, const double* packed_p,
+                                      double* score, double* y_out, int64_t N, int64_t D, int64_t n,
+                                      runia_stream_t stream) {
+  if (N < 0 || D <= 0 || n <= 0) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!h || !md_mean || !packed_p || !score) return RUNIA_E_INVALID;
+  if (packed_ct ? !bias : (n != D)) return RUNIA_E_INVALID;
+  PcaMdArgs g{h, packed_ct, bias, scale, md_mean, packed_p, score, y_out, N, D, n};
+  // 32-row tiles halve the L2 traffic of the packed weights but need >= ~4 tiles per CU to balance
+  const int64_t tiles32 = (N + 31) / 32;
+  const int64_t n_pad = (n + BN - 1) / BN * BN;
+  const bool fits32 = ((size_t)2 * 32 * APITCH + (size_t)32 * (n_pad + 2) + 128) * 8 <= 160 * 1024;
+  if (tiles32 >= 1024 && fits32) return launch_pca_md<2>(g, as_stream(stream));
+  return launch_pca_md<1>(g, as_stream(stream));
+}
+
+extern "C" int runia_mc_entropy_f32(const float* x, const float* rnd, int64_t rand_image_stride, double* h,
+                                    float* z_out, int64_t N, int C, int H, int W, int n_mc, double drop_prob,
+                                    int block_size, int k, double min_dist, runia_stream_t stream) {
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0 || n_mc < 2 || n_mc > kMaxMC || block_size < 1 || k < 1 || k >= n_mc)
+    return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!x || !h || N > 65535) return RUNIA_E_INVALID;
+  const int identity = (drop_prob == 0.0);
+  if (!identity && !rnd) return RUNIA_E_INVALID;
+  const float gamma = (float)(drop_prob / (double)(block_size * block_size));
+  const double ct = digamma_diff(n_mc, k), inv_n = 1.0 / (double)n_mc;
+  dim3 grid((C + 255) / 256, (unsigned)N);
+  hipStream_t s = as_stream(stream);
+  const bool x16 = ((((uintptr_t)x) & 15) == 0);
+#define RUNIA_MCE(HH, WW, NPP, KK)                                                                         \
+  if (H == HH && W == WW && n_mc <= NPP && n_mc > NPP / 2 && k == KK && (x16 || (HH * WW) % 4 != 0)) {     \
+    mc_entropy_kernel<HH, WW, NPP, KK><<<grid, 256, 0, s>>>(x, rnd, rand_image_stride, h, z_out, C, n_mc,  \
+                                                           gamma, block_size, identity, min_dist, ct,      \
+                                                           inv_n);                                         \
+    return runia_check_launch();                                                                           \
+  }
+  RUNIA_MCE(4, 4, 16, 5)
+  RUNIA_MCE(4, 4, 32, 5)
+  RUNIA_MCE(4, 4, 8, 5)
+  RUNIA_MCE(2, 2, 16, 5)
+  RUNIA_MCE(7, 7, 16, 5)
+  RUNIA_MCE(8, 8, 16, 5)
+#undef RUNIA_MCE
+  return RUNIA_E_INVALID;  // unsupported shape: callers use runia_mc_stack_f32 + runia_kl_entropy_per_dim_f32
+}
+
+extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k) {
+  if (k != 5) return 0;
+  const bool hw = (H == 4 && W == 4);
+  if (hw && n_mc > 4 && n_mc <= 32) return 1;
+  if (n_mc > 8 && n_mc <= 16 && ((H == 2 && W == 2) || (H == 7 && W == 7) || (H == 8 && W == 8))) return 1;
+  return 0;
+}

@@ -108,27 +108,38 @@ __global__ __launch_bounds__(256) void mc_stack_small_kernel(const float* __rest
   const int tid = threadIdx.x;
   const int64_t img = blockIdx.y;
   const int pad = block_size / 2;
-  // 1) one thread per drop layer builds its keep mask (HW <= 64 bits)
-  if (tid < n_mc) {
-    unsigned long long bits = ~0ull >> (64 - HW);
+  // 1) block masks: draws -> LDS with one coalesced pass, then one thread per (layer, position)
+  __shared__ float draws[kMaxMC * HW];
+  __shared__ unsigned keep_lo[kMaxMC], keep_hi[kMaxMC];
+  if (tid < n_mc) { keep_lo[tid] = 0u; keep_hi[tid] = 0u; }
+  if (!identity) {
+    const float* r = rnd + img * rand_stride;
+    for (int i = tid; i < n_mc * HW; i += 256) draws[i] = r[i];
+  }
+  __syncthreads();
+  for (int i = tid; i < n_mc * HW; i += 256) {
+    const int s = i / HW, p = i - s * HW;
+    bool dropped = false;
     if (!identity) {
-      const float* r = rnd + img * rand_stride + (int64_t)tid * HW;
-      bits = 0ull;
-      for (int p = 0; p < HW; ++p) {
-        const int y = p / WT, xw = p - y * WT;
-        bool dropped = false;
-        for (int dy = 0; dy < block_size && !dropped; ++dy) {
-          const int yy = y - pad + dy;
-          if (yy < 0 || yy >= HT) continue;
-          for (int dx = 0; dx < block_size; ++dx) {
-            const int xx = xw - pad + dx;
-            if (xx < 0 || xx >= WT) continue;
-            if (r[yy * WT + xx] < gamma) { dropped = true; break; }
-          }
+      const int y = p / WT, xw = p - y * WT;
+      for (int dy = 0; dy < block_size; ++dy) {
+        const int yy = y - pad + dy;
+        if (yy < 0 || yy >= HT) continue;
+        for (int dx = 0; dx < block_size; ++dx) {
+          const int xx = xw - pad + dx;
+          if (xx < 0 || xx >= WT) continue;
+          dropped = dropped || (draws[s * HW + yy * WT + xx] < gamma);
         }
-        if (!dropped) bits |= (1ull << p);
       }
     }
+    if (!dropped) {
+      if (p < 32) atomicOr(&keep_lo[s], 1u << p);
+      else atomicOr(&keep_hi[s], 1u << (p - 32));
+    }
+  }
+  __syncthreads();
+  if (tid < n_mc) {
+    const unsigned long long bits = ((unsigned long long)keep_hi[tid] << 32) | keep_lo[tid];
     keep_bits[tid] = bits;
     const float cnt = (float)__popcll(bits);
     msum[tid] = cnt;

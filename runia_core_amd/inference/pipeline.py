@@ -49,7 +49,35 @@ class LaREMPipeline:
     def entropy(self, z: Tensor) -> Tensor:
         return _hip.kl_entropy_per_dim(z, self.n_mc, self.k, MIN_DIST)
 
+    def entropy_from_latents(self, latents: Tensor, rand: Optional[Tensor]) -> Tensor:
+        """Sampler + per-dimension entropy in one launch when the map shape is supported
+        (``runia_mc_entropy_f32``), else the two unfused kernels."""
+        _, _, h, w = latents.shape
+        if _hip.mc_entropy_supported(h, w, self.n_mc, self.k):
+            return _hip.mc_entropy(latents, rand, self.n_mc, self.drop_prob if rand is not None else 0.0,
+                                   self.block_size, self.k, MIN_DIST)
+        return self.entropy(self.stack(latents, rand))
+
+    def _md_state(self):
+        """(mean f64 [n], packed P) of a set-up ``MDLatentSpace`` or ``None`` for other postprocessors."""
+        pp = self.postprocessor
+        if pp is None or not hasattr(pp, "_device_state") or not hasattr(pp, "feats_mean"):
+            return None
+        st = pp._device_state()
+        return pp._mean(torch.float64), st["packed_p"]
+
     def score_entropies(self, h: Tensor) -> Tensor:
+        """PCA transform + postprocessor.  LaREM (``MDLatentSpace``) on f64 rows takes the fused
+        ``runia_pca_md_score_f64`` launch; anything else goes stage by stage."""
+        md = self._md_state()
+        if md is not None and h.dtype == torch.float64:
+            mean, packed_p = md
+            if self.pca is not None:
+                if h.shape[1] != self.pca.n_features:
+                    raise ValueError(f"X has {h.shape[1]} features, but PCA is expecting {self.pca.n_features} features as input.")
+                return _hip.pca_md_score(h, self.pca.packed_ct, self.pca.bias, self.pca.scale, mean, packed_p,
+                                         self.pca.n_components)
+            return _hip.pca_md_score(h, None, None, None, mean, packed_p, h.shape[1])
         y = self.pca.transform_device(h) if self.pca is not None else h
         return self.postprocessor.postprocess_device(y)
 
@@ -60,7 +88,7 @@ class LaREMPipeline:
 
     def score_latents(self, latents: Tensor, rand: Optional[Tensor]) -> Tensor:
         """Hooked activations ``(N, C, H, W)`` + uniform draws ``(N, n_mc, H, W)`` -> scores ``(N,)``."""
-        return self.score_samples(self.stack(latents, rand))
+        return self.score_entropies(self.entropy_from_latents(latents, rand))
 
     def score_samples_host(self, z: np.ndarray) -> np.ndarray:
         return self.score_samples(_hip.to_device(z, torch.float32)).cpu().numpy()

@@ -314,3 +314,62 @@ def test_larem_chain_unfused(hip):
     s = hip.md_score(y, dev(mean.ravel(), torch.float64), hip.pack_weights(dev(prec, torch.float64))).cpu().numpy()
     assert np.abs(h.cpu().numpy() - h_exp).max() < 1e-11
     assert rel_err(s, exp) < 1e-9
+
+
+# ---------------- a11 fused launches --------------------------------------------------------------------
+@pytest.mark.parametrize("c,h,w,bs,p,n_mc,n", [(512, 4, 4, 2, 0.5, 16, 33), (100, 4, 4, 2, 0.7, 32, 5), (64, 4, 4, 3, 0.5, 7, 4),
+                                               (70, 7, 7, 3, 0.4, 16, 3), (130, 8, 8, 4, 0.4, 12, 3), (33, 2, 2, 1, 0.5, 16, 6),
+                                               (512, 4, 4, 2, 0.0, 16, 3)])
+def test_mc_entropy_fused_equals_unfused(hip, c, h, w, bs, p, n_mc, n):
+    torch.manual_seed(c + n_mc)
+    x = torch.relu(torch.randn(n, c, h, w)).cuda()
+    rand = torch.rand(n, n_mc, h, w).cuda() if p > 0 else None
+    k = 5
+    assert hip.mc_entropy_supported(h, w, n_mc, k)
+    hf, zf = hip.mc_entropy(x, rand, n_mc, p, bs, k, want_samples=True)
+    z = hip.mc_stack(x, rand, n_mc, p, bs)
+    hu = hip.kl_entropy_per_dim(z, n_mc, k)
+    # same samples (as multisets per image/channel: the fused kernel visits drop layers in mask-sum order)
+    zs = np.sort(z.cpu().numpy().reshape(n, n_mc, c), axis=1)
+    zfs = np.sort(zf.cpu().numpy().reshape(n, n_mc, c), axis=1)
+    assert np.array_equal(zs, zfs, equal_nan=True)
+    a, b = hf.cpu().numpy(), hu.cpu().numpy()
+    fin = np.isfinite(zs).all(axis=1)  # a fully dropped map is NaN upstream -> NaN entropy
+    assert np.array_equal(a[fin], b[fin])
+    assert np.isnan(a[~fin]).all()
+    exp = oracle.kl_entropy_per_dim_vectorized(np.where(np.isfinite(z.cpu().numpy()), z.cpu().numpy(), 0.0), n_mc, k)
+    assert np.abs(a[fin] - exp[fin]).max() < 1e-11
+
+
+def test_mc_entropy_unsupported_shape_is_refused(hip):
+    assert not hip.mc_entropy_supported(5, 5, 16, 5) and not hip.mc_entropy_supported(4, 4, 3, 2)
+    x = torch.rand(2, 8, 5, 5, device="cuda")
+    with pytest.raises(hip.RuniaHipError):
+        hip.mc_entropy(x, torch.rand(2, 16, 5, 5, device="cuda"), 16, 0.5, 2, 5)
+
+
+@pytest.mark.parametrize("n_rows,d,n,pca", [(1, 20, 4, True), (33, 512, 256, True), (1000, 512, 256, True), (40000, 64, 16, True),
+                                            (70, 100, 300, True), (50, 24, 24, False), (17, 300, 300, False)])
+def test_pca_md_fused_equals_unfused(hip, n_rows, d, n, pca):
+    rng = np.random.default_rng(n_rows + d + n)
+    h = rng.standard_normal((n_rows, d))
+    a = rng.standard_normal((n, n))
+    prec = a @ a.T / n + np.eye(n)
+    md_mean = rng.standard_normal(n) * 0.3
+    packed_p = hip.pack_weights(dev(prec, torch.float64))
+    if pca:
+        comp = rng.standard_normal((n, d)) / np.sqrt(d)
+        mean = rng.standard_normal(d)
+        var = rng.random(n) + 0.2
+        bias = (mean.reshape(1, -1) @ comp.T).ravel()
+        packed_ct = hip.pack_weights(dev(comp.T.copy(), torch.float64))
+        s, y = hip.pca_md_score(dev(h, torch.float64), packed_ct, dev(bias, torch.float64), dev(np.sqrt(var), torch.float64),
+                                dev(md_mean, torch.float64), packed_p, n, want_projection=True)
+        y_ref = oracle.pca_transform(h, comp, mean, var)
+        yu = hip.pca_transform(dev(h, torch.float64), packed_ct, dev(bias, torch.float64), dev(np.sqrt(var), torch.float64), n)
+        assert torch.equal(y, yu)
+        assert rel_err(y.cpu().numpy(), y_ref) < 1e-11
+    else:
+        s = hip.pca_md_score(dev(h, torch.float64), None, None, None, dev(md_mean, torch.float64), packed_p, n)
+        y_ref = h
+    assert rel_err(s.cpu().numpy(), oracle.md_score(y_ref, md_mean.reshape(1, -1), prec)) < 1e-11
