@@ -76,6 +76,7 @@ def main():
 
     import runia_core_amd as rc
     from runia_core_amd import _hip
+    from runia_core_amd.distributed import gather_scores
     from runia_core_amd.inference import LaREMPipeline, MDLatentSpace
 
     _hip.require_gpu()
@@ -94,7 +95,6 @@ def main():
 
     n = args.images
     x, rand = synth_latents(n, 1235 + rank, 0.0, device)  # this rank's shard
-    gathered = torch.empty(world * n, dtype=torch.float64, device=device) if world > 1 else None
 
     ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
 
@@ -105,10 +105,7 @@ def main():
         if i is not None:
             ev[i][1].record()
         s = pipe.score_entropies(h)             # K2: PCA + LaREM
-        if world > 1:
-            dist.all_gather_into_tensor(gathered, s)
-            return gathered
-        return s
+        return gather_scores(s, world * n) if world > 1 else s  # the single RCCL all_gather
 
     for _ in range(args.warmup):
         step()
