@@ -57,6 +57,7 @@ def main():
     ap.add_argument("--ood-scale", type=float, default=1.03)
     ap.add_argument("--cpu-sample", type=int, default=1280, help="images timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--chunks", type=int, default=None, help="row blocks pipelined over two streams (default: pipeline's)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -96,15 +97,10 @@ def main():
     n = args.images
     x, rand = synth_latents(n, 1235 + rank, 0.0, device)  # this rank's shard
 
-    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    k1_events = []  # (start, end) HIP event pairs around every K1 launch of the timed region
 
-    def step(i=None):
-        if i is not None:
-            ev[i][0].record()
-        h = pipe.entropy_from_latents(x, rand)  # K1: sampler + entropy (dominant kernel)
-        if i is not None:
-            ev[i][1].record()
-        s = pipe.score_entropies(h)             # K2: PCA + LaREM
+    def step(timed=False):
+        s = pipe.score_latents(x, rand, chunks=args.chunks, k1_events=k1_events if timed else None)
         return gather_scores(s, world * n) if world > 1 else s  # the single RCCL all_gather
 
     for _ in range(args.warmup):
@@ -120,21 +116,19 @@ def main():
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        scores = step(i)
+        scores = step(True)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    if os.environ.get("RUNIA_BENCH_DEBUG"):
-        print("step gaps ms:", [round(ev[i][0].elapsed_time(ev[i + 1][0]), 3) for i in range(args.steps - 1)],
-              file=sys.stderr)
     gc.enable()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in ev]))
+    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in k1_events])) if k1_events else float('nan')
+    k1_launches_per_step = max(1, len(k1_events) // max(1, args.steps))
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -147,18 +141,22 @@ def main():
     # algorithmic bytes of K1 per image ("with MC stacking from latent"): the latent map
     # C*H*W*4, the draws n_mc*H*W*4, and the C entropies written as f64
     kname, bytes_per_img = "mc_entropy_kernel", C * H * W * 4 + N_MC * H * W * 4 + C * 8
-    achieved = bytes_per_img * n / (kernel_ms * 1e-3) / 1e9
+    imgs_per_launch = n / k1_launches_per_step
+    achieved = bytes_per_img * imgs_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic = None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_file):
         try:
-            traffic = json.load(open(pmc_file)).get(kname, {}).get("hbm_bytes_per_launch")
+            rec = json.load(open(pmc_file)).get(kname, {})
+            # PMC bytes were collected at `images_per_launch` images per launch; scale to this run's launch size
+            traffic = int(rec["hbm_bytes_per_launch"] * imgs_per_launch / rec.get("images_per_launch", 10000))
         except Exception:
             traffic = None
     roofline = {
         "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "algorithmic_bytes_per_launch": bytes_per_img * n, "avg_launch_ms": round(kernel_ms, 4),
+        "algorithmic_bytes_per_launch": int(bytes_per_img * imgs_per_launch), "avg_launch_ms": round(kernel_ms, 4),
+        "launches_per_step": k1_launches_per_step,
     }
 
     # ---------------- parity on a bounded sample + CPU baseline (oracle = checker / baseline only) --
@@ -169,7 +167,7 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "config": {"workload": "CIFAR10 ResNet-18 LaREM: 16 MC samples, 512-d latent -> PCA-256, 10000 test images per GPU",
                    "images_per_gpu": n, "mc_samples": N_MC, "latent": [C, H, W], "pca_components": N_PCA,
-                   "launches_per_step": 2 if fused else 4, "input_dtype": "f32"},
+                   "row_blocks_per_step": k1_launches_per_step, "input_dtype": "f32"},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

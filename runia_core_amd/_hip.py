@@ -342,7 +342,7 @@ def mc_entropy_supported(h: int, w: int, n_mc: int, k: int) -> bool:
 
 
 def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob: float, block_size: int, k: int,
-               min_dist: float = 1e-5, want_samples: bool = False):
+               min_dist: float = 1e-5, want_samples: bool = False, out: Optional[torch.Tensor] = None):
     """Fused sampler + entropy: x [N,C,H,W] f32 (+ draws) -> h [N, C] f64 (and optionally the MC samples)."""
     lib = load_library()
     require_gpu()
@@ -358,7 +358,11 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
             stride = n_mc * hh * ww
         else:
             assert rand.shape == (n_mc, hh, ww)
-    h = torch.empty((n, c), dtype=torch.float64, device=x.device)
+    if out is None:
+        h = torch.empty((n, c), dtype=torch.float64, device=x.device)
+    else:
+        assert out.is_cuda and out.dtype == torch.float64 and out.shape == (n, c) and out.is_contiguous()
+        h = out
     z = torch.empty((n * n_mc, c), dtype=torch.float32, device=x.device) if want_samples else None
     done = 0
     while done < n:
@@ -377,14 +381,18 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
 
 def pca_md_score(h: torch.Tensor, packed_ct: Optional[torch.Tensor], bias: Optional[torch.Tensor],
                  scale: Optional[torch.Tensor], md_mean: torch.Tensor, packed_p: torch.Tensor, n: int,
-                 want_projection: bool = False):
+                 want_projection: bool = False, out: Optional[torch.Tensor] = None):
     """Fused PCA transform + LaREM score: h [N, D] f64 -> score [N] f64 (projected rows stay on chip)."""
     lib = load_library()
     require_gpu()
     assert h.is_cuda and h.dtype == torch.float64 and h.dim() == 2
     h = h.contiguous()
     nrow, d = h.shape
-    s = torch.empty((nrow,), dtype=torch.float64, device=h.device)
+    if out is None:
+        s = torch.empty((nrow,), dtype=torch.float64, device=h.device)
+    else:
+        assert out.is_cuda and out.dtype == torch.float64 and out.shape == (nrow,) and out.is_contiguous()
+        s = out
     y = torch.empty((nrow, n), dtype=torch.float64, device=h.device) if want_projection else None
     _check(
         lib.runia_pca_md_score_f64(h.data_ptr(), _ptr(packed_ct), _ptr(bias), _ptr(scale), md_mean.data_ptr(),

@@ -16,10 +16,12 @@
 // changes (wave-uniform branch): same bits as the upstream op order, ~1/3 fewer VALU ops.
 #include "common.hpp"
 #include "entropy_core.hpp"
+#include "mfma_f64_tile.hpp"
 
 namespace {
 
 using namespace runia_entropy;
+using namespace runia_mfma;
 
 constexpr int kMaxMC = 64;
 
@@ -164,10 +166,6 @@ __global__ __launch_bounds__(256) void mc_entropy_kernel(const float* __restrict
 // K2: H -> PCA (optional) -> LaREM score.  One workgroup = BM rows; both contractions on f64 MFMA.
 // Packed weights layout: see gemm_f64.hip.
 // ------------------------------------------------------------------------------------------
-constexpr int KC = 32;
-constexpr int APITCH = 34;
-constexpr int BN = 256;
-
 struct PcaMdArgs {
   const double* h;         // [N, D]
   const double* packed_ct; // pack(C.T [D, n]) or null (no PCA: n == D)
@@ -185,75 +183,50 @@ __global__ __launch_bounds__(256) void pca_md_kernel(PcaMdArgs g) {
   constexpr int BM = 16 * RT;
   extern __shared__ double lds[];
   // layout: lds_a [2][BM][APITCH] | lds_y [BM][ypitch] | part [4][BM]
-  const int64_t n_pad = (g.n + BN - 1) / BN * BN;
+  const int64_t n_pad = n_padded(g.n);
   const int ypitch = (int)n_pad + 2;  // == 2 mod 32 -> conflict-free A-fragment reads
   double* lds_a = lds;
   double* lds_y = lds + 2 * BM * APITCH;
   double* part = lds_y + (size_t)BM * ypitch;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int64_t NT = n_pad / 16;
   const int64_t r0 = (int64_t)blockIdx.x * BM;
 
   // ---------------- phase A: d = (H C^T - bias) / scale - md_mean  -> lds_y ----------------
   if (g.packed_ct) {
-    const int64_t K_pad = (g.D + 7) / 8 * 8;
-    const int64_t nchunks = (K_pad + KC - 1) / KC;
+    const int64_t nchunks = k_padded(g.D) / KC;
     constexpr int PER_T = BM * KC / 256;  // doubles staged per thread per chunk (4 or 2)
     for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
       const int64_t ctbase = cb * 16 + wave * 4;
-      const bool active = (ctbase * 16 < g.n);
       d4 acc[RT][4];
 #pragma unroll
       for (int a = 0; a < RT; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+      const double2* bp = reinterpret_cast<const double2*>(g.packed_ct) + ctbase * 64 + lane;
+      double2 b0[4];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b0[c] = bp[c * 64];
       double areg[PER_T];
+      const int srow = (tid * PER_T) / KC, skk = (tid * PER_T) % KC;
       auto load_a = [&](int64_t kc) {
-        const int row = (tid * PER_T) / KC, kk = (tid * PER_T) % KC;
-        const int64_t gr = r0 + row;
+        const int64_t gr = r0 + srow;
 #pragma unroll
         for (int q = 0; q < PER_T; ++q) {
-          const int64_t gk = kc + kk + q;
+          const int64_t gk = kc + skk + q;
           areg[q] = (gr < g.N && gk < g.D) ? g.h[gr * g.D + gk] : 0.0;
         }
       };
       load_a(0);
       int buf = 0;
       for (int64_t ch = 0; ch < nchunks; ++ch) {
-        {
-          const int row = (tid * PER_T) / KC, kk = (tid * PER_T) % KC;
 #pragma unroll
-          for (int q = 0; q < PER_T; ++q) lds_a[(buf * BM + row) * APITCH + kk + q] = areg[q];
-        }
+        for (int q = 0; q < PER_T; ++q) lds_a[(buf * BM + srow) * APITCH + skk + q] = areg[q];
         __syncthreads();
         if (ch + 1 < nchunks) load_a((ch + 1) * KC);
-        if (active) {
-          const int64_t s2_base = ch * (KC / 8);
-          const int steps2 = (int)(((K_pad - ch * KC) < KC ? (K_pad - ch * KC) : KC) / 8);
-#pragma unroll
-          for (int s2 = 0; s2 < KC / 8; ++s2) {
-            if (s2 < steps2) {
-              double2 b[4];
-#pragma unroll
-              for (int c = 0; c < 4; ++c)
-                b[c] = reinterpret_cast<const double2*>(g.packed_ct)[((s2_base + s2) * NT + ctbase + c) * 64 + lane];
-#pragma unroll
-              for (int hh = 0; hh < 2; ++hh) {
-                double av[RT];
-#pragma unroll
-                for (int a = 0; a < RT; ++a) av[a] = lds_a[(buf * BM + 16 * a + li) * APITCH + 8 * s2 + 4 * hh + lg];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                  const double bv = hh ? b[c].y : b[c].x;
-#pragma unroll
-                  for (int a = 0; a < RT; ++a)
-                    acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv, acc[a][c], 0, 0, 0);
-                }
-              }
-            }
-          }
-        }
+        mfma_chunk<RT>(acc, lds_a + buf * BM * APITCH, APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
         buf ^= 1;
       }
       // epilogue: sklearn transform then the LaREM centring, kept in LDS
@@ -266,7 +239,7 @@ __global__ __launch_bounds__(256) void pca_md_kernel(PcaMdArgs g) {
           for (int r = 0; r < 4; ++r) {
             const int row = 16 * a + lg + 4 * r;
             double d = 0.0;
-            if (active && col < g.n) {
+            if (col < g.n) {
               double y = acc[a][c][r] - g.bias[col];
               if (g.scale) y = y / g.scale[col];
               if (g.y_out && r0 + row < g.N) g.y_out[(r0 + row) * g.n + col] = y;
@@ -294,43 +267,28 @@ __global__ __launch_bounds__(256) void pca_md_kernel(PcaMdArgs g) {
   for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) rowdot[a][r] = 0.0;
-  const int64_t Kp = (g.n + 7) / 8 * 8;
+  const int64_t kchunks = k_padded(g.n) / KC;
   for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
     const int64_t ctbase = cb * 16 + wave * 4;
-    if (ctbase * 16 < g.n) {
-      d4 acc[RT][4];
+    d4 acc[RT][4];
 #pragma unroll
-      for (int a = 0; a < RT; ++a)
+    for (int a = 0; a < RT; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
-      for (int64_t s2 = 0; s2 < Kp / 8; ++s2) {
-        double2 b[4];
+      for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double2* bp = reinterpret_cast<const double2*>(g.packed_p) + ctbase * 64 + lane;
+    double2 b0[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          b[c] = reinterpret_cast<const double2*>(g.packed_p)[(s2 * NT + ctbase + c) * 64 + lane];
+    for (int c = 0; c < 4; ++c) b0[c] = bp[c * 64];
+    for (int64_t ch = 0; ch < kchunks; ++ch)
+      mfma_chunk<RT>(acc, lds_y + ch * KC, ypitch, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
 #pragma unroll
-        for (int hh = 0; hh < 2; ++hh) {
-          double av[RT];
+    for (int a = 0; a < RT; ++a)
 #pragma unroll
-          for (int a = 0; a < RT; ++a) av[a] = lds_y[(16 * a + li) * ypitch + 8 * s2 + 4 * hh + lg];
+      for (int c = 0; c < 4; ++c) {
+        const int col = (int)((ctbase + c) * 16) + li;
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            const double bv = hh ? b[c].y : b[c].x;
-#pragma unroll
-            for (int a = 0; a < RT; ++a)
-              acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a], bv, acc[a][c], 0, 0, 0);
-          }
-        }
+        for (int r = 0; r < 4; ++r) rowdot[a][r] += acc[a][c][r] * lds_y[(16 * a + lg + 4 * r) * ypitch + col];
       }
-#pragma unroll
-      for (int a = 0; a < RT; ++a)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int col = (int)((ctbase + c) * 16) + li;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) rowdot[a][r] += acc[a][c][r] * lds_y[(16 * a + lg + 4 * r) * ypitch + col];
-        }
-    }
   }
 #pragma unroll
   for (int a = 0; a < RT; ++a)
@@ -359,7 +317,7 @@ double digamma_diff(int n, int k) {
 template <int RT>
 int launch_pca_md(const PcaMdArgs& g, hipStream_t s) {
   constexpr int BM = 16 * RT;
-  const int64_t n_pad = (g.n + BN - 1) / BN * BN;
+  const int64_t n_pad = n_padded(g.n);
   const size_t shmem = ((size_t)2 * BM * APITCH + (size_t)BM * (n_pad + 2) + 4 * BM) * sizeof(double);
   if (shmem > 160 * 1024) return RUNIA_E_INVALID;
   static bool attr_set = false;
@@ -387,7 +345,7 @@ extern "C" int runia_pca_md_score_f64(const double* h, const double* packed_ct, 
   PcaMdArgs g{h, packed_ct, bias, scale, md_mean, packed_p, score, y_out, N, D, n};
   // 32-row tiles halve the L2 traffic of the packed weights but need >= ~4 tiles per CU to balance
   const int64_t tiles32 = (N + 31) / 32;
-  const int64_t n_pad = (n + BN - 1) / BN * BN;
+  const int64_t n_pad = n_padded(n);
   const bool fits32 = ((size_t)2 * 32 * APITCH + (size_t)32 * (n_pad + 2) + 128) * 8 <= 160 * 1024;
   if (tiles32 >= 1024 && fits32) return launch_pca_md<2>(g, as_stream(stream));
   return launch_pca_md<1>(g, as_stream(stream));

@@ -7,7 +7,7 @@
 // Layout.  The right-hand matrix B [K, n] is constant after setup(), so it is repacked
 // once into MFMA fragment order: for k-step pair s2 (8 k values) and 16-column tile ct,
 //   packed[((s2*NT + ct)*64 + lane)*2 + h] = B[8*s2 + 4*h + (lane>>4)][16*ct + (lane&15)]
-// (zero padded to K%8==0, n%256==0).  One wave-wide 16-byte load then yields the B operand
+// (zero padded to K%32==0 plus one zero k-step pair, n%256==0; see mfma_f64_tile.hpp).  One wave-wide 16-byte load then yields the B operand
 // of two MFMA k-steps, fully coalesced (1 KiB per instruction, 4 KiB per wave per k-step pair)
 // and served by the XCD L2 (the whole matrix is <= a few MiB).
 // The left-hand rows stream from HBM exactly once: a 32-row x 32-k chunk is staged into LDS
@@ -18,13 +18,13 @@
 // f64 MFMA fragment maps (guide section 3): A lane l -> A[l&15][l>>4]; B lane l -> B[l>>4][l&15];
 // C/D lane l, reg r -> C[(l>>4) + 4r][l&15].
 #include "common.hpp"
+#include "mfma_f64_tile.hpp"
 
 namespace {
 
-constexpr int BM = 32;        // rows per workgroup
-constexpr int KC = 32;        // k values per staged chunk
-constexpr int APITCH = 34;    // doubles; 34 mod 32 == 2 -> 16 rows x 2 k hit 32 distinct bank pairs
-constexpr int BN = 256;       // columns per workgroup pass (4 waves x 4 tiles x 16)
+using namespace runia_mfma;
+
+constexpr int BM = 32;  // rows per workgroup (2 row tiles of 16)
 
 enum Epilogue { EPI_PCA = 0, EPI_ROWDOT = 1, EPI_STORE = 2 };
 
@@ -81,18 +81,20 @@ __device__ __forceinline__ void load_a_regs(const GemmArgs& g, int64_t r0, int64
   }
 }
 
+// One workgroup = 32 rows x all n columns (256 at a time); wave w owns the 64-column slice w of each pass.
+// The rows stream from HBM once per 256-column pass through a double-buffered 32x32 LDS chunk; the packed
+// weights come from L2 one k-step pair ahead (mfma_chunk).
 template <typename TA, typename TS, int EPI>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   __shared__ double lds_a[2][BM][APITCH];
   __shared__ double lds_part[4][BM];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
-  const int wave = tid >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
-  const int64_t n_pad = (g.n + BN - 1) / BN * BN;
+  const int64_t n_pad = n_padded(g.n);
   const int64_t NT = n_pad / 16;
-  const int64_t K_pad = (g.K + 7) / 8 * 8;
-  const int64_t nchunks = (K_pad + KC - 1) / KC;
+  const int64_t nchunks = k_padded(g.K) / KC;
   const int64_t r0 = (int64_t)blockIdx.x * BM;
 
   double rowdot[2][4];
@@ -103,12 +105,15 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
 
   for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
     const int64_t ctbase = cb * 16 + wave * 4;
-    const bool active = (ctbase * 16 < g.n);  // wave-uniform: this wave's 64 columns hold real data
     d4 acc[2][4];
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double2* bp = reinterpret_cast<const double2*>(g.packed) + ctbase * 64 + lane;
+    double2 b0[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b0[c] = bp[c * 64];
 
     double areg[4];
     load_a_regs<TA, TS>(g, r0, 0, tid, areg);
@@ -121,57 +126,32 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
       }
       __syncthreads();
       if (ch + 1 < nchunks) load_a_regs<TA, TS>(g, r0, (ch + 1) * KC, tid, areg);
-      if (active) {
-        const int64_t s2_base = ch * (KC / 8);
-        const int steps2 = (int)(((K_pad - ch * KC) < KC ? (K_pad - ch * KC) : KC) / 8);
-#pragma unroll
-        for (int s2 = 0; s2 < KC / 8; ++s2) {
-          if (s2 < steps2) {
-            double2 b[4];
-#pragma unroll
-            for (int c = 0; c < 4; ++c)
-              b[c] = reinterpret_cast<const double2*>(g.packed)[((s2_base + s2) * NT + ctbase + c) * 64 + lane];
-#pragma unroll
-            for (int h = 0; h < 2; ++h) {
-              const double a0 = lds_a[buf][li][8 * s2 + 4 * h + lg];
-              const double a1 = lds_a[buf][16 + li][8 * s2 + 4 * h + lg];
-#pragma unroll
-              for (int c = 0; c < 4; ++c) {
-                const double bv = h ? b[c].y : b[c].x;
-                acc[0][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, bv, acc[0][c], 0, 0, 0);
-                acc[1][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, bv, acc[1][c], 0, 0, 0);
-              }
-            }
-          }
-        }
-      }
+      mfma_chunk<2>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
       buf ^= 1;
     }
 
     // ---- epilogue for this 256-column block ----
-    if (active) {
 #pragma unroll
-      for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < 2; ++a) {
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const int64_t col = (ctbase + c) * 16 + li;
+      for (int c = 0; c < 4; ++c) {
+        const int64_t col = (ctbase + c) * 16 + li;
 #pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int64_t row = r0 + 16 * a + lg + 4 * r;
-            if (row < g.N && col < g.n) {
-              const double v = acc[a][c][r];
-              if constexpr (EPI == EPI_PCA) {
-                double y = v - g.bias[col];
-                if (g.scale) y = y / g.scale[col];
-                g.out[row * g.n + col] = y;
-              } else if constexpr (EPI == EPI_STORE) {
-                g.out[row * g.n + col] = v;
-              } else {  // EPI_ROWDOT: sum_j (d P)_j d_j with d = x - sub
-                const TA* x = reinterpret_cast<const TA*>(g.x);
-                const TA xv = x[row * g.ldx + col];
-                const double d = g.sub ? sub_promote<TA, TS>(xv, reinterpret_cast<const TS*>(g.sub)[col]) : (double)xv;
-                rowdot[a][r] += v * d;
-              }
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = r0 + 16 * a + lg + 4 * r;
+          if (row < g.N && col < g.n) {
+            const double v = acc[a][c][r];
+            if constexpr (EPI == EPI_PCA) {
+              double y = v - g.bias[col];
+              if (g.scale) y = y / g.scale[col];
+              g.out[row * g.n + col] = y;
+            } else if constexpr (EPI == EPI_STORE) {
+              g.out[row * g.n + col] = v;
+            } else {  // EPI_ROWDOT: sum_j (d P)_j d_j with d = x - sub
+              const TA* x = reinterpret_cast<const TA*>(g.x);
+              const TA xv = x[row * g.ldx + col];
+              const double d = g.sub ? sub_promote<TA, TS>(xv, reinterpret_cast<const TS*>(g.sub)[col]) : (double)xv;
+              rowdot[a][r] += v * d;
             }
           }
         }
@@ -248,19 +228,15 @@ __global__ __launch_bounds__(256) void maha_class_kernel(const TX* __restrict__ 
 
 extern "C" size_t runia_packed_weights_bytes(int64_t K, int64_t n) {
   if (K <= 0 || n <= 0) return 0;
-  const int64_t n_pad = (n + BN - 1) / BN * BN;
-  const int64_t K_pad = (K + 7) / 8 * 8;
-  return (size_t)(n_pad * K_pad) * sizeof(double);
+  return (size_t)packed_elems(K, n) * sizeof(double);
 }
 
 extern "C" int runia_pack_weights_f64(const double* B, int64_t ldb, int64_t K, int64_t n, double* packed,
                                       runia_stream_t stream) {
   if (!B || !packed || K <= 0 || n <= 0 || ldb < n) return RUNIA_E_INVALID;
-  const int64_t n_pad = (n + BN - 1) / BN * BN;
-  const int64_t K_pad = (K + 7) / 8 * 8;
-  const int64_t total = n_pad * K_pad;
+  const int64_t total = packed_elems(K, n);
   pack_weights_kernel<<<runia_stream_grid(total, 256), 256, 0, as_stream(stream)>>>(B, ldb, K, n, packed,
-                                                                                     n_pad / 16, total);
+                                                                                     n_padded(n) / 16, total);
   return runia_check_launch();
 }
 

@@ -1,0 +1,65 @@
+// Shared pieces of the f64 matrix-core kernels (gemm_f64.hip, fused.hip).
+//
+// Packed weights.  A constant right-hand matrix B [K, n] is stored in MFMA fragment order:
+//   packed[((s2*NT + ct)*64 + lane)*2 + h] = B[8*s2 + 4*h + (lane>>4)][16*ct + (lane&15)]
+// for k-step pair s2 and 16-column tile ct (NT = n_pad/16).  K is zero padded to a multiple of 32 (= one staged
+// A chunk, so the MFMA loops carry no tail conditions) plus ONE extra all-zero k-step pair (so the B prefetch of
+// "the next pair" never needs a bounds check); n is zero padded to a multiple of 256.
+//
+// v_mfma_f64_16x16x4_f64 fragment maps: A lane l -> A[l&15][l>>4]; B lane l -> B[l>>4][l&15];
+// C/D lane l, reg r -> C[(l>>4) + 4r][l&15].
+#pragma once
+#include "common.hpp"
+
+namespace runia_mfma {
+
+constexpr int KC = 32;      // k values per staged A chunk (4 k-step pairs)
+constexpr int APITCH = 34;  // doubles; == 2 mod 32 -> the 16 rows x 2 k of a ds_read_b64 group hit 32 distinct bank pairs
+constexpr int BN = 256;     // columns per workgroup pass: 4 waves x 4 tiles x 16
+
+__host__ __device__ inline int64_t n_padded(int64_t n) { return (n + BN - 1) / BN * BN; }
+__host__ __device__ inline int64_t k_padded(int64_t K) { return (K + KC - 1) / KC * KC; }        // multiple of 32
+__host__ __device__ inline int64_t packed_pairs(int64_t K) { return k_padded(K) / 8 + 1; }       // + 1 zero pair
+__host__ __device__ inline int64_t packed_elems(int64_t K, int64_t n) { return packed_pairs(K) * 8 * n_padded(n); }
+
+// Multiply-accumulate one 32-deep chunk: acc[a][c] += A[16a.., chunk] * B[chunk, this wave's 4 column tiles].
+//   a_tile : LDS, row-major [>=16*RT rows][pitch doubles], already offset to the chunk's first k
+//   bp     : this wave's packed-B pointer at the chunk's first k-step pair, already offset by (ctbase*64 + lane);
+//            consecutive pairs are pair_stride double2 apart, consecutive column tiles 64 double2 apart
+//   b0     : B fragments of the chunk's first pair (loaded by the previous call / the prologue); on return it holds
+//            the first pair of the NEXT chunk, so B loads stay one pair (8 MFMAs = 512 matrix-pipe cycles) ahead.
+// Branch-free on purpose: a conditional around an MFMA makes hipcc shuttle the accumulators between VGPRs and
+// AGPRs (64 v_accvgpr moves per 8 MFMAs were measured before this form).
+template <int RT>
+__device__ __forceinline__ void mfma_chunk(d4 (&acc)[RT][4], const double* a_tile, int pitch, int li, int lg,
+                                           const double2* __restrict__ bp, int64_t pair_stride, double2 (&b0)[4]) {
+  double av[RT][8];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) av[a][t] = a_tile[(16 * a + li) * pitch + 4 * t + lg];
+  double2 b1[4];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) {
+    if ((s2 & 1) == 0) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b1[c] = bp[(s2 + 1) * pair_stride + c * 64];
+    } else {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) b0[c] = bp[(s2 + 1) * pair_stride + c * 64];
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const double2 bb = (s2 & 1) ? b1[c] : b0[c];
+        const double bv = hh ? bb.y : bb.x;
+#pragma unroll
+        for (int a = 0; a < RT; ++a)
+          acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][2 * s2 + hh], bv, acc[a][c], 0, 0, 0);
+      }
+    }
+  }
+}
+
+}  // namespace runia_mfma
