@@ -19,7 +19,24 @@ from .. import _hip
 from ..dimensionality_reduction import DevicePCA, device_pca_for
 from ..evaluation.entropy import MIN_DIST, neighbors_for
 
-__all__ = ["LaREMPipeline"]
+__all__ = ["LaREMPipeline", "AsyncScores"]
+
+
+class AsyncScores:
+    """Scores of one batch still in flight on the pipeline's side streams."""
+
+    def __init__(self, scores: Tensor, done: "torch.cuda.Event"):
+        self.scores = scores
+        self.done = done
+
+    def wait(self) -> Tensor:
+        """Make the current stream wait for the batch (no host sync) and return the device scores."""
+        torch.cuda.current_stream().wait_event(self.done)
+        return self.scores
+
+    def result(self) -> np.ndarray:
+        self.done.synchronize()
+        return self.scores.cpu().numpy()
 
 
 class LaREMPipeline:
@@ -149,6 +166,69 @@ class LaREMPipeline:
         main.wait_event(s_k1.record_event())
         main.wait_event(s_k2.record_event())
         return scores
+
+    def score_latents_async(self, latents: Tensor, rand: Optional[Tensor], k1_events: Optional[list] = None,
+                            inputs_ready: Optional["torch.cuda.Event"] = None) -> AsyncScores:
+        """Pipelined form for streams of batches: the sampler + entropy kernel (vector ALUs) runs on one HIP
+        stream and the PCA + LaREM kernel (matrix cores) on another, so batch i+1's K1 overlaps batch i's K2.
+        Entropy buffers form a ring of two; a batch's K1 waits for the K2 that last read its buffer.
+        ``inputs_ready``: event after which ``latents`` / ``rand`` are valid (default: everything queued so far
+        on the caller's stream - note that this includes any ``AsyncScores.wait()`` the caller did, which would
+        serialise consecutive batches).  Returns immediately with an :class:`AsyncScores` handle."""
+        n, c, hh, ww = latents.shape
+        md = self._md_state()
+        if not (_hip.mc_entropy_supported(hh, ww, self.n_mc, self.k) and md is not None):
+            s = self.score_latents(latents, rand)
+            return AsyncScores(s, torch.cuda.current_stream().record_event())
+        mean, packed_p = md
+        if self._side_streams is None:
+            self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        s_k1, s_k2 = self._side_streams
+        ring = getattr(self, "_ring", None)
+        if ring is None or ring["shape"] != (n, c) or ring["device"] != latents.device:
+            ring = {"shape": (n, c), "device": latents.device, "slot": 0,
+                    "h": [torch.empty((n, c), dtype=torch.float64, device=latents.device) for _ in range(2)],
+                    "free": [None, None]}
+            self._ring = ring
+        slot = ring["slot"]
+        ring["slot"] = slot ^ 1
+        h = ring["h"][slot]
+        scores = torch.empty((n,), dtype=torch.float64, device=latents.device)
+        s_k1.wait_event(inputs_ready if inputs_ready is not None else torch.cuda.current_stream().record_event())
+        if ring["free"][slot] is not None:
+            s_k1.wait_event(ring["free"][slot])
+        drop = self.drop_prob if rand is not None else 0.0
+        with torch.cuda.stream(s_k1):
+            if k1_events is not None:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            _hip.mc_entropy(latents, rand, self.n_mc, drop, self.block_size, self.k, MIN_DIST, out=h)
+            if k1_events is not None:
+                e1.record()
+                k1_events.append((e0, e1))
+            ready = s_k1.record_event()
+        s_k2.wait_event(ready)
+        with torch.cuda.stream(s_k2):
+            if self.pca is not None:
+                _hip.pca_md_score(h, self.pca.packed_ct, self.pca.bias, self.pca.scale, mean, packed_p,
+                                  self.pca.n_components, out=scores)
+            else:
+                _hip.pca_md_score(h, None, None, None, mean, packed_p, c, out=scores)
+            done = s_k2.record_event()
+        ring["free"][slot] = done
+        # keep the caller's tensors alive for the side streams (caching-allocator stream safety)
+        latents.record_stream(s_k1)
+        if rand is not None:
+            rand.record_stream(s_k1)
+        scores.record_stream(s_k2)
+        return AsyncScores(scores, done)
+
+    @property
+    def k2_stream(self):
+        """Stream on which the scores of ``score_latents_async`` are produced (consumers may enqueue there)."""
+        if self._side_streams is None:
+            self._side_streams = (torch.cuda.Stream(), torch.cuda.Stream())
+        return self._side_streams[1]
 
     def score_samples_host(self, z: np.ndarray) -> np.ndarray:
         return self.score_samples(_hip.to_device(z, torch.float32)).cpu().numpy()
