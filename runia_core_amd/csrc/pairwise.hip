@@ -4,62 +4,124 @@
 //   a9  LaRED : sklearn KernelDensity(gaussian).score_samples
 //               (reference inference/postprocessors.py:118-128)
 //
-// Round-1 form: exact-difference distances on the vector ALUs (faiss's own path for
-// the reference's one-query-at-a-time search accumulates sum((q-b)^2) directly, without
-// the norm expansion), one workgroup per query row, bank streamed from L2/HBM.
-// The k-th order statistic is found by an 8-bit radix select over the distance bits
-// (distances are >= 0, so unsigned integer order == float order) - no sort, no top-k list.
+// kNN = the one f32 dense contraction of the path, on the matrix cores:
+//   d2[q, m] = |q|^2 + |b_m|^2 - 2 q.b_m          (v_mfma_f32_32x32x2_f32, exact-f32 fma chain)
+// A workgroup owns a 128-query x 128-bank-row tile (4 waves x 64x64, i.e. 2x2 MFMA tiles of 32x32 per wave);
+// both operands are K-contiguous rows, staged 32 k at a time into LDS with a 34-float pitch (conflict-free
+// ds_read_b64: one 8-byte read feeds two MFMA k-steps, A and B use the same k permutation).  Distances go to a
+// row-chunked workspace [Qc, M]; the k-th order statistic of each row is then found by an 8-bit radix select over
+// the distance bits (distances are clamped >= 0, so unsigned integer order == float order) - no sort, no top-k list.
+// blockIdx.x walks the bank tiles so that the workgroups dealt to one XCD share the same query panel in L2.
 #include "common.hpp"
 
 namespace {
 
 constexpr float kFltMax = 3.4028234663852886e38f;
+typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-// squared L2 between the workgroup's query (in LDS) and every bank row -> dist[M] (global)
-__device__ __forceinline__ void distances_to_bank(const float* __restrict__ qs, const float* __restrict__ bank,
-                                                   float* __restrict__ dist, int64_t M, int64_t D, bool vec) {
+constexpr int TQ = 128, TB = 128, KCH = 32, KP = 34;
+
+__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          int64_t N, int64_t D) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t m = wave; m < M; m += 4) {
-    const float* b = bank + m * D;
-    float acc = 0.f;
-    if (vec) {
-      const float4* b4 = reinterpret_cast<const float4*>(b);
-      const float4* q4 = reinterpret_cast<const float4*>(qs);
-      for (int64_t i = lane; i < (D >> 2); i += 64) {
-        const float4 bv = b4[i], qv = q4[i];
-        const float d0 = qv.x - bv.x, d1 = qv.y - bv.y, d2 = qv.z - bv.z, d3 = qv.w - bv.w;
-        acc += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
-      }
-    } else {
-      for (int64_t i = lane; i < D; i += 64) {
-        const float d = qs[i] - b[i];
-        acc += d * d;
-      }
-    }
-    acc = wave_sum_f32(acc);
-    if (lane == 0) dist[m] = acc;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+    const float* p = x + row * D;
+    float s = 0.f;
+    for (int64_t i = lane; i < D; i += 64) s = fmaf(p[i], p[i], s);
+    s = wave_sum_f32(s);
+    if (lane == 0) out[row] = s;
   }
 }
 
-__global__ __launch_bounds__(256) void knn_kth_kernel(const float* __restrict__ q, const float* __restrict__ bank,
-                                                       float* __restrict__ score, float* __restrict__ work,
-                                                       int64_t N, int64_t M, int64_t D, int k) {
-  extern __shared__ float qs[];  // D floats (16-byte aligned by construction)
+// stage a [rows x 32] K-chunk of a K-contiguous matrix into LDS (zero filled outside the matrix)
+__device__ __forceinline__ void stage_chunk(const float* __restrict__ src, int64_t row0, int64_t nrows, int64_t D,
+                                            int64_t k0, float (*dst)[KP], int tid, bool vec) {
+  const int row = tid >> 1, half = tid & 1;  // 128 rows x 2 halves of 16 floats
+  const int64_t gr = row0 + row;
+  const float* p = src + gr * D + k0 + half * 16;
+  float v[16];
+  if (gr < nrows && vec && k0 + half * 16 + 16 <= D) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float4 t = reinterpret_cast<const float4*>(p)[j];
+      v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (gr < nrows && k0 + half * 16 + j < D) ? p[j] : 0.f;
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j)
+    *reinterpret_cast<float2*>(&dst[row][half * 16 + 2 * j]) = make_float2(v[2 * j], v[2 * j + 1]);
+}
+
+__global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__ q, const float* __restrict__ bank,
+                                                        const float* __restrict__ qn, const float* __restrict__ bn,
+                                                        float* __restrict__ dist, int64_t Q, int64_t M, int64_t D) {
+  __shared__ __attribute__((aligned(16))) float As[TQ][KP];
+  __shared__ __attribute__((aligned(16))) float Bs[TB][KP];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wave >> 1, wb = wave & 1;   // 2 x 2 waves
+  const int li = lane & 31, lh = lane >> 5;
+  const int64_t q0 = (int64_t)blockIdx.y * TQ, m0 = (int64_t)blockIdx.x * TB;
+  const bool vec = ((D & 3) == 0) && ((((uintptr_t)q) & 15) == 0) && ((((uintptr_t)bank) & 15) == 0);
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  for (int64_t k0 = 0; k0 < D; k0 += KCH) {
+    __syncthreads();
+    stage_chunk(q, q0, Q, D, k0, As, tid, vec);
+    stage_chunk(bank, m0, M, D, k0, Bs, tid, vec);
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < KCH / 4; ++s) {
+      float2 av[2], bv[2];
+#pragma unroll
+      for (int a = 0; a < 2; ++a) av[a] = *reinterpret_cast<const float2*>(&As[wq * 64 + a * 32 + li][4 * s + 2 * lh]);
+#pragma unroll
+      for (int b = 0; b < 2; ++b) bv[b] = *reinterpret_cast<const float2*>(&Bs[wb * 64 + b * 32 + li][4 * s + 2 * lh]);
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].x, bv[b].x, acc[a][b], 0, 0, 0);
+          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].y, bv[b].y, acc[a][b], 0, 0, 0);
+        }
+    }
+  }
+  // epilogue: C[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+      const int64_t col = m0 + wb * 64 + b * 32 + li;
+      const float bnv = (col < M) ? bn[col] : 0.f;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int64_t row = q0 + wq * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        if (row < Q && col < M) {
+          const float d = (qn[row] + bnv) - 2.0f * acc[a][b][r];
+          dist[row * M + col] = fmaxf(d, 0.f);
+        }
+      }
+    }
+}
+
+// k-th smallest (1-based) of each row of dist [Q, M]: 4-pass 8-bit radix select, one workgroup per row
+__global__ __launch_bounds__(256) void kth_select_kernel(const float* __restrict__ dist, float* __restrict__ score,
+                                                          int64_t Q, int64_t M, int k) {
   __shared__ unsigned hist[256];
   __shared__ unsigned sel_prefix, sel_rank;
   const int tid = threadIdx.x;
-  float* dist = work + (int64_t)blockIdx.x * M;
-  const bool vec = ((D & 3) == 0) && ((((uintptr_t)bank) & 15) == 0) && ((((uintptr_t)q) & 15) == 0);
-  for (int64_t row = blockIdx.x; row < N; row += gridDim.x) {
+  for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+    const unsigned* bits = reinterpret_cast<const unsigned*>(dist + row * M);
     __syncthreads();
-    for (int64_t i = tid; i < D; i += 256) qs[i] = q[row * D + i];
-    __syncthreads();
-    distances_to_bank(qs, bank, dist, M, D, vec);
-    __threadfence_block();
-    __syncthreads();
-    // radix select of the k-th smallest (1-based) among dist[0..M)
     if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)k; }
-    const unsigned* bits = reinterpret_cast<const unsigned*>(dist);
     for (int pass = 3; pass >= 0; --pass) {
       hist[tid] = 0u;
       __syncthreads();
@@ -132,39 +194,57 @@ __global__ __launch_bounds__(256) void kde_kernel(const double* __restrict__ tra
   }
 }
 
+constexpr int64_t kQueryChunk = 8192;  // query rows per distance-workspace pass
+
 }  // namespace
 
 extern "C" size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {
   (void)D; (void)k;
   if (N <= 0 || M <= 0) return 0;
-  const int64_t slots = N < 1024 ? N : 1024;  // one distance row per resident workgroup
-  return (size_t)(slots * M) * sizeof(float);
+  const int64_t qc = N < kQueryChunk ? N : kQueryChunk;
+  // distance tile rows + |q|^2 for one chunk + |b|^2
+  return (size_t)(qc * M + qc + M) * sizeof(float);
 }
 
 extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score, void* workspace,
                                  size_t workspace_bytes, int64_t N, int64_t M, int64_t D, int k,
                                  runia_stream_t stream) {
-  if (N < 0 || M < 0 || D <= 0 || k < 1 || (N > 0 && (!q || !score)) || (M > 0 && !bank)) return RUNIA_E_INVALID;
+  if (N < 0 || M < 0 || D <= 0 || k < 1) return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
+  if (!q || !score || (M > 0 && !bank)) return RUNIA_E_INVALID;
   hipStream_t s = as_stream(stream);
   if (k > M) {  // faiss fills missing neighbours with FLT_MAX
     fill_kernel<<<runia_stream_grid(N, 256), 256, 0, s>>>(score, N, -kFltMax);
     return runia_check_launch();
   }
-  int64_t slots = (int64_t)(workspace_bytes / ((size_t)M * sizeof(float)));
-  if (!workspace || slots < 1) return RUNIA_E_WORKSPACE;
-  if (slots > N) slots = N;
-  if (slots > 1024) slots = 1024;
-  const size_t shmem = (size_t)((D + 3) / 4 * 4) * sizeof(float);
-  if (shmem > 64 * 1024) return RUNIA_E_INVALID;
-  knn_kth_kernel<<<(unsigned)slots, 256, shmem, s>>>(q, bank, score, reinterpret_cast<float*>(workspace), N, M, D, k);
-  return runia_check_launch();
+  if (!workspace || workspace_bytes < (size_t)(2 * M + 1) * sizeof(float)) return RUNIA_E_WORKSPACE;
+  int64_t qc = (int64_t)((workspace_bytes / sizeof(float) - (size_t)M) / (size_t)(M + 1));
+  if (qc < 1) return RUNIA_E_WORKSPACE;
+  if (qc > N) qc = N;
+  if (qc > kQueryChunk) qc = kQueryChunk;
+  float* dist = reinterpret_cast<float*>(workspace);
+  float* qn = dist + qc * M;
+  float* bn = qn + qc;
+  row_sqnorm_kernel<<<runia_stream_grid(M, 4), 256, 0, s>>>(bank, bn, M, D);
+  int rc = runia_check_launch();
+  if (rc != RUNIA_OK) return rc;
+  for (int64_t r0 = 0; r0 < N; r0 += qc) {
+    const int64_t rows = (N - r0 < qc) ? (N - r0) : qc;
+    row_sqnorm_kernel<<<runia_stream_grid(rows, 4), 256, 0, s>>>(q + r0 * D, qn, rows, D);
+    dim3 grid((unsigned)((M + TB - 1) / TB), (unsigned)((rows + TQ - 1) / TQ));
+    knn_dist_kernel<<<grid, 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D);
+    kth_select_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(dist, score + r0, rows, M, k);
+    rc = runia_check_launch();
+    if (rc != RUNIA_OK) return rc;
+  }
+  return RUNIA_OK;
 }
 
 extern "C" int runia_kde_score_f64(const double* train, const double* x, double* score, int64_t M, int64_t N,
                                    int64_t D, double bandwidth, runia_stream_t stream) {
-  if (M <= 0 || N < 0 || D <= 0 || !(bandwidth > 0.0) || !train || (N > 0 && (!x || !score))) return RUNIA_E_INVALID;
+  if (M <= 0 || N < 0 || D <= 0 || !(bandwidth > 0.0)) return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
+  if (!train || !x || !score) return RUNIA_E_INVALID;
   const size_t shmem = (size_t)D * sizeof(double);
   if (shmem > 64 * 1024) return RUNIA_E_INVALID;
   const double log_norm = -log((double)M) - (double)D * log(bandwidth) - 0.5 * (double)D * log(2.0 * M_PI);
