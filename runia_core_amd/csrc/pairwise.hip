@@ -112,16 +112,27 @@ __global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__
     }
 }
 
-// k-th smallest (1-based) of each row of dist [Q, M]: 4-pass 8-bit radix select, one workgroup per row
-__global__ __launch_bounds__(256) void kth_select_kernel(const float* __restrict__ dist, float* __restrict__ score,
-                                                          int64_t Q, int64_t M, int k) {
+// k-th smallest (1-based) of each row of dist [Q, M]: 4-pass 8-bit radix select, one workgroup per row, followed
+// by an exact refinement.  The norm-expansion distances carry ~K*eps cancellation error (4e-6 at D = 2048), while
+// faiss's one-query path accumulates sum((q-b)^2) directly; so every bank row whose approximate distance lies within
+// +-kRefineDelta of the selected value is re-measured with exact f32 differences and the k-th order statistic is
+// re-taken among them (rows below the window keep their rank; a copied bank row gives exactly 0 again).
+constexpr float kRefineDelta = 2e-5f;
+constexpr int kMaxCand = 512;
+
+__global__ __launch_bounds__(256) void kth_select_kernel(const float* __restrict__ dist, const float* __restrict__ q,
+                                                          const float* __restrict__ bank, float* __restrict__ score,
+                                                          int64_t Q, int64_t M, int64_t D, int k) {
   __shared__ unsigned hist[256];
-  __shared__ unsigned sel_prefix, sel_rank;
-  const int tid = threadIdx.x;
+  __shared__ unsigned sel_prefix, sel_rank, n_below, n_cand;
+  __shared__ int cand_idx[kMaxCand];
+  __shared__ float cand_d[kMaxCand];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
-    const unsigned* bits = reinterpret_cast<const unsigned*>(dist + row * M);
+    const float* drow = dist + row * M;
+    const unsigned* bits = reinterpret_cast<const unsigned*>(drow);
     __syncthreads();
-    if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)k; }
+    if (tid == 0) { sel_prefix = 0u; sel_rank = (unsigned)k; n_below = 0u; n_cand = 0u; }
     for (int pass = 3; pass >= 0; --pass) {
       hist[tid] = 0u;
       __syncthreads();
@@ -145,7 +156,49 @@ __global__ __launch_bounds__(256) void kth_select_kernel(const float* __restrict
       }
       __syncthreads();
     }
-    if (tid == 0) score[row] = -__uint_as_float(sel_prefix);
+    const float approx = __uint_as_float(sel_prefix);
+    // ---- refinement window ----
+    const float lo = approx - kRefineDelta, hi = approx + kRefineDelta;
+    unsigned below = 0;
+    for (int64_t m = tid; m < M; m += 256) {
+      const float d = drow[m];
+      if (d < lo) {
+        ++below;
+      } else if (d <= hi) {
+        const unsigned slot = atomicAdd(&n_cand, 1u);
+        if (slot < (unsigned)kMaxCand) cand_idx[slot] = (int)m;
+      }
+    }
+    atomicAdd(&n_below, below);
+    __syncthreads();
+    const unsigned nc = n_cand;
+    if (nc > (unsigned)kMaxCand) {  // pathological tie cluster: keep the approximate value
+      if (tid == 0) score[row] = -approx;
+      continue;
+    }
+    const float* qr = q + row * D;
+    for (unsigned c = wave; c < nc; c += 4) {
+      const float* br = bank + (int64_t)cand_idx[c] * D;
+      float acc = 0.f;
+      for (int64_t i = lane; i < D; i += 64) {
+        const float df = qr[i] - br[i];
+        acc = fmaf(df, df, acc);
+      }
+      acc = wave_sum_f32(acc);
+      if (lane == 0) cand_d[c] = acc;
+    }
+    __syncthreads();
+    // the (k - n_below)-th smallest exact distance among the candidates (rank by counting; nc is tiny)
+    const int want = k - (int)n_below;  // 1-based, 1 <= want <= nc by construction of the window
+    for (unsigned c = tid; c < nc; c += 256) {
+      const float dc = cand_d[c];
+      int less = 0, leq = 0;
+      for (unsigned o = 0; o < nc; ++o) {
+        less += (cand_d[o] < dc);
+        leq += (cand_d[o] <= dc);
+      }
+      if (less < want && want <= leq) score[row] = -dc;  // all writers hold the same value
+    }
   }
 }
 
@@ -233,7 +286,8 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
     row_sqnorm_kernel<<<runia_stream_grid(rows, 4), 256, 0, s>>>(q + r0 * D, qn, rows, D);
     dim3 grid((unsigned)((M + TB - 1) / TB), (unsigned)((rows + TQ - 1) / TQ));
     knn_dist_kernel<<<grid, 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D);
-    kth_select_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(dist, score + r0, rows, M, k);
+    kth_select_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(dist, q + r0 * D, bank, score + r0, rows, M,
+                                                                           D, k);
     rc = runia_check_launch();
     if (rc != RUNIA_OK) return rc;
   }
