@@ -247,6 +247,72 @@ __global__ __launch_bounds__(256) void kde_kernel(const double* __restrict__ tra
   }
 }
 
+// Gaussian KDE for D <= 64 (the regime where the reference's tree evaluation is converged): one thread
+// owns one query with its D coordinates in registers; training rows are staged through LDS and read as broadcasts;
+// the four waves of a workgroup take a quarter of every staged tile each and merge their (max, sum) pairs at the end.
+// Per (query, train row): 2*D f64 ops + one f64 exp; logsumexp is kept online per group of 8 rows.
+template <int DP>
+__global__ __launch_bounds__(256) void kde_small_kernel(const double* __restrict__ train,
+                                                         const double* __restrict__ x, double* __restrict__ score,
+                                                         int64_t M, int64_t N, int D, double neg_half_inv_h2,
+                                                         double log_norm) {
+  constexpr int TM = 64;  // staged training rows
+  __shared__ double tile[TM][DP];
+  __shared__ double pm[4][64], ps[4][64];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int64_t qrow = (int64_t)blockIdx.x * 64 + lane;
+  double xq[DP];
+#pragma unroll
+  for (int i = 0; i < DP; ++i) xq[i] = (qrow < N && i < D) ? x[qrow * D + i] : 0.0;
+  double mx = -kInfD(), sum = 0.0;
+  for (int64_t t0 = 0; t0 < M; t0 += TM) {
+    __syncthreads();
+    for (int i = tid; i < TM * DP; i += 256) {
+      const int r = i / DP, c = i - r * DP;
+      tile[r][c] = (t0 + r < M && c < D) ? train[(t0 + r) * D + c] : 0.0;
+    }
+    __syncthreads();
+    const int rows = (int)((M - t0 < TM) ? (M - t0) : TM);
+#pragma unroll
+    for (int g = 0; g < TM / 4 / 8; ++g) {  // this wave's quarter, 8 rows at a time
+      const int r0 = wave * (TM / 4) + g * 8;
+      double v[8];
+      double gmax = -kInfD();
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        double acc = 0.0;
+#pragma unroll
+        for (int i = 0; i < DP; ++i) {
+          const double d = xq[i] - tile[r0 + j][i];
+          acc = fma(d, d, acc);
+        }
+        v[j] = (r0 + j < rows) ? acc * neg_half_inv_h2 : -kInfD();
+        gmax = fmax(gmax, v[j]);
+      }
+      if (gmax > -kInfD()) {
+        const double mnew = fmax(mx, gmax);
+        double part = 0.0;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) part += exp(v[j] - mnew);
+        sum = sum * exp(mx - mnew) + part;
+        mx = mnew;
+      }
+    }
+  }
+  pm[wave][lane] = mx;
+  ps[wave][lane] = sum;
+  __syncthreads();
+  if (wave == 0 && qrow < N) {
+    const double gm = fmax(fmax(pm[0][lane], pm[1][lane]), fmax(pm[2][lane], pm[3][lane]));
+    double gs = 0.0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w)
+      if (ps[w][lane] > 0.0) gs += ps[w][lane] * exp(pm[w][lane] - gm);
+    score[qrow] = log(gs) + gm + log_norm;
+  }
+}
+
 constexpr int64_t kQueryChunk = 8192;  // query rows per distance-workspace pass
 
 }  // namespace
@@ -299,10 +365,18 @@ extern "C" int runia_kde_score_f64(const double* train, const double* x, double*
   if (M <= 0 || N < 0 || D <= 0 || !(bandwidth > 0.0)) return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
   if (!train || !x || !score) return RUNIA_E_INVALID;
-  const size_t shmem = (size_t)D * sizeof(double);
-  if (shmem > 64 * 1024) return RUNIA_E_INVALID;
   const double log_norm = -log((double)M) - (double)D * log(bandwidth) - 0.5 * (double)D * log(2.0 * M_PI);
-  kde_kernel<<<runia_stream_grid(N, 1), 256, shmem, as_stream(stream)>>>(
-      train, x, score, M, N, D, -0.5 / (bandwidth * bandwidth), log_norm);
+  const double nh = -0.5 / (bandwidth * bandwidth);
+  hipStream_t s = as_stream(stream);
+  const unsigned qblocks = (unsigned)((N + 63) / 64);
+  if (D <= 8) kde_small_kernel<8><<<qblocks, 256, 0, s>>>(train, x, score, M, N, (int)D, nh, log_norm);
+  else if (D <= 16) kde_small_kernel<16><<<qblocks, 256, 0, s>>>(train, x, score, M, N, (int)D, nh, log_norm);
+  else if (D <= 32) kde_small_kernel<32><<<qblocks, 256, 0, s>>>(train, x, score, M, N, (int)D, nh, log_norm);
+  else if (D <= 64) kde_small_kernel<64><<<qblocks, 256, 0, s>>>(train, x, score, M, N, (int)D, nh, log_norm);
+  else {
+    const size_t shmem = (size_t)D * sizeof(double);
+    if (shmem > 64 * 1024) return RUNIA_E_INVALID;
+    kde_kernel<<<runia_stream_grid(N, 1), 256, shmem, s>>>(train, x, score, M, N, D, nh, log_norm);
+  }
   return runia_check_launch();
 }
