@@ -165,6 +165,17 @@ int runia_pca_md_score_f64(const double* h, const double* packed_ct, const doubl
                            double* score, double* y_out, int64_t N, int64_t D, int64_t n,
                            runia_stream_t stream);
 
+/* ---- f1  setup-time covariance on the device (SURVEY 8f "next #1") ----------- *
+ * Replaces np.cov(X.T, bias=1) inside sklearn EmpiricalCovariance.fit
+ * (inference/postprocessors.py:217-220, inference/funcs.py:62-66):
+ * mean [D] = column means, cov [D, D] = (X - mean)^T (X - mean) / N, f64 (f32 rows are promoted).
+ * x [N, D]; workspace from runia_covariance_workspace_bytes. */
+size_t runia_covariance_workspace_bytes(int64_t N, int64_t D);
+int runia_covariance_f64(const double* x, double* mean, double* cov, void* workspace,
+                         size_t workspace_bytes, int64_t N, int64_t D, runia_stream_t stream);
+int runia_covariance_f32in(const float* x, double* mean, double* cov, void* workspace,
+                           size_t workspace_bytes, int64_t N, int64_t D, runia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -64,6 +64,9 @@ _SIGNATURES = {
         [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_int,
          c_double, c_void_p],
     ),
+    "runia_covariance_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "runia_covariance_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
+    "runia_covariance_f32in": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
     "runia_pca_md_score_f64": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64,
@@ -400,3 +403,19 @@ def pca_md_score(h: torch.Tensor, packed_ct: Optional[torch.Tensor], bias: Optio
         "runia_pca_md_score_f64",
     )
     return (s, y) if want_projection else s
+
+
+def covariance(x: torch.Tensor):
+    """x [N, D] f64/f32 (device) -> (mean [D] f64, cov [D, D] f64) = np.cov(x.T, bias=1) with its column means."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.float64)
+    x = x.contiguous()
+    n, d = x.shape
+    mean = torch.empty((d,), dtype=torch.float64, device=x.device)
+    cov = torch.empty((d, d), dtype=torch.float64, device=x.device)
+    ws_bytes = lib.runia_covariance_workspace_bytes(n, d)
+    ws = torch.empty((max(ws_bytes, 8) // 8,), dtype=torch.float64, device=x.device)
+    fn = lib.runia_covariance_f32in if x.dtype == torch.float32 else lib.runia_covariance_f64
+    _check(fn(x.data_ptr(), mean.data_ptr(), cov.data_ptr(), ws.data_ptr(), ws_bytes, n, d, _stream()), "runia_covariance")
+    return mean, cov

@@ -11,7 +11,8 @@ from typing import Dict, Tuple
 import numpy as np
 import torch
 
-from .. import _hip
+from .. import _hip, config
+from ..device_fit import empirical_precision_device
 
 __all__ = ["mahalanobis_preprocess", "mahalanobis_postprocess", "normalizer", "MahalanobisState"]
 
@@ -34,8 +35,11 @@ def mahalanobis_preprocess(ind_data: Dict[str, np.ndarray], num_classes: int) ->
             class_mean.append(class_samples.mean(0))
         centered.append(class_samples - class_mean[c].reshape(1, -1))
     class_mean = np.stack(class_mean)
+    pooled = np.concatenate(centered).astype(np.float32)
+    if config.device_fit:
+        return class_mean, empirical_precision_device(pooled)
     estimator = EmpiricalCovariance(assume_centered=False)
-    estimator.fit(np.concatenate(centered).astype(np.float32))
+    estimator.fit(pooled)
     return class_mean, estimator.precision_
 
 

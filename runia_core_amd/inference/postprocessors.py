@@ -21,7 +21,8 @@ import numpy as np
 import torch
 from torch import Tensor
 
-from .. import _hip
+from .. import _hip, config
+from ..device_fit import empirical_precision_device
 from .abstract_classes import OodPostprocessor, Postprocessor
 from .funcs import MahalanobisState, _maha_dtype, mahalanobis_preprocess, normalizer
 
@@ -128,9 +129,12 @@ class MDLatentSpace(Postprocessor):
 
             self.feats_mean = np.mean(ind_train_data, 0, keepdims=True)
             self.centered_data = ind_train_data - self.feats_mean
-            estimator = EmpiricalCovariance(assume_centered=False)
-            estimator.fit(self.centered_data)
-            self.precision = estimator.precision_
+            if config.device_fit:
+                self.precision = empirical_precision_device(self.centered_data)
+            else:
+                estimator = EmpiricalCovariance(assume_centered=False)
+                estimator.fit(self.centered_data)
+                self.precision = estimator.precision_
             self._dev = None
             self._setup_flag = True
         else:

@@ -285,3 +285,34 @@ def test_pipeline_full_size_properties():
     h = pipe.entropy(z[: 32 * n_mc])
     h2 = pipe.entropy((z[: 32 * n_mc] * 2).contiguous())
     assert float((h2 - h - np.log(2.0)).abs().max()) < 1e-12
+
+
+def test_device_fit_matches_host_fit():
+    """SURVEY 8f #1: covariance on the f64 matrix cores + eigh/pinvh on the GPU vs the reference's host calls."""
+    from runia_core_amd import _hip, config
+    from runia_core_amd.device_fit import empirical_precision_device
+
+    rng = np.random.default_rng(3)
+    for n, d, dt in ((1000, 20, np.float64), (5000, 256, np.float64), (777, 96, np.float32), (300, 70, np.float64)):
+        x = (rng.standard_normal((n, d)) * (0.5 + rng.random(d)) + rng.standard_normal(d)).astype(dt)
+        mean, cov = _hip.covariance(torch.from_numpy(x).cuda())
+        assert rel_err(mean.cpu().numpy(), x.astype(np.float64).mean(0)) < 1e-13
+        assert rel_err(cov.cpu().numpy(), np.cov(x.astype(np.float64).T, bias=1)) < 1e-12
+        assert rel_err(empirical_precision_device(x), oracle.empirical_precision(x)) < 1e-8
+    # rank-deficient case of the reference's own unit test (10 samples x 32 dims): same pinvh cut-off
+    tr, _, _ = generate_test_data(seed=42)
+    te, _, _ = generate_test_data(seed=43)
+    g = load_npz("ref_md.npz")
+    config.device_fit = True
+    try:
+        md = MDLatentSpace()
+        md.setup(tr)
+        assert rel_err(md.precision, g["unit_precision"]) < 1e-8
+        assert rel_err(md.postprocess(te), g["unit_scores"]) < 1e-8
+        gm = load_npz("ref_mahalanobis.npz")
+        m = Mahalanobis(flip_sign=False, num_classes=7)
+        m.setup(gm["d96_train"], train_labels=gm["d96_labels"], valid_feats=gm["d96_train"][:100])
+        assert rel_err(m.precision, gm["d96_precision"]) < 1e-8
+        assert rel_err(m.postprocess(gm["d96_test"]), gm["d96_scores"]) < 1e-8
+    finally:
+        config.device_fit = False
