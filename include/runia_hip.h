@@ -176,6 +176,19 @@ int runia_covariance_f64(const double* x, double* mean, double* cov, void* works
 int runia_covariance_f32in(const float* x, double* mean, double* cov, void* workspace,
                            size_t workspace_bytes, int64_t N, int64_t D, runia_stream_t stream);
 
+/* ---- f4  remaining logits/features postprocessors (SURVEY 8f "next #4") ------- *
+ * runia_linear_f32: out [N, C] = min(x, clip_max) @ w.T + bias on the f32 matrix cores - the final linear layer
+ *   that ReAct / ASH / DICE re-apply to (transformed) features (inference/postprocessors.py:1193, 1441, 1466;
+ *   RouteDICE.forward inference/funcs.py:180-189 with the masked weight).  x [N, D], w [C, D] K-contiguous rows,
+ *   bias [C] or NULL, clip_max = +inf for no clipping.  Energy = runia_row_lse_msp_f32 on `out`.
+ * runia_ash_s_f32: ASH-S pruning + sharpening of 2-D activations (ash_s_linear_layer, inference/funcs.py:234-261).
+ * runia_gen_score_f32: generalized_entropy(softmax(logits), gamma, M) (inference/funcs.py:347-375). */
+int runia_linear_f32(const float* x, const float* w, const float* bias, float* out, int64_t N, int64_t D,
+                     int64_t C, float clip_max, runia_stream_t stream);
+int runia_ash_s_f32(const float* x, float* y, int64_t N, int64_t D, int percentile, runia_stream_t stream);
+int runia_gen_score_f32(const float* logits, float* score, int64_t N, int64_t C, int M, double gamma,
+                        runia_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -43,6 +43,15 @@ __all__ = [
     "binary_clf_curve",
     "auroc_fpr95_aupr",
     "larem_pipeline",
+    "ash_s_linear_layer",
+    "ash_s_defined",
+    "linear_energy",
+    "react_threshold",
+    "react_score",
+    "dice_masked_weight",
+    "dice_logits",
+    "generalized_entropy",
+    "gen_score",
     "FLT_MAX",
 ]
 
@@ -427,3 +436,87 @@ def larem_pipeline(z, n_mc, pca_components, pca_mean, pca_var, md_mean, md_preci
         h = kl_entropy_per_dim_vectorized(z, n_mc)
     y = pca_transform(h, pca_components, pca_mean, pca_var, whiten=True)
     return md_score(y, md_mean, md_precision), h
+
+
+# --------------------------------------------------------------------------
+# f4  remaining logits/features postprocessors (SURVEY 8f "next #4")
+# --------------------------------------------------------------------------
+def ash_s_linear_layer(x: np.ndarray, percentile: int = 85) -> np.ndarray:
+    """inference/funcs.py:234-261: keep the top-k entries per row (k = n - round(n*p/100)), zero the rest,
+    scale by exp(sum(row) / sum(kept))."""
+    assert x.ndim == 2 and 0 <= percentile <= 100
+    s1 = x.sum(axis=1)
+    n = x.shape[1]
+    k = n - int(np.round(n * percentile / 100.0))
+    idx = np.argpartition(x, -k)[:, -k:]
+    top_k = np.partition(x, -k)[:, -k:]
+    scattered = np.zeros_like(x)
+    np.put_along_axis(scattered, indices=idx, values=top_k, axis=1)
+    s2 = scattered.sum(axis=1)
+    return scattered * np.exp((s1 / s2)[:, None])
+
+
+def ash_s_defined(x: np.ndarray, percentile: int = 85) -> np.ndarray:
+    """ASH-S as defined (each kept activation stays at its own index).  The reference scatters the VALUES of
+    ``np.partition`` at the INDICES of ``np.argpartition``; the two selections agree only as sets, so its kept
+    values can come out permuted within a row (observed with numpy 2.2 at D = 300) - an implementation artefact
+    that no other implementation can reproduce.  Rows where the reference is self-consistent equal this function."""
+    assert x.ndim == 2 and 0 <= percentile <= 100
+    n = x.shape[1]
+    k = n - int(np.round(n * percentile / 100.0))
+    if k == 0:
+        k = n
+    kth = np.partition(x, -k, axis=1)[:, -k][:, None]
+    out = np.zeros_like(x)
+    for r in range(x.shape[0]):
+        gt = np.flatnonzero(x[r] > kth[r, 0])
+        eq = np.flatnonzero(x[r] == kth[r, 0])[: k - gt.size]  # ties at the threshold: lowest indices first
+        keep = np.concatenate([gt, eq])
+        out[r, keep] = x[r, keep]
+    s1 = x.sum(axis=1)
+    s2 = out.sum(axis=1)
+    return out * np.exp((s1 / s2)[:, None])
+
+
+def linear_energy(x: np.ndarray, w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """logsumexp(x @ w.T + b, axis=1) (inference/postprocessors.py:1193-1194, 1441-1442)."""
+    return logsumexp(np.matmul(x, w.T) + b, axis=1)
+
+
+def react_threshold(train_feats: np.ndarray, percentile: int) -> float:
+    """inference/postprocessors.py:1437."""
+    return np.percentile(train_feats.flatten(), percentile)
+
+
+def react_score(feats: np.ndarray, w, b, threshold) -> np.ndarray:
+    """inference/postprocessors.py:1465-1467 (clip is done in the feature dtype, as numpy==1.26 does)."""
+    thr = np.asarray(threshold).astype(feats.dtype)
+    return linear_energy(feats.clip(max=thr), w, b)
+
+
+def dice_masked_weight(train_feats: np.ndarray, w: np.ndarray, p: int) -> np.ndarray:
+    """RouteDICE.calculate_mask_weight (inference/funcs.py:173-181) with info = mean feature vector
+    (inference/postprocessors.py:1288): weights whose contribution info*w is <= the p-th percentile are zeroed."""
+    import torch
+
+    info = torch.Tensor(train_feats).mean(0).numpy()
+    contrib = info[None, :] * w
+    thresh = np.percentile(contrib, p)
+    return (w * (contrib > thresh).astype(np.float32)).astype(np.float32)
+
+
+def dice_logits(x: np.ndarray, masked_w: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """RouteDICE.forward (inference/funcs.py:183-190): vote = x[:, None, :] * masked_w; vote.sum(2) + bias, f32."""
+    x = np.asarray(x, dtype=np.float32)
+    return (x[:, None, :] * masked_w[None]).sum(axis=2, dtype=np.float32) + b
+
+
+def generalized_entropy(probs: np.ndarray, gamma: float, M: int) -> np.ndarray:
+    """inference/funcs.py:347-375."""
+    probs_sorted = np.sort(probs, axis=1)[:, -M:]
+    return -np.sum(probs_sorted**gamma * (1 - probs_sorted) ** gamma, axis=1)
+
+
+def gen_score(logits: np.ndarray, gamma: float, M: int) -> np.ndarray:
+    """GEN.postprocess (inference/postprocessors.py:688-689)."""
+    return generalized_entropy(softmax(logits, axis=1), gamma, M)

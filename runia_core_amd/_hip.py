@@ -8,7 +8,7 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_int, c_int64, c_size_t, c_void_p
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
 from typing import Optional
 
 import numpy as np
@@ -64,6 +64,9 @@ _SIGNATURES = {
         [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_int,
          c_double, c_void_p],
     ),
+    "runia_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
+    "runia_ash_s_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
+    "runia_gen_score_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
     "runia_covariance_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "runia_covariance_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
     "runia_covariance_f32in": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
@@ -419,3 +422,38 @@ def covariance(x: torch.Tensor):
     fn = lib.runia_covariance_f32in if x.dtype == torch.float32 else lib.runia_covariance_f64
     _check(fn(x.data_ptr(), mean.data_ptr(), cov.data_ptr(), ws.data_ptr(), ws_bytes, n, d, _stream()), "runia_covariance")
     return mean, cov
+
+
+def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], clip_max: float = float("inf")) -> torch.Tensor:
+    """logits [N, C] = min(x, clip_max) @ w.T + bias  (x [N, D], w [C, D], all f32 on the device)."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and w.is_cuda and x.dtype == torch.float32 and w.dtype == torch.float32 and x.shape[1] == w.shape[1]
+    x, w = x.contiguous(), w.contiguous()
+    n, d = x.shape
+    c = w.shape[0]
+    out = torch.empty((n, c), dtype=torch.float32, device=x.device)
+    _check(lib.runia_linear_f32(x.data_ptr(), w.data_ptr(), _ptr(bias), out.data_ptr(), n, d, c, float(clip_max), _stream()),
+           "runia_linear_f32")
+    return out
+
+
+def ash_s(x: torch.Tensor, percentile: int) -> torch.Tensor:
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+    x = x.contiguous()
+    y = torch.empty_like(x)
+    _check(lib.runia_ash_s_f32(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], int(percentile), _stream()), "runia_ash_s_f32")
+    return y
+
+
+def gen_score(logits: torch.Tensor, gamma: float, m: int) -> torch.Tensor:
+    lib = load_library()
+    require_gpu()
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2
+    logits = logits.contiguous()
+    s = torch.empty((logits.shape[0],), dtype=torch.float32, device=logits.device)
+    _check(lib.runia_gen_score_f32(logits.data_ptr(), s.data_ptr(), logits.shape[0], logits.shape[1], int(m), float(gamma), _stream()),
+           "runia_gen_score_f32")
+    return s

@@ -35,7 +35,8 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict
 
 // stage a [rows x 32] K-chunk of a K-contiguous matrix into LDS (zero filled outside the matrix)
 __device__ __forceinline__ void stage_chunk(const float* __restrict__ src, int64_t row0, int64_t nrows, int64_t D,
-                                            int64_t k0, float (*dst)[KP], int tid, bool vec) {
+                                            int64_t k0, float (*dst)[KP], int tid, bool vec,
+                                            float clip_max = INFINITY) {
   const int row = tid >> 1, half = tid & 1;  // 128 rows x 2 halves of 16 floats
   const int64_t gr = row0 + row;
   const float* p = src + gr * D + k0 + half * 16;
@@ -52,12 +53,19 @@ __device__ __forceinline__ void stage_chunk(const float* __restrict__ src, int64
   }
 #pragma unroll
   for (int j = 0; j < 8; ++j)
-    *reinterpret_cast<float2*>(&dst[row][half * 16 + 2 * j]) = make_float2(v[2 * j], v[2 * j + 1]);
+    *reinterpret_cast<float2*>(&dst[row][half * 16 + 2 * j]) =
+        make_float2(fminf(v[2 * j], clip_max), fminf(v[2 * j + 1], clip_max));
 }
 
+// EPI_DIST  : out[q, m] = max(0, |q|^2 + |b_m|^2 - 2 q.b_m)                  (kNN distances; qn = |q|^2, bn = |b|^2)
+// EPI_LINEAR: out[q, m] = min(x_q, clip).w_m + bias_m                          (final linear layer; bn = bias, qn unused)
+enum NtEpilogue { EPI_DIST = 0, EPI_LINEAR = 1 };
+
+template <int EPI>
 __global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__ q, const float* __restrict__ bank,
                                                         const float* __restrict__ qn, const float* __restrict__ bn,
-                                                        float* __restrict__ dist, int64_t Q, int64_t M, int64_t D) {
+                                                        float* __restrict__ dist, int64_t Q, int64_t M, int64_t D,
+                                                        float clip_max) {
   __shared__ __attribute__((aligned(16))) float As[TQ][KP];
   __shared__ __attribute__((aligned(16))) float Bs[TB][KP];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -75,7 +83,7 @@ __global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
   for (int64_t k0 = 0; k0 < D; k0 += KCH) {
     __syncthreads();
-    stage_chunk(q, q0, Q, D, k0, As, tid, vec);
+    stage_chunk(q, q0, Q, D, k0, As, tid, vec, EPI == EPI_LINEAR ? clip_max : INFINITY);
     stage_chunk(bank, m0, M, D, k0, Bs, tid, vec);
     __syncthreads();
 #pragma unroll
@@ -100,13 +108,17 @@ __global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__
 #pragma unroll
     for (int b = 0; b < 2; ++b) {
       const int64_t col = m0 + wb * 64 + b * 32 + li;
-      const float bnv = (col < M) ? bn[col] : 0.f;
+      const float bnv = (col < M && bn) ? bn[col] : 0.f;
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int64_t row = q0 + wq * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
         if (row < Q && col < M) {
-          const float d = (qn[row] + bnv) - 2.0f * acc[a][b][r];
-          dist[row * M + col] = fmaxf(d, 0.f);
+          if constexpr (EPI == EPI_DIST) {
+            const float d = (qn[row] + bnv) - 2.0f * acc[a][b][r];
+            dist[row * M + col] = fmaxf(d, 0.f);
+          } else {
+            dist[row * M + col] = acc[a][b][r] + bnv;
+          }
         }
       }
     }
@@ -351,13 +363,30 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
     const int64_t rows = (N - r0 < qc) ? (N - r0) : qc;
     row_sqnorm_kernel<<<runia_stream_grid(rows, 4), 256, 0, s>>>(q + r0 * D, qn, rows, D);
     dim3 grid((unsigned)((M + TB - 1) / TB), (unsigned)((rows + TQ - 1) / TQ));
-    knn_dist_kernel<<<grid, 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D);
+    knn_dist_kernel<EPI_DIST><<<grid, 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D, INFINITY);
     kth_select_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(dist, q + r0 * D, bank, score + r0, rows, M,
                                                                            D, k);
     rc = runia_check_launch();
     if (rc != RUNIA_OK) return rc;
   }
   return RUNIA_OK;
+}
+
+extern "C" int runia_linear_f32(const float* x, const float* w, const float* bias, float* out, int64_t N, int64_t D,
+                                int64_t C, float clip_max, runia_stream_t stream) {
+  if (N < 0 || D <= 0 || C <= 0) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!x || !w || !out) return RUNIA_E_INVALID;
+  const int64_t qt = (N + TQ - 1) / TQ;
+  hipStream_t s = as_stream(stream);
+  for (int64_t t0 = 0; t0 < qt; t0 += 65535) {  // grid.y limit
+    const int64_t tiles = (qt - t0 < 65535) ? (qt - t0) : 65535;
+    const int64_t r0 = t0 * TQ;
+    const int64_t rows = (N - r0 < tiles * TQ) ? (N - r0) : tiles * TQ;
+    dim3 grid((unsigned)((C + TB - 1) / TB), (unsigned)tiles);
+    knn_dist_kernel<EPI_LINEAR><<<grid, 256, 0, s>>>(x + r0 * D, w, nullptr, bias, out + r0 * C, rows, C, D, clip_max);
+  }
+  return runia_check_launch();
 }
 
 extern "C" int runia_kde_score_f64(const double* train, const double* x, double* score, int64_t M, int64_t N,

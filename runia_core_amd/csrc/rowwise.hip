@@ -135,6 +135,141 @@ __global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restri
   }
 }
 
+
+// ---- per-row order statistics in registers (ASH-S pruning, GEN top-M) -------------------------------------
+// One wave owns one row; lane l holds elements l, l+64, ...  The k-th largest value is found by a 32-step binary
+// search on the order-preserving integer image of the floats (count(key >= candidate) via per-lane counts and a
+// wave reduction) - no sort, no LDS.
+__device__ __forceinline__ unsigned sort_key(float x) {
+  const unsigned u = __float_as_uint(x);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending in x
+}
+
+template <int NV>
+__device__ __forceinline__ unsigned kth_largest_key(const unsigned (&key)[NV], int k) {
+  unsigned prefix = 0u;
+#pragma unroll 1
+  for (int bit = 31; bit >= 0; --bit) {
+    const unsigned cand = prefix | (1u << bit);
+    int cnt = 0;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) cnt += (key[t] >= cand);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) cnt += __shfl_xor(cnt, o, 64);
+    if (cnt >= k) prefix = cand;
+  }
+  return prefix;  // key of the k-th largest element
+}
+
+// ASH-S for 2-D activations (reference inference/funcs.py:234-261): keep the k = n - round(n*p/100) largest entries
+// of each row, zero the rest, multiply by exp(sum(row) / sum(kept)).  Ties at the threshold are kept in index order.
+template <int NV>
+__global__ __launch_bounds__(256) void ash_s_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t N,
+                                                     int D, int k) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+    const float* p = x + row * D;
+    float v[NV];
+    unsigned key[NV];
+    float s1 = 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      const int j = lane + 64 * t;
+      v[t] = (j < D) ? p[j] : 0.f;
+      key[t] = (j < D) ? sort_key(v[t]) : 0u;  // padding sorts below every real value
+      s1 += v[t];
+    }
+    s1 = wave_sum_f32(s1);
+    float s2 = 0.f;
+    if (k > 0) {
+      const unsigned thr = kth_largest_key<NV>(key, k);
+      int gt = 0;
+#pragma unroll
+      for (int t = 0; t < NV; ++t) gt += (key[t] > thr);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) gt += __shfl_xor(gt, o, 64);
+      int ties_left = k - gt;  // how many elements equal to the threshold are kept (index order)
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        const bool tie = (key[t] == thr) && (lane + 64 * t < D);
+        const unsigned long long m = __ballot(tie);
+        const int rank = __popcll(m & ((1ull << lane) - 1ull));
+        const bool keep = (key[t] > thr) || (tie && rank < ties_left);
+        ties_left -= __popcll(m);
+        v[t] = keep ? v[t] : 0.f;
+        s2 += v[t];
+      }
+      s2 = wave_sum_f32(s2);
+    } else {
+#pragma unroll
+      for (int t = 0; t < NV; ++t) v[t] = 0.f;
+    }
+    const float sc = expf(s1 / s2);
+    float* q = y + row * D;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      const int j = lane + 64 * t;
+      if (j < D) q[j] = v[t] * sc;
+    }
+  }
+}
+
+// GEN (reference inference/funcs.py:347-375 on softmax(logits)): -sum over the M largest probabilities of
+// p^gamma * (1-p)^gamma, f32.
+template <int NV>
+__global__ __launch_bounds__(256) void gen_kernel(const float* __restrict__ logits, float* __restrict__ score,
+                                                   int64_t N, int C, int M, float gamma) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+    const float* p = logits + row * C;
+    float v[NV];
+    float m = -INFINITY;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      const int j = lane + 64 * t;
+      v[t] = (j < C) ? p[j] : -INFINITY;
+      m = fmaxf(m, v[t]);
+    }
+    m = wave_max_f32(m);
+    float s = 0.f;
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      v[t] = expf(v[t] - m);  // padding -> 0
+      s += v[t];
+    }
+    s = wave_sum_f32(s);
+    unsigned key[NV];
+#pragma unroll
+    for (int t = 0; t < NV; ++t) {
+      v[t] = v[t] / s;  // softmax probability
+      key[t] = (lane + 64 * t < C) ? (__float_as_uint(v[t]) | 0x80000000u) : 0u;  // p >= 0
+    }
+    float acc = 0.f;
+    if (M >= C) {
+#pragma unroll
+      for (int t = 0; t < NV; ++t)
+        if (lane + 64 * t < C) acc += powf(v[t], gamma) * powf(1.0f - v[t], gamma);
+      acc = wave_sum_f32(acc);
+    } else {
+      const unsigned thr = kth_largest_key<NV>(key, M);
+      int gt = 0;
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        if (key[t] > thr) {
+          acc += powf(v[t], gamma) * powf(1.0f - v[t], gamma);
+          ++gt;
+        }
+      }
+      acc = wave_sum_f32(acc);
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) gt += __shfl_xor(gt, o, 64);
+      const float pt = __uint_as_float(thr & 0x7fffffffu);
+      acc += (float)(M - gt) * (powf(pt, gamma) * powf(1.0f - pt, gamma));
+    }
+    if (lane == 0) score[row] = -acc;
+  }
+}
+
 }  // namespace
 
 extern "C" int runia_row_lse_msp_f32(const float* logits, float* lse, float* msp, int64_t N, int64_t C,
@@ -168,5 +303,38 @@ extern "C" int runia_l2_normalize_f32(const float* x, float* y, int64_t N, int64
   if (N < 0 || D <= 0 || (N > 0 && (!x || !y))) return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
   l2_normalize_kernel<<<runia_stream_grid(N, 4), 256, 0, as_stream(stream)>>>(x, y, N, D);
+  return runia_check_launch();
+}
+
+extern "C" int runia_ash_s_f32(const float* x, float* y, int64_t N, int64_t D, int percentile,
+                               runia_stream_t stream) {
+  if (N < 0 || D <= 0 || D > 4096 || percentile < 0 || percentile > 100) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!x || !y) return RUNIA_E_INVALID;
+  // k = n - int(np.round(n * percentile / 100.0))   (round half to even, as NumPy)
+  const double frac = (double)D * (double)percentile / 100.0;
+  int k = (int)D - (int)nearbyint(frac);
+  if (k == 0) k = (int)D;  // NumPy: x[:, -0:] is the whole row, i.e. nothing is pruned at percentile 100
+  const unsigned grid = runia_stream_grid(N, 4);
+  hipStream_t s = as_stream(stream);
+  if (D <= 512) ash_s_kernel<8><<<grid, 256, 0, s>>>(x, y, N, (int)D, k);
+  else if (D <= 1024) ash_s_kernel<16><<<grid, 256, 0, s>>>(x, y, N, (int)D, k);
+  else if (D <= 2048) ash_s_kernel<32><<<grid, 256, 0, s>>>(x, y, N, (int)D, k);
+  else ash_s_kernel<64><<<grid, 256, 0, s>>>(x, y, N, (int)D, k);
+  return runia_check_launch();
+}
+
+extern "C" int runia_gen_score_f32(const float* logits, float* score, int64_t N, int64_t C, int M, double gamma,
+                                   runia_stream_t stream) {
+  if (N < 0 || C <= 0 || C > 4096 || M < 1) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!logits || !score) return RUNIA_E_INVALID;
+  const unsigned grid = runia_stream_grid(N, 4);
+  hipStream_t s = as_stream(stream);
+  const float g = (float)gamma;
+  if (C <= 64) gen_kernel<1><<<grid, 256, 0, s>>>(logits, score, N, (int)C, M, g);
+  else if (C <= 256) gen_kernel<4><<<grid, 256, 0, s>>>(logits, score, N, (int)C, M, g);
+  else if (C <= 1024) gen_kernel<16><<<grid, 256, 0, s>>>(logits, score, N, (int)C, M, g);
+  else gen_kernel<64><<<grid, 256, 0, s>>>(logits, score, N, (int)C, M, g);
   return runia_check_launch();
 }

@@ -12,8 +12,13 @@ from .funcs import mahalanobis_postprocess, mahalanobis_preprocess, normalizer  
 from .image_level import LaRDInference, LaRExInference  # noqa: F401
 from .pipeline import LaREMPipeline  # noqa: F401
 from .postprocessors import (  # noqa: F401
+    ASH,
+    DICE,
+    GEN,
     KNN,
     MSP,
+    DICEReAct,
+    ReAct,
     DetectorKDE,
     Energy,
     FlatL2Bank,

@@ -360,3 +360,188 @@ class Mahalanobis(OodPostprocessor):
         if isinstance(test_data, Tensor):
             test_data = test_data.cpu().numpy()
         return self.flip_sign_fn(self._scores(test_data))
+
+
+# --------------------------------------------------------------------------------------
+# SURVEY 8f "next #4": linear-layer energy family (ReAct, ASH, DICE, DICE+ReAct) and GEN
+# --------------------------------------------------------------------------------------
+def _fc_params(kwargs, who: str):
+    assert "final_linear_layer_params" in kwargs, f"final_linear_layer_params must be provided for {who}"
+    assert "valid_feats" in kwargs, f"valid_feats must be provided for {who}"
+    w, b = kwargs["final_linear_layer_params"]["weight"], kwargs["final_linear_layer_params"]["bias"]
+    if isinstance(w, Tensor):
+        w = w.detach().cpu().numpy()
+    if isinstance(b, Tensor):
+        b = b.detach().cpu().numpy()
+    return w, b
+
+
+def _feats_to_device(x) -> Tensor:
+    if isinstance(x, Tensor):
+        x = x.detach()
+    return _hip.to_device(x, torch.float32)
+
+
+class _LinearEnergy(OodPostprocessor):
+    """``logsumexp(transform(x) @ W.T + b)`` on the GPU: f32 MFMA linear layer + the row LSE kernel."""
+
+    def _init_linear(self):
+        self.w = None
+        self.b = None
+        self._wd = None
+        self._bd = None
+
+    def _device_linear(self):
+        if self._wd is None:
+            self._wd = _hip.to_device(np.asarray(self._effective_weight(), dtype=np.float32), torch.float32)
+            self._bd = _hip.to_device(np.asarray(self.b, dtype=np.float32), torch.float32)
+        return self._wd, self._bd
+
+    def _effective_weight(self):
+        return self.w
+
+    def _clip(self) -> float:
+        return float("inf")
+
+    def _transform(self, x: Tensor) -> Tensor:
+        return x
+
+    def postprocess_device(self, feats: Tensor) -> Tensor:
+        w, b = self._device_linear()
+        logits = _hip.linear(self._transform(feats), w, b, self._clip())
+        lse, _ = _hip.row_lse_msp(logits, True, False)
+        return -lse if self.flip_sign else lse
+
+    def _scores(self, feats) -> np.ndarray:
+        w, b = self._device_linear()
+        logits = _hip.linear(self._transform(_feats_to_device(feats)), w, b, self._clip())
+        lse, _ = _hip.row_lse_msp(logits, True, False)
+        return lse.cpu().numpy()
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        assert self._setup_flag, "setup() must be called before postprocess()"
+        return self.flip_sign_fn(self._scores(test_data))
+
+
+@register_postprocessor("ash", postprocessor_input=["features"])
+class ASH(_LinearEnergy):
+    """ASH-S: prune each feature row to its top ``100 - ash_percentile`` %, sharpen, then energy of the logits."""
+
+    def __init__(self, flip_sign: bool, ash_percentile: int = 85, cfg=None):
+        super().__init__(flip_sign, cfg)
+        self.ash_percentile = ash_percentile
+        self._init_linear()
+
+    def _transform(self, x: Tensor) -> Tensor:
+        return _hip.ash_s(x, self.ash_percentile)
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs):
+        self.w, self.b = _fc_params(kwargs, "ASH")
+        self._wd = None
+        # the reference scores ind_train_data here (not valid_feats) to set the threshold
+        self.set_threshold(self.flip_sign_fn(self._scores(ind_train_data)))
+
+
+@register_postprocessor("react", postprocessor_input=["features"])
+class ReAct(_LinearEnergy):
+    """ReAct: clip activations at a percentile of the training features, then energy of the logits."""
+
+    def __init__(self, flip_sign: bool, react_percentile: int = 90, cfg=None):
+        super().__init__(flip_sign, cfg)
+        self.react_percentile = react_percentile
+        self.activation_threshold = None
+        self._init_linear()
+
+    def _clip(self) -> float:
+        return float(np.float32(self.activation_threshold))
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs):
+        self.w, self.b = _fc_params(kwargs, "ReAct")
+        self._wd = None
+        self.activation_threshold = np.percentile(np.asarray(ind_train_data).flatten(), self.react_percentile)
+        self.set_threshold(self.flip_sign_fn(self._scores(kwargs["valid_feats"])))
+
+
+class MaskedLinear:
+    """What ``RouteDICE`` holds after ``calculate_mask_weight``: the sparsified weight, the contributions and
+    their percentile threshold (attributes ``masked_w``, ``contrib``, ``thresh``, ``info``, ``p``)."""
+
+    def __init__(self, weight: np.ndarray, bias: np.ndarray, p: int, info: np.ndarray):
+        assert 0 < p < 100, "p must be greater than 0 and less than 100"
+        assert isinstance(info, np.ndarray), "info must be a numpy array or None"
+        self.p, self.info = p, info
+        self.weight, self.bias = np.asarray(weight, dtype=np.float32), np.asarray(bias, dtype=np.float32)
+        self.contrib = self.info[None, :] * self.weight
+        self.thresh = np.percentile(self.contrib, self.p)
+        self.masked_w = (self.weight * (self.contrib > self.thresh).astype(np.float32)).astype(np.float32)
+
+
+@register_postprocessor("dice", postprocessor_input=["features"])
+class DICE(_LinearEnergy):
+    """DICE: energy of the logits of a sparsified final layer (weights with low mean contribution removed)."""
+
+    def __init__(self, flip_sign: bool, dice_percentile: int = 90, num_classes: int = 10, cfg=None):
+        super().__init__(flip_sign, cfg)
+        self.dice_percentile = dice_percentile
+        self.num_classes = num_classes
+        self.dice_layer = None
+        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        self._init_linear()
+
+    def _effective_weight(self):
+        return self.dice_layer.masked_w
+
+    def _fit_layer(self, ind_train_data, kwargs, who):
+        self.w, self.b = _fc_params(kwargs, who)
+        self._wd = None
+        info = torch.Tensor(np.asarray(ind_train_data)).mean(0).numpy()  # f32 mean, as the reference's Tensor(...).mean(0)
+        self.dice_layer = MaskedLinear(self.w, self.b, self.dice_percentile, info)
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs):
+        self._fit_layer(ind_train_data, kwargs, "DICE")
+        self.set_threshold(self.flip_sign_fn(self._scores(kwargs["valid_feats"])))
+
+
+@register_postprocessor("dice_react", postprocessor_input=["features"])
+class DICEReAct(DICE):
+    """DICE on ReAct-clipped activations."""
+
+    def __init__(self, flip_sign: bool, dice_percentile: int = 90, react_percentile: int = 90, num_classes: int = 10,
+                 cfg=None):
+        super().__init__(flip_sign, dice_percentile, num_classes, cfg)
+        self.react_percentile = react_percentile
+        self.react_activation_threshold = None
+
+    def _clip(self) -> float:
+        return float(np.float32(self.react_activation_threshold))
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs):
+        self._fit_layer(ind_train_data, kwargs, "DICE")
+        self.react_activation_threshold = np.percentile(np.asarray(ind_train_data).flatten(), self.react_percentile)
+        self.set_threshold(self.flip_sign_fn(self._scores(kwargs["valid_feats"])))
+
+
+@register_postprocessor("gen", postprocessor_input=["logits"])
+class GEN(OodPostprocessor):
+    """Generalized entropy of the ``num_classes`` largest softmax probabilities (negated)."""
+
+    def __init__(self, flip_sign: bool, gamma: float, num_classes: int, cfg=None):
+        super().__init__(flip_sign, cfg)
+        self.gamma = gamma
+        self.num_classes = num_classes
+
+    def _scores(self, logits) -> np.ndarray:
+        if isinstance(logits, Tensor):
+            logits = logits.detach()
+        return _hip.gen_score(_hip.to_device(logits, torch.float32), self.gamma, self.num_classes).cpu().numpy()
+
+    def postprocess_device(self, logits: Tensor) -> Tensor:
+        s = _hip.gen_score(logits, self.gamma, self.num_classes)
+        return -s if self.flip_sign else s
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs):
+        self.set_threshold(self.flip_sign_fn(self._scores(ind_train_data)))
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        assert self._setup_flag, "setup() must be called before postprocess()"
+        return self.flip_sign_fn(self._scores(test_data))

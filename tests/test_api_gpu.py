@@ -316,3 +316,78 @@ def test_device_fit_matches_host_fit():
         assert rel_err(m.postprocess(gm["d96_test"]), gm["d96_scores"]) < 1e-8
     finally:
         config.device_fit = False
+
+
+def test_f4_kernels_and_classes(ref_vectors):
+    """ASH / ReAct / DICE / DICE+ReAct / GEN through the registry against the reference fixtures,
+    the reference's all-baselines goldens and the oracle."""
+    from runia_core_amd import _hip
+    from runia_core_amd.inference import ASH, DICE, GEN, DICEReAct, ReAct
+    from test_oracle_goldens import _fc_params, logsumexp_rows
+
+    g = load_npz("ref_f4.npz")
+    w, b, tr, va, te = g["w"], g["b"], g["train"], g["valid"], g["test"]
+    fc = {"weight": w, "bias": b}
+    dv = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()  # noqa: E731
+    # kernels
+    for pct in (90, 65, 100, 0):
+        got = _hip.ash_s(dv(te), pct).cpu().numpy()
+        exp = oracle.ash_s_defined(te.copy(), pct)
+        assert np.array_equal(got != 0, exp != 0) and np.allclose(got, exp, rtol=2e-6, atol=0), pct
+        if f"ash{pct}_transformed" in g:  # the reference itself: same kept positions; equal on its self-consistent rows
+            ref = g[f"ash{pct}_transformed"]
+            ok = np.all(np.isclose(ref, exp, rtol=1e-6), axis=1)
+            assert np.array_equal(got != 0, ref != 0) and np.allclose(got[ok], ref[ok], rtol=2e-6)
+    logits = _hip.linear(dv(te), dv(w), dv(b)).cpu().numpy()
+    assert rel_err(logits, te @ w.T + b) < 1e-5
+    assert rel_err(_hip.linear(dv(te), dv(w), dv(b), 0.7).cpu().numpy(), te.clip(max=np.float32(0.7)) @ w.T + b) < 1e-5
+    for M in (37, 10, 100, 1):
+        exp = g[f"gen{M}_scores"] if f"gen{M}_scores" in g else oracle.gen_score(g["logits_test"], 0.1, M)
+        assert rel_err(_hip.gen_score(dv(g["logits_test"]), 0.1, M).cpu().numpy(), exp) < 1e-5, M
+    big = (np.random.default_rng(2).standard_normal((300, 1000)) * 2).astype(np.float32)
+    for M in (1000, 100):
+        assert rel_err(_hip.gen_score(dv(big), 0.1, M).cpu().numpy(), oracle.gen_score(big, 0.1, M)) < 1e-5
+    # classes vs the by-path reference fixtures
+    for pct in (90, 65):
+        p = ASH(flip_sign=False, ash_percentile=pct)
+        p.setup(tr, valid_feats=va, final_linear_layer_params=fc)
+        s_dev = p.postprocess(te)
+        assert rel_err(s_dev, oracle.linear_energy(oracle.ash_s_defined(te.copy(), pct), w, b)) < 1e-5
+        ok = np.all(np.isclose(g[f"ash{pct}_transformed"], oracle.ash_s_defined(te.copy(), pct), rtol=1e-6), axis=1)
+        assert rel_err(s_dev[ok], g[f"ash{pct}_scores"][ok]) < 1e-5  # rows where the reference's scatter is consistent
+    p = ReAct(flip_sign=False, react_percentile=90)
+    p.setup(tr, valid_feats=va, final_linear_layer_params=fc)
+    assert p.activation_threshold == float(g["react_clip"])
+    assert rel_err(p.postprocess(te), g["react_scores"]) < 1e-5
+    assert np.array_equal(p.postprocess(torch.Tensor(te)), p.postprocess(te))
+    for M in (37, 10):
+        p = GEN(flip_sign=False, gamma=0.1, num_classes=M)
+        p.setup(g["logits_train"])
+        assert rel_err(p.postprocess(g["logits_test"]), g[f"gen{M}_scores"]) < 1e-5
+        assert abs(p.threshold - float(g[f"gen{M}_threshold"])) < 1e-4
+    p = DICE(flip_sign=False, dice_percentile=90, num_classes=37)
+    p.setup(tr, valid_feats=va, final_linear_layer_params=fc)
+    mw = oracle.dice_masked_weight(tr, w, 90)
+    assert np.array_equal(p.dice_layer.masked_w, mw)
+    assert rel_err(p.postprocess(te), logsumexp_rows(oracle.dice_logits(te, mw, b))) < 1e-5
+    # the reference's own goldens (tests/unit_test_baselines.py:255-268) through the harness calling convention
+    d = _all_baselines_inputs()
+    wf, bf = _fc_params()
+    fcp = {"weight": wf, "bias": bf}
+    sc = [s["value"] for s in ref_vectors["all_baselines_means"]["scalars"]]
+    kw = dict(ind_train_data=d["tr_f"], valid_feats=d["va_f"], final_linear_layer_params=fcp)
+    for cls, args, gold, tol in ((ASH, dict(ash_percentile=90), sc[3], 1e-3), (ReAct, dict(react_percentile=90), sc[5], 1e-5),
+                                 (DICE, dict(dice_percentile=90, num_classes=20), sc[6], 1e-5),
+                                 (DICEReAct, dict(dice_percentile=90, react_percentile=90, num_classes=20), sc[7], 1e-5)):
+        p = cls(flip_sign=False, **args)
+        p.setup(**kw)
+        assert abs(p.postprocess(test_data=d["ood_f"]).mean() - gold) < tol, cls.__name__
+    p = GEN(flip_sign=False, gamma=0.1, num_classes=20)
+    p.setup(ind_train_data=d["tr_l"])
+    assert abs(p.postprocess(test_data=d["ood_l"]).mean() - sc[4]) < 1e-5
+    with pytest.raises(AssertionError, match="final_linear_layer_params must be provided for ReAct"):
+        ReAct(flip_sign=False).setup(tr, valid_feats=va)
+    with pytest.raises(AssertionError, match="valid_feats must be provided for ASH"):
+        ASH(flip_sign=False).setup(tr, final_linear_layer_params=fc)
+    with pytest.raises(AssertionError, match=r"setup\(\) must be called"):
+        GEN(flip_sign=False, gamma=0.1, num_classes=5).postprocess(g["logits_test"])

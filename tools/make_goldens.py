@@ -217,6 +217,33 @@ def main():
     cases["d512_test_f32_transformed"] = dr.apply_pca_transform(xt.astype(np.float32), pca)
     np.savez_compressed(os.path.join(OUT, "ref_pca.npz"), **cases)
 
+    # ---------------- f4: GEN / ASH / ReAct (DICE needs .cuda() in the reference: pinned by its test golden) ----
+    cases = {}
+    C, D = 37, 300
+    w = (rng.standard_normal((C, D)) / np.sqrt(D)).astype(np.float32)
+    b = rng.standard_normal(C).astype(np.float32)
+    tr = np.maximum(rng.standard_normal((400, D)), 0).astype(np.float32)
+    va = np.maximum(rng.standard_normal((64, D)), 0).astype(np.float32)
+    te = np.maximum(rng.standard_normal((150, D)) * 1.3, 0).astype(np.float32)
+    fc = {"weight": w, "bias": b}
+    cases.update(w=w, b=b, train=tr, valid=va, test=te)
+    for pct in (90, 65):
+        p = pp.ASH(flip_sign=False, ash_percentile=pct)
+        p.setup(tr, valid_feats=va, final_linear_layer_params=fc)
+        cases[f"ash{pct}_scores"], cases[f"ash{pct}_threshold"] = p.postprocess(te), np.array(p.threshold)
+        cases[f"ash{pct}_transformed"] = funcs.ash_s_linear_layer(te.copy(), pct)
+    p = pp.ReAct(flip_sign=False, react_percentile=90)
+    p.setup(tr, valid_feats=va, final_linear_layer_params=fc)
+    cases["react_scores"], cases["react_threshold"], cases["react_clip"] = p.postprocess(te), np.array(p.threshold), np.array(p.activation_threshold)
+    logits_tr = (tr @ w.T + b).astype(np.float32)
+    logits_te = (te @ w.T + b).astype(np.float32)
+    cases.update(logits_train=logits_tr, logits_test=logits_te)
+    for M in (37, 10, 100):
+        p = pp.GEN(flip_sign=False, gamma=0.1, num_classes=M)
+        p.setup(logits_tr)
+        cases[f"gen{M}_scores"], cases[f"gen{M}_threshold"] = p.postprocess(logits_te), np.array(p.threshold)
+    np.savez_compressed(os.path.join(OUT, "ref_f4.npz"), **cases)
+
     # ---------------- thresholds -------------------------------------------------
     sc = rng.standard_normal(1000) * 3 - 7
     np.savez_compressed(
