@@ -26,6 +26,7 @@ from .postprocessors import (  # noqa: F401
     KNNLatentSpace,
     Mahalanobis,
     MDLatentSpace,
+    cMDLatentSpace,
     postprocessor_input_dict,
     postprocessors_dict,
     register_postprocessor,

@@ -164,6 +164,72 @@ class MDLatentSpace(Postprocessor):
         return self.postprocess_device(x).cpu().numpy()
 
 
+@register_postprocessor("cMD", postprocessor_input=["latent_space_means"])
+class cMDLatentSpace(Postprocessor):
+    """LaREM with class-conditional means: max over classes of ``-(x - mu_c) P (x - mu_c)^T`` with one pooled
+    precision matrix (float32 arithmetic in the reference, float32 scores)."""
+
+    def __init__(self, cfg=None):
+        super().__init__(cfg)
+        try:
+            self.num_classes = cfg.num_classes
+        except AttributeError:
+            self.num_classes = 10
+        self.feats_mean = None
+        self.precision = None
+        self.class_mean = None
+        self._state = None
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs) -> None:
+        try:
+            ind_train_labels = kwargs["ind_train_labels"]
+            if isinstance(ind_train_labels, np.ndarray):
+                ind_train_labels = Tensor(ind_train_labels)
+        except KeyError:
+            raise ValueError("id_labels not provided. Pass ID train labels as 'ind_train_labels' argument.")
+        if isinstance(ind_train_data, np.ndarray):
+            ind_train_data = Tensor(ind_train_data)
+        assert ind_train_data.ndim == 2, "ind_feats must be 2 dimensional"
+        if not self._setup_flag:
+            from sklearn.covariance import EmpiricalCovariance
+
+            self.class_mean = []
+            centered_data = []
+            for c in range(self.num_classes):
+                class_samples = ind_train_data[ind_train_labels.eq(c)].data
+                if len(class_samples) == 0:
+                    warnings.warn(f"No examples for class {c} to build class-wise Mahalanobis Distance score")
+                self.class_mean.append(class_samples.mean(0))
+                centered_data.append(class_samples - self.class_mean[c].view(1, -1))
+            self.class_mean = torch.stack(self.class_mean)
+            pooled = torch.cat(centered_data).cpu().numpy().astype(np.float32)
+            if config.device_fit:
+                precision = empirical_precision_device(pooled)
+            else:
+                precision = EmpiricalCovariance(assume_centered=False).fit(pooled).precision_
+            self.precision = torch.from_numpy(precision).float()
+            self._state = None
+            self._setup_flag = True
+        else:
+            warnings.warn("cMDPostprocessor already trained")
+
+    def postprocess_device(self, test_data: Tensor) -> Tensor:
+        if self._state is None:
+            # the f32 precision the reference multiplies with, widened exactly; the quadratic form itself runs in f64
+            self._state = MahalanobisState(self.class_mean.numpy(), self.precision.double().numpy())
+        return self._state.score_device(test_data.to(torch.float32)).to(torch.float32)
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        try:
+            kwargs["pred_labels"]  # required by the reference's signature, not used by its arithmetic
+        except KeyError:
+            raise ValueError("pred_logits not provided")
+        if isinstance(test_data, np.ndarray):
+            test_data = Tensor(test_data)
+        assert test_data.ndim == 2, "test_feats must be 2 dimensional"
+        return self.postprocess_device(_hip.to_device(test_data, torch.float32)).cpu().numpy()
+
+
 @register_postprocessor("KNN", postprocessor_input=["latent_space_means"])
 class KNNLatentSpace(Postprocessor):
     """k-th nearest-neighbour distance score on L2-normalised latent representations."""
