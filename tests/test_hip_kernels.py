@@ -373,3 +373,37 @@ def test_pca_md_fused_equals_unfused(hip, n_rows, d, n, pca):
         s = hip.pca_md_score(dev(h, torch.float64), None, None, None, dev(md_mean, torch.float64), packed_p, n)
         y_ref = h
     assert rel_err(s.cpu().numpy(), oracle.md_score(y_ref, md_mean.reshape(1, -1), prec)) < 1e-11
+
+
+# ---------------- edge cases: empty and single-row inputs through every entry point --------------------------
+def test_empty_and_single_row_inputs(hip):
+    e = lambda *shape, dt=torch.float32: torch.empty(shape, dtype=dt, device="cuda")  # noqa: E731
+    r = lambda *shape, dt=torch.float32: torch.rand(shape, dtype=dt, device="cuda")  # noqa: E731
+    assert hip.kl_entropy_per_dim(e(0, 8), 4, 3).shape == (0, 8)
+    assert hip.kl_entropy_joint(e(0, 8), 4, 3).shape == (0,)
+    assert hip.mc_stack(e(0, 8, 4, 4), e(0, 4, 4, 4), 4, 0.5, 2).shape == (0, 8)
+    assert hip.mc_entropy(e(0, 8, 4, 4), e(0, 16, 4, 4), 16, 0.5, 2, 5).shape == (0, 8)
+    assert hip.l2_normalize(e(0, 8)).shape == (0, 8)
+    assert hip.knn_kth(e(0, 8), r(5, 8), 2).shape == (0,)
+    assert hip.kde_score(r(5, 3, dt=torch.float64), e(0, 3, dt=torch.float64)).shape == (0,)
+    assert hip.gen_score(e(0, 7), 0.1, 3).shape == (0,)
+    assert hip.ash_s(e(0, 7), 50).shape == (0, 7)
+    assert hip.linear(e(0, 7), r(3, 7), r(3)).shape == (0, 3)
+    p = hip.pack_weights(r(8, 4, dt=torch.float64))
+    assert hip.pca_transform(e(0, 8, dt=torch.float64), p, r(4, dt=torch.float64), r(4, dt=torch.float64), 4).shape == (0, 4)
+    pp = hip.pack_weights(torch.eye(4, dtype=torch.float64, device="cuda"))
+    assert hip.md_score(e(0, 4, dt=torch.float64), r(4, dt=torch.float64), pp).shape == (0,)
+    assert hip.pca_md_score(e(0, 8, dt=torch.float64), p, r(4, dt=torch.float64), r(4, dt=torch.float64), r(4, dt=torch.float64), pp, 4).shape == (0,)
+    assert hip.mahalanobis_score(e(0, 4), r(3, 4), pp, r(3, 4, dt=torch.float64)).shape == (0,)
+    # single rows against the oracle
+    rng = np.random.default_rng(9)
+    z = rng.standard_normal((16, 5)).astype(np.float32)
+    assert np.abs(hip.kl_entropy_per_dim(dev(z, torch.float32), 16, 5).cpu().numpy() - oracle.kl_entropy_per_dim_vectorized(z, 16)).max() < 1e-12
+    x = rng.standard_normal((1, 1000)).astype(np.float32)
+    lse, msp = hip.row_lse_msp(dev(x, torch.float32), True, True)
+    assert rel_err(lse.cpu().numpy(), oracle.energy_score(x)) < 1e-6 and rel_err(msp.cpu().numpy(), oracle.msp_score(x)) < 1e-6
+    # invalid arguments are refused, not launched
+    with pytest.raises(hip.RuniaHipError):
+        hip.kl_entropy_per_dim(r(8, 4), 4, 4)  # k must be < n_mc
+    with pytest.raises(hip.RuniaHipError):
+        hip.kl_entropy_per_dim(r(130, 4), 65, 5)  # n_mc > 64
