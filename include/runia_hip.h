@@ -188,6 +188,13 @@ int runia_linear_f32(const float* x, const float* w, const float* bias, float* o
 int runia_ash_s_f32(const float* x, float* y, int64_t N, int64_t D, int percentile, runia_stream_t stream);
 int runia_gen_score_f32(const float* logits, float* score, int64_t N, int64_t C, int M, double gamma,
                         runia_stream_t stream);
+/* runia_proj_norm_*: ViM residual norm || (x - u) @ NS ||_2 per row (inference/postprocessors.py:1106):
+ *   x [N, D], u [D] (same dtype as x; f32 - f32 is rounded to f32 first, as NumPy), packed_ns = pack(NS [D, n]),
+ *   norm [N] f64. */
+int runia_proj_norm_f32(const float* x, const float* u, const double* packed_ns, double* norm, int64_t N,
+                        int64_t D, int64_t n, runia_stream_t stream);
+int runia_proj_norm_f64(const double* x, const double* u, const double* packed_ns, double* norm, int64_t N,
+                        int64_t D, int64_t n, runia_stream_t stream);
 
 #ifdef __cplusplus
 }

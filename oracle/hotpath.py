@@ -52,6 +52,8 @@ __all__ = [
     "dice_logits",
     "generalized_entropy",
     "gen_score",
+    "vim_setup",
+    "vim_score",
     "FLT_MAX",
 ]
 
@@ -520,3 +522,24 @@ def generalized_entropy(probs: np.ndarray, gamma: float, M: int) -> np.ndarray:
 def gen_score(logits: np.ndarray, gamma: float, M: int) -> np.ndarray:
     """GEN.postprocess (inference/postprocessors.py:688-689)."""
     return generalized_entropy(softmax(logits, axis=1), gamma, M)
+
+
+def vim_setup(train_feats, train_logits, w, b):
+    """ViM.setup (inference/postprocessors.py:1044-1066): u = -pinv(W) b; NS = eigenvectors of the
+    (assumed-centred) covariance of train - u beyond the DIM largest eigenvalues; alpha matches the scales."""
+    u = -np.matmul(np.linalg.pinv(w), b)
+    d = train_feats.shape[-1]
+    dim = 1000 if d >= 2048 else (512 if d >= 768 else d // 2)
+    xc = train_feats - u
+    cov = np.dot(xc.T, xc) / xc.shape[0]  # sklearn empirical_covariance(assume_centered=True)
+    eig_vals, eig_vecs = np.linalg.eig(cov)
+    ns = np.ascontiguousarray((eig_vecs.T[np.argsort(eig_vals * -1)[dim:]]).T)
+    vlogit = np.linalg.norm(np.matmul(train_feats - u, ns), axis=-1)
+    alpha = train_logits.max(axis=-1).mean() / vlogit.mean()
+    return u, ns, alpha
+
+
+def vim_score(feats, logits, u, ns, alpha):
+    """ViM.postprocess (inference/postprocessors.py:1106-1109)."""
+    vlogit = np.linalg.norm(np.matmul(feats - u, ns), axis=-1) * alpha
+    return -vlogit + logsumexp(logits, axis=-1)

@@ -67,6 +67,8 @@ _SIGNATURES = {
     "runia_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "runia_ash_s_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "runia_gen_score_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
+    "runia_proj_norm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "runia_proj_norm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "runia_covariance_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "runia_covariance_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
     "runia_covariance_f32in": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
@@ -457,3 +459,16 @@ def gen_score(logits: torch.Tensor, gamma: float, m: int) -> torch.Tensor:
     _check(lib.runia_gen_score_f32(logits.data_ptr(), s.data_ptr(), logits.shape[0], logits.shape[1], int(m), float(gamma), _stream()),
            "runia_gen_score_f32")
     return s
+
+
+def proj_norm(x: torch.Tensor, u: torch.Tensor, packed_ns: torch.Tensor, n: int) -> torch.Tensor:
+    """|| (x - u) @ NS ||_2 per row -> [N] f64 (x, u both f32 or both f64)."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dim() == 2 and x.dtype == u.dtype and x.dtype in (torch.float32, torch.float64)
+    x, u = x.contiguous(), u.contiguous()
+    nrow, d = x.shape
+    out = torch.empty((nrow,), dtype=torch.float64, device=x.device)
+    fn = lib.runia_proj_norm_f32 if x.dtype == torch.float32 else lib.runia_proj_norm_f64
+    _check(fn(x.data_ptr(), u.data_ptr(), packed_ns.data_ptr(), out.data_ptr(), nrow, d, int(n), _stream()), "runia_proj_norm")
+    return out

@@ -26,7 +26,7 @@ using namespace runia_mfma;
 
 constexpr int BM = 32;  // rows per workgroup (2 row tiles of 16)
 
-enum Epilogue { EPI_PCA = 0, EPI_ROWDOT = 1, EPI_STORE = 2 };
+enum Epilogue { EPI_PCA = 0, EPI_ROWDOT = 1, EPI_STORE = 2, EPI_ROWNORM = 3 };
 
 struct GemmArgs {
   const void* x;        // [N, K] rows (TA), ld = ldx
@@ -147,6 +147,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
               g.out[row * g.n + col] = y;
             } else if constexpr (EPI == EPI_STORE) {
               g.out[row * g.n + col] = v;
+            } else if constexpr (EPI == EPI_ROWNORM) {  // || (x - sub) B ||_2: sum of squares here, sqrt at the end
+              rowdot[a][r] += v * v;
             } else {  // EPI_ROWDOT: sum_j (d P)_j d_j with d = x - sub
               const TA* x = reinterpret_cast<const TA*>(g.x);
               const TA xv = x[row * g.ldx + col];
@@ -160,7 +162,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     __syncthreads();  // all waves done with the last chunk before the next block restages LDS
   }
 
-  if constexpr (EPI == EPI_ROWDOT) {
+  if constexpr (EPI == EPI_ROWDOT || EPI == EPI_ROWNORM) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -175,8 +177,10 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     __syncthreads();
     if (tid < BM) {
       const int64_t row = r0 + tid;
-      if (row < g.N)
-        g.out[row] = -(((lds_part[0][tid] + lds_part[1][tid]) + lds_part[2][tid]) + lds_part[3][tid]);
+      if (row < g.N) {
+        const double t = ((lds_part[0][tid] + lds_part[1][tid]) + lds_part[2][tid]) + lds_part[3][tid];
+        g.out[row] = (EPI == EPI_ROWNORM) ? sqrt(t) : -t;
+      }
     }
   }
 }
@@ -286,6 +290,28 @@ extern "C" int runia_md_score_f32(const float* x, const float* mean, const doubl
 extern "C" int runia_md_score_f32x_f64mean(const float* x, const double* mean, const double* packed_p,
                                            double* score, int64_t N, int64_t n, runia_stream_t stream) {
   return md_impl<float, double>(x, mean, packed_p, score, N, n, stream);
+}
+
+// ViM residual: || (x - u) @ NS ||_2 per row (reference inference/postprocessors.py:1106): x - u follows NumPy's
+// dtype rules (f32 - f32 in f32), the projection and the norm are f64.
+template <typename TA, typename TS>
+static int proj_norm_impl(const TA* x, const TS* u, const double* packed_ns, double* norm, int64_t N, int64_t D,
+                          int64_t n, runia_stream_t stream) {
+  if (N < 0 || D <= 0 || n <= 0) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!x || !u || !packed_ns || !norm) return RUNIA_E_INVALID;
+  GemmArgs g{};
+  g.x = x; g.ldx = D; g.packed = packed_ns; g.N = N; g.K = D; g.n = n;
+  g.sub = u; g.bias = nullptr; g.scale = nullptr; g.out = norm;
+  return launch_gemm<TA, EPI_ROWNORM, TS>(g, as_stream(stream));
+}
+extern "C" int runia_proj_norm_f32(const float* x, const float* u, const double* packed_ns, double* norm, int64_t N,
+                                   int64_t D, int64_t n, runia_stream_t stream) {
+  return proj_norm_impl<float, float>(x, u, packed_ns, norm, N, D, n, stream);
+}
+extern "C" int runia_proj_norm_f64(const double* x, const double* u, const double* packed_ns, double* norm, int64_t N,
+                                   int64_t D, int64_t n, runia_stream_t stream) {
+  return proj_norm_impl<double, double>(x, u, packed_ns, norm, N, D, n, stream);
 }
 
 extern "C" size_t runia_mahalanobis_workspace_bytes(int64_t N, int64_t D) {

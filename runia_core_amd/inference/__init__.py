@@ -19,6 +19,7 @@ from .postprocessors import (  # noqa: F401
     MSP,
     DICEReAct,
     ReAct,
+    ViM,
     DetectorKDE,
     Energy,
     FlatL2Bank,

@@ -611,3 +611,72 @@ class GEN(OodPostprocessor):
     def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
         assert self._setup_flag, "setup() must be called before postprocess()"
         return self.flip_sign_fn(self._scores(test_data))
+
+
+@register_postprocessor("vim", postprocessor_input=["features", "logits"])
+class ViM(OodPostprocessor):
+    """Virtual-logit Matching: ``logsumexp(logits) - alpha * ||(x - u) NS||``, NS = the residual (null-space)
+    eigenvectors of the training feature covariance."""
+
+    def __init__(self, flip_sign: bool, cfg=None):
+        super().__init__(flip_sign, cfg)
+        self.u = None
+        self.DIM = None
+        self.NS = None
+        self.alpha = None
+        self._dev = None
+
+    def _residual_norm(self, feats) -> np.ndarray:
+        if self._dev is None:
+            ns = np.asarray(self.NS)
+            if np.iscomplexobj(ns):
+                raise NotImplementedError("ViM on MI355X: np.linalg.eig returned complex eigenvectors")
+            self._dev = {"packed": _hip.pack_weights(_hip.to_device(np.ascontiguousarray(ns, dtype=np.float64), torch.float64)),
+                         "u": {}}
+        f32 = getattr(feats, "dtype", None) in (np.float32, torch.float32) and np.asarray(self.u).dtype == np.float32
+        dt = torch.float32 if f32 else torch.float64
+        if dt not in self._dev["u"]:
+            self._dev["u"][dt] = _hip.to_device(np.asarray(self.u), dt)
+        x = _hip.to_device(feats, dt)
+        return _hip.proj_norm(x, self._dev["u"][dt], self._dev["packed"], np.asarray(self.NS).shape[1]).cpu().numpy()
+
+    @staticmethod
+    def _energy(logits) -> np.ndarray:
+        if isinstance(logits, Tensor):
+            logits = logits.detach().cpu().numpy()
+        lse, _ = _hip.row_lse_msp(_hip.to_device(logits, torch.float32), True, False)
+        return _restore_dtype(lse, logits)
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs):
+        assert "final_linear_layer_params" in kwargs, "final_linear_layer_params must be provided for ViM"
+        assert "train_logits" in kwargs, "train_logits must be provided for ViM"
+        assert "valid_feats" in kwargs, "valid_feats must be provided for ViM"
+        assert "valid_logits" in kwargs, "valid_logits must be provided for ViM"
+        from sklearn.covariance import EmpiricalCovariance
+
+        w, b = kwargs["final_linear_layer_params"]["weight"], kwargs["final_linear_layer_params"]["bias"]
+        if isinstance(w, Tensor):
+            w = w.numpy()
+        if isinstance(b, Tensor):
+            b = b.numpy()
+        self.u = -np.matmul(np.linalg.pinv(w), b)
+        d = ind_train_data.shape[-1]
+        self.DIM = 1000 if d >= 2048 else (512 if d >= 768 else d // 2)
+        ec = EmpiricalCovariance(assume_centered=True)
+        ec.fit(ind_train_data - self.u)
+        eig_vals, eigen_vectors = np.linalg.eig(ec.covariance_)
+        self.NS = np.ascontiguousarray((eigen_vectors.T[np.argsort(eig_vals * -1)[self.DIM:]]).T)
+        self._dev = None
+        vlogit_id_train = self._residual_norm(ind_train_data)
+        self.alpha = kwargs["train_logits"].max(axis=-1).mean() / vlogit_id_train.mean()
+        vlogit_id_val = self._residual_norm(kwargs["valid_feats"]) * self.alpha
+        ind_scores = -vlogit_id_val + self._energy(kwargs["valid_logits"])
+        self.set_threshold(self.flip_sign_fn(ind_scores))
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        assert self._setup_flag, "setup() must be called before postprocess()"
+        if isinstance(test_data, Tensor):
+            test_data = test_data.cpu().numpy()
+        vlogit_test = self._residual_norm(test_data) * self.alpha
+        # like the reference, the score is NOT passed through flip_sign_fn here (postprocessors.py:1106-1111)
+        return -vlogit_test + self._energy(kwargs["logits"])

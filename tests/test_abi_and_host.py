@@ -86,7 +86,7 @@ def test_registry_matches_reference_keys():
         "KDE": ["latent_space_means"], "MD": ["latent_space_means"], "KNN": ["latent_space_means"],
         "energy": ["logits"], "msp": ["logits"], "knn": ["features"], "mahalanobis": ["features"],
         "cMD": ["latent_space_means"], "gen": ["logits"], "ash": ["features"], "react": ["features"],
-        "dice": ["features"], "dice_react": ["features"],
+        "dice": ["features"], "dice_react": ["features"], "vim": ["features", "logits"],
     }
     for k, v in expect.items():
         assert postprocessor_input_dict[k] == v

@@ -421,3 +421,32 @@ def test_cmd_unit_golden(ref_vectors):
     exp = _list(ref_vectors, "cmd_unit")
     assert abs((exp - s).sum()) < 1e-5  # float32 arithmetic in the reference (its own test allows 1e-6 on the signed sum)
     assert rel_err(s, exp) < 1e-5
+
+
+def test_vim_fixture_and_contract():
+    from runia_core_amd.inference import ViM
+
+    g = load_npz("ref_f4.npz")
+    fc = {"weight": g["w"], "bias": g["b"]}
+    p = ViM(flip_sign=False)
+    assert p.u is None and p.NS is None and p.alpha is None
+    with pytest.raises(AssertionError, match="train_logits must be provided for ViM"):
+        p.setup(g["train"], final_linear_layer_params=fc, valid_feats=g["valid"], valid_logits=g["logits_valid"])
+    p.setup(g["train"], final_linear_layer_params=fc, train_logits=g["logits_train"], valid_feats=g["valid"],
+            valid_logits=g["logits_valid"])
+    assert p.DIM == 150 and p.NS.shape == (300, 150)
+    # the reference runs ViM in float32 end to end for float32 features (covariance, eigenvectors, norms, alpha);
+    # the kernel projects in f64, so agreement is at the f32 level
+    assert abs(p.alpha - float(g["vim_alpha"])) < 1e-6 * abs(p.alpha)
+    s = p.postprocess(g["test"], logits=g["logits_test"])
+    assert rel_err(s, g["vim_scores"]) < 1e-5
+    assert abs(p.threshold - float(g["vim_threshold"])) < 1e-4
+    assert np.allclose(p.postprocess(torch.Tensor(g["test"]), logits=torch.Tensor(g["logits_test"])), s)
+    # the residual-norm kernel alone, against the fitted state of the reference
+    from runia_core_amd import _hip
+
+    dv = lambda a, t: torch.from_numpy(np.ascontiguousarray(a)).to("cuda", t)  # noqa: E731
+    nrm = _hip.proj_norm(dv(g["test"], torch.float32), dv(g["vim_u"], torch.float32),
+                         _hip.pack_weights(dv(g["vim_NS"], torch.float64)), 150).cpu().numpy()
+    exp = np.linalg.norm(np.matmul((g["test"] - g["vim_u"]).astype(np.float64), g["vim_NS"].astype(np.float64)), axis=-1)
+    assert rel_err(nrm, exp) < 1e-12

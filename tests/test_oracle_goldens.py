@@ -343,3 +343,11 @@ def test_f4_fixtures():
     assert rel_err(oracle.react_score(g["test"], w, b, g["react_clip"]), g["react_scores"]) < 1e-6
     for M in (37, 10, 100):
         assert rel_err(oracle.gen_score(g["logits_test"], 0.1, M), g[f"gen{M}_scores"]) < 1e-6
+
+
+def test_vim_fixture():
+    g = load_npz("ref_f4.npz")
+    u, ns, alpha = oracle.vim_setup(g["train"], g["logits_train"], g["w"], g["b"])
+    assert rel_err(u, g["vim_u"]) < 1e-6 and abs(alpha - float(g["vim_alpha"])) < 1e-6 * abs(alpha)
+    got = oracle.vim_score(g["test"], g["logits_test"], g["vim_u"], g["vim_NS"], float(g["vim_alpha"]))
+    assert rel_err(got, g["vim_scores"]) < 1e-6  # float32 arithmetic in the reference for float32 features

@@ -242,6 +242,12 @@ def main():
         p = pp.GEN(flip_sign=False, gamma=0.1, num_classes=M)
         p.setup(logits_tr)
         cases[f"gen{M}_scores"], cases[f"gen{M}_threshold"] = p.postprocess(logits_te), np.array(p.threshold)
+    logits_va = (va @ w.T + b).astype(np.float32)
+    cases["logits_valid"] = logits_va
+    p = pp.ViM(flip_sign=False)
+    p.setup(tr, final_linear_layer_params=fc, train_logits=logits_tr, valid_feats=va, valid_logits=logits_va)
+    cases["vim_u"], cases["vim_NS"], cases["vim_alpha"] = p.u, p.NS, np.array(p.alpha)
+    cases["vim_scores"], cases["vim_threshold"] = p.postprocess(te, logits=logits_te), np.array(p.threshold)
     np.savez_compressed(os.path.join(OUT, "ref_f4.npz"), **cases)
 
     # ---------------- thresholds -------------------------------------------------
