@@ -52,6 +52,7 @@ __all__ = [
     "dice_logits",
     "generalized_entropy",
     "gen_score",
+    "gmm_energy",
     "vim_setup",
     "vim_score",
     "FLT_MAX",
@@ -543,3 +544,11 @@ def vim_score(feats, logits, u, ns, alpha):
     """ViM.postprocess (inference/postprocessors.py:1106-1109)."""
     vlogit = np.linalg.norm(np.matmul(feats - u, ns), axis=-1) * alpha
     return -vlogit + logsumexp(logits, axis=-1)
+
+
+def gmm_energy(gmm, x: np.ndarray) -> np.ndarray:
+    """GMMLatentSpace / DDU scoring (inference/postprocessors.py:490-491, 778-779): torch's own
+    ``MultivariateNormal.log_prob`` on the host followed by scipy logsumexp over the components."""
+    import torch
+
+    return logsumexp(gmm.log_prob(torch.Tensor(np.asarray(x)[:, None, :])).numpy(), axis=1)

@@ -8,11 +8,12 @@ from .abstract_classes import (  # noqa: F401
     get_method_threshold,
     record_time,
 )
-from .funcs import mahalanobis_postprocess, mahalanobis_preprocess, normalizer  # noqa: F401
+from .funcs import gmm_fit, mahalanobis_postprocess, mahalanobis_preprocess, normalizer  # noqa: F401
 from .image_level import LaRDInference, LaRExInference  # noqa: F401
 from .pipeline import LaREMPipeline  # noqa: F401
 from .postprocessors import (  # noqa: F401
     ASH,
+    DDU,
     DICE,
     GEN,
     KNN,
@@ -23,6 +24,7 @@ from .postprocessors import (  # noqa: F401
     DetectorKDE,
     Energy,
     FlatL2Bank,
+    GMMLatentSpace,
     KDELatentSpace,
     KNNLatentSpace,
     Mahalanobis,

@@ -14,7 +14,7 @@ import torch
 from .. import _hip, config
 from ..device_fit import empirical_precision_device
 
-__all__ = ["mahalanobis_preprocess", "mahalanobis_postprocess", "normalizer", "MahalanobisState"]
+__all__ = ["mahalanobis_preprocess", "mahalanobis_postprocess", "normalizer", "MahalanobisState", "gmm_fit", "GmmState"]
 
 
 def mahalanobis_preprocess(ind_data: Dict[str, np.ndarray], num_classes: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -88,3 +88,69 @@ def normalizer(x):
     flat = arr.reshape(-1, arr.shape[-1])
     out = _hip.l2_normalize(_hip.to_device(flat, torch.float32)).cpu().numpy()
     return out.reshape(arr.shape)
+
+
+def gmm_fit(embeddings: torch.Tensor, labels: torch.Tensor, num_classes: int):
+    """Class-wise Gaussians (reference ``inference/funcs.py:265-344``): per-class mean and covariance
+    ``x_c^T x_c / (n_c - 1)`` in float32, classes without samples dropped, and the smallest jitter of
+    ``[0, 1e-20, ..., 1e-1]`` for which ``torch.distributions.MultivariateNormal`` accepts ``cov + jitter * I``
+    (its float32 Cholesky must succeed).  Setup-time host fit with the reference's own torch calls.
+
+    Returns ``(MultivariateNormal, jitter)``."""
+    jitters = [0] + [10**exp for exp in range(-20, 0, 1)]
+
+    def centered_cov(x):
+        n = x.shape[0]
+        if n == 1:
+            n += 1
+        return 1 / (n - 1) * x.t().mm(x)
+
+    with torch.no_grad():
+        means = torch.stack([torch.mean(embeddings[labels == c], dim=0) for c in range(num_classes)])
+        covs = torch.stack([centered_cov(embeddings[labels == c] - means[c]) for c in range(num_classes)])
+        keep = ~torch.any(means.isnan(), dim=1)
+        if not bool(keep.all()):
+            means, covs = means[keep], covs[keep]
+        gmm, jitter_eps = None, None
+        for jitter_eps in jitters:
+            try:
+                jitter = jitter_eps * torch.eye(covs.shape[1], device=covs.device).unsqueeze(0)
+                gmm = torch.distributions.MultivariateNormal(loc=means, covariance_matrix=(covs + jitter))
+            except RuntimeError as e:
+                if "cholesky" in str(e):
+                    continue
+            except ValueError as e:
+                if "found invalid values" in str(e):
+                    continue
+            break
+    return gmm, jitter_eps
+
+
+class GmmState:
+    """Device-resident form of a fitted class-wise ``MultivariateNormal``: for every component the precision
+    ``(L L^T)^-1`` (float32 ``scale_tril`` widened exactly, inverted in f64, packed for the MFMA kernel), the mean and
+    ``-0.5 * D * log(2 pi) - sum(log diag L)``.  ``log_prob`` = ``gmm.log_prob(x[:, None, :])`` -> ``(N, C)`` f32."""
+
+    def __init__(self, gmm):
+        loc = gmm.loc.detach().cpu()
+        tril = gmm.scale_tril.detach().cpu()
+        self.n_comp, self.dim = loc.shape
+        self.means = [_hip.to_device(loc[c].numpy(), torch.float32) for c in range(self.n_comp)]
+        self.packed = []
+        for c in range(self.n_comp):
+            prec = torch.cholesky_inverse(tril[c].double()).numpy()
+            self.packed.append(_hip.pack_weights(_hip.to_device(prec, torch.float64)))
+        half_log_det = tril.diagonal(dim1=-2, dim2=-1).log().sum(-1)  # f32, as torch
+        self.const = (-0.5 * self.dim * float(np.log(2 * np.pi)) - half_log_det.double()).tolist()
+
+    def log_prob_device(self, x: torch.Tensor) -> torch.Tensor:
+        x = x.to(torch.float32).contiguous()
+        cols = []
+        for c in range(self.n_comp):
+            neg_m = _hip.md_score(x, self.means[c], self.packed[c])  # -(x-mu)^T P (x-mu), diff in f32 like torch
+            cols.append((0.5 * neg_m + self.const[c]).to(torch.float32))
+        return torch.stack(cols, dim=1).contiguous()
+
+    def energy_device(self, x: torch.Tensor) -> torch.Tensor:
+        lse, _ = _hip.row_lse_msp(self.log_prob_device(x), True, False)
+        return lse

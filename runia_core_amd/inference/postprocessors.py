@@ -24,7 +24,7 @@ from torch import Tensor
 from .. import _hip, config
 from ..device_fit import empirical_precision_device
 from .abstract_classes import OodPostprocessor, Postprocessor
-from .funcs import MahalanobisState, _maha_dtype, mahalanobis_preprocess, normalizer
+from .funcs import GmmState, MahalanobisState, _maha_dtype, gmm_fit, mahalanobis_preprocess
 
 __all__ = ["postprocessors_dict", "postprocessor_input_dict", "register_postprocessor"]
 
@@ -295,6 +295,44 @@ class FlatL2Bank:
         """``-D[:, -1]`` of ``search(normalizer(feats), k)`` for every row, f32."""
         q = _hip.l2_normalize(_hip.to_device(np.asarray(feats), torch.float32))
         return self.kth_score_device(q, k).cpu().numpy()
+
+
+@register_postprocessor("GMM", postprocessor_input=["latent_space_means"])
+class GMMLatentSpace(Postprocessor):
+    """LaREG: log-sum-exp of the class-wise Gaussian log-densities of latent representations."""
+
+    def __init__(self, cfg=None):
+        super().__init__(cfg)
+        try:
+            self.num_classes = cfg.num_classes
+        except AttributeError:
+            self.num_classes = 10
+        self.gmm = None
+        self._state = None
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs) -> None:
+        assert ind_train_data.ndim == 2, "ind_train_feats must be 2 dimensional"
+        if not self._setup_flag:
+            try:
+                labels = kwargs["ind_train_labels"]
+                if isinstance(labels, np.ndarray):
+                    labels = Tensor(labels)
+            except KeyError:
+                raise ValueError("id_labels not provided")
+            self.gmm, _ = gmm_fit(embeddings=Tensor(ind_train_data), labels=labels, num_classes=self.num_classes)
+            self._state = None
+            self._setup_flag = True
+        else:
+            warnings.warn("GMMPostprocessor already trained")
+
+    def postprocess_device(self, test_data: Tensor) -> Tensor:
+        if self._state is None:
+            self._state = GmmState(self.gmm)
+        return self._state.energy_device(test_data)
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        assert test_data.ndim == 2, "test_feats must be 2 dimensional"
+        return self.postprocess_device(_hip.to_device(test_data, torch.float32)).cpu().numpy()
 
 
 # --------------------------------------------------------------------------------------
@@ -680,3 +718,40 @@ class ViM(OodPostprocessor):
         vlogit_test = self._residual_norm(test_data) * self.alpha
         # like the reference, the score is NOT passed through flip_sign_fn here (postprocessors.py:1106-1111)
         return -vlogit_test + self._energy(kwargs["logits"])
+
+
+@register_postprocessor("ddu", postprocessor_input=["features"])
+class DDU(OodPostprocessor):
+    """Deep Deterministic Uncertainty: log-sum-exp of class-wise Gaussian log-densities of the features."""
+
+    def __init__(self, flip_sign: bool, num_classes: int, cfg=None):
+        super().__init__(flip_sign, cfg)
+        self.num_classes = num_classes
+        self.gmm = None
+        self.device = "cuda" if torch.cuda.is_available() else "cpu"
+        self._state = None
+
+    def _scores(self, feats) -> np.ndarray:
+        if self._state is None:
+            self._state = GmmState(self.gmm)
+        if isinstance(feats, Tensor):
+            feats = feats.detach()
+        return self._state.energy_device(_hip.to_device(feats, torch.float32)).cpu().numpy()
+
+    def postprocess_device(self, feats: Tensor) -> Tensor:
+        if self._state is None:
+            self._state = GmmState(self.gmm)
+        s = self._state.energy_device(feats)
+        return -s if self.flip_sign else s
+
+    def setup(self, ind_train_data: np.ndarray, **kwargs):
+        assert "valid_feats" in kwargs, "valid_feats must be provided for DDU"
+        assert "train_labels" in kwargs, "train_labels must be provided for DDU"
+        self.gmm, _ = gmm_fit(embeddings=Tensor(ind_train_data), labels=Tensor(kwargs["train_labels"]),
+                              num_classes=self.num_classes)
+        self._state = None
+        self.set_threshold(self.flip_sign_fn(self._scores(kwargs["valid_feats"])))
+
+    def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
+        assert self._setup_flag, "setup() must be called before postprocess()"
+        return self.flip_sign_fn(self._scores(test_data))

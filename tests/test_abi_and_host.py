@@ -87,11 +87,13 @@ def test_registry_matches_reference_keys():
         "energy": ["logits"], "msp": ["logits"], "knn": ["features"], "mahalanobis": ["features"],
         "cMD": ["latent_space_means"], "gen": ["logits"], "ash": ["features"], "react": ["features"],
         "dice": ["features"], "dice_react": ["features"], "vim": ["features", "logits"],
+        "GMM": ["latent_space_means"], "ddu": ["features"],
     }
     for k, v in expect.items():
         assert postprocessor_input_dict[k] == v
         assert issubclass(postprocessors_dict[k], Postprocessor)
     assert postprocessors_dict["MD"] is MDLatentSpace and postprocessors_dict["mahalanobis"] is Mahalanobis
+    assert len(postprocessors_dict) == 16  # every key of the reference registry
     with pytest.raises(AssertionError, match="Invalid input type"):
         rc.inference.register_postprocessor("bad", ["pixels"])(type("X", (), {}))
 

@@ -248,6 +248,21 @@ def main():
     p.setup(tr, final_linear_layer_params=fc, train_logits=logits_tr, valid_feats=va, valid_logits=logits_va)
     cases["vim_u"], cases["vim_NS"], cases["vim_alpha"] = p.u, p.NS, np.array(p.alpha)
     cases["vim_scores"], cases["vim_threshold"] = p.postprocess(te, logits=logits_te), np.array(p.threshold)
+    # GMM / DDU on well-conditioned data (the reference's own unit goldens sit on singular covariances where the
+    # float32 Cholesky + jitter search decides the value)
+    Cg, Dg = 6, 24
+    cen = rng.standard_normal((Cg, Dg)).astype(np.float32) * 2
+    lab_g = rng.integers(0, Cg, 1800)
+    fg = (cen[lab_g] + rng.standard_normal((1800, Dg)) * (0.5 + rng.random(Dg))).astype(np.float32)
+    fg_te = (cen[rng.integers(0, Cg, 120)] * 0.8 + 1.1 * rng.standard_normal((120, Dg))).astype(np.float32)
+    p = pp.GMMLatentSpace()
+    p.setup(fg, ind_train_labels=lab_g)
+    cases.update(gmm_train=fg, gmm_labels=lab_g, gmm_test=fg_te, gmm_scores=p.postprocess(fg_te),
+                 gmm_loc=p.gmm.loc.numpy(), gmm_tril=p.gmm.scale_tril.numpy())
+    p = pp.DDU(flip_sign=False, num_classes=Cg)
+    p.device = "cpu"
+    p.setup(fg, valid_feats=fg[:200], train_labels=lab_g)
+    cases.update(ddu_scores=p.postprocess(fg_te), ddu_threshold=np.array(p.threshold))
     np.savez_compressed(os.path.join(OUT, "ref_f4.npz"), **cases)
 
     # ---------------- thresholds -------------------------------------------------
