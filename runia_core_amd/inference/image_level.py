@@ -68,22 +68,20 @@ class LaRExInference(ProbabilisticInferenceModule):
                 pass
             output = self.model(input_image)
             latent_rep = layer_hook.output
-        mc_samples_t = self.mc_sampler(latent_rep)
-        pipe = self._pipe()
-        h = pipe.entropy(mc_samples_t)
-        if self.pca_transform:
-            h = device_pca_for(self.pca_transform).transform_device(h)
-        return output, _score_rows_device(self.postprocessor, h)
+        return output, self.get_scores_from_latents(latent_rep)
 
     def get_scores_from_latents(self, latents: torch.Tensor, rand: torch.Tensor = None) -> np.ndarray:
         """Additive batched entry point: hooked activations ``(N, C, H, W)`` -> ``(N,)`` scores.
         ``rand`` ``(N, n_mc, H, W)`` supplies the DropBlock draws (default: the sampler's CPU-generator stream)."""
         x = _hip.to_device(latents, torch.float32)
-        if rand is None and self.mc_sampler.training and self.drop_block_prob != 0.0:
+        active = self.mc_sampler.training and self.drop_block_prob != 0.0
+        if rand is None and active:
             rand = self.mc_sampler.draw(x.shape[0], x.shape[2], x.shape[3], x.device)
-        z = self.mc_sampler(x, rand=rand)
         pipe = self._pipe()
-        h = pipe.entropy(z)
+        if pipe._md_state() is not None:
+            # LaREM: sampler + entropy and PCA + score as two fused launches (same arithmetic as the stages below)
+            return pipe.score_latents(x, rand if active else None).cpu().numpy()
+        h = pipe.entropy(self.mc_sampler(x, rand=rand))
         if self.pca_transform:
             h = device_pca_for(self.pca_transform).transform_device(h)
         return _score_rows_device(self.postprocessor, h)
