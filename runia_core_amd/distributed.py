@@ -37,11 +37,14 @@ def _world(group) -> Tuple[int, int]:
 def gather_scores(local: torch.Tensor, n_rows: int, group=None) -> torch.Tensor:
     """One all_gather of the per-rank score shards (padded to ``ceil(N/world)``) -> ``(N,)`` on every rank."""
     world, _ = _world(group)
-    if world == 1:
+    if not (dist.is_available() and dist.is_initialized()):
         return local
     per = -(-n_rows // world) if n_rows > 0 else 0
-    buf = torch.zeros(per, dtype=local.dtype, device=local.device)
-    buf[: local.numel()] = local
+    if local.numel() == per and local.is_contiguous():
+        buf = local  # even split: no padding copy
+    else:
+        buf = torch.zeros(per, dtype=local.dtype, device=local.device)
+        buf[: local.numel()] = local
     out = torch.empty(world * per, dtype=local.dtype, device=local.device)
     if local.is_cuda:
         dist.all_gather_into_tensor(out, buf, group=group)
