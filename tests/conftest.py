@@ -14,6 +14,15 @@ GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    # librunia_hip.so is a build artefact (git-ignored): make sure it exists and is not older than its sources.
+    # `make` is incremental; hipcc cross-compiles gfx950 without a GPU.
+    import subprocess
+
+    csrc = os.path.join(ROOT, "runia_core_amd", "csrc")
+    try:
+        subprocess.run(["make", "-C", csrc, "-j8", "-s"], check=True, stdout=subprocess.DEVNULL)
+    except Exception as e:  # pragma: no cover - surfaces as loud failures of every test that needs the library
+        print(f"WARNING: could not (re)build librunia_hip.so: {e}", file=sys.stderr)
 
 
 def load_npz(name):
