@@ -93,6 +93,15 @@ def load_library() -> ctypes.CDLL:
     global _lib
     if _lib is None:
         if not os.path.exists(_LIB_PATH):
+            # a missing build artefact is built, never replaced: there is no other implementation to fall back to
+            import subprocess
+
+            try:
+                subprocess.run(["make", "-C", os.path.join(os.path.dirname(_LIB_PATH), "csrc"), "-j8", "-s"], check=True,
+                               stdout=subprocess.DEVNULL)
+            except Exception:
+                pass
+        if not os.path.exists(_LIB_PATH):
             raise RuniaHipError(
                 f"{_LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                 "(hipcc --offload-arch=gfx950).  runia_core_amd has no CPU fallback."
