@@ -31,14 +31,18 @@ DROP_PROB, BLOCK = 0.5, 2
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def synth_latents(n, seed, shift, device, scale=1.0):
-    """cfg2-synth: X ~ ReLU(N(shift,1)) on (n,512,4,4); draws U(0,1) on (n,16,4,4).
+def synth_latents(n, seed, shift, device, scale=1.0, corr=0.0):
+    """cfg2-synth: X ~ ReLU(N(shift,1)) on (n,512,4,4) with a fixed per-channel scale; draws U(0,1) on (n,16,4,4).
     Draws whose block mask would drop the whole 4x4 map (sum(bm)=0 -> inf/NaN in the reference
     as well) are replaced by "no seed" so that every score is finite."""
     g0 = torch.Generator(device=device).manual_seed(77)  # per-channel scale: a property of the "layer", same for all sets
     chan = torch.rand(1, C, 1, 1, device=device, generator=g0) * 1.5 + 0.25
     g = torch.Generator(device=device).manual_seed(seed)
-    x = torch.relu(torch.randn(n, C, H, W, device=device, generator=g) * (chan * scale) + shift).contiguous()
+    noise = torch.randn(n, C, H, W, device=device, generator=g)
+    if corr > 0.0:  # OOD variant: part of every map is spatially constant -> DropBlock perturbs the channel mean less
+        shared = torch.randn(n, C, 1, 1, device=device, generator=g)
+        noise = corr * shared + (1.0 - corr * corr) ** 0.5 * noise
+    x = torch.relu(noise * (chan * scale) + shift).contiguous()
     rand = torch.rand(n, N_MC, H, W, device=device, generator=g)
     mask = (rand < DROP_PROB / BLOCK**2).float().reshape(n * N_MC, 1, H, W)
     bm = 1 - torch.nn.functional.max_pool2d(mask, BLOCK, 1, BLOCK // 2)[:, :, :-1, :-1]
@@ -54,7 +58,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--images", type=int, default=10000, help="test images per GPU (workload: 10 000)")
     ap.add_argument("--train-images", type=int, default=4096)
-    ap.add_argument("--ood-scale", type=float, default=1.03)
+    ap.add_argument("--ood-corr", type=float, default=0.25, help="spatial correlation of the OOD sample's latent maps")
     ap.add_argument("--cpu-sample", type=int, default=1280, help="images timed on the CPU oracle")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--overlap", action="store_true",
@@ -205,7 +209,7 @@ def main():
 
         m = min(args.cpu_sample, n)
         xs, rs = x[:m].cpu().numpy(), rand[:m].cpu().numpy()
-        xo, ro = synth_latents(m, 999, 0.0, device, args.ood_scale)  # wider activations -> OOD sample for the AUROC check
+        xo, ro = synth_latents(m, 999, 0.0, device, corr=args.ood_corr)  # spatially correlated maps -> OOD sample for the AUROC check
         gpu_ind = scores[:m].cpu().numpy()
         gpu_ood = pipe.score_latents(xo, ro).cpu().numpy()
         comp, mean, var = pca.components_, pca.mean_, pca.explained_variance_
