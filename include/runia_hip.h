@@ -164,6 +164,11 @@ int runia_pca_md_score_f64(const double* h, const double* packed_ct, const doubl
                            const double* scale, const double* md_mean, const double* packed_p,
                            double* score, double* y_out, int64_t N, int64_t D, int64_t n,
                            runia_stream_t stream);
+/* (2') runia_proj_sq_score_f64: the same LaREM score from ONE contraction, score = -|| M h + c ||^2, where the
+ *     caller folded PCA transform, centring and the factor W of precision = W^T W into M [r, D] = W diag(1/scale) C
+ *     and c [r] = W (-bias/scale - md_mean) at setup (exact algebra, f64): packed_m = pack(M.T [D, r]). */
+int runia_proj_sq_score_f64(const double* h, const double* packed_m, const double* c, double* score,
+                            int64_t N, int64_t D, int64_t r, runia_stream_t stream);
 
 /* ---- f1  setup-time covariance on the device (SURVEY 8f "next #1") ----------- *
  * Replaces np.cov(X.T, bias=1) inside sklearn EmpiricalCovariance.fit

@@ -69,6 +69,7 @@ _SIGNATURES = {
     "runia_gen_score_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
     "runia_proj_norm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "runia_proj_norm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "runia_proj_sq_score_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "runia_covariance_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "runia_covariance_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
     "runia_covariance_f32in": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
@@ -481,3 +482,16 @@ def proj_norm(x: torch.Tensor, u: torch.Tensor, packed_ns: torch.Tensor, n: int)
     fn = lib.runia_proj_norm_f32 if x.dtype == torch.float32 else lib.runia_proj_norm_f64
     _check(fn(x.data_ptr(), u.data_ptr(), packed_ns.data_ptr(), out.data_ptr(), nrow, d, int(n), _stream()), "runia_proj_norm")
     return out
+
+
+def proj_sq_score(h: torch.Tensor, packed_m: torch.Tensor, c: torch.Tensor, r: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """score [N] = -|| M h + c ||^2 (h [N, D] f64, packed_m = pack(M.T), c [r])."""
+    lib = load_library()
+    require_gpu()
+    assert h.is_cuda and h.dtype == torch.float64 and h.dim() == 2
+    h = h.contiguous()
+    nrow, d = h.shape
+    s = torch.empty((nrow,), dtype=torch.float64, device=h.device) if out is None else out
+    _check(lib.runia_proj_sq_score_f64(h.data_ptr(), packed_m.data_ptr(), c.data_ptr(), s.data_ptr(), nrow, d, int(r), _stream()),
+           "runia_proj_sq_score_f64")
+    return s

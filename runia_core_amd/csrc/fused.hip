@@ -308,6 +308,101 @@ __global__ __launch_bounds__(256) void pca_md_kernel(PcaMdArgs g) {
   }
 }
 
+// ------------------------------------------------------------------------------------------
+// K2': the same score as K2 from ONE contraction.  With d = A h + b (A = diag(1/scale) C, b = -bias/scale - mu) and
+// P = W^T W (W = diag(1/sqrt(s)) U^T over the eigenpairs pinvh kept),  -d^T P d = -|| (W A) h + W b ||^2, so the
+// 512->256 projection, the whitening, the centring and the 256x256 quadratic form collapse into M = W A (r x D) and
+// c = W b, folded once at setup.  2*D*r FLOP per row instead of 2*D*n + 2*n^2; no LDS round trip for the projection.
+// ------------------------------------------------------------------------------------------
+struct ProjSqArgs {
+  const double* h;        // [N, D]
+  const double* packed_m; // pack(M^T [D, r])
+  const double* c;        // [r]
+  double* score;          // [N]
+  int64_t N, D, r;
+};
+
+template <int RT>
+__global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
+  constexpr int BM = 16 * RT;
+  __shared__ double lds_a[2 * BM * APITCH];
+  __shared__ double part[4 * BM];
+  const int64_t n_pad = n_padded(g.r);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int64_t NT = n_pad / 16;
+  const int64_t r0 = (int64_t)blockIdx.x * BM;
+  const int64_t nchunks = k_padded(g.D) / KC;
+  constexpr int PER_T = BM * KC / 256;
+  double rowsq[RT][4];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) rowsq[a][r] = 0.0;
+  for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
+    const int64_t ctbase = cb * 16 + wave * 4;
+    d4 acc[RT][4];
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double2* bp = reinterpret_cast<const double2*>(g.packed_m) + ctbase * 64 + lane;
+    double2 b0[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) b0[c] = bp[c * 64];
+    double areg[PER_T];
+    const int srow = (tid * PER_T) / KC, skk = (tid * PER_T) % KC;
+    auto load_a = [&](int64_t kc) {
+      const int64_t gr = r0 + srow;
+#pragma unroll
+      for (int q = 0; q < PER_T; ++q) {
+        const int64_t gk = kc + skk + q;
+        areg[q] = (gr < g.N && gk < g.D) ? g.h[gr * g.D + gk] : 0.0;
+      }
+    };
+    load_a(0);
+    int buf = 0;
+    for (int64_t ch = 0; ch < nchunks; ++ch) {
+#pragma unroll
+      for (int q = 0; q < PER_T; ++q) lds_a[(buf * BM + srow) * APITCH + skk + q] = areg[q];
+      __syncthreads();
+      if (ch + 1 < nchunks) load_a((ch + 1) * KC);
+      mfma_chunk<RT>(acc, lds_a + buf * BM * APITCH, APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
+      buf ^= 1;
+    }
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+      for (int c = 0; c < 4; ++c) {
+        const int64_t col = (ctbase + c) * 16 + li;
+        const double cc = (col < g.r) ? g.c[col] : 0.0;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const double v = acc[a][c][r] + cc;  // zero-padded columns contribute 0
+          rowsq[a][r] = fma(v, v, rowsq[a][r]);
+        }
+      }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double v = rowsq[a][r];
+      v += shfl_xor_f64(v, 1);
+      v += shfl_xor_f64(v, 2);
+      v += shfl_xor_f64(v, 4);
+      v += shfl_xor_f64(v, 8);
+      if (li == 0) part[wave * BM + 16 * a + lg + 4 * r] = v;
+    }
+  __syncthreads();
+  if (tid < BM) {
+    const int64_t row = r0 + tid;
+    if (row < g.N) g.score[row] = -(((part[tid] + part[BM + tid]) + part[2 * BM + tid]) + part[3 * BM + tid]);
+  }
+}
+
 double digamma_diff(int n, int k) {
   double s = 0.0;
   for (int j = n - 1; j >= k; --j) s += 1.0 / (double)j;
@@ -388,4 +483,19 @@ extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k) {
   if (hw && n_mc > 4 && n_mc <= 32) return 1;
   if (n_mc > 8 && n_mc <= 16 && ((H == 2 && W == 2) || (H == 7 && W == 7) || (H == 8 && W == 8))) return 1;
   return 0;
+}
+
+extern "C" int runia_proj_sq_score_f64(const double* h, const double* packed_m, const double* c, double* score,
+                                       int64_t N, int64_t D, int64_t r, runia_stream_t stream) {
+  if (N < 0 || D <= 0 || r <= 0) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!h || !packed_m || !c || !score) return RUNIA_E_INVALID;
+  ProjSqArgs g{h, packed_m, c, score, N, D, r};
+  hipStream_t s = as_stream(stream);
+  if ((N + 31) / 32 >= 1024) {
+    proj_sq_kernel<2><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
+  } else {
+    proj_sq_kernel<1><<<(unsigned)((N + 15) / 16), 256, 0, s>>>(g);
+  }
+  return runia_check_launch();
 }

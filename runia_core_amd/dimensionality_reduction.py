@@ -32,6 +32,7 @@ class DevicePCA:
             bias = np.zeros(self.n_components)
         else:
             bias = (np.asarray(mean, dtype=np.float64).reshape(1, -1) @ components.T).ravel()
+        self.components_host, self.bias_host, self.scale_host = components, bias, None
         self.packed_ct = _hip.pack_weights(_hip.to_device(np.ascontiguousarray(components.T), torch.float64))
         self.bias = _hip.to_device(bias, torch.float64)
         self.scale = None
@@ -39,6 +40,7 @@ class DevicePCA:
             scale = np.sqrt(np.asarray(explained_variance, dtype=np.float64))
             min_scale = np.finfo(scale.dtype).eps
             scale = np.where(scale < min_scale, min_scale, scale)
+            self.scale_host = scale
             self.scale = _hip.to_device(scale, torch.float64)
 
     @classmethod

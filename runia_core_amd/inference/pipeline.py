@@ -62,6 +62,11 @@ class LaREMPipeline:
         # the extra launches, so pipelining is opt-in (useful from ~10^5 rows per block).
         self.overlap_chunks = 1
         self._side_streams = None
+        # Fold PCA transform + centring + the factor of the precision matrix into one contraction at first use
+        # (score = -||M h + c||^2, exact algebra in f64; `runia_proj_sq_score_f64`).  Set False to keep the two-stage
+        # K2 (`runia_pca_md_score_f64`), which also materialises the projection in LDS.
+        self.fold_weights = True
+        self._folded = None
 
     # -- stages ---------------------------------------------------------------------
     def stack(self, latents: Tensor, rand: Optional[Tensor]) -> Tensor:
@@ -88,12 +93,46 @@ class LaREMPipeline:
         st = pp._device_state()
         return pp._mean(torch.float64), st["packed_p"]
 
+    def _folded_state(self):
+        """(packed M^T, c, r) with M = W diag(1/scale) C, c = W (-bias/scale - mu), precision = W^T W; None when the
+        precision matrix is not positive semi-definite to rounding (then the two-stage kernel is used)."""
+        if self._folded is None:
+            pp = self.postprocessor
+            prec = np.asarray(pp.precision, dtype=np.float64)
+            lam, vec = np.linalg.eigh((prec + prec.T) * 0.5)
+            top = float(np.abs(lam).max()) if lam.size else 0.0
+            if top == 0.0 or lam.min() < -1e-10 * top:
+                self._folded = False
+                return None
+            keep = lam > top * max(prec.shape) * np.finfo(np.float64).eps
+            w = np.sqrt(lam[keep])[:, None] * vec[:, keep].T                      # (r, n): precision = w.T @ w
+            mu = np.asarray(pp.feats_mean, dtype=np.float64).ravel()
+            if self.pca is not None:
+                comp = self.pca.components_host
+                scale = self.pca.scale_host if self.pca.scale_host is not None else np.ones(comp.shape[0])
+                a = comp / scale[:, None]                                        # (n, D)
+                b = -self.pca.bias_host / scale - mu
+            else:
+                a = np.eye(prec.shape[0])
+                b = -mu
+            m = w @ a                                                             # (r, D)
+            c = w @ b
+            self._folded = (_hip.pack_weights(_hip.to_device(np.ascontiguousarray(m.T), torch.float64)),
+                            _hip.to_device(c, torch.float64), int(m.shape[0]))
+        return self._folded or None
+
     def score_entropies(self, h: Tensor) -> Tensor:
         """PCA transform + postprocessor.  LaREM (``MDLatentSpace``) on f64 rows takes the fused
         ``runia_pca_md_score_f64`` launch; anything else goes stage by stage."""
         md = self._md_state()
         if md is not None and h.dtype == torch.float64:
             mean, packed_p = md
+            if self.pca is not None and h.shape[1] != self.pca.n_features:
+                raise ValueError(f"X has {h.shape[1]} features, but PCA is expecting {self.pca.n_features} features as input.")
+            if self.fold_weights:
+                folded = self._folded_state()
+                if folded is not None:
+                    return _hip.proj_sq_score(h, *folded)
             if self.pca is not None:
                 if h.shape[1] != self.pca.n_features:
                     raise ValueError(f"X has {h.shape[1]} features, but PCA is expecting {self.pca.n_features} features as input.")
@@ -102,6 +141,17 @@ class LaREMPipeline:
             return _hip.pca_md_score(h, None, None, None, mean, packed_p, h.shape[1])
         y = self.pca.transform_device(h) if self.pca is not None else h
         return self.postprocessor.postprocess_device(y)
+
+    def _score_h_into(self, h: Tensor, out: Tensor, mean: Tensor, packed_p: Tensor) -> None:
+        """LaREM score of entropy rows ``h`` written into ``out`` (folded single contraction or two-stage K2)."""
+        folded = self._folded_state() if self.fold_weights else None
+        if folded is not None:
+            _hip.proj_sq_score(h, *folded, out=out)
+        elif self.pca is not None:
+            _hip.pca_md_score(h, self.pca.packed_ct, self.pca.bias, self.pca.scale, mean, packed_p,
+                              self.pca.n_components, out=out)
+        else:
+            _hip.pca_md_score(h, None, None, None, mean, packed_p, h.shape[1], out=out)
 
     # -- chains ---------------------------------------------------------------------
     def score_samples(self, z: Tensor) -> Tensor:
@@ -158,11 +208,7 @@ class LaREMPipeline:
                 ready = s_k1.record_event()
             s_k2.wait_event(ready)
             with torch.cuda.stream(s_k2):
-                if self.pca is not None:
-                    _hip.pca_md_score(h[a:b], self.pca.packed_ct, self.pca.bias, self.pca.scale, mean, packed_p,
-                                      self.pca.n_components, out=scores[a:b])
-                else:
-                    _hip.pca_md_score(h[a:b], None, None, None, mean, packed_p, h.shape[1], out=scores[a:b])
+                self._score_h_into(h[a:b], scores[a:b], mean, packed_p)
         main.wait_event(s_k1.record_event())
         main.wait_event(s_k2.record_event())
         return scores
@@ -209,11 +255,7 @@ class LaREMPipeline:
             ready = s_k1.record_event()
         s_k2.wait_event(ready)
         with torch.cuda.stream(s_k2):
-            if self.pca is not None:
-                _hip.pca_md_score(h, self.pca.packed_ct, self.pca.bias, self.pca.scale, mean, packed_p,
-                                  self.pca.n_components, out=scores)
-            else:
-                _hip.pca_md_score(h, None, None, None, mean, packed_p, c, out=scores)
+            self._score_h_into(h, scores, mean, packed_p)
             done = s_k2.record_event()
         ring["free"][slot] = done
         # keep the caller's tensors alive for the side streams (caching-allocator stream safety)

@@ -517,3 +517,44 @@ def test_latent_methods_harness_goldens(ref_vectors=None):
     assert abs(best["KNN"] - 0.9881750345230103) < 1e-6
     assert abs(best["MD"] - 0.837399959564209) < 1e-6
     assert abs(best["GMM"] - 0.801800012588501) < 1e-6
+
+
+def test_folded_single_contraction_equals_two_stage():
+    """LaREMPipeline's folded weights (score = -||M h + c||^2) against the two-stage kernel and the oracle,
+    incl. a rank-deficient precision matrix (pinvh dropped directions) and the no-PCA case."""
+    from runia_core_amd.dimensionality_reduction import DevicePCA
+
+    rng = np.random.default_rng(12)
+    gp, gm = load_npz("ref_pca.npz"), load_npz("ref_md.npz")
+    h = rng.standard_normal((700, 512)) * 0.7 + 0.3
+    hd = torch.from_numpy(h).cuda()
+    md = MDLatentSpace()
+    md.feats_mean, md.precision, md._setup_flag = gm["d256_mean"], gm["d256_precision"], True
+    pca = DevicePCA(gp["d512_components"], gp["d512_mean"], gp["d512_var"], True)
+    pipe = LaREMPipeline(md, pca, 16)
+    assert pipe.fold_weights
+    s_fold = pipe.score_entropies(hd).cpu().numpy()
+    pipe2 = LaREMPipeline(md, pca, 16)
+    pipe2.fold_weights = False
+    s_two = pipe2.score_entropies(hd).cpu().numpy()
+    y = oracle.pca_transform(h, gp["d512_components"], gp["d512_mean"], gp["d512_var"])
+    exp = oracle.md_score(y, gm["d256_mean"], gm["d256_precision"])
+    assert rel_err(s_two, exp) < 1e-11 and rel_err(s_fold, exp) < 1e-10
+    # rank-deficient precision (the reference's unit case: 10 samples x 32 dims), no PCA
+    tr, _, _ = generate_test_data(seed=42)
+    te, _, _ = generate_test_data(seed=43)
+    md2 = MDLatentSpace()
+    md2.setup(tr.astype(np.float64))
+    p3 = LaREMPipeline(md2, None, 16)
+    s3 = p3.score_entropies(torch.from_numpy(te.astype(np.float64)).cuda()).cpu().numpy()
+    assert p3._folded_state() is not None and p3._folded_state()[2] == 9  # rank 9 = samples - 1
+    assert rel_err(s3, oracle.md_score(te.astype(np.float64), md2.feats_mean, md2.precision)) < 1e-9
+    # an indefinite "precision" cannot be factored: the pipeline keeps the two-stage kernel
+    md3 = MDLatentSpace()
+    a = rng.standard_normal((8, 8))
+    md3.feats_mean, md3.precision, md3._setup_flag = np.zeros((1, 8)), (a + a.T), True
+    p4 = LaREMPipeline(md3, None, 16)
+    x8 = rng.standard_normal((20, 8))
+    s4 = p4.score_entropies(torch.from_numpy(x8).cuda()).cpu().numpy()
+    assert p4._folded_state() is None
+    assert rel_err(s4, oracle.md_score(x8, md3.feats_mean, md3.precision)) < 1e-11
