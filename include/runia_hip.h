@@ -152,14 +152,19 @@ int runia_kde_score_f64(const double* train, const double* x, double* score, int
  *     z_out (optional, may be NULL): [N*n_mc, C] f32 copy of the samples, drop layers in
  *     mask-sum order (entropy is invariant to their order).  Shapes outside
  *     runia_mc_entropy_supported() return RUNIA_E_INVALID: use the two unfused calls.
+ *     workspace: runia_mc_entropy_workspace_bytes(N, H, W, n_mc) bytes of device memory, 16-byte
+ *     aligned (the per-image keep-flag table a first small launch derives from the draws;
+ *     RUNIA_E_WORKSPACE if missing or short).
  * (2) runia_pca_md_score_f64 = apply_pca_transform + MDLatentSpace.postprocess:
  *     h [N, D] f64 -> score [N] f64; packed_ct/bias/scale as runia_pca_transform_f64
  *     (packed_ct NULL = no PCA, n == D), md_mean [n], packed_p = pack(P [n, n]);
  *     y_out (optional) receives the projected rows [N, n]. */
 int runia_mc_entropy_supported(int H, int W, int n_mc, int k);
+size_t runia_mc_entropy_workspace_bytes(int64_t N, int H, int W, int n_mc);
 int runia_mc_entropy_f32(const float* x, const float* rand, int64_t rand_image_stride, double* h,
-                         float* z_out, int64_t N, int C, int H, int W, int n_mc, double drop_prob,
-                         int block_size, int k, double min_dist, runia_stream_t stream);
+                         float* z_out, void* workspace, size_t workspace_bytes, int64_t N, int C, int H,
+                         int W, int n_mc, double drop_prob, int block_size, int k, double min_dist,
+                         runia_stream_t stream);
 int runia_pca_md_score_f64(const double* h, const double* packed_ct, const double* bias,
                            const double* scale, const double* md_mean, const double* packed_p,
                            double* score, double* y_out, int64_t N, int64_t D, int64_t n,

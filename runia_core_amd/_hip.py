@@ -59,10 +59,11 @@ _SIGNATURES = {
     ),
     "runia_kde_score_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p]),
     "runia_mc_entropy_supported": (c_int, [c_int, c_int, c_int, c_int]),
+    "runia_mc_entropy_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "runia_mc_entropy_f32": (
         c_int,
-        [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_int,
-         c_double, c_void_p],
+        [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int,
+         c_double, c_int, c_int, c_double, c_void_p],
     ),
     "runia_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "runia_ash_s_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
@@ -382,6 +383,8 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
         assert out.is_cuda and out.dtype == torch.float64 and out.shape == (n, c) and out.is_contiguous()
         h = out
     z = torch.empty((n * n_mc, c), dtype=torch.float32, device=x.device) if want_samples else None
+    ws_bytes = int(lib.runia_mc_entropy_workspace_bytes(min(65535, n), hh, ww, n_mc))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)  # stream-ordered: reused per slice
     done = 0
     while done < n:
         m = min(65535, n - done)
@@ -389,8 +392,8 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
         zp = None if z is None else z.data_ptr() + done * n_mc * c * 4
         _check(
             lib.runia_mc_entropy_f32(x.data_ptr() + done * c * hh * ww * 4, rp, stride, h.data_ptr() + done * c * 8, zp,
-                                     m, c, hh, ww, n_mc, float(drop_prob), int(block_size), int(k), float(min_dist),
-                                     _stream()),
+                                     ws.data_ptr(), ws_bytes, m, c, hh, ww, n_mc, float(drop_prob), int(block_size),
+                                     int(k), float(min_dist), _stream()),
             "runia_mc_entropy_f32",
         )
         done += m

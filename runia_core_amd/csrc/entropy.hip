@@ -49,7 +49,7 @@ __global__ __launch_bounds__(256) void entropy_per_dim_kernel(const float* __res
     double out[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
-      bitonic_sort_asc<NP>(v[q]);
+      sort_asc<NP>(v[q]);
       out[q] = const_term + inv_n * column_log_sum<NP, K>(v[q], n, min_dist);
     }
     double* dst = h + img * D + c * VEC;

@@ -24,6 +24,7 @@ using namespace runia_entropy;
 using namespace runia_mfma;
 
 constexpr int kMaxMC = 64;
+typedef float f2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ float div_newton(float u, float den, float r) {
   const float q = u * r;
@@ -32,32 +33,41 @@ __device__ __forceinline__ float div_newton(float u, float den, float r) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K1: latent map -> MC samples -> entropy.   grid = (ceil(C/256), N)
+// K0: DropBlock draws -> per-image mask table (the scalar operands of K1).   grid = N, 256 threads
+//   table of one image = n_mc records of HW floats (0.0 / 1.0 keep flags, drop layers sorted by mask sum,
+//   positions in K1's operand order, see mask_slot) followed by n_mc mask sums and n_mc reciprocals.
 // ------------------------------------------------------------------------------------------
-template <int HT, int WT, int NP, int K>
-__global__ __launch_bounds__(256) void mc_entropy_kernel(const float* __restrict__ x,
-                                                          const float* __restrict__ rnd, int64_t rand_stride,
-                                                          double* __restrict__ h, float* __restrict__ z_out, int C,
-                                                          int n_mc, float gamma, int block_size, int identity,
-                                                          double min_dist, double const_term, double inv_n) {
+template <int HT, int WT>
+__host__ __device__ constexpr int mask_slot(int p) {
+  // even H: rows 2k and 2k+1 are interleaved so that one 64-bit scalar operand feeds a packed FMA
+  if constexpr (HT % 2 == 0) {
+    const int y = p / WT, xw = p - y * WT;
+    return ((y >> 1) * WT + xw) * 2 + (y & 1);
+  } else {
+    return p;
+  }
+}
+
+template <int HT, int WT>
+__global__ __launch_bounds__(256) void mc_mask_kernel(const float* __restrict__ rnd, int64_t rand_stride,
+                                                       float* __restrict__ table, int n_mc, float gamma,
+                                                       int block_size, int identity) {
   constexpr int HW = HT * WT;
-  __shared__ unsigned long long keep_bits[kMaxMC], sbits[kMaxMC];
-  __shared__ float msum[kMaxMC], sden[kMaxMC], srcp[kMaxMC];
-  const int tid = threadIdx.x;
-  const int64_t img = blockIdx.y;
-  const int pad = block_size / 2;
-  // Block masks.  The image's n_mc*HW uniform draws are pulled into LDS with one coalesced pass, then one
-  // thread per (drop layer, position) evaluates its max-pool window and ORs its keep bit into the layer's
-  // 64-bit mask.  (A serial per-layer loop over global memory here costs ~20 us of dependent-load latency
-  // per workgroup.)
   __shared__ float draws[kMaxMC * HW];
   __shared__ unsigned keep_lo[kMaxMC], keep_hi[kMaxMC];
+  __shared__ unsigned long long keep_bits[kMaxMC], sbits[kMaxMC];
+  __shared__ float msum[kMaxMC];
+  const int tid = threadIdx.x;
+  const int64_t img = blockIdx.x;
+  const int pad = block_size / 2;
+  float* out = table + img * (int64_t)(n_mc * (HW + 2));
   if (tid < n_mc) { keep_lo[tid] = 0u; keep_hi[tid] = 0u; }
   if (!identity) {
     const float* r = rnd + img * rand_stride;
     for (int i = tid; i < n_mc * HW; i += 256) draws[i] = r[i];
   }
   __syncthreads();
+  // one thread per (drop layer, position): max-pool window of the seed mask, keep bit ORed into the layer's mask
   for (int i = tid; i < n_mc * HW; i += 256) {
     const int s = i / HW, p = i - s * HW;
     bool dropped = false;
@@ -93,16 +103,41 @@ __global__ __launch_bounds__(256) void mc_entropy_kernel(const float* __restrict
       rank += (o < mine) || (o == mine && j < tid);
     }
     sbits[rank] = keep_bits[tid];
-    sden[rank] = mine;
-    srcp[rank] = 1.0f / mine;
+    out[n_mc * HW + rank] = mine;
+    out[n_mc * (HW + 1) + rank] = 1.0f / mine;
   }
   __syncthreads();
-  const int c = blockIdx.x * 256 + tid;
+  for (int i = tid; i < n_mc * HW; i += 256) {
+    const int s = i / HW, p = i - s * HW;
+    out[s * HW + mask_slot<HT, WT>(p)] = (float)((sbits[s] >> p) & 1ull);
+  }
+}
+
+// ------------------------------------------------------------------------------------------
+// K1: latent map -> MC samples -> entropy.   grid = (ceil(C/256), N); no LDS, no barrier.
+// The mask table is wave-uniform: it arrives through the scalar cache (s_load) and enters the arithmetic as
+// SGPR operands.  A drop layer is acc = fma(q, keep, acc) over the map in the upstream summation order
+// (keep = 1: the add of the reference; keep = 0: acc unchanged), two rows per v_pk_fma_f32.
+// ------------------------------------------------------------------------------------------
+template <int HT, int WT, int NP, int K, bool FULL>
+__global__ __launch_bounds__(256) void mc_entropy_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ table,
+                                                          double* __restrict__ h, float* __restrict__ z_out, int C,
+                                                          int n_mc_rt, double min_dist, double const_term,
+                                                          double inv_n) {
+  constexpr int HW = HT * WT;
+  constexpr bool PAIRS = (HT % 2 == 0);
+  const int n_mc = FULL ? NP : n_mc_rt;
+  const int64_t img = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c >= C) return;
+  const float* mk = table + img * (int64_t)(n_mc * (HW + 2));  // wave-uniform
+  const float* dens = mk + n_mc * HW;
+  const float* rcps = dens + n_mc;
   float u[HW];
   {
     // 16-byte loads at a 4*HW-byte lane stride: measured faster than staging the block's contiguous run
     // through LDS (214 vs 271 us at N = 10 000, profiles/README.md) - the kernel is VALU-bound, not HBM-bound
-    if (c >= C) return;
     const float* xc = x + (img * C + c) * (int64_t)HW;
     if constexpr (HW % 4 == 0) {
 #pragma unroll
@@ -120,44 +155,92 @@ __global__ __launch_bounds__(256) void mc_entropy_kernel(const float* __restrict
   constexpr bool w_pow2 = (WT & (WT - 1)) == 0, h_pow2 = (HT & (HT - 1)) == 0;
   const float rW = 1.0f / (float)WT, rH = 1.0f / (float)HT;
   float z[NP];
-  float q[HW];
+  float q[PAIRS ? 1 : HW];   // quotients (x*numel)/sum ...
+  f2 q2[PAIRS ? HW / 2 : 1];  // ... as row pairs in mask_slot order when H is even
   float cur_den = -1.f;
   bool bad = false;
+  // G drop layers per trip of a rolled loop: G*HW keep flags live in SGPRs at a time (a fully unrolled loop
+  // lets the compiler hoist all n_mc*HW scalar loads and spill them).  z is a shift register: constant indices
+  // only, and the sample order is irrelevant to the sort that follows.
+  constexpr int G = (64 / HW < 1) ? 1 : ((64 / HW > NP) ? NP : 64 / HW);
 #pragma unroll
-  for (int s = 0; s < NP; ++s) {
-    if (s < n_mc) {
-      const float den = sden[s];
-      if (den != cur_den) {  // wave-uniform: every thread of the block works on the same image
-        const float r = srcp[s];
+  for (int s = 0; s < NP; ++s) z[s] = INFINITY;
+#pragma unroll 1
+  for (int s0 = 0; s0 < NP; s0 += G) {
+    float znew[G];
+    // all scalar operands of this trip are requested up front (one wait instead of one per drop layer)
+    float dg[G], rg[G], mg[G][HW];
 #pragma unroll
-        for (int p = 0; p < HW; ++p) q[p] = div_newton(u[p], den, r);
-        cur_den = den;
-      }
-      const unsigned long long bits = sbits[s];  // wave-uniform (LDS broadcast)
-      float col = 0.f;
+    for (int g = 0; g < G; ++g) {
+      const int sc = FULL ? s0 + g : ((s0 + g < n_mc) ? s0 + g : n_mc - 1);
+      dg[g] = dens[sc];
+      rg[g] = rcps[sc];
 #pragma unroll
-      for (int y = 0; y < HT; ++y) {
-        float rowsum = 0.f;
-#pragma unroll
-        for (int xw = 0; xw < WT; ++xw) {
-          const int p = y * WT + xw;
-          rowsum += ((bits >> p) & 1ull) ? q[p] : 0.f;  // wave-uniform predicate (s_bitcmp + v_cndmask)
-        }
-        col += w_pow2 ? rowsum * rW : div_newton(rowsum, (float)WT, rW);
-      }
-      z[s] = h_pow2 ? col * rH : div_newton(col, (float)HT, rH);
-      bad = bad || (den == 0.f);
-    } else {
-      z[s] = INFINITY;
+      for (int p = 0; p < HW; ++p) mg[g][p] = mk[sc * HW + p];
     }
-  }
-  if (z_out) {  // optional copy of the MC samples (drop-layer order is the mask-sum order; tests only)
 #pragma unroll
-    for (int s = 0; s < NP; ++s)
-      if (s < n_mc) z_out[(img * n_mc + s) * (int64_t)C + c] = bad && sden[s] == 0.f ? NAN : z[s];
+    for (int g = 0; g < G; ++g) {
+      const int s = s0 + g;
+      znew[g] = INFINITY;
+      if (FULL || s < n_mc) {
+        const float den = dg[g];
+        if (den != cur_den) {  // wave-uniform: every thread of the block works on the same image
+          const float r = rg[g];
+#pragma unroll
+          for (int p = 0; p < HW; ++p) {
+            const float qv = div_newton(u[p], den, r);
+            if constexpr (PAIRS) q2[mask_slot<HT, WT>(p) >> 1][mask_slot<HT, WT>(p) & 1] = qv;
+            else q[p] = qv;
+          }
+          cur_den = den;
+        }
+        const float* m = mg[g];
+        float col;
+        if constexpr (PAIRS) {
+          float rows[HT];
+#pragma unroll
+          for (int k2 = 0; k2 < HT / 2; ++k2) {
+            const f2* qq = q2 + k2 * WT;
+            const float* mm = m + 2 * k2 * WT;
+            f2 acc = qq[0] * (f2){mm[0], mm[1]};
+#pragma unroll
+            for (int xw = 1; xw < WT; ++xw)
+              acc = __builtin_elementwise_fma(qq[xw], (f2){mm[2 * xw], mm[2 * xw + 1]}, acc);
+            if constexpr (w_pow2) {
+              acc = acc * (f2){rW, rW};
+            } else {
+              acc = (f2){div_newton(acc.x, (float)WT, rW), div_newton(acc.y, (float)WT, rW)};
+            }
+            rows[2 * k2] = acc.x;
+            rows[2 * k2 + 1] = acc.y;
+          }
+          col = rows[0];
+#pragma unroll
+          for (int y = 1; y < HT; ++y) col += rows[y];
+        } else {
+          col = 0.f;
+#pragma unroll
+          for (int y = 0; y < HT; ++y) {
+            float rowsum = q[y * WT] * m[y * WT];
+#pragma unroll
+            for (int xw = 1; xw < WT; ++xw) rowsum = fmaf(q[y * WT + xw], m[y * WT + xw], rowsum);
+            const float rm = w_pow2 ? rowsum * rW : div_newton(rowsum, (float)WT, rW);
+            col = (y == 0) ? rm : col + rm;
+          }
+        }
+        znew[g] = h_pow2 ? col * rH : div_newton(col, (float)HT, rH);
+        bad = bad || (den == 0.f);
+        if (z_out)  // optional copy of the MC samples (drop-layer order is the mask-sum order; tests only)
+          z_out[(img * n_mc + s) * (int64_t)C + c] = (den == 0.f) ? NAN : znew[g];
+      }
+    }
+#pragma unroll
+    for (int i = NP - 1; i >= G; --i) z[i] = z[i - G];
+#pragma unroll
+    for (int g = 0; g < G; ++g) z[g] = znew[g];
   }
-  bitonic_sort_asc<NP>(z);
-  double res = const_term + inv_n * column_log_sum<NP, K>(z, n_mc, min_dist);
+  sort_asc<NP>(z);
+  double res = const_term + inv_n * column_log_sum<NP, K, FULL>(z, n_mc, min_dist);
   if (bad) res = NAN;  // a fully dropped map is 0*numel/0 = NaN upstream
   h[img * C + c] = res;
 }
@@ -446,26 +529,44 @@ extern "C" int runia_pca_md_score_f64(const double* h, const double* packed_ct, 
   return launch_pca_md<1>(g, as_stream(stream));
 }
 
+extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k);
+
+extern "C" size_t runia_mc_entropy_workspace_bytes(int64_t N, int H, int W, int n_mc) {
+  if (N <= 0 || H <= 0 || W <= 0 || n_mc <= 0) return 0;
+  return (size_t)N * (size_t)n_mc * (size_t)(H * W + 2) * sizeof(float);
+}
+
 extern "C" int runia_mc_entropy_f32(const float* x, const float* rnd, int64_t rand_image_stride, double* h,
-                                    float* z_out, int64_t N, int C, int H, int W, int n_mc, double drop_prob,
-                                    int block_size, int k, double min_dist, runia_stream_t stream) {
+                                    float* z_out, void* workspace, size_t workspace_bytes, int64_t N, int C,
+                                    int H, int W, int n_mc, double drop_prob, int block_size, int k,
+                                    double min_dist, runia_stream_t stream) {
   if (N < 0 || C <= 0 || H <= 0 || W <= 0 || n_mc < 2 || n_mc > kMaxMC || block_size < 1 || k < 1 || k >= n_mc)
     return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
   if (!x || !h || N > 65535) return RUNIA_E_INVALID;
+  if (!runia_mc_entropy_supported(H, W, n_mc, k)) return RUNIA_E_INVALID;  // callers: mc_stack + kl_entropy_per_dim
   const int identity = (drop_prob == 0.0);
   if (!identity && !rnd) return RUNIA_E_INVALID;
+  if (!workspace || workspace_bytes < runia_mc_entropy_workspace_bytes(N, H, W, n_mc) ||
+      (((uintptr_t)workspace) & 15) != 0)
+    return RUNIA_E_WORKSPACE;
+  float* table = reinterpret_cast<float*>(workspace);
   const float gamma = (float)(drop_prob / (double)(block_size * block_size));
   const double ct = digamma_diff(n_mc, k), inv_n = 1.0 / (double)n_mc;
   dim3 grid((C + 255) / 256, (unsigned)N);
   hipStream_t s = as_stream(stream);
   const bool x16 = ((((uintptr_t)x) & 15) == 0);
-#define RUNIA_MCE(HH, WW, NPP, KK)                                                                         \
-  if (H == HH && W == WW && n_mc <= NPP && n_mc > NPP / 2 && k == KK && (x16 || (HH * WW) % 4 != 0)) {     \
-    mc_entropy_kernel<HH, WW, NPP, KK><<<grid, 256, 0, s>>>(x, rnd, rand_image_stride, h, z_out, C, n_mc,  \
-                                                           gamma, block_size, identity, min_dist, ct,      \
-                                                           inv_n);                                         \
-    return runia_check_launch();                                                                           \
+#define RUNIA_MCE(HH, WW, NPP, KK)                                                                          \
+  if (H == HH && W == WW && n_mc <= NPP && n_mc > NPP / 2 && k == KK && (x16 || (HH * WW) % 4 != 0)) {      \
+    mc_mask_kernel<HH, WW><<<(unsigned)N, 256, 0, s>>>(rnd, rand_image_stride, table, n_mc, gamma,          \
+                                                       block_size, identity);                               \
+    if (n_mc == NPP)                                                                                        \
+      mc_entropy_kernel<HH, WW, NPP, KK, true><<<grid, 256, 0, s>>>(x, table, h, z_out, C, n_mc, min_dist,  \
+                                                                    ct, inv_n);                             \
+    else                                                                                                    \
+      mc_entropy_kernel<HH, WW, NPP, KK, false><<<grid, 256, 0, s>>>(x, table, h, z_out, C, n_mc, min_dist, \
+                                                                     ct, inv_n);                            \
+    return runia_check_launch();                                                                            \
   }
   RUNIA_MCE(4, 4, 16, 5)
   RUNIA_MCE(4, 4, 32, 5)
@@ -474,7 +575,7 @@ extern "C" int runia_mc_entropy_f32(const float* x, const float* rnd, int64_t ra
   RUNIA_MCE(7, 7, 16, 5)
   RUNIA_MCE(8, 8, 16, 5)
 #undef RUNIA_MCE
-  return RUNIA_E_INVALID;  // unsupported shape: callers use runia_mc_stack_f32 + runia_kl_entropy_per_dim_f32
+  return RUNIA_E_INVALID;  // e.g. misaligned x: callers use runia_mc_stack_f32 + runia_kl_entropy_per_dim_f32
 }
 
 extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k) {
