@@ -113,6 +113,106 @@ __global__ __launch_bounds__(256) void mc_mask_kernel(const float* __restrict__ 
   }
 }
 
+// K0 for maps of at most 64 positions whose size divides 64 (2x2, 4x4, 8x8): a drop layer is one 64-bit word and
+// the whole derivation is bit arithmetic in registers - no LDS, no barrier, one HBM round trip.
+//   seeds   : lane = (layer, position); `draw < gamma` -> ballot -> 64/HW layers per word
+//   dilation: lane = layer; separable OR of the seed word shifted over the block window (columns, then rows)
+//   sort    : rank by popcount through readlane broadcasts; each lane stores its own table record
+// The LDS version above spends ~110 instructions per (layer, position) and 17-18 us per 10 000 images whatever its
+// workgroup shape (an empty launch of the same grid takes 5 us; profiles/README.md).
+template <int HT, int WT>
+__host__ __device__ constexpr int slot_position(int slot) {  // inverse of mask_slot
+  if constexpr (HT % 2 == 0) {
+    const int e = slot & 1, t = slot >> 1;
+    const int k = t / WT, xw = t - k * WT;
+    return (2 * k + e) * WT + xw;
+  } else {
+    return slot;
+  }
+}
+
+template <int HT, int WT>
+__device__ __forceinline__ unsigned long long columns_below(int k) {  // positions (y, x) with x < k
+  unsigned long long row = (k >= 64) ? ~0ull : ((1ull << k) - 1ull), m = 0ull;
+#pragma unroll
+  for (int y = 0; y < HT; ++y) m |= row << (y * WT);
+  return m;
+}
+
+constexpr int kMaskBitsWaves = 4;  // images per workgroup (independent waves)
+
+template <int HT, int WT, int NP>
+__global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const float* __restrict__ rnd,
+                                                                           int64_t rand_stride,
+                                                                           float* __restrict__ table, int64_t N,
+                                                                           int n_mc, float gamma, int block_size,
+                                                                           int identity) {
+  constexpr int HW = HT * WT;
+  static_assert(64 % HW == 0 && NP <= 64, "one drop layer per 64-bit word");
+  constexpr int LPW = 64 / HW;                 // layers per ballot word
+  constexpr int WORDS = (NP + LPW - 1) / LPW;
+  constexpr unsigned long long FULL = (HW == 64) ? ~0ull : ((1ull << HW) - 1ull);
+  const int lane = threadIdx.x & 63;
+  const int64_t img = (int64_t)blockIdx.x * kMaskBitsWaves + (threadIdx.x >> 6);
+  if (img >= N) return;  // wave-uniform
+  float d[WORDS];
+  if (!identity) {
+    const float* r = rnd + img * rand_stride;
+#pragma unroll
+    for (int t = 0; t < WORDS; ++t) {
+      const int i = lane + 64 * t;
+      d[t] = (i < n_mc * HW) ? r[i] : 1.0f;
+    }
+  }
+  unsigned long long seed = 0ull;  // this lane's layer (lane = layer index)
+#pragma unroll
+  for (int t = 0; t < WORDS; ++t) {
+    const unsigned long long w = identity ? 0ull : __ballot(d[t] < gamma);
+    if (lane / LPW == t) seed = (w >> ((lane % LPW) * HW)) & FULL;
+  }
+  const int pad = block_size / 2;
+  unsigned long long hx = 0ull;
+  for (int dx = 0; dx < block_size; ++dx) {  // dropped(y, x) |= seed(y, x + ox)
+    const int ox = dx - pad;
+    if (ox >= WT || -ox >= WT) continue;
+    hx |= (ox >= 0) ? ((seed >> ox) & columns_below<HT, WT>(WT - ox))
+                    : ((seed << -ox) & ~columns_below<HT, WT>(-ox) & FULL);
+  }
+  unsigned long long dropped = 0ull;
+  for (int dy = 0; dy < block_size; ++dy) {  // ... |= hx(y + oy, x)
+    const int oy = dy - pad;
+    if (oy >= HT || -oy >= HT) continue;
+    dropped |= (oy >= 0) ? (hx >> (oy * WT)) : ((hx << (-oy * WT)) & FULL);
+  }
+  const unsigned long long keep = ~dropped & FULL;
+  const int cnt = __popcll(keep);
+  int rank = 0;  // stable counting sort of the drop layers by mask sum
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const int o = __shfl(cnt, j, 64);
+    rank += (j < n_mc) && ((o < cnt) || (o == cnt && j < lane));
+  }
+  if (lane >= n_mc) return;
+  float* out = table + img * (int64_t)(n_mc * (HW + 2));
+  float* rec = out + rank * HW;
+  if constexpr (HW % 4 == 0) {
+#pragma unroll
+    for (int c = 0; c < HW / 4; ++c) {
+      float4 v;
+      v.x = (float)((keep >> slot_position<HT, WT>(4 * c)) & 1ull);
+      v.y = (float)((keep >> slot_position<HT, WT>(4 * c + 1)) & 1ull);
+      v.z = (float)((keep >> slot_position<HT, WT>(4 * c + 2)) & 1ull);
+      v.w = (float)((keep >> slot_position<HT, WT>(4 * c + 3)) & 1ull);
+      reinterpret_cast<float4*>(rec)[c] = v;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < HW; ++q) rec[q] = (float)((keep >> slot_position<HT, WT>(q)) & 1ull);
+  }
+  out[n_mc * HW + rank] = (float)cnt;
+  out[n_mc * (HW + 1) + rank] = 1.0f / (float)cnt;
+}
+
 // ------------------------------------------------------------------------------------------
 // K1: latent map -> MC samples -> entropy.   grid = (ceil(C/kK1Block), N); no LDS, no barrier.
 // The mask table is wave-uniform: it arrives through the scalar cache (s_load) and enters the arithmetic as
@@ -531,6 +631,20 @@ extern "C" int runia_pca_md_score_f64(const double* h, const double* packed_ct, 
   return launch_pca_md<1>(g, as_stream(stream));
 }
 
+namespace {
+template <int HH, int WW, int NPP>
+void launch_mask(const float* rnd, int64_t rand_image_stride, float* table, int64_t N, int n_mc, float gamma,
+                 int block_size, int identity, hipStream_t s) {
+  if constexpr (64 % (HH * WW) == 0) {
+    mc_mask_bits_kernel<HH, WW, NPP><<<(unsigned)((N + kMaskBitsWaves - 1) / kMaskBitsWaves), 64 * kMaskBitsWaves, 0,
+                                       s>>>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity);
+  } else {
+    mc_mask_kernel<HH, WW><<<(unsigned)N, 256, 0, s>>>(rnd, rand_image_stride, table, n_mc, gamma, block_size,
+                                                       identity);
+  }
+}
+}  // namespace
+
 extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k);
 
 extern "C" size_t runia_mc_entropy_workspace_bytes(int64_t N, int H, int W, int n_mc) {
@@ -560,8 +674,7 @@ extern "C" int runia_mc_entropy_f32(const float* x, const float* rnd, int64_t ra
   const bool x16 = ((((uintptr_t)x) & 15) == 0);
 #define RUNIA_MCE(HH, WW, NPP, KK)                                                                          \
   if (H == HH && W == WW && n_mc <= NPP && n_mc > NPP / 2 && k == KK && (x16 || (HH * WW) % 4 != 0)) {      \
-    mc_mask_kernel<HH, WW><<<(unsigned)N, 256, 0, s>>>(rnd, rand_image_stride, table, n_mc, gamma,          \
-                                                       block_size, identity);                               \
+    launch_mask<HH, WW, NPP>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity, s);       \
     if (n_mc == NPP)                                                                                        \
       mc_entropy_kernel<HH, WW, NPP, KK, true><<<grid, kK1Block, 0, s>>>(x, table, h, z_out, C, n_mc, min_dist,  \
                                                                     ct, inv_n);                             \

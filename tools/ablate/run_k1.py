@@ -7,7 +7,7 @@ n, C, H, W, n_mc = 10000, 512, 4, 4, 16
 x = torch.relu(torch.randn(n, C, H, W, device="cuda")).contiguous()
 rand = torch.rand(n, n_mc, H, W, device="cuda")
 h = torch.empty(n, C, dtype=torch.float64, device="cuda")
-for so in sorted(glob.glob(os.path.join(here, "libk1_*.so"))):
+for so in sorted(glob.glob(os.path.join(here, os.environ.get("K1_GLOB", "libk1_*.so")))):
     lib = ctypes.CDLL(so)
     f = lib.runia_mc_entropy_f32
     f.restype = c_int
