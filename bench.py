@@ -171,9 +171,10 @@ def main():
     value = world * n * args.steps / elapsed
 
     # ---------------- roofline of the dominant kernel ------------------------------------------
-    # algorithmic bytes of K1 per image ("with MC stacking from latent"): the latent map
-    # C*H*W*4, the draws n_mc*H*W*4, and the C entropies written as f64
-    kname, bytes_per_img = "mc_entropy_kernel", C * H * W * 4 + N_MC * H * W * 4 + C * 8
+    # algorithmic bytes of K1 per image ("with MC stacking from latent"): the latent map C*H*W*4, the
+    # keep-flag table of the image n_mc*(H*W+2)*4 (what the small launch before it makes of the n_mc*H*W*4 draws)
+    # and the C entropies written as f64.  HIP events bracket this kernel alone (pipeline.k1_events).
+    kname, bytes_per_img = "mc_entropy_kernel", C * H * W * 4 + N_MC * (H * W + 2) * 4 + C * 8
     imgs_per_launch = n / k1_launches_per_step
     achieved = bytes_per_img * imgs_per_launch / (kernel_ms * 1e-3) / 1e9
     traffic = None

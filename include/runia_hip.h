@@ -161,6 +161,16 @@ int runia_kde_score_f64(const double* train, const double* x, double* score, int
  *     y_out (optional) receives the projected rows [N, n]. */
 int runia_mc_entropy_supported(int H, int W, int n_mc, int k);
 size_t runia_mc_entropy_workspace_bytes(int64_t N, int H, int W, int n_mc);
+/* The two launches of runia_mc_entropy_f32 on their own (same arguments, same workspace): the keep-flag table
+ * of the draws (the DropBlock2D mask of feature_extraction/abstract_classes.py:91-96, drop layers sorted by mask
+ * sum), then sampler + entropy from that table.  A table may be reused for other latents of the same batch
+ * geometry (upstream draws the masks once per forward pass and applies them to every hooked layer). */
+int runia_mc_mask_table_f32(const float* rand, int64_t rand_image_stride, void* workspace,
+                            size_t workspace_bytes, int64_t N, int H, int W, int n_mc, double drop_prob,
+                            int block_size, runia_stream_t stream);
+int runia_mc_entropy_from_table_f32(const float* x, const void* workspace, size_t workspace_bytes, double* h,
+                                    float* z_out, int64_t N, int C, int H, int W, int n_mc, int k,
+                                    double min_dist, runia_stream_t stream);
 int runia_mc_entropy_f32(const float* x, const float* rand, int64_t rand_image_stride, double* h,
                          float* z_out, void* workspace, size_t workspace_bytes, int64_t N, int C, int H,
                          int W, int n_mc, double drop_prob, int block_size, int k, double min_dist,

@@ -60,6 +60,15 @@ _SIGNATURES = {
     "runia_kde_score_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p]),
     "runia_mc_entropy_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "runia_mc_entropy_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
+    "runia_mc_mask_table_f32": (
+        c_int,
+        [c_void_p, c_int64, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_double, c_int, c_void_p],
+    ),
+    "runia_mc_entropy_from_table_f32": (
+        c_int,
+        [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_double,
+         c_void_p],
+    ),
     "runia_mc_entropy_f32": (
         c_int,
         [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int,
@@ -361,8 +370,11 @@ def mc_entropy_supported(h: int, w: int, n_mc: int, k: int) -> bool:
 
 
 def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob: float, block_size: int, k: int,
-               min_dist: float = 1e-5, want_samples: bool = False, out: Optional[torch.Tensor] = None):
-    """Fused sampler + entropy: x [N,C,H,W] f32 (+ draws) -> h [N, C] f64 (and optionally the MC samples)."""
+               min_dist: float = 1e-5, want_samples: bool = False, out: Optional[torch.Tensor] = None,
+               kernel_events: Optional[list] = None):
+    """Fused sampler + entropy: x [N,C,H,W] f32 (+ draws) -> h [N, C] f64 (and optionally the MC samples).
+    ``kernel_events``: if a list, (start, end) HIP event pairs around the sampler + entropy launch alone (the
+    keep-flag table launch before it is left out) are appended - bench.py times the dominant kernel with it."""
     lib = load_library()
     require_gpu()
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
@@ -390,12 +402,29 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
         m = min(65535, n - done)
         rp = None if rand is None else rand.data_ptr() + done * stride * 4
         zp = None if z is None else z.data_ptr() + done * n_mc * c * 4
-        _check(
-            lib.runia_mc_entropy_f32(x.data_ptr() + done * c * hh * ww * 4, rp, stride, h.data_ptr() + done * c * 8, zp,
-                                     ws.data_ptr(), ws_bytes, m, c, hh, ww, n_mc, float(drop_prob), int(block_size),
-                                     int(k), float(min_dist), _stream()),
-            "runia_mc_entropy_f32",
-        )
+        if kernel_events is None:
+            _check(
+                lib.runia_mc_entropy_f32(x.data_ptr() + done * c * hh * ww * 4, rp, stride, h.data_ptr() + done * c * 8,
+                                         zp, ws.data_ptr(), ws_bytes, m, c, hh, ww, n_mc, float(drop_prob),
+                                         int(block_size), int(k), float(min_dist), _stream()),
+                "runia_mc_entropy_f32",
+            )
+        else:
+            _check(
+                lib.runia_mc_mask_table_f32(rp, stride, ws.data_ptr(), ws_bytes, m, hh, ww, n_mc, float(drop_prob),
+                                            int(block_size), _stream()),
+                "runia_mc_mask_table_f32",
+            )
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            _check(
+                lib.runia_mc_entropy_from_table_f32(x.data_ptr() + done * c * hh * ww * 4, ws.data_ptr(), ws_bytes,
+                                                    h.data_ptr() + done * c * 8, zp, m, c, hh, ww, n_mc, int(k),
+                                                    float(min_dist), _stream()),
+                "runia_mc_entropy_from_table_f32",
+            )
+            e1.record()
+            kernel_events.append((e0, e1))
         done += m
     return (h, z) if want_samples else h
 

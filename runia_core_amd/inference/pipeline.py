@@ -76,13 +76,13 @@ class LaREMPipeline:
     def entropy(self, z: Tensor) -> Tensor:
         return _hip.kl_entropy_per_dim(z, self.n_mc, self.k, MIN_DIST)
 
-    def entropy_from_latents(self, latents: Tensor, rand: Optional[Tensor]) -> Tensor:
-        """Sampler + per-dimension entropy in one launch when the map shape is supported
-        (``runia_mc_entropy_f32``), else the two unfused kernels."""
+    def entropy_from_latents(self, latents: Tensor, rand: Optional[Tensor], kernel_events: Optional[list] = None) -> Tensor:
+        """Sampler + per-dimension entropy without materialising the MC samples when the map shape is supported
+        (``runia_mc_entropy_f32``: keep-flag table launch + sampler/entropy launch), else the two unfused kernels."""
         _, _, h, w = latents.shape
         if _hip.mc_entropy_supported(h, w, self.n_mc, self.k):
             return _hip.mc_entropy(latents, rand, self.n_mc, self.drop_prob if rand is not None else 0.0,
-                                   self.block_size, self.k, MIN_DIST)
+                                   self.block_size, self.k, MIN_DIST, kernel_events=kernel_events)
         return self.entropy(self.stack(latents, rand))
 
     def _md_state(self):
@@ -165,20 +165,14 @@ class LaREMPipeline:
         Large LaREM batches are cut into ``chunks`` row blocks pipelined over two HIP streams: the sampler +
         entropy kernel (vector ALUs) of block i+1 runs beside the PCA + LaREM kernel (matrix cores) of block i.
         Rows are independent, so the result is identical to the single-launch form.  ``k1_events`` (optional list)
-        receives one (start, end) event pair per K1 launch, recorded on the stream the kernel is launched on."""
+        receives one (start, end) event pair per sampler + entropy launch (the keep-flag table launch before it is
+        left out), recorded on the stream the kernel is launched on."""
         n, _, hh, ww = latents.shape
         chunks = self.overlap_chunks if chunks is None else int(chunks)
         md = self._md_state()
         fused = _hip.mc_entropy_supported(hh, ww, self.n_mc, self.k) and md is not None
         if not fused or chunks <= 1 or n < 2048 * chunks or (rand is not None and rand.dim() != 4):
-            if k1_events is not None and fused:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                h = self.entropy_from_latents(latents, rand)
-                e1.record()
-                k1_events.append((e0, e1))
-                return self.score_entropies(h)
-            return self.score_entropies(self.entropy_from_latents(latents, rand))
+            return self.score_entropies(self.entropy_from_latents(latents, rand, k1_events if fused else None))
         latents = latents.contiguous()
         if rand is not None:
             rand = rand.contiguous()
@@ -197,14 +191,8 @@ class LaREMPipeline:
         for a in range(0, n, per):
             b = min(a + per, n)
             with torch.cuda.stream(s_k1):
-                if k1_events is not None:
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
                 _hip.mc_entropy(latents[a:b], None if rand is None else rand[a:b], self.n_mc, drop, self.block_size,
-                                self.k, MIN_DIST, out=h[a:b])
-                if k1_events is not None:
-                    e1.record()
-                    k1_events.append((e0, e1))
+                                self.k, MIN_DIST, out=h[a:b], kernel_events=k1_events)
                 ready = s_k1.record_event()
             s_k2.wait_event(ready)
             with torch.cuda.stream(s_k2):
@@ -245,13 +233,8 @@ class LaREMPipeline:
             s_k1.wait_event(ring["free"][slot])
         drop = self.drop_prob if rand is not None else 0.0
         with torch.cuda.stream(s_k1):
-            if k1_events is not None:
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-            _hip.mc_entropy(latents, rand, self.n_mc, drop, self.block_size, self.k, MIN_DIST, out=h)
-            if k1_events is not None:
-                e1.record()
-                k1_events.append((e0, e1))
+            _hip.mc_entropy(latents, rand, self.n_mc, drop, self.block_size, self.k, MIN_DIST, out=h,
+                            kernel_events=k1_events)
             ready = s_k1.record_event()
         s_k2.wait_event(ready)
         with torch.cuda.stream(s_k2):
