@@ -182,8 +182,12 @@ int runia_pca_md_score_f64(const double* h, const double* packed_ct, const doubl
 /* (2') runia_proj_sq_score_f64: the same LaREM score from ONE contraction, score = -|| M h + c ||^2, where the
  *     caller folded PCA transform, centring and the factor W of precision = W^T W into M [r, D] = W diag(1/scale) C
  *     and c [r] = W (-bias/scale - md_mean) at setup (exact algebra, f64): packed_m = pack(M.T [D, r]). */
+/*     workspace (optional: NULL / 0 is accepted): runia_proj_sq_workspace_bytes(N) bytes let batches of a few
+ *     row tiles per compute unit be cut in column halves (two partial row sums + one small combine launch). */
+size_t runia_proj_sq_workspace_bytes(int64_t N);
 int runia_proj_sq_score_f64(const double* h, const double* packed_m, const double* c, double* score,
-                            int64_t N, int64_t D, int64_t r, runia_stream_t stream);
+                            void* workspace, size_t workspace_bytes, int64_t N, int64_t D, int64_t r,
+                            runia_stream_t stream);
 
 /* ---- f1  setup-time covariance on the device (SURVEY 8f "next #1") ----------- *
  * Replaces np.cov(X.T, bias=1) inside sklearn EmpiricalCovariance.fit

@@ -79,7 +79,11 @@ _SIGNATURES = {
     "runia_gen_score_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
     "runia_proj_norm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "runia_proj_norm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
-    "runia_proj_sq_score_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
+    "runia_proj_sq_workspace_bytes": (c_size_t, [c_int64]),
+    "runia_proj_sq_score_f64": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int64, c_void_p],
+    ),
     "runia_covariance_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "runia_covariance_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
     "runia_covariance_f32in": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
@@ -524,6 +528,9 @@ def proj_sq_score(h: torch.Tensor, packed_m: torch.Tensor, c: torch.Tensor, r: i
     h = h.contiguous()
     nrow, d = h.shape
     s = torch.empty((nrow,), dtype=torch.float64, device=h.device) if out is None else out
-    _check(lib.runia_proj_sq_score_f64(h.data_ptr(), packed_m.data_ptr(), c.data_ptr(), s.data_ptr(), nrow, d, int(r), _stream()),
+    ws_bytes = int(lib.runia_proj_sq_workspace_bytes(nrow))
+    ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=h.device)
+    _check(lib.runia_proj_sq_score_f64(h.data_ptr(), packed_m.data_ptr(), c.data_ptr(), s.data_ptr(), ws.data_ptr(),
+                                       ws_bytes, nrow, d, int(r), _stream()),
            "runia_proj_sq_score_f64")
     return s

@@ -26,6 +26,20 @@ static inline unsigned runia_stream_grid(int64_t work_items, int per_block) {
   return (unsigned)blocks;
 }
 
+// Compute units of the current device (256 on MI355X); cached after the first call.
+static inline int64_t runia_cu_count() {
+  static int64_t cus = 0;
+  if (cus == 0) {
+    int dev = 0, n = 0;
+    if (hipGetDevice(&dev) == hipSuccess &&
+        hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && n > 0)
+      cus = n;
+    else
+      cus = 256;
+  }
+  return cus;
+}
+
 __device__ __forceinline__ double kInfD() { return __builtin_inf(); }
 
 __device__ __forceinline__ float wave_max_f32(float v) {

@@ -509,15 +509,21 @@ struct ProjSqArgs {
   const double* h;        // [N, D]
   const double* packed_m; // pack(M^T [D, r])
   const double* c;        // [r]
-  double* score;          // [N]
+  double* score;          // [N]            (column split 1)
+  double* partial;        // [2, N] row sums (column split 2; proj_sq_combine_kernel finishes)
   int64_t N, D, r;
 };
 
-template <int RT>
+// NCT column tiles per wave: 4 = the workgroup covers every 256-column block whole (grid.y = 1); 2 = two
+// workgroups share a row tile, each taking one 128-column half of every block (grid.y = 2) and leaving its row
+// sums of squares in `partial`.  The split halves the unit of work: at N = 10 000 the 625 row tiles are 2.44 per
+// CU (3 on some, 2 on most: 19 % of the matrix pipes idle at the end); 1250 half tiles finish within 3 %.
+template <int RT, int NCT>
 __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
   constexpr int BM = 16 * RT;
   __shared__ double lds_a[2 * BM * APITCH];
-  __shared__ double part[4 * BM];
+  constexpr int NG = NCT / 2;  // 32-column groups per wave: the unit of the (launch-independent) summation order
+  __shared__ double part[4 * NG * BM];
   const int64_t n_pad = n_padded(g.r);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -526,22 +532,24 @@ __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
   const int64_t r0 = (int64_t)blockIdx.x * BM;
   const int64_t nchunks = k_padded(g.D) / KC;
   constexpr int PER_T = BM * KC / 256;
-  double rowsq[RT][4];
+  double rowsq[NG][RT][4];
 #pragma unroll
-  for (int a = 0; a < RT; ++a)
-#pragma unroll
-    for (int r = 0; r < 4; ++r) rowsq[a][r] = 0.0;
-  for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
-    const int64_t ctbase = cb * 16 + wave * 4;
-    d4 acc[RT][4];
+  for (int q = 0; q < NG; ++q)
 #pragma unroll
     for (int a = 0; a < RT; ++a)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
-    const double2* bp = reinterpret_cast<const double2*>(g.packed_m) + ctbase * 64 + lane;
-    double2 b0[4];
+      for (int r = 0; r < 4; ++r) rowsq[q][a][r] = 0.0;
+  for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
+    const int64_t ctbase = cb * 16 + (int64_t)blockIdx.y * (4 * NCT) + wave * NCT;
+    d4 acc[RT][NCT];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) b0[c] = bp[c * 64];
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+    const double2* bp = reinterpret_cast<const double2*>(g.packed_m) + ctbase * 64 + lane;
+    double2 b0[NCT];
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) b0[c] = bp[c * 64];
     double areg[PER_T];
     const int srow = (tid * PER_T) / KC, skk = (tid * PER_T) % KC;
     auto load_a = [&](int64_t kc) {
@@ -559,39 +567,57 @@ __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
       for (int q = 0; q < PER_T; ++q) lds_a[(buf * BM + srow) * APITCH + skk + q] = areg[q];
       __syncthreads();
       if (ch + 1 < nchunks) load_a((ch + 1) * KC);
-      mfma_chunk<RT>(acc, lds_a + buf * BM * APITCH, APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
+      mfma_chunk<RT, NCT>(acc, lds_a + buf * BM * APITCH, APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
       buf ^= 1;
     }
 #pragma unroll
     for (int a = 0; a < RT; ++a)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < NCT; ++c) {
         const int64_t col = (ctbase + c) * 16 + li;
         const double cc = (col < g.r) ? g.c[col] : 0.0;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const double v = acc[a][c][r] + cc;  // zero-padded columns contribute 0
-          rowsq[a][r] = fma(v, v, rowsq[a][r]);
+          rowsq[c / 2][a][r] = fma(v, v, rowsq[c / 2][a][r]);
         }
       }
     __syncthreads();
   }
+  // A row's sum of squares is added up in ONE order whatever the launch shape (so a batch scores the same bits
+  // sharded, chunked or whole): 32-column groups g = 0..7 of every 256-column block, each accumulated over the
+  // blocks and its 16 lanes, then ((g0+g1)+g2)+g3 and ((g4+g5)+g6)+g7, then the sum of the two halves.
 #pragma unroll
-  for (int a = 0; a < RT; ++a)
+  for (int q = 0; q < NG; ++q)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      double v = rowsq[a][r];
-      v += shfl_xor_f64(v, 1);
-      v += shfl_xor_f64(v, 2);
-      v += shfl_xor_f64(v, 4);
-      v += shfl_xor_f64(v, 8);
-      if (li == 0) part[wave * BM + 16 * a + lg + 4 * r] = v;
-    }
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double v = rowsq[q][a][r];
+        v += shfl_xor_f64(v, 1);
+        v += shfl_xor_f64(v, 2);
+        v += shfl_xor_f64(v, 4);
+        v += shfl_xor_f64(v, 8);
+        if (li == 0) part[(wave * NG + q) * BM + 16 * a + lg + 4 * r] = v;
+      }
   __syncthreads();
   if (tid < BM) {
     const int64_t row = r0 + tid;
-    if (row < g.N) g.score[row] = -(((part[tid] + part[BM + tid]) + part[2 * BM + tid]) + part[3 * BM + tid]);
+    if (row < g.N) {
+      const double lo = ((part[tid] + part[BM + tid]) + part[2 * BM + tid]) + part[3 * BM + tid];
+      if constexpr (NCT == 4) {
+        const double hi = ((part[4 * BM + tid] + part[5 * BM + tid]) + part[6 * BM + tid]) + part[7 * BM + tid];
+        g.score[row] = -(lo + hi);
+      } else {
+        g.partial[(int64_t)blockIdx.y * g.N + row] = lo;
+      }
+    }
   }
+}
+
+__global__ void proj_sq_combine_kernel(const double* __restrict__ partial, double* __restrict__ score, int64_t N) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < N) score[i] = -(partial[i] + partial[N + i]);
 }
 
 double digamma_diff(int n, int k) {
@@ -744,17 +770,24 @@ extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k) {
   return 0;
 }
 
+extern "C" size_t runia_proj_sq_workspace_bytes(int64_t N) { return N > 0 ? (size_t)N * 2 * sizeof(double) : 0; }
+
 extern "C" int runia_proj_sq_score_f64(const double* h, const double* packed_m, const double* c, double* score,
-                                       int64_t N, int64_t D, int64_t r, runia_stream_t stream) {
+                                       void* workspace, size_t workspace_bytes, int64_t N, int64_t D, int64_t r,
+                                       runia_stream_t stream) {
   if (N < 0 || D <= 0 || r <= 0) return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
   if (!h || !packed_m || !c || !score) return RUNIA_E_INVALID;
-  ProjSqArgs g{h, packed_m, c, score, N, D, r};
+  ProjSqArgs g{h, packed_m, c, score, reinterpret_cast<double*>(workspace), N, D, r};
   hipStream_t s = as_stream(stream);
-  if ((N + 31) / 32 >= 1024) {
-    proj_sq_kernel<2><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
+  const int64_t tiles16 = (N + 15) / 16, cus = runia_cu_count();
+  if (tiles16 >= 4 * cus) {  // many tiles per CU: the tail is short, take the larger tile (fewer re-reads of M)
+    proj_sq_kernel<2, 4><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
+  } else if (tiles16 > cus / 2 && workspace && workspace_bytes >= runia_proj_sq_workspace_bytes(N)) {
+    proj_sq_kernel<1, 2><<<dim3((unsigned)tiles16, 2), 256, 0, s>>>(g);
+    proj_sq_combine_kernel<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(g.partial, score, N);
   } else {
-    proj_sq_kernel<1><<<(unsigned)((N + 15) / 16), 256, 0, s>>>(g);
+    proj_sq_kernel<1, 4><<<(unsigned)tiles16, 256, 0, s>>>(g);
   }
   return runia_check_launch();
 }

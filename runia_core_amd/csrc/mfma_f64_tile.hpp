@@ -30,28 +30,30 @@ __host__ __device__ inline int64_t packed_elems(int64_t K, int64_t n) { return p
 //            the first pair of the NEXT chunk, so B loads stay one pair (8 MFMAs = 512 matrix-pipe cycles) ahead.
 // Branch-free on purpose: a conditional around an MFMA makes hipcc shuttle the accumulators between VGPRs and
 // AGPRs (64 v_accvgpr moves per 8 MFMAs were measured before this form).
-template <int RT>
-__device__ __forceinline__ void mfma_chunk(d4 (&acc)[RT][4], const double* a_tile, int pitch, int li, int lg,
-                                           const double2* __restrict__ bp, int64_t pair_stride, double2 (&b0)[4]) {
+// NCT = column tiles per wave (4: a workgroup pass covers 256 columns; 2: 128 columns).
+template <int RT, int NCT = 4>
+__device__ __forceinline__ void mfma_chunk(d4 (&acc)[RT][NCT], const double* a_tile, int pitch, int li, int lg,
+                                           const double2* __restrict__ bp, int64_t pair_stride,
+                                           double2 (&b0)[NCT]) {
   double av[RT][8];
 #pragma unroll
   for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int t = 0; t < 8; ++t) av[a][t] = a_tile[(16 * a + li) * pitch + 4 * t + lg];
-  double2 b1[4];
+  double2 b1[NCT];
 #pragma unroll
   for (int s2 = 0; s2 < 4; ++s2) {
     if ((s2 & 1) == 0) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) b1[c] = bp[(s2 + 1) * pair_stride + c * 64];
+      for (int c = 0; c < NCT; ++c) b1[c] = bp[(s2 + 1) * pair_stride + c * 64];
     } else {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) b0[c] = bp[(s2 + 1) * pair_stride + c * 64];
+      for (int c = 0; c < NCT; ++c) b0[c] = bp[(s2 + 1) * pair_stride + c * 64];
     }
 #pragma unroll
     for (int hh = 0; hh < 2; ++hh) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < NCT; ++c) {
         const double2 bb = (s2 & 1) ? b1[c] : b0[c];
         const double bv = hh ? bb.y : bb.x;
 #pragma unroll
