@@ -171,6 +171,16 @@ add("LaREM / MD (a5)", f"{N}x{NP} f64", "rows", N, ms, "mfma_f64", 2.0 * NP * NP
 ms = gpu_ms(lambda: _hip.pca_md_score(h, pct, bias, scale, mdmd, pp, NP))
 add("K2 pca_md (a4+a5)", f"{N}x{C} f64", "rows", N, ms, "mfma_f64", 2.0 * C * NP + 2.0 * NP * NP + 2 * NP, float("nan"), "-", rel(_hip.pca_md_score(h, pct, bias, scale, mdmd, pp, NP)[:2000].cpu().numpy(), oracle.md_score(ys, mdm, prec)))
 
+# K2': the same score from one folded contraction (LaREMPipeline default): M = W diag(1/scale) C, c = W(-bias/scale - mu)
+evals, evecs = np.linalg.eigh(prec)
+Wf = (evecs * np.sqrt(np.maximum(evals, 0.0))).T
+Mf = Wf @ (comp / np.sqrt(var)[:, None])
+cf = Wf @ (-(mean.reshape(1, -1) @ comp.T).ravel() / np.sqrt(var) - mdm.ravel())
+pm = _hip.pack_weights(torch.from_numpy(np.ascontiguousarray(Mf.T)).to(dev))
+cfd = torch.from_numpy(cf).to(dev)
+ms = gpu_ms(lambda: _hip.proj_sq_score(h, pm, cfd, NP))
+add("K2' proj_sq (a4+a5 folded)", f"{N}x{C} f64", "rows", N, ms, "mfma_f64", 2.0 * C * NP + 2 * NP, float("nan"), "-", rel(_hip.proj_sq_score(h, pm, cfd, NP)[:2000].cpu().numpy(), oracle.md_score(ys, mdm, prec)))
+
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"host_cores": os.cpu_count(), "device": torch.cuda.get_device_name(0), "rows": rows},
           open(os.path.join(ROOT, "gpurun_out", "stages.json"), "w"), indent=1)
