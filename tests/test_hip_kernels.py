@@ -319,7 +319,8 @@ def test_larem_chain_unfused(hip):
 # ---------------- a11 fused launches --------------------------------------------------------------------
 @pytest.mark.parametrize("c,h,w,bs,p,n_mc,n", [(512, 4, 4, 2, 0.5, 16, 33), (100, 4, 4, 2, 0.7, 32, 5), (64, 4, 4, 3, 0.5, 7, 4),
                                                (70, 7, 7, 3, 0.4, 16, 3), (130, 8, 8, 4, 0.4, 12, 3), (33, 2, 2, 1, 0.5, 16, 6),
-                                               (512, 4, 4, 2, 0.0, 16, 3)])
+                                               (512, 4, 4, 2, 0.0, 16, 3), (40, 4, 4, 4, 0.6, 16, 9), (24, 8, 8, 5, 0.5, 16, 4),
+                                               (24, 8, 8, 8, 0.9, 10, 4), (70, 2, 2, 2, 0.15, 16, 5), (64, 4, 4, 7, 0.05, 16, 12)])
 def test_mc_entropy_fused_equals_unfused(hip, c, h, w, bs, p, n_mc, n):
     torch.manual_seed(c + n_mc)
     x = torch.relu(torch.randn(n, c, h, w)).cuda()
@@ -339,6 +340,19 @@ def test_mc_entropy_fused_equals_unfused(hip, c, h, w, bs, p, n_mc, n):
     assert np.isnan(a[~fin]).all()
     exp = oracle.kl_entropy_per_dim_vectorized(np.where(np.isfinite(z.cpu().numpy()), z.cpu().numpy(), 0.0), n_mc, k)
     assert np.abs(a[fin] - exp[fin]).max() < 1e-11
+
+
+def test_mc_entropy_two_call_form_equals_one_call(hip):
+    """runia_mc_mask_table_f32 + runia_mc_entropy_from_table_f32 (what bench.py times) = runia_mc_entropy_f32."""
+    torch.manual_seed(5)
+    x = torch.relu(torch.randn(37, 512, 4, 4)).cuda()
+    rand = torch.rand(37, 16, 4, 4).cuda()
+    ev = []
+    a = hip.mc_entropy(x, rand, 16, 0.5, 2, 5, kernel_events=ev)
+    b = hip.mc_entropy(x, rand, 16, 0.5, 2, 5)
+    torch.cuda.synchronize()
+    assert len(ev) == 1 and ev[0][0].elapsed_time(ev[0][1]) > 0
+    assert torch.equal(a, b)
 
 
 def test_mc_entropy_unsupported_shape_is_refused(hip):
