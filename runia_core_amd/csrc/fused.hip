@@ -258,9 +258,15 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
       for (int p = 0; p < HW; ++p) u[p] = xc[p];
     }
   }
-#pragma unroll
-  for (int p = 0; p < HW; ++p) u[p] *= (float)HW;
   constexpr bool w_pow2 = (WT & (WT - 1)) == 0, h_pow2 = (HT & (HT - 1)) == 0;
+  // Power-of-two scalings are exact and commute with rounding (no overflow / underflow at feature-map magnitudes),
+  // so they are moved to where they cost least: (x*numel)/sum = x/(sum/numel) when numel = H*W is a power of two, and
+  // mean_H(mean_W(.)) = (sum over the map in the upstream order) * (1/(H*W)) when H and W are.
+  constexpr bool hw_pow2 = w_pow2 && h_pow2;
+  if constexpr (!hw_pow2) {
+#pragma unroll
+    for (int p = 0; p < HW; ++p) u[p] *= (float)HW;
+  }
   const float rW = 1.0f / (float)WT, rH = 1.0f / (float)HT;
   float z[NP];
   float q[PAIRS ? 1 : HW];   // quotients (x*numel)/sum ...
@@ -293,10 +299,11 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
       if (FULL || s < n_mc) {
         const float den = dg[g];
         if (den != cur_den) {  // wave-uniform: every thread of the block works on the same image
-          const float r = rg[g];
+          const float r = hw_pow2 ? rg[g] * (float)HW : rg[g];
+          const float dd = hw_pow2 ? den * (1.0f / (float)HW) : den;
 #pragma unroll
           for (int p = 0; p < HW; ++p) {
-            const float qv = div_newton(u[p], den, r);
+            const float qv = div_newton(u[p], dd, r);
             if constexpr (PAIRS) q2[mask_slot<HT, WT>(p) >> 1][mask_slot<HT, WT>(p) & 1] = qv;
             else q[p] = qv;
           }
@@ -314,7 +321,9 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
 #pragma unroll
             for (int xw = 1; xw < WT; ++xw)
               acc = __builtin_elementwise_fma(qq[xw], (f2){mm[2 * xw], mm[2 * xw + 1]}, acc);
-            if constexpr (w_pow2) {
+            if constexpr (hw_pow2) {
+              // scaled once below
+            } else if constexpr (w_pow2) {
               acc = acc * (f2){rW, rW};
             } else {
               acc = (f2){div_newton(acc.x, (float)WT, rW), div_newton(acc.y, (float)WT, rW)};
@@ -336,7 +345,8 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
             col = (y == 0) ? rm : col + rm;
           }
         }
-        znew[g] = h_pow2 ? col * rH : div_newton(col, (float)HT, rH);
+        if constexpr (hw_pow2 && PAIRS) znew[g] = col * (rW * rH);
+        else znew[g] = h_pow2 ? col * rH : div_newton(col, (float)HT, rH);
         bad = bad || (den == 0.f);
         if (z_out)  // optional copy of the MC samples (drop-layer order is the mask-sum order; tests only)
           z_out[(img * n_mc + s) * (int64_t)C + c] = (den == 0.f) ? NAN : znew[g];
