@@ -109,54 +109,84 @@ __global__ __launch_bounds__(64) void entropy_per_dim_generic_kernel(const float
   }
 }
 
-// Joint (D-dimensional, Chebyshev) entropy: one workgroup per image.  Each lane owns
-// sample pairs (a<b); the image's samples are staged through LDS in chunks of dims.
+// Joint (D-dimensional, Chebyshev) entropy: one workgroup per image.
+//   task = (sample pair a<b, slice of the staged dims): n = 16 gives 120 pairs x 2 slices = 240 busy lanes.
+//   The image's samples are staged through LDS in chunks of dims, already promoted to f64 (the reference promotes
+//   before its tree query), so the inner step is two 8-byte LDS reads + v_add_f64 + v_max_f64(|.|).
+//   Slices of a pair meet in dist[a][b] through an LDS max on the bit pattern (distances are >= 0).
+// LDS is sized by n at launch: tile n x (chunk+2) + dist n x (n+1) doubles (18.8 KB at n = 16: 8 images per CU).
 constexpr int kJointChunk = 128;  // dims per staged chunk
+constexpr int kJointTasks = 8;    // tasks per thread at most (n = 64: 2016 pairs)
 __global__ __launch_bounds__(256) void entropy_joint_kernel(const float* __restrict__ z,
                                                              double* __restrict__ h_mvn, int64_t N, int n,
                                                              int64_t D, int k, double min_dist,
                                                              double const_term, double d_over_n) {
-  __shared__ float tile[64][kJointChunk + 1];
-  __shared__ double dist[64][65];
+  extern __shared__ __attribute__((aligned(16))) double joint_lds[];
+  constexpr int TP = kJointChunk + 2;           // even pitch: 16-byte aligned rows, 4-bank row offset
+  double* tile = joint_lds;                     // [n][TP]
+  double* dist = joint_lds + (size_t)n * TP;    // [n][n + 1]
+  const int DP = n + 1;
   const int tid = threadIdx.x;
   const int npairs = n * (n - 1) / 2;
+  const int slices = (npairs >= 256) ? 1 : 256 / npairs;
+  const int ntasks = npairs * slices;
+  // this thread's tasks: t = tid, tid + 256, ...  -> (a, b, slice); fixed for the whole launch
+  int ta[kJointTasks], tb[kJointTasks], ts[kJointTasks];
+#pragma unroll
+  for (int q = 0; q < kJointTasks; ++q) {
+    const int t = tid + 256 * q;
+    ta[q] = -1; tb[q] = 0; ts[q] = 0;
+    if (t < ntasks) {
+      const int p = t / slices;
+      ts[q] = t - p * slices;
+      int a = 0, rem = p;
+      while (rem >= n - 1 - a) { rem -= n - 1 - a; ++a; }
+      ta[q] = a;
+      tb[q] = a + 1 + rem;
+    }
+  }
   for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
     const float* base = z + img * n * D;
-    // pairs owned by this thread: p = tid, tid+256, ... (at most 8 for n = 64)
-    double best[8];
+    double best[kJointTasks];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) best[q] = 0.0;
+    for (int q = 0; q < kJointTasks; ++q) best[q] = 0.0;
+    for (int i = tid; i < n * DP; i += 256) dist[i] = 0.0;
     for (int64_t d0 = 0; d0 < D; d0 += kJointChunk) {
       const int w = (int)((D - d0 < kJointChunk) ? (D - d0) : kJointChunk);
       __syncthreads();
       for (int i = tid; i < n * w; i += 256) {
         const int s = i / w, j = i - s * w;
-        tile[s][j] = base[(int64_t)s * D + d0 + j];
+        tile[s * TP + j] = (double)base[(int64_t)s * D + d0 + j];
       }
       __syncthreads();
+      const int per = ((w + slices - 1) / slices + 3) & ~3;  // multiple of 4: slices start 32-byte aligned
 #pragma unroll
-      for (int q = 0; q < 8; ++q) {
-        const int p = tid + 256 * q;
-        if (p < npairs) {
-          // decode pair index -> (a, b), a < b
-          int a = 0, rem = p;
-          while (rem >= n - 1 - a) { rem -= n - 1 - a; ++a; }
-          const int b = a + 1 + rem;
-          double m = best[q];
-          for (int j = 0; j < w; ++j) m = fmax(m, fabs((double)tile[a][j] - (double)tile[b][j]));
-          best[q] = m;
+      for (int q = 0; q < kJointTasks; ++q) {
+        if (ta[q] >= 0) {
+          const double* ra = tile + ta[q] * TP;
+          const double* rb = tile + tb[q] * TP;
+          const int j0 = ts[q] * per, j1 = (j0 + per < w) ? j0 + per : w;
+          double m0 = best[q], m1 = 0.0, m2 = 0.0, m3 = 0.0;
+          int j = j0;
+          for (; j + 4 <= j1; j += 4) {  // rows are 16-byte aligned (even pitch): two ds_read_b128 per row
+            const double2 a01 = *reinterpret_cast<const double2*>(ra + j), a23 = *reinterpret_cast<const double2*>(ra + j + 2);
+            const double2 b01 = *reinterpret_cast<const double2*>(rb + j), b23 = *reinterpret_cast<const double2*>(rb + j + 2);
+            m0 = fmax(m0, fabs(a01.x - b01.x));
+            m1 = fmax(m1, fabs(a01.y - b01.y));
+            m2 = fmax(m2, fabs(a23.x - b23.x));
+            m3 = fmax(m3, fabs(a23.y - b23.y));
+          }
+          for (; j < j1; ++j) m0 = fmax(m0, fabs(ra[j] - rb[j]));
+          best[q] = fmax(fmax(m0, m1), fmax(m2, m3));
         }
       }
     }
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      const int p = tid + 256 * q;
-      if (p < npairs) {
-        int a = 0, rem = p;
-        while (rem >= n - 1 - a) { rem -= n - 1 - a; ++a; }
-        const int b = a + 1 + rem;
-        dist[a][b] = best[q];
-        dist[b][a] = best[q];
+    for (int q = 0; q < kJointTasks; ++q) {
+      if (ta[q] >= 0) {  // non-negative doubles order like their bit patterns
+        const unsigned long long bits = (unsigned long long)__double_as_longlong(best[q]);
+        atomicMax(reinterpret_cast<unsigned long long*>(&dist[ta[q] * DP + tb[q]]), bits);
+        atomicMax(reinterpret_cast<unsigned long long*>(&dist[tb[q] * DP + ta[q]]), bits);
       }
     }
     __syncthreads();
@@ -167,11 +197,11 @@ __global__ __launch_bounds__(256) void entropy_joint_kernel(const float* __restr
       double kth = kInf;
       for (int c = 0; c < n; ++c) {
         if (c == i) continue;
-        const double dc = dist[i][c];
+        const double dc = dist[i * DP + c];
         int less = 0, leq = 0;
         for (int o = 0; o < n; ++o) {
           if (o == i) continue;
-          const double d_o = dist[i][o];
+          const double d_o = dist[i * DP + o];
           less += (d_o < dc);
           leq += (d_o <= dc);
         }
@@ -250,7 +280,15 @@ extern "C" int runia_kl_entropy_joint_f32(const float* z, double* h_mvn, int64_t
   if (N == 0) return RUNIA_OK;
   const double ct = digamma_diff(n_mc, k);
   const double d_over_n = (double)D / (double)n_mc;
-  entropy_joint_kernel<<<runia_stream_grid(N, 1), 256, 0, as_stream(stream)>>>(z, h_mvn, N, n_mc, D, k,
-                                                                               min_dist, ct, d_over_n);
+  const size_t lds = ((size_t)n_mc * (kJointChunk + 2) + (size_t)n_mc * (n_mc + 1)) * sizeof(double);  // <= 99 KB
+  static bool attr_set = false;
+  if (!attr_set) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void*>(entropy_joint_kernel),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess)
+      return RUNIA_E_LAUNCH;
+    attr_set = true;
+  }
+  const unsigned grid = (unsigned)(N < 65535 ? N : 65535);
+  entropy_joint_kernel<<<grid, 256, lds, as_stream(stream)>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n);
   return runia_check_launch();
 }
