@@ -54,7 +54,7 @@ def synth_latents(n, seed, shift, device, scale=1.0, corr=0.0):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--images", type=int, default=10000, help="test images per GPU (workload: 10 000)")
     ap.add_argument("--train-images", type=int, default=4096)
@@ -64,6 +64,18 @@ def main():
     ap.add_argument("--overlap", action="store_true",
                     help="two HIP streams: K1 of batch i+1 beside K2 of batch i (measured: no gain, 0.324 vs 0.329 ms)")
     ap.add_argument("--chunks", type=int, default=None, help="row blocks pipelined over two streams (default: pipeline's)")
+    ap.add_argument("--clock-warmup", type=float, default=1.0,
+                    help="seconds of the same step run untimed before the W warm-up steps: the GPU needs ~0.1 s of "
+                         "sustained load to reach its working clocks (measured: 0.261 ms/step over the first 10 steps, "
+                         "0.205 ms/step over 2000)")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="HIP events bracket the dominant kernel on every n-th timed step (a bracketed step runs the "
+                         "table launch and the kernel as two C calls with two event records between them: ~40 us "
+                         "slower than an unbracketed step, so bracketing every step would tax the metric by 16 %%)")
+    ap.add_argument("--gather-stream", choices=["auto", "same", "side"], default="auto",
+                    help="queue the all_gather on the compute stream, or on a second stream behind an event with "
+                         "two output buffers in turn (the next step's kernels then start without waiting for it); "
+                         "auto: time both during the warm-up and keep the faster (all ranks agree through a MAX)")
     args = ap.parse_args()
 
     # Exactly one line may reach stdout (the JSON record): RCCL prints its version banner to stdout when
@@ -115,15 +127,28 @@ def main():
     torch.cuda.synchronize()
     inputs_ready = torch.cuda.current_stream().record_event()  # x / rand are resident from here on
 
-    gathered = torch.empty(world * n, dtype=torch.float64, device=device) if use_dist else None
+    gathered = [torch.empty(world * n, dtype=torch.float64, device=device) for _ in range(2)] if use_dist else None
+    side_stream = torch.cuda.Stream() if (use_dist and args.gather_stream != "same") else None
+    gather_mode = {"side": args.gather_stream == "side"}
+    gather_turn = [0]
 
     def gather(s):
-        """The single RCCL all_gather of the path: equal shards, preallocated output, queued on the
-        compute stream (measured on the one-GPU rehearsal: cheaper than a side stream with its event hand-off)."""
-        dist.all_gather_into_tensor(gathered, s)
-        return gathered
+        """The single RCCL all_gather of the path: equal shards, preallocated output.  Default: queued
+        on the compute stream.  --gather-stream side: queued on a second stream behind an event; outputs alternate
+        between two buffers (a buffer is rewritten two steps later, in stream order on the same stream)."""
+        out = gathered[gather_turn[0]]
+        gather_turn[0] ^= 1
+        if not gather_mode["side"]:
+            dist.all_gather_into_tensor(out, s)
+            return out
+        side_stream.wait_event(torch.cuda.current_stream().record_event())
+        with torch.cuda.stream(side_stream):
+            dist.all_gather_into_tensor(out, s)
+        s.record_stream(side_stream)
+        return out
 
-    def step(timed=False):
+    def step(timed=False, index=0):
+        timed = timed and (index % max(1, args.event_every) == 0)
         if not args.overlap:
             s = pipe.score_latents(x, rand, chunks=args.chunks, k1_events=k1_events if timed else None)
             return gather(s) if use_dist else s
@@ -135,23 +160,51 @@ def main():
                 return gather(a.scores)
         return a.scores
 
-    for _ in range(args.warmup):
-        step()
-    if use_dist:
-        assert step().shape == (world * n,)
-    # keep the interpreter's cyclic GC out of the timed region (a gen-2 pass over the torch/sklearn heap
-    # costs tens of ms, i.e. far more than the 10-step GPU work it would be charged to)
+    # The interpreter's cyclic GC stays out of everything from here on: a gen-2 pass over the torch / sklearn heap
+    # takes 60-80 ms, during which the GPU sits idle and drops its clocks (and inside the timed region it would be
+    # charged to ~300 steps).  It runs once now, BEFORE the warm-up, so that nothing idles the GPU between the
+    # warm-up and the timed region.
     import gc
 
     gc.collect()
     gc.disable()
+    t_spin = time.perf_counter()
+    while time.perf_counter() - t_spin < args.clock_warmup:  # untimed: bring the clocks up (same work as a step)
+        for _ in range(50):
+            step()
+        torch.cuda.synchronize()
+    for _ in range(args.warmup):
+        step()
+    if use_dist:
+        assert step().shape == (world * n,)
+    if use_dist and args.gather_stream == "auto" and not args.overlap:
+        # untimed: which placement of the collective is faster on this node?  (one-GPU rehearsal: same stream
+        # +9 us, side stream +23 us per step; with real peers the same-stream form also exposes the ring latency)
+        trial = {False: float("inf"), True: float("inf")}
+        for mode in (False, True, False, True, False, True):  # best of three interleaved trials per placement
+            gather_mode["side"] = mode
+            for _ in range(3):
+                step()
+            dist.barrier()
+            torch.cuda.synchronize()
+            t_a = time.perf_counter()
+            for _ in range(30):
+                step()
+            torch.cuda.synchronize()
+            t_m = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device=device)
+            dist.all_reduce(t_m, op=dist.ReduceOp.MAX)
+            trial[mode] = min(trial[mode], float(t_m.item()))
+        gather_mode["side"] = trial[True] < 0.98 * trial[False]  # the simpler placement unless clearly slower
+        if rank == 0:
+            print(f"gather placement trial: same {trial[False] / 30 * 1e3:.4f} ms/step, side {trial[True] / 30 * 1e3:.4f} ms/step",
+                  file=sys.stderr)
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for i in range(args.steps):
-        scores = step(True)
-    torch.cuda.synchronize()
+        scores = step(True, i)
+    torch.cuda.synchronize()  # every stream of the device, the gather stream included
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
@@ -162,7 +215,8 @@ def main():
         elapsed = float(t.item())
 
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in k1_events])) if k1_events else float('nan')
-    k1_launches_per_step = max(1, len(k1_events) // max(1, args.steps))
+    bracketed_steps = len(range(0, args.steps, max(1, args.event_every)))
+    k1_launches_per_step = max(1, len(k1_events) // max(1, bracketed_steps))
     if rank != 0:
         dist.destroy_process_group()
         return
@@ -190,7 +244,7 @@ def main():
         "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
         "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
         "algorithmic_bytes_per_launch": int(bytes_per_img * imgs_per_launch), "avg_launch_ms": round(kernel_ms, 4),
-        "launches_per_step": k1_launches_per_step,
+        "launches_per_step": k1_launches_per_step, "launches_timed": len(k1_events),
     }
 
     # ---------------- parity on a bounded sample + CPU baseline (oracle = checker / baseline only) --
@@ -202,7 +256,10 @@ def main():
         "config": {"workload": "CIFAR10 ResNet-18 LaREM: 16 MC samples, 512-d latent -> PCA-256, 10000 test images per GPU",
                    "images_per_gpu": n, "mc_samples": N_MC, "latent": [C, H, W], "pca_components": N_PCA,
                    "row_blocks_per_step": k1_launches_per_step, "input_dtype": "f32",
-                   "pipelining": "batch i+1 K1 overlaps batch i K2 (two HIP streams)" if args.overlap else "none (one stream)"},
+                   "pipelining": "batch i+1 K1 overlaps batch i K2 (two HIP streams)" if args.overlap else "none (one stream)",
+                   "clock_warmup_s": args.clock_warmup,
+                   "gather": ("none (1 GPU)" if not use_dist else
+                              ("all_gather on a second stream" if gather_mode["side"] else "all_gather on the compute stream"))},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline:

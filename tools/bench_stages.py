@@ -25,8 +25,12 @@ rows = []
 
 
 def gpu_ms(fn, reps=7):
-    fn()
-    torch.cuda.synchronize()
+    # warm the stage up for ~0.25 s first: after an idle spell (a CPU-oracle timing, a gen-2 GC pass) the GPU takes
+    # tens of ms of sustained load to return to its working clocks
+    t0 = time.perf_counter()
+    while time.perf_counter() - t0 < 0.25:
+        fn()
+        torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
