@@ -90,6 +90,11 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    # RUNIA_BENCH_REHEARSE=gloo: several ranks share the visible GPUs over gloo (control-flow rehearsal of the N > 1
+    # path on a one-GPU box; RCCL refuses two ranks on one device).  Never set by the driver.
+    rehearse = os.environ.get("RUNIA_BENCH_REHEARSE")
+    if rehearse:
+        local_rank = local_rank % max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     dist = None
@@ -99,7 +104,10 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29533")
-        dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
+        if rehearse:
+            dist.init_process_group(backend=rehearse, rank=rank, world_size=world)
+        else:
+            dist.init_process_group(backend="nccl", device_id=device, rank=rank, world_size=world)
 
     import runia_core_amd as rc
     from runia_core_amd import _hip
@@ -147,11 +155,11 @@ def main():
         s.record_stream(side_stream)
         return out
 
-    def step(timed=False, index=0):
+    def step(timed=False, index=0, collective=True):
         timed = timed and (index % max(1, args.event_every) == 0)
         if not args.overlap:
             s = pipe.score_latents(x, rand, chunks=args.chunks, k1_events=k1_events if timed else None)
-            return gather(s) if use_dist else s
+            return gather(s) if (use_dist and collective) else s
         # streaming form: K1 of this batch overlaps K2 of the previous one (two HIP streams); the gather is
         # queued behind this batch's K2 on the same stream, nothing waits on the host until the final sync
         a = pipe.score_latents_async(x, rand, k1_events=k1_events if timed else None, inputs_ready=inputs_ready)
@@ -169,9 +177,11 @@ def main():
     gc.collect()
     gc.disable()
     t_spin = time.perf_counter()
-    while time.perf_counter() - t_spin < args.clock_warmup:  # untimed: bring the clocks up (same work as a step)
+    while time.perf_counter() - t_spin < args.clock_warmup and not args.overlap:
+        # untimed: bring the clocks up with the step's own kernels.  No collective in here: the trip count of a
+        # time-based loop differs from rank to rank, and mismatched collectives deadlock.
         for _ in range(50):
-            step()
+            step(collective=False)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
         step()

@@ -1,22 +1,30 @@
-import torch, sys, os
-sys.path.insert(0, os.getcwd())
-import runia_core_amd._hip as _hip
-if os.environ.get('RUNIA_LIB'):
-    import ctypes
-    _hip._LIB_PATH = os.environ['RUNIA_LIB']
-import numpy as np
+"""K2' (runia_proj_sq_score_f64) with and without the column-split workspace, GPU at working clocks."""
+import gc, os, sys, time, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from runia_core_amd import _hip
 torch.manual_seed(0)
-N, D, r = 10000, 512, 256
-h = torch.randn(N, D, dtype=torch.float64, device="cuda")
-M = torch.randn(D, r, dtype=torch.float64, device="cuda") * 0.05
-c = torch.randn(r, dtype=torch.float64, device="cuda")
-pm = _hip.pack_weights(M)
-out = torch.empty(N, dtype=torch.float64, device="cuda")
-ref = -((h @ M + c) ** 2).sum(1)
-for _ in range(3): _hip.proj_sq_score(h, pm, c, r, out=out)
-torch.cuda.synchronize()
-e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-e0.record()
-for _ in range(50): _hip.proj_sq_score(h, pm, c, r, out=out)
-e1.record(); torch.cuda.synchronize()
-print("RT", os.environ.get("RUNIA_PROJ_RT"), "%.1f us" % (e0.elapsed_time(e1) * 20), "err", float(((out - ref).abs() / ref.abs()).max()))
+gc.disable()
+lib = _hip.load_library()
+for N in (10000, 4096, 20000, 65536):
+    D, r = 512, 256
+    h = torch.randn(N, D, dtype=torch.float64, device="cuda")
+    M = torch.randn(D, r, dtype=torch.float64, device="cuda") * 0.05
+    c = torch.randn(r, dtype=torch.float64, device="cuda")
+    pm = _hip.pack_weights(M)
+    out = torch.empty(N, dtype=torch.float64, device="cuda")
+    ws = torch.empty(N * 16, dtype=torch.uint8, device="cuda")
+    ref = -((h @ M + c) ** 2).sum(1)
+    st = torch.cuda.current_stream().cuda_stream
+    for name, wsb in (("no workspace", 0), ("workspace", N * 16)):
+        def call():
+            rc = lib.runia_proj_sq_score_f64(h.data_ptr(), pm.data_ptr(), c.data_ptr(), out.data_ptr(), ws.data_ptr(), wsb, N, D, r, st)
+            assert rc == 0
+        t0 = time.perf_counter()
+        while time.perf_counter() - t0 < 0.5:
+            for _ in range(50): call()
+            torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(200): call()
+        e1.record(); torch.cuda.synchronize()
+        print(f"N {N:6d} {name:13s} {e0.elapsed_time(e1) * 5:.1f} us  err {float(((out - ref).abs() / ref.abs()).max()):.1e}")
