@@ -219,9 +219,15 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
 // SGPR operands.  A drop layer is acc = fma(q, keep, acc) over the map in the upstream summation order
 // (keep = 1: the add of the reference; keep = 0: acc unchanged), two rows per v_pk_fma_f32.
 // ------------------------------------------------------------------------------------------
-constexpr int kK1Block = 128;  // channels (threads) per workgroup: 185 us vs 199 us with 256 at N = 10 000
+#ifndef K1_BLOCK
+#define K1_BLOCK 128
+#endif
+constexpr int kK1Block = K1_BLOCK;  // channels (threads) per workgroup: 185 us vs 199 us with 256 at N = 10 000
 
 template <int HT, int WT, int NP, int K, bool FULL>
+#ifdef K1_WAVES
+__attribute__((amdgpu_waves_per_eu(K1_WAVES, 8)))
+#endif
 __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ table,
                                                           double* __restrict__ h, float* __restrict__ z_out,
@@ -276,7 +282,10 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
   // G drop layers per trip of a rolled loop: G*HW keep flags live in SGPRs at a time (a fully unrolled loop
   // lets the compiler hoist all n_mc*HW scalar loads and spill them).  z is a shift register: constant indices
   // only, and the sample order is irrelevant to the sort that follows.
-  constexpr int G = (64 / HW < 1) ? 1 : ((64 / HW > NP) ? NP : 64 / HW);
+#ifndef K1_GCAP
+#define K1_GCAP 128
+#endif
+  constexpr int G = (K1_GCAP / HW < 1) ? 1 : ((K1_GCAP / HW > NP) ? NP : K1_GCAP / HW);
 #pragma unroll
   for (int s = 0; s < NP; ++s) z[s] = INFINITY;
 #pragma unroll 1
