@@ -152,6 +152,8 @@ int runia_kde_score_f64(const double* train, const double* x, double* score, int
  *     z_out (optional, may be NULL): [N*n_mc, C] f32 copy of the samples, drop layers in
  *     mask-sum order (entropy is invariant to their order).  Shapes outside
  *     runia_mc_entropy_supported() return RUNIA_E_INVALID: use the two unfused calls.
+ *     zero_fill (optional, may be NULL): [N] f64 set to 0.0 by the launch - the accumulator that
+ *     runia_proj_sq_accumulate_f64 adds into, cleared here for free instead of by a launch of its own.
  *     workspace: runia_mc_entropy_workspace_bytes(N, H, W, n_mc) bytes of device memory, 16-byte
  *     aligned (the per-image keep-flag table a first small launch derives from the draws;
  *     RUNIA_E_WORKSPACE if missing or short).
@@ -169,11 +171,11 @@ int runia_mc_mask_table_f32(const float* rand, int64_t rand_image_stride, void* 
                             size_t workspace_bytes, int64_t N, int H, int W, int n_mc, double drop_prob,
                             int block_size, runia_stream_t stream);
 int runia_mc_entropy_from_table_f32(const float* x, const void* workspace, size_t workspace_bytes, double* h,
-                                    float* z_out, int64_t N, int C, int H, int W, int n_mc, int k,
-                                    double min_dist, runia_stream_t stream);
+                                    float* z_out, double* zero_fill, int64_t N, int C, int H, int W, int n_mc,
+                                    int k, double min_dist, runia_stream_t stream);
 int runia_mc_entropy_f32(const float* x, const float* rand, int64_t rand_image_stride, double* h,
-                         float* z_out, void* workspace, size_t workspace_bytes, int64_t N, int C, int H,
-                         int W, int n_mc, double drop_prob, int block_size, int k, double min_dist,
+                         float* z_out, double* zero_fill, void* workspace, size_t workspace_bytes, int64_t N,
+                         int C, int H, int W, int n_mc, double drop_prob, int block_size, int k, double min_dist,
                          runia_stream_t stream);
 int runia_pca_md_score_f64(const double* h, const double* packed_ct, const double* bias,
                            const double* scale, const double* md_mean, const double* packed_p,
@@ -185,6 +187,12 @@ int runia_pca_md_score_f64(const double* h, const double* packed_ct, const doubl
 /*     workspace (optional: NULL / 0 is accepted): runia_proj_sq_workspace_bytes(N) bytes let batches of a few
  *     row tiles per compute unit be cut in column halves (two partial row sums + one small combine launch). */
 size_t runia_proj_sq_workspace_bytes(int64_t N);
+/*     runia_proj_sq_accumulate_f64: the same score ADDED into `score`, which the caller zeroed earlier in the
+ *     stream (runia_mc_entropy_f32's zero_fill): the column halves of a row tile each add their row sums with one
+ *     f64 atomic - two addends per row, so the result does not depend on their order - and no combine launch or
+ *     workspace is needed.  Bit-identical to runia_proj_sq_score_f64. */
+int runia_proj_sq_accumulate_f64(const double* h, const double* packed_m, const double* c, double* score,
+                                 int64_t N, int64_t D, int64_t r, runia_stream_t stream);
 int runia_proj_sq_score_f64(const double* h, const double* packed_m, const double* c, double* score,
                             void* workspace, size_t workspace_bytes, int64_t N, int64_t D, int64_t r,
                             runia_stream_t stream);

@@ -66,13 +66,13 @@ _SIGNATURES = {
     ),
     "runia_mc_entropy_from_table_f32": (
         c_int,
-        [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int, c_double,
-         c_void_p],
+        [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
+         c_double, c_void_p],
     ),
     "runia_mc_entropy_f32": (
         c_int,
-        [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int,
-         c_double, c_int, c_int, c_double, c_void_p],
+        [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int,
+         c_int, c_double, c_int, c_int, c_double, c_void_p],
     ),
     "runia_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "runia_ash_s_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
@@ -80,6 +80,7 @@ _SIGNATURES = {
     "runia_proj_norm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "runia_proj_norm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "runia_proj_sq_workspace_bytes": (c_size_t, [c_int64]),
+    "runia_proj_sq_accumulate_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "runia_proj_sq_score_f64": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int64, c_void_p],
@@ -375,10 +376,11 @@ def mc_entropy_supported(h: int, w: int, n_mc: int, k: int) -> bool:
 
 def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob: float, block_size: int, k: int,
                min_dist: float = 1e-5, want_samples: bool = False, out: Optional[torch.Tensor] = None,
-               kernel_events: Optional[list] = None):
+               kernel_events: Optional[list] = None, zero_fill: Optional[torch.Tensor] = None):
     """Fused sampler + entropy: x [N,C,H,W] f32 (+ draws) -> h [N, C] f64 (and optionally the MC samples).
     ``kernel_events``: if a list, (start, end) HIP event pairs around the sampler + entropy launch alone (the
-    keep-flag table launch before it is left out) are appended - bench.py times the dominant kernel with it."""
+    keep-flag table launch before it is left out) are appended - bench.py times the dominant kernel with it.
+    ``zero_fill``: optional [N] f64 tensor cleared by the launch (the accumulator of ``proj_sq_accumulate``)."""
     lib = load_library()
     require_gpu()
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
@@ -399,6 +401,8 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
         assert out.is_cuda and out.dtype == torch.float64 and out.shape == (n, c) and out.is_contiguous()
         h = out
     z = torch.empty((n * n_mc, c), dtype=torch.float32, device=x.device) if want_samples else None
+    if zero_fill is not None:
+        assert zero_fill.is_cuda and zero_fill.dtype == torch.float64 and zero_fill.shape == (n,) and zero_fill.is_contiguous()
     ws_bytes = int(lib.runia_mc_entropy_workspace_bytes(min(65535, n), hh, ww, n_mc))
     ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)  # stream-ordered: reused per slice
     done = 0
@@ -406,10 +410,11 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
         m = min(65535, n - done)
         rp = None if rand is None else rand.data_ptr() + done * stride * 4
         zp = None if z is None else z.data_ptr() + done * n_mc * c * 4
+        zf = None if zero_fill is None else zero_fill.data_ptr() + done * 8
         if kernel_events is None:
             _check(
                 lib.runia_mc_entropy_f32(x.data_ptr() + done * c * hh * ww * 4, rp, stride, h.data_ptr() + done * c * 8,
-                                         zp, ws.data_ptr(), ws_bytes, m, c, hh, ww, n_mc, float(drop_prob),
+                                         zp, zf, ws.data_ptr(), ws_bytes, m, c, hh, ww, n_mc, float(drop_prob),
                                          int(block_size), int(k), float(min_dist), _stream()),
                 "runia_mc_entropy_f32",
             )
@@ -423,7 +428,7 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
             e0.record()
             _check(
                 lib.runia_mc_entropy_from_table_f32(x.data_ptr() + done * c * hh * ww * 4, ws.data_ptr(), ws_bytes,
-                                                    h.data_ptr() + done * c * 8, zp, m, c, hh, ww, n_mc, int(k),
+                                                    h.data_ptr() + done * c * 8, zp, zf, m, c, hh, ww, n_mc, int(k),
                                                     float(min_dist), _stream()),
                 "runia_mc_entropy_from_table_f32",
             )
@@ -431,6 +436,21 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
             kernel_events.append((e0, e1))
         done += m
     return (h, z) if want_samples else h
+
+
+def proj_sq_accumulate(h: torch.Tensor, packed_m: torch.Tensor, c: torch.Tensor, r: int, out: torch.Tensor) -> torch.Tensor:
+    """``out`` [N] f64 += -|| M h + c ||^2 where ``out`` was zeroed earlier on the stream (``mc_entropy(zero_fill=out)``):
+    the score of ``proj_sq_score`` bit for bit, without its workspace and combine launch."""
+    lib = load_library()
+    require_gpu()
+    assert h.is_cuda and h.dtype == torch.float64 and h.dim() == 2
+    h = h.contiguous()
+    nrow, d = h.shape
+    assert out.is_cuda and out.dtype == torch.float64 and out.shape == (nrow,) and out.is_contiguous()
+    _check(lib.runia_proj_sq_accumulate_f64(h.data_ptr(), packed_m.data_ptr(), c.data_ptr(), out.data_ptr(), nrow, d, int(r),
+                                            _stream()),
+           "runia_proj_sq_accumulate_f64")
+    return out
 
 
 def pca_md_score(h: torch.Tensor, packed_ct: Optional[torch.Tensor], bias: Optional[torch.Tensor],

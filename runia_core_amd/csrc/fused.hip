@@ -231,8 +231,9 @@ __attribute__((amdgpu_waves_per_eu(K1_WAVES, 8)))
 __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __restrict__ x,
                                                           const float* __restrict__ table,
                                                           double* __restrict__ h, float* __restrict__ z_out,
-                                                          int64_t N, int C, int n_mc_rt, double min_dist,
-                                                          double const_term, double inv_n) {
+                                                          double* __restrict__ zero_fill, int64_t N, int C,
+                                                          int n_mc_rt, double min_dist, double const_term,
+                                                          double inv_n) {
   constexpr int HW = HT * WT;
   constexpr bool PAIRS = (HT % 2 == 0);
   const int n_mc = FULL ? NP : n_mc_rt;
@@ -244,6 +245,7 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
   const int64_t img = (int64_t)(slot / chunks) * 8 + (blockIdx.x & 7);
   if (img >= N) return;
   const int c = (int)(slot % chunks) * kK1Block + threadIdx.x;
+  if (zero_fill && c == 0) zero_fill[img] = 0.0;  // the accumulator of the score launch that follows (optional)
   if (c >= C) return;
   const float* mk = table + img * (int64_t)(n_mc * (HW + 2));  // wave-uniform
   const float* dens = mk + n_mc * HW;
@@ -537,7 +539,7 @@ struct ProjSqArgs {
 // workgroups share a row tile, each taking one 128-column half of every block (grid.y = 2) and leaving its row
 // sums of squares in `partial`.  The split halves the unit of work: at N = 10 000 the 625 row tiles are 2.44 per
 // CU (3 on some, 2 on most: 19 % of the matrix pipes idle at the end); 1250 half tiles finish within 3 %.
-template <int RT, int NCT>
+template <int RT, int NCT, bool ACCUMULATE = false>
 __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
   constexpr int BM = 16 * RT;
   __shared__ double lds_a[2 * BM * APITCH];
@@ -628,6 +630,9 @@ __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
       if constexpr (NCT == 4) {
         const double hi = ((part[4 * BM + tid] + part[5 * BM + tid]) + part[6 * BM + tid]) + part[7 * BM + tid];
         g.score[row] = -(lo + hi);
+      } else if constexpr (ACCUMULATE) {
+        // score was zeroed earlier in the stream: two addends per row, and 0 + a + b = 0 + b + a bit for bit
+        unsafeAtomicAdd(&g.score[row], -lo);
       } else {
         g.partial[(int64_t)blockIdx.y * g.N + row] = lo;
       }
@@ -737,8 +742,9 @@ extern "C" int runia_mc_mask_table_f32(const float* rnd, int64_t rand_image_stri
 }
 
 extern "C" int runia_mc_entropy_from_table_f32(const float* x, const void* workspace, size_t workspace_bytes,
-                                               double* h, float* z_out, int64_t N, int C, int H, int W, int n_mc,
-                                               int k, double min_dist, runia_stream_t stream) {
+                                               double* h, float* z_out, double* zero_fill, int64_t N, int C,
+                                               int H, int W, int n_mc, int k, double min_dist,
+                                               runia_stream_t stream) {
   if (C <= 0 || k < 1 || k >= n_mc) return RUNIA_E_INVALID;
   if (int rc = mc_args_ok(N, H, W, n_mc, workspace, workspace_bytes)) return rc;
   if (N == 0) return RUNIA_OK;
@@ -752,11 +758,11 @@ extern "C" int runia_mc_entropy_from_table_f32(const float* x, const void* works
 #define RUNIA_MCE(HH, WW, NPP, KK)                                                                          \
   if (H == HH && W == WW && n_mc <= NPP && n_mc > NPP / 2 && k == KK && (x16 || (HH * WW) % 4 != 0)) {      \
     if (n_mc == NPP)                                                                                        \
-      mc_entropy_kernel<HH, WW, NPP, KK, true><<<grid, kK1Block, 0, s>>>(x, table, h, z_out, N, C, n_mc,    \
-                                                                         min_dist, ct, inv_n);              \
+      mc_entropy_kernel<HH, WW, NPP, KK, true><<<grid, kK1Block, 0, s>>>(x, table, h, z_out, zero_fill, N,  \
+                                                                         C, n_mc, min_dist, ct, inv_n);     \
     else                                                                                                    \
-      mc_entropy_kernel<HH, WW, NPP, KK, false><<<grid, kK1Block, 0, s>>>(x, table, h, z_out, N, C, n_mc,   \
-                                                                          min_dist, ct, inv_n);             \
+      mc_entropy_kernel<HH, WW, NPP, KK, false><<<grid, kK1Block, 0, s>>>(x, table, h, z_out, zero_fill, N, \
+                                                                          C, n_mc, min_dist, ct, inv_n);    \
     return runia_check_launch();                                                                            \
   }
   RUNIA_MCE_SHAPES(RUNIA_MCE)
@@ -765,9 +771,9 @@ extern "C" int runia_mc_entropy_from_table_f32(const float* x, const void* works
 }
 
 extern "C" int runia_mc_entropy_f32(const float* x, const float* rnd, int64_t rand_image_stride, double* h,
-                                    float* z_out, void* workspace, size_t workspace_bytes, int64_t N, int C,
-                                    int H, int W, int n_mc, double drop_prob, int block_size, int k,
-                                    double min_dist, runia_stream_t stream) {
+                                    float* z_out, double* zero_fill, void* workspace, size_t workspace_bytes,
+                                    int64_t N, int C, int H, int W, int n_mc, double drop_prob, int block_size,
+                                    int k, double min_dist, runia_stream_t stream) {
   if (N < 0 || C <= 0 || H <= 0 || W <= 0 || n_mc < 2 || n_mc > kMaxMC || block_size < 1 || k < 1 || k >= n_mc)
     return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
@@ -778,8 +784,8 @@ extern "C" int runia_mc_entropy_f32(const float* x, const float* rnd, int64_t ra
   if (int rc = runia_mc_mask_table_f32(rnd, rand_image_stride, workspace, workspace_bytes, N, H, W, n_mc, drop_prob,
                                        block_size, stream))
     return rc;
-  return runia_mc_entropy_from_table_f32(x, workspace, workspace_bytes, h, z_out, N, C, H, W, n_mc, k, min_dist,
-                                         stream);
+  return runia_mc_entropy_from_table_f32(x, workspace, workspace_bytes, h, z_out, zero_fill, N, C, H, W, n_mc, k,
+                                         min_dist, stream);
 }
 
 extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k) {
@@ -788,6 +794,20 @@ extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k) {
   if (hw && n_mc > 4 && n_mc <= 32) return 1;
   if (n_mc > 8 && n_mc <= 16 && ((H == 2 && W == 2) || (H == 7 && W == 7) || (H == 8 && W == 8))) return 1;
   return 0;
+}
+
+extern "C" int runia_proj_sq_accumulate_f64(const double* h, const double* packed_m, const double* c, double* score,
+                                            int64_t N, int64_t D, int64_t r, runia_stream_t stream) {
+  if (N < 0 || D <= 0 || r <= 0) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!h || !packed_m || !c || !score) return RUNIA_E_INVALID;
+  ProjSqArgs g{h, packed_m, c, score, nullptr, N, D, r};
+  hipStream_t s = as_stream(stream);
+  const int64_t tiles16 = (N + 15) / 16, cus = runia_cu_count();
+  if (tiles16 >= 4 * cus) proj_sq_kernel<2, 4><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
+  else if (tiles16 > cus / 2) proj_sq_kernel<1, 2, true><<<dim3((unsigned)tiles16, 2), 256, 0, s>>>(g);
+  else proj_sq_kernel<1, 4><<<(unsigned)tiles16, 256, 0, s>>>(g);
+  return runia_check_launch();
 }
 
 extern "C" size_t runia_proj_sq_workspace_bytes(int64_t N) { return N > 0 ? (size_t)N * 2 * sizeof(double) : 0; }

@@ -76,13 +76,16 @@ class LaREMPipeline:
     def entropy(self, z: Tensor) -> Tensor:
         return _hip.kl_entropy_per_dim(z, self.n_mc, self.k, MIN_DIST)
 
-    def entropy_from_latents(self, latents: Tensor, rand: Optional[Tensor], kernel_events: Optional[list] = None) -> Tensor:
+    def entropy_from_latents(self, latents: Tensor, rand: Optional[Tensor], kernel_events: Optional[list] = None,
+                             zero_fill: Optional[Tensor] = None) -> Tensor:
         """Sampler + per-dimension entropy without materialising the MC samples when the map shape is supported
         (``runia_mc_entropy_f32``: keep-flag table launch + sampler/entropy launch), else the two unfused kernels."""
         _, _, h, w = latents.shape
         if _hip.mc_entropy_supported(h, w, self.n_mc, self.k):
             return _hip.mc_entropy(latents, rand, self.n_mc, self.drop_prob if rand is not None else 0.0,
-                                   self.block_size, self.k, MIN_DIST, kernel_events=kernel_events)
+                                   self.block_size, self.k, MIN_DIST, kernel_events=kernel_events, zero_fill=zero_fill)
+        if zero_fill is not None:
+            zero_fill.zero_()
         return self.entropy(self.stack(latents, rand))
 
     def _md_state(self):
@@ -172,6 +175,13 @@ class LaREMPipeline:
         md = self._md_state()
         fused = _hip.mc_entropy_supported(hh, ww, self.n_mc, self.k) and md is not None
         if not fused or chunks <= 1 or n < 2048 * chunks or (rand is not None and rand.dim() != 4):
+            folded = self._folded_state() if (fused and self.fold_weights) else None
+            if folded is not None and (self.pca is None or latents.shape[1] == self.pca.n_features):
+                # K1 clears the score vector on its way, K2' adds the two column halves of each row into it: no
+                # workspace, no combine launch (bit-identical to the store form)
+                scores = torch.empty((n,), dtype=torch.float64, device=latents.device)
+                h = self.entropy_from_latents(latents, rand, k1_events, zero_fill=scores)
+                return _hip.proj_sq_accumulate(h, *folded, out=scores)
             return self.score_entropies(self.entropy_from_latents(latents, rand, k1_events if fused else None))
         latents = latents.contiguous()
         if rand is not None:

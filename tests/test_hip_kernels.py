@@ -421,3 +421,22 @@ def test_empty_and_single_row_inputs(hip):
         hip.kl_entropy_per_dim(r(8, 4), 4, 4)  # k must be < n_mc
     with pytest.raises(hip.RuniaHipError):
         hip.kl_entropy_per_dim(r(130, 4), 65, 5)  # n_mc > 64
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_rows", [1, 100, 2100, 10000, 70000])
+def test_proj_sq_accumulate_equals_store_form(hip, n_rows):
+    """runia_proj_sq_accumulate_f64 (column halves added into a cleared vector) = runia_proj_sq_score_f64, bit for bit,
+    whatever tile shape the row count selects."""
+    torch.manual_seed(n_rows)
+    d, r = 96, 40
+    h = torch.randn(n_rows, d, dtype=torch.float64, device="cuda")
+    m = torch.randn(d, r, dtype=torch.float64, device="cuda") * 0.1
+    c = torch.randn(r, dtype=torch.float64, device="cuda")
+    pm = hip.pack_weights(m)
+    a = hip.proj_sq_score(h, pm, c, r)
+    out = torch.zeros(n_rows, dtype=torch.float64, device="cuda")
+    b = hip.proj_sq_accumulate(h, pm, c, r, out)
+    assert torch.equal(a, b)
+    ref = -((h @ m + c) ** 2).sum(1)
+    assert float(((a - ref).abs() / ref.abs().clamp_min(1.0)).max()) < 1e-12

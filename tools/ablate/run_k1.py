@@ -12,13 +12,13 @@ for so in sorted(glob.glob(os.path.join(here, os.environ.get("K1_GLOB", "libk1_*
     lib = ctypes.CDLL(so)
     f = lib.runia_mc_entropy_f32
     f.restype = c_int
-    f.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_double, c_void_p]
+    f.argtypes = [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_int, c_double, c_void_p]
     lib.runia_mc_entropy_workspace_bytes.restype = c_size_t
     lib.runia_mc_entropy_workspace_bytes.argtypes = [c_int64, c_int, c_int, c_int]
     wsb = lib.runia_mc_entropy_workspace_bytes(n, H, W, n_mc)
     ws = torch.empty(wsb, dtype=torch.uint8, device="cuda")
     def call():
-        rc = f(x.data_ptr(), rand.data_ptr(), n_mc * H * W, h.data_ptr(), None, ws.data_ptr(), wsb, n, C, H, W, n_mc, 0.5, 2, 5, 1e-5, torch.cuda.current_stream().cuda_stream)
+        rc = f(x.data_ptr(), rand.data_ptr(), n_mc * H * W, h.data_ptr(), None, None, ws.data_ptr(), wsb, n, C, H, W, n_mc, 0.5, 2, 5, 1e-5, torch.cuda.current_stream().cuda_stream)
         assert rc == 0, rc
     import time
     t0 = time.perf_counter()
