@@ -170,6 +170,11 @@ size_t runia_mc_entropy_workspace_bytes(int64_t N, int H, int W, int n_mc);
 int runia_mc_mask_table_f32(const float* rand, int64_t rand_image_stride, void* workspace,
                             size_t workspace_bytes, int64_t N, int H, int W, int n_mc, double drop_prob,
                             int block_size, runia_stream_t stream);
+/* runia_mc_stack_table_f32 = runia_mc_stack_f32 (same samples, same order, same bits) on the table path, for the
+ * map shapes of runia_mc_entropy_supported(H, W, n_mc, 5); workspace as for runia_mc_entropy_f32. */
+int runia_mc_stack_table_f32(const float* x, const float* rand, int64_t rand_image_stride, float* z,
+                             void* workspace, size_t workspace_bytes, int64_t N, int C, int H, int W, int n_mc,
+                             double drop_prob, int block_size, runia_stream_t stream);
 int runia_mc_entropy_from_table_f32(const float* x, const void* workspace, size_t workspace_bytes, double* h,
                                     float* z_out, double* zero_fill, int64_t N, int C, int H, int W, int n_mc,
                                     int k, double min_dist, runia_stream_t stream);

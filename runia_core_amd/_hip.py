@@ -64,6 +64,11 @@ _SIGNATURES = {
         c_int,
         [c_void_p, c_int64, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_double, c_int, c_void_p],
     ),
+    "runia_mc_stack_table_f32": (
+        c_int,
+        [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_int, c_double, c_int,
+         c_void_p],
+    ),
     "runia_mc_entropy_from_table_f32": (
         c_int,
         [c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_int,
@@ -192,10 +197,24 @@ def mc_stack(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob
         else:
             assert rand.shape == (n_mc, h, w)
     out = torch.empty((n * n_mc, c), dtype=torch.float32, device=x.device)
+    table_path = n_mc >= 2 and bool(lib.runia_mc_entropy_supported(h, w, n_mc, 5)) and (x.data_ptr() % 16 == 0 or (h * w) % 4)
+    if table_path:
+        ws_bytes = int(lib.runia_mc_entropy_workspace_bytes(min(65535, n), h, w, n_mc))
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x.device)
     done = 0
-    while done < n:  # grid.y limit of the kernel
+    while done < n:  # grid limit of the kernels
         m = min(65535, n - done)
         rp = None if rand is None else rand.data_ptr() + (done * stride * 4)
+        if table_path:
+            _check(
+                lib.runia_mc_stack_table_f32(
+                    x.data_ptr() + done * c * h * w * 4, rp, stride, out.data_ptr() + done * n_mc * c * 4, ws.data_ptr(),
+                    ws_bytes, m, c, h, w, n_mc, float(drop_prob), int(block_size), _stream(),
+                ),
+                "runia_mc_stack_table_f32",
+            )
+            done += m
+            continue
         _check(
             lib.runia_mc_stack_f32(
                 x.data_ptr() + done * c * h * w * 4, rp, stride, out.data_ptr() + done * n_mc * c * 4,

@@ -51,7 +51,7 @@ __host__ __device__ constexpr int mask_slot(int p) {
 template <int HT, int WT>
 __global__ __launch_bounds__(256) void mc_mask_kernel(const float* __restrict__ rnd, int64_t rand_stride,
                                                        float* __restrict__ table, int n_mc, float gamma,
-                                                       int block_size, int identity) {
+                                                       int block_size, int identity, int sort_layers) {
   constexpr int HW = HT * WT;
   __shared__ float draws[kMaxMC * HW];
   __shared__ unsigned keep_lo[kMaxMC], keep_hi[kMaxMC];
@@ -102,6 +102,7 @@ __global__ __launch_bounds__(256) void mc_mask_kernel(const float* __restrict__ 
       const float o = msum[j];
       rank += (o < mine) || (o == mine && j < tid);
     }
+    if (!sort_layers) rank = tid;  // table in the order of the draws (runia_mc_stack_table_f32)
     sbits[rank] = keep_bits[tid];
     out[n_mc * HW + rank] = mine;
     out[n_mc * (HW + 1) + rank] = 1.0f / mine;
@@ -146,7 +147,7 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
                                                                            int64_t rand_stride,
                                                                            float* __restrict__ table, int64_t N,
                                                                            int n_mc, float gamma, int block_size,
-                                                                           int identity) {
+                                                                           int identity, int sort_layers) {
   constexpr int HW = HT * WT;
   static_assert(64 % HW == 0 && NP <= 64, "one drop layer per 64-bit word");
   constexpr int LPW = 64 / HW;                 // layers per ballot word
@@ -192,6 +193,7 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
     const int o = __shfl(cnt, j, 64);
     rank += (j < n_mc) && ((o < cnt) || (o == cnt && j < lane));
   }
+  if (!sort_layers) rank = lane;  // table in the order of the draws (runia_mc_stack_table_f32)
   if (lane >= n_mc) return;
   float* out = table + img * (int64_t)(n_mc * (HW + 2));
   float* rec = out + rank * HW;
@@ -224,7 +226,7 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
 #endif
 constexpr int kK1Block = K1_BLOCK;  // channels (threads) per workgroup: 185 us vs 199 us with 256 at N = 10 000
 
-template <int HT, int WT, int NP, int K, bool FULL>
+template <int HT, int WT, int NP, int K, bool FULL, bool ENTROPY = true>
 #ifdef K1_WAVES
 __attribute__((amdgpu_waves_per_eu(K1_WAVES, 8)))
 #endif
@@ -368,10 +370,12 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
 #pragma unroll
     for (int g = 0; g < G; ++g) z[g] = znew[g];
   }
-  sort_asc<NP>(z);
-  double res = const_term + inv_n * column_log_sum<NP, K, FULL>(z, n_mc, min_dist);
-  if (bad) res = NAN;  // a fully dropped map is 0*numel/0 = NaN upstream
-  h[img * C + c] = res;
+  if constexpr (ENTROPY) {
+    sort_asc<NP>(z);
+    double res = const_term + inv_n * column_log_sum<NP, K, FULL>(z, n_mc, min_dist);
+    if (bad) res = NAN;  // a fully dropped map is 0*numel/0 = NaN upstream
+    h[img * C + c] = res;
+  }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -691,13 +695,14 @@ extern "C" int runia_pca_md_score_f64(const double* h, const double* packed_ct, 
 namespace {
 template <int HH, int WW, int NPP>
 void launch_mask(const float* rnd, int64_t rand_image_stride, float* table, int64_t N, int n_mc, float gamma,
-                 int block_size, int identity, hipStream_t s) {
+                 int block_size, int identity, int sort_layers, hipStream_t s) {
   if constexpr (64 % (HH * WW) == 0) {
     mc_mask_bits_kernel<HH, WW, NPP><<<(unsigned)((N + kMaskBitsWaves - 1) / kMaskBitsWaves), 64 * kMaskBitsWaves, 0,
-                                       s>>>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity);
+                                       s>>>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity,
+                                            sort_layers);
   } else {
     mc_mask_kernel<HH, WW><<<(unsigned)N, 256, 0, s>>>(rnd, rand_image_stride, table, n_mc, gamma, block_size,
-                                                       identity);
+                                                       identity, sort_layers);
   }
 }
 }  // namespace
@@ -720,9 +725,9 @@ static int mc_args_ok(int64_t N, int H, int W, int n_mc, const void* workspace, 
 
 #define RUNIA_MCE_SHAPES(F) F(4, 4, 16, 5) F(4, 4, 32, 5) F(4, 4, 8, 5) F(2, 2, 16, 5) F(7, 7, 16, 5) F(8, 8, 16, 5)
 
-extern "C" int runia_mc_mask_table_f32(const float* rnd, int64_t rand_image_stride, void* workspace,
-                                       size_t workspace_bytes, int64_t N, int H, int W, int n_mc, double drop_prob,
-                                       int block_size, runia_stream_t stream) {
+static int mc_mask_table(const float* rnd, int64_t rand_image_stride, void* workspace, size_t workspace_bytes,
+                         int64_t N, int H, int W, int n_mc, double drop_prob, int block_size, int sort_layers,
+                         runia_stream_t stream) {
   if (block_size < 1) return RUNIA_E_INVALID;
   if (int rc = mc_args_ok(N, H, W, n_mc, workspace, workspace_bytes)) return rc;
   if (N == 0) return RUNIA_OK;
@@ -733,7 +738,48 @@ extern "C" int runia_mc_mask_table_f32(const float* rnd, int64_t rand_image_stri
   hipStream_t s = as_stream(stream);
 #define RUNIA_MCE(HH, WW, NPP, KK)                                                                          \
   if (H == HH && W == WW && n_mc <= NPP && n_mc > NPP / 2) {                                                \
-    launch_mask<HH, WW, NPP>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity, s);       \
+    launch_mask<HH, WW, NPP>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity,           \
+                             sort_layers, s);                                                               \
+    return runia_check_launch();                                                                            \
+  }
+  RUNIA_MCE_SHAPES(RUNIA_MCE)
+#undef RUNIA_MCE
+  return RUNIA_E_INVALID;
+}
+
+extern "C" int runia_mc_mask_table_f32(const float* rnd, int64_t rand_image_stride, void* workspace,
+                                       size_t workspace_bytes, int64_t N, int H, int W, int n_mc, double drop_prob,
+                                       int block_size, runia_stream_t stream) {
+  return mc_mask_table(rnd, rand_image_stride, workspace, workspace_bytes, N, H, W, n_mc, drop_prob, block_size, 1,
+                       stream);
+}
+
+// MCSamplerModule.forward alone (the samples, in the order of the draws) on the table path: the keep-flag table is
+// left unsorted and K1 stops after the sampler.  Same bits as runia_mc_stack_f32.
+extern "C" int runia_mc_stack_table_f32(const float* x, const float* rnd, int64_t rand_image_stride, float* z,
+                                        void* workspace, size_t workspace_bytes, int64_t N, int C, int H, int W,
+                                        int n_mc, double drop_prob, int block_size, runia_stream_t stream) {
+  if (C <= 0) return RUNIA_E_INVALID;
+  if (int rc = mc_args_ok(N, H, W, n_mc, workspace, workspace_bytes)) return rc;
+  if (N == 0) return RUNIA_OK;
+  if (!x || !z || !runia_mc_entropy_supported(H, W, n_mc, 5)) return RUNIA_E_INVALID;
+  if (!(((((uintptr_t)x) & 15) == 0) || (H * W) % 4 != 0)) return RUNIA_E_INVALID;
+  if (int rc = mc_mask_table(rnd, rand_image_stride, workspace, workspace_bytes, N, H, W, n_mc, drop_prob,
+                             block_size, 0, stream))
+    return rc;
+  const float* table = reinterpret_cast<const float*>(workspace);
+  const unsigned grid = (unsigned)(((N + 7) / 8) * 8 * ((C + kK1Block - 1) / kK1Block));
+  hipStream_t s = as_stream(stream);
+#define RUNIA_MCE(HH, WW, NPP, KK)                                                                          \
+  if (H == HH && W == WW && n_mc <= NPP && n_mc > NPP / 2) {                                                \
+    if (n_mc == NPP)                                                                                        \
+      mc_entropy_kernel<HH, WW, NPP, KK, true, false><<<grid, kK1Block, 0, s>>>(x, table, nullptr, z,       \
+                                                                                nullptr, N, C, n_mc, 0.0,   \
+                                                                                0.0, 0.0);                  \
+    else                                                                                                    \
+      mc_entropy_kernel<HH, WW, NPP, KK, false, false><<<grid, kK1Block, 0, s>>>(x, table, nullptr, z,      \
+                                                                                 nullptr, N, C, n_mc, 0.0,  \
+                                                                                 0.0, 0.0);                 \
     return runia_check_launch();                                                                            \
   }
   RUNIA_MCE_SHAPES(RUNIA_MCE)

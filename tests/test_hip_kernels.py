@@ -440,3 +440,21 @@ def test_proj_sq_accumulate_equals_store_form(hip, n_rows):
     assert torch.equal(a, b)
     ref = -((h @ m + c) ** 2).sum(1)
     assert float(((a - ref).abs() / ref.abs().clamp_min(1.0)).max()) < 1e-12
+
+
+@pytest.mark.parametrize("c,h,w,bs,p,n_mc,n", [(512, 4, 4, 2, 0.5, 16, 9), (33, 8, 8, 3, 0.4, 12, 3), (70, 7, 7, 3, 0.4, 16, 3),
+                                               (20, 2, 2, 1, 0.3, 16, 5), (64, 4, 4, 2, 0.0, 16, 2)])
+def test_mc_stack_table_path_equals_register_kernel(hip, c, h, w, bs, p, n_mc, n):
+    """runia_mc_stack_table_f32 (what hip.mc_stack takes for the supported map shapes) = runia_mc_stack_f32, same
+    samples in the same order, bit for bit."""
+    torch.manual_seed(c)
+    x = torch.relu(torch.randn(n, c, h, w)).cuda()
+    rand = torch.rand(n, n_mc, h, w).cuda() if p > 0 else None
+    a = hip.mc_stack(x, rand, n_mc, p, bs)
+    lib = hip.load_library()
+    b = torch.empty_like(a)
+    rc = lib.runia_mc_stack_f32(x.data_ptr(), None if rand is None else rand.data_ptr(), 0 if rand is None else n_mc * h * w,
+                                b.data_ptr(), n, c, h, w, n_mc, float(p), bs, torch.cuda.current_stream().cuda_stream)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)
