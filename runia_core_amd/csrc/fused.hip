@@ -1,19 +1,24 @@
 // Fused LaREM row pipeline (a11): LaRExInference.get_score after the backbone
-// (reference inference/image_level.py:115-119) as two launches per batch instead of
+// (reference inference/image_level.py:115-119) as three launches per batch instead of
 // ~100 tiny ones per image:
 //
-//   K1  mc_entropy   hooked latent maps (N,C,H,W) + DropBlock draws -> per-dimension entropies H (N,C) f64
+//   K0  mc_mask      DropBlock draws (N,n_mc,H,W) -> per-image keep-flag table (the DropBlock2D masks of
+//                    feature_extraction/abstract_classes.py:91-96 as 0/1 floats, drop layers sorted by mask sum).
+//                    Bit arithmetic on one 64-bit word per drop layer; ~9 us per 10 000 images.
+//   K1  mc_entropy   hooked latent maps (N,C,H,W) + table -> per-dimension entropies H (N,C) f64
 //                    = MCSamplerModule.forward (feature_extraction/abstract_classes.py:81-101) fused with
 //                      the per-dimension loop of get_dl_h_z (evaluation/entropy.py:77-82).  One thread owns
 //                      one (image, channel): its H*W map stays in VGPRs, the n_mc MC samples are produced,
-//                      sorted and reduced to one entropy without ever leaving registers.  VALU-bound.
-//   K2  pca_md       H (N,D) f64 -> LaREM score (N) = apply_pca_transform (dimensionality_reduction.py:86)
-//                    + MDLatentSpace.postprocess (inference/postprocessors.py:241-242).  Both contractions run
-//                    on the f64 matrix cores; the projected rows never leave LDS.
+//                      sorted and reduced to one entropy without ever leaving registers.  VALU-issue-bound.
+//   K2' proj_sq      H (N,D) f64 -> LaREM score (N) = apply_pca_transform (dimensionality_reduction.py:86)
+//                    + MDLatentSpace.postprocess (inference/postprocessors.py:241-242) folded into ONE contraction
+//                    on the f64 matrix cores (K2 pca_md is the two-contraction form, kept for non-PSD precisions).
 //
 // Sample order inside an image is irrelevant to the entropy (order statistics), so K1 visits the drop
 // layers sorted by their mask sum and recomputes the per-element quotients (x*numel)/sum only when the sum
-// changes (wave-uniform branch): same bits as the upstream op order, ~1/3 fewer VALU ops.
+// changes (wave-uniform branch): same bits as the upstream op order.
+// K1 (vector ALU) and K2' (f64 matrix instructions) share the SIMD's issue port on gfx950 and do not overlap
+// (tools/microbench/mfma_valu_overlap.hip); they run back to back on one stream.
 #include "common.hpp"
 #include "entropy_core.hpp"
 #include "mfma_f64_tile.hpp"
@@ -33,7 +38,7 @@ __device__ __forceinline__ float div_newton(float u, float den, float r) {
 }
 
 // ------------------------------------------------------------------------------------------
-// K0: DropBlock draws -> per-image mask table (the scalar operands of K1).   grid = N, 256 threads
+// K0, LDS form (maps whose size does not divide 64): DropBlock draws -> per-image mask table.   grid = N, 256 threads
 //   table of one image = n_mc records of HW floats (0.0 / 1.0 keep flags, drop layers sorted by mask sum,
 //   positions in K1's operand order, see mask_slot) followed by n_mc mask sums and n_mc reciprocals.
 // ------------------------------------------------------------------------------------------
