@@ -263,14 +263,18 @@ __global__ __launch_bounds__(256) void kde_kernel(const double* __restrict__ tra
 // owns one query with its D coordinates in registers; training rows are staged through LDS and read as broadcasts;
 // the four waves of a workgroup take a quarter of every staged tile each and merge their (max, sum) pairs at the end.
 // Per (query, train row): 2*D f64 ops + one f64 exp; logsumexp is kept online per group of 8 rows.
-template <int DP>
-__global__ __launch_bounds__(256) void kde_small_kernel(const double* __restrict__ train,
-                                                         const double* __restrict__ x, double* __restrict__ score,
-                                                         int64_t M, int64_t N, int D, double neg_half_inv_h2,
-                                                         double log_norm) {
-  constexpr int TM = 64;  // staged training rows
+// Any D <= DP: training rows staged through LDS and read as broadcasts; NW waves share 64 queries and split every
+// staged tile.  NW = 16 (8 at DP = 64: register budget) when the batch has too few 64-query groups to fill the chip.
+template <int DP, int NW>
+__global__ __launch_bounds__(64 * NW) void kde_small_kernel(const double* __restrict__ train,
+                                                             const double* __restrict__ x,
+                                                             double* __restrict__ score, int64_t M, int64_t N, int D,
+                                                             double neg_half_inv_h2, double log_norm) {
+  constexpr int TM = (NW == 4) ? 64 : ((DP <= 32) ? 128 : 64);  // staged training rows (<= 32 KB of LDS)
+  constexpr int RPW = TM / NW;                                   // rows per wave and tile
+  constexpr int GS = (RPW < 8) ? RPW : 8;                        // rows per online-logsumexp group
   __shared__ double tile[TM][DP];
-  __shared__ double pm[4][64], ps[4][64];
+  __shared__ double pm[NW][64], ps[NW][64];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int64_t qrow = (int64_t)blockIdx.x * 64 + lane;
@@ -280,19 +284,19 @@ __global__ __launch_bounds__(256) void kde_small_kernel(const double* __restrict
   double mx = -kInfD(), sum = 0.0;
   for (int64_t t0 = 0; t0 < M; t0 += TM) {
     __syncthreads();
-    for (int i = tid; i < TM * DP; i += 256) {
+    for (int i = tid; i < TM * DP; i += 64 * NW) {
       const int r = i / DP, c = i - r * DP;
       tile[r][c] = (t0 + r < M && c < D) ? train[(t0 + r) * D + c] : 0.0;
     }
     __syncthreads();
     const int rows = (int)((M - t0 < TM) ? (M - t0) : TM);
 #pragma unroll
-    for (int g = 0; g < TM / 4 / 8; ++g) {  // this wave's quarter, 8 rows at a time
-      const int r0 = wave * (TM / 4) + g * 8;
-      double v[8];
+    for (int g = 0; g < RPW / GS; ++g) {  // this wave's share of the tile, GS rows at a time
+      const int r0 = wave * RPW + g * GS;
+      double v[GS];
       double gmax = -kInfD();
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < GS; ++j) {
         double acc = 0.0;
 #pragma unroll
         for (int i = 0; i < DP; ++i) {
@@ -306,7 +310,7 @@ __global__ __launch_bounds__(256) void kde_small_kernel(const double* __restrict
         const double mnew = fmax(mx, gmax);
         double part = 0.0;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) part += exp(v[j] - mnew);
+        for (int j = 0; j < GS; ++j) part += exp(v[j] - mnew);
         sum = sum * exp(mx - mnew) + part;
         mx = mnew;
       }
@@ -316,12 +320,29 @@ __global__ __launch_bounds__(256) void kde_small_kernel(const double* __restrict
   ps[wave][lane] = sum;
   __syncthreads();
   if (wave == 0 && qrow < N) {
-    const double gm = fmax(fmax(pm[0][lane], pm[1][lane]), fmax(pm[2][lane], pm[3][lane]));
+    double gm = pm[0][lane];
+#pragma unroll
+    for (int w = 1; w < NW; ++w) gm = fmax(gm, pm[w][lane]);
     double gs = 0.0;
 #pragma unroll
-    for (int w = 0; w < 4; ++w)
+    for (int w = 0; w < NW; ++w)
       if (ps[w][lane] > 0.0) gs += ps[w][lane] * exp(pm[w][lane] - gm);
     score[qrow] = log(gs) + gm + log_norm;
+  }
+}
+
+template <int DP>
+void launch_kde_small(const double* train, const double* x, double* score, int64_t M, int64_t N, int D, double nh,
+                      double log_norm, hipStream_t s) {
+  const unsigned qblocks = (unsigned)((N + 63) / 64);
+  const bool few = (int64_t)qblocks < 2 * runia_cu_count();
+  // (training rows through the scalar cache instead of LDS - s_load_dwordx16, SGPR operands - measured 0.355 / 3.81 /
+  //  2.60 ms against 0.365 / 2.90 / 1.84 ms at D = 16 / 32 / 64: not kept)
+  if (few) {  // 16 waves leave 128 VGPRs per lane: enough for D <= 32, not for a 64-wide query -> 8 waves there
+    if constexpr (DP <= 32) kde_small_kernel<DP, 16><<<qblocks, 1024, 0, s>>>(train, x, score, M, N, D, nh, log_norm);
+    else kde_small_kernel<DP, 8><<<qblocks, 512, 0, s>>>(train, x, score, M, N, D, nh, log_norm);
+  } else {
+    kde_small_kernel<DP, 4><<<qblocks, 256, 0, s>>>(train, x, score, M, N, D, nh, log_norm);
   }
 }
 
@@ -397,11 +418,10 @@ extern "C" int runia_kde_score_f64(const double* train, const double* x, double*
   const double log_norm = -log((double)M) - (double)D * log(bandwidth) - 0.5 * (double)D * log(2.0 * M_PI);
   const double nh = -0.5 / (bandwidth * bandwidth);
   hipStream_t s = as_stream(stream);
-  const unsigned qblocks = (unsigned)((N + 63) / 64);
-  if (D <= 8) kde_small_kernel<8><<<qblocks, 256, 0, s>>>(train, x, score, M, N, (int)D, nh, log_norm);
-  else if (D <= 16) kde_small_kernel<16><<<qblocks, 256, 0, s>>>(train, x, score, M, N, (int)D, nh, log_norm);
-  else if (D <= 32) kde_small_kernel<32><<<qblocks, 256, 0, s>>>(train, x, score, M, N, (int)D, nh, log_norm);
-  else if (D <= 64) kde_small_kernel<64><<<qblocks, 256, 0, s>>>(train, x, score, M, N, (int)D, nh, log_norm);
+  if (D <= 8) launch_kde_small<8>(train, x, score, M, N, (int)D, nh, log_norm, s);
+  else if (D <= 16) launch_kde_small<16>(train, x, score, M, N, (int)D, nh, log_norm, s);
+  else if (D <= 32) launch_kde_small<32>(train, x, score, M, N, (int)D, nh, log_norm, s);
+  else if (D <= 64) launch_kde_small<64>(train, x, score, M, N, (int)D, nh, log_norm, s);
   else {
     const size_t shmem = (size_t)D * sizeof(double);
     if (shmem > 64 * 1024) return RUNIA_E_INVALID;
