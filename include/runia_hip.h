@@ -142,6 +142,14 @@ int runia_knn_kth_f32(const float* q, const float* bank, float* score, void* wor
  *   train [M, D] f64, x [N, D] f64, score [N] f64 */
 int runia_kde_score_f64(const double* train, const double* x, double* score, int64_t M, int64_t N,
                         int64_t D, double bandwidth, runia_stream_t stream);
+/* The same log-density with the pair distances on the f64 matrix cores, |x - t|^2 = |x|^2 + |t|^2 - 2 x.t (for
+ * wide embeddings, D > 64): packed_train_t = runia_pack_weights_f64 of train^T [D, M] and train_sqnorm [M] =
+ * runia_row_sqnorm_f64(train), both made once at setup; workspace: N doubles (the query norms).  The logsumexp over
+ * the M training rows is kept online in the accumulator lanes; no [N, M] matrix is written. */
+int runia_row_sqnorm_f64(const double* x, double* out, int64_t N, int64_t D, runia_stream_t stream);
+int runia_kde_score_packed_f64(const double* packed_train_t, const double* train_sqnorm, const double* x,
+                               double* score, void* workspace, size_t workspace_bytes, int64_t M, int64_t N,
+                               int64_t D, double bandwidth, runia_stream_t stream);
 
 /* ---- a11 fused LaREM row pipeline ------------------------------------------- *
  * LaRExInference.get_score after the backbone (inference/image_level.py:115-119) as two

@@ -58,6 +58,11 @@ _SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int64, c_int, c_void_p],
     ),
     "runia_kde_score_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p]),
+    "runia_row_sqnorm_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "runia_kde_score_packed_f64": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int64, c_double, c_void_p],
+    ),
     "runia_mc_entropy_supported": (c_int, [c_int, c_int, c_int, c_int]),
     "runia_mc_entropy_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int]),
     "runia_mc_mask_table_f32": (
@@ -370,6 +375,40 @@ def knn_kth(q: torch.Tensor, bank: torch.Tensor, k: int) -> torch.Tensor:
         "runia_knn_kth_f32",
     )
     return s
+
+
+def row_sqnorm(x: torch.Tensor) -> torch.Tensor:
+    """x [N, D] f64 -> squared row norms [N] f64."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float64 and x.dim() == 2
+    x = x.contiguous()
+    out = torch.empty((x.shape[0],), dtype=torch.float64, device=x.device)
+    _check(lib.runia_row_sqnorm_f64(x.data_ptr(), out.data_ptr(), x.shape[0], x.shape[1], _stream()), "runia_row_sqnorm_f64")
+    return out
+
+
+def kde_pack_train(train: torch.Tensor):
+    """Setup-time state of ``kde_score_packed``: (pack(train^T), squared row norms, M, D)."""
+    assert train.is_cuda and train.dtype == torch.float64 and train.dim() == 2
+    train = train.contiguous()
+    return pack_weights(train.t().contiguous()), row_sqnorm(train), int(train.shape[0]), int(train.shape[1])
+
+
+def kde_score_packed(state, x: torch.Tensor, bandwidth: float = 1.0) -> torch.Tensor:
+    """Gaussian-KDE log-density [N] f64 of x [N, D] f64 against a packed training set (matrix-core path)."""
+    lib = load_library()
+    require_gpu()
+    packed, tn, m, d = state
+    assert x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.shape[1] == d
+    x = x.contiguous()
+    n = x.shape[0]
+    out = torch.empty((n,), dtype=torch.float64, device=x.device)
+    ws = torch.empty((max(n, 1),), dtype=torch.float64, device=x.device)
+    _check(lib.runia_kde_score_packed_f64(packed.data_ptr(), tn.data_ptr(), x.data_ptr(), out.data_ptr(), ws.data_ptr(),
+                                          n * 8, m, n, d, float(bandwidth), _stream()),
+           "runia_kde_score_packed_f64")
+    return out
 
 
 def kde_score(train: torch.Tensor, x: torch.Tensor, bandwidth: float = 1.0) -> torch.Tensor:

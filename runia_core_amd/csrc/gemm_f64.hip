@@ -26,7 +26,7 @@ using namespace runia_mfma;
 
 constexpr int BM = 32;  // rows per workgroup (2 row tiles of 16)
 
-enum Epilogue { EPI_PCA = 0, EPI_ROWDOT = 1, EPI_STORE = 2, EPI_ROWNORM = 3 };
+enum Epilogue { EPI_PCA = 0, EPI_ROWDOT = 1, EPI_STORE = 2, EPI_ROWNORM = 3, EPI_KDE = 4 };
 
 struct GemmArgs {
   const void* x;        // [N, K] rows (TA), ld = ldx
@@ -38,8 +38,12 @@ struct GemmArgs {
   // EPI_PCA
   const double* bias;   // [n]
   const double* scale;  // [n] or null
+  // EPI_KDE: out[row] = logsumexp_col alpha * (rown[row] + coln[col] - 2 (x B)[row][col]) + addc
+  const double* rown;   // [N] squared norms of the rows of x
+  const double* coln;   // [n] squared norms of the columns of B
+  double alpha, addc;
   // outputs
-  double* out;          // EPI_PCA / EPI_STORE: [N, n] (ld = n); EPI_ROWDOT: [N]
+  double* out;          // EPI_PCA / EPI_STORE: [N, n] (ld = n); EPI_ROWDOT / EPI_ROWNORM / EPI_KDE: [N]
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const double* __restrict__ B, int64_t ldb,
@@ -88,6 +92,7 @@ template <typename TA, typename TS, int EPI>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   __shared__ double lds_a[2][BM][APITCH];
   __shared__ double lds_part[4][BM];
+  __shared__ double lds_part2[(EPI == EPI_KDE) ? 4 : 1][BM];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -97,11 +102,12 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   const int64_t nchunks = k_padded(g.K) / KC;
   const int64_t r0 = (int64_t)blockIdx.x * BM;
 
-  double rowdot[2][4];
+  double rowdot[2][4];   // EPI_KDE: running sum of exp(. - rowmax)
+  double rowmax[2][4];   // EPI_KDE only
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) rowdot[a][r] = 0.0;
+    for (int r = 0; r < 4; ++r) { rowdot[a][r] = 0.0; rowmax[a][r] = -kInfD(); }
 
   for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
     const int64_t ctbase = cb * 16 + wave * 4;
@@ -131,6 +137,32 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     }
 
     // ---- epilogue for this 256-column block ----
+    if constexpr (EPI == EPI_KDE) {
+      // online logsumexp over this lane's 4 columns of the block, per accumulator row
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int64_t row = r0 + 16 * a + lg + 4 * r;
+          const double rn = (row < g.N) ? g.rown[row] : 0.0;
+          double val[4];
+          double gmax = -kInfD();
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const int64_t col = (ctbase + c) * 16 + li;
+            val[c] = (col < g.n) ? g.alpha * (rn + g.coln[col] - 2.0 * acc[a][c][r]) : -kInfD();
+            gmax = fmax(gmax, val[c]);
+          }
+          if (gmax > -kInfD()) {
+            const double mnew = fmax(rowmax[a][r], gmax);
+            double part = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) part += exp(val[c] - mnew);
+            rowdot[a][r] = rowdot[a][r] * exp(rowmax[a][r] - mnew) + part;
+            rowmax[a][r] = mnew;
+          }
+        }
+    } else
 #pragma unroll
     for (int a = 0; a < 2; ++a) {
 #pragma unroll
@@ -162,6 +194,38 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     __syncthreads();  // all waves done with the last chunk before the next block restages LDS
   }
 
+  if constexpr (EPI == EPI_KDE) {
+    // merge the (max, sum) pairs of the 16 lanes that share a row, then of the four waves
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double m = rowmax[a][r], sm = rowdot[a][r];
+#pragma unroll
+        for (int o = 1; o < 16; o <<= 1) {
+          const double m2 = shfl_xor_f64(m, o), s2 = shfl_xor_f64(sm, o);
+          const double mn = fmax(m, m2);
+          sm = (mn > -kInfD()) ? sm * exp(m - mn) + s2 * exp(m2 - mn) : 0.0;
+          m = mn;
+        }
+        if (li == 0) {
+          lds_part[wave][16 * a + lg + 4 * r] = m;
+          lds_part2[wave][16 * a + lg + 4 * r] = sm;
+        }
+      }
+    __syncthreads();
+    if (tid < BM) {
+      const int64_t row = r0 + tid;
+      if (row < g.N) {
+        const double gm = fmax(fmax(lds_part[0][tid], lds_part[1][tid]), fmax(lds_part[2][tid], lds_part[3][tid]));
+        double gs = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w)
+          if (lds_part2[w][tid] > 0.0) gs += lds_part2[w][tid] * exp(lds_part[w][tid] - gm);
+        g.out[row] = log(gs) + gm + g.addc;
+      }
+    }
+  }
   if constexpr (EPI == EPI_ROWDOT || EPI == EPI_ROWNORM) {
 #pragma unroll
     for (int a = 0; a < 2; ++a)
@@ -183,6 +247,22 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
       }
     }
   }
+}
+
+// squared L2 norm of every row, f64: one wave per row, fixed summation order
+__global__ __launch_bounds__(256) void row_sqnorm_f64_kernel(const double* __restrict__ x, double* __restrict__ out,
+                                                              int64_t N, int64_t D) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= N) return;
+  double s = 0.0;
+  for (int64_t i = lane; i < D; i += 64) {
+    const double v = x[row * D + i];
+    s = fma(v, v, s);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) s += shfl_xor_f64(s, o);
+  if (lane == 0) out[row] = s;
 }
 
 template <typename TA, int EPI, typename TS = double>
@@ -312,6 +392,31 @@ extern "C" int runia_proj_norm_f32(const float* x, const float* u, const double*
 extern "C" int runia_proj_norm_f64(const double* x, const double* u, const double* packed_ns, double* norm, int64_t N,
                                    int64_t D, int64_t n, runia_stream_t stream) {
   return proj_norm_impl<double, double>(x, u, packed_ns, norm, N, D, n, stream);
+}
+
+extern "C" int runia_row_sqnorm_f64(const double* x, double* out, int64_t N, int64_t D, runia_stream_t stream) {
+  if (N < 0 || D <= 0 || (N > 0 && (!x || !out))) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  row_sqnorm_f64_kernel<<<(unsigned)((N + 3) / 4), 256, 0, as_stream(stream)>>>(x, out, N, D);
+  return runia_check_launch();
+}
+
+extern "C" int runia_kde_score_packed_f64(const double* packed_train_t, const double* train_sqnorm, const double* x,
+                                          double* score, void* workspace, size_t workspace_bytes, int64_t M,
+                                          int64_t N, int64_t D, double bandwidth, runia_stream_t stream) {
+  if (M <= 0 || N < 0 || D <= 0 || !(bandwidth > 0.0)) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!packed_train_t || !train_sqnorm || !x || !score) return RUNIA_E_INVALID;
+  if (!workspace || workspace_bytes < (size_t)N * sizeof(double)) return RUNIA_E_WORKSPACE;
+  double* qn = reinterpret_cast<double*>(workspace);
+  if (int rc = runia_row_sqnorm_f64(x, qn, N, D, stream)) return rc;
+  GemmArgs g{};
+  g.x = x; g.ldx = D; g.packed = packed_train_t; g.N = N; g.K = D; g.n = M;
+  g.rown = qn; g.coln = train_sqnorm;
+  g.alpha = -0.5 / (bandwidth * bandwidth);
+  g.addc = -log((double)M) - (double)D * log(bandwidth) - 0.5 * (double)D * log(2.0 * M_PI);
+  g.out = score;
+  return launch_gemm<double, EPI_KDE>(g, as_stream(stream));
 }
 
 extern "C" size_t runia_mahalanobis_workspace_bytes(int64_t N, int64_t D) {

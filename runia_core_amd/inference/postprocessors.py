@@ -72,6 +72,7 @@ class DetectorKDE:
 
     def density_fit(self):
         self._train_dev = None  # uploaded on first use so that setup works without a GPU
+        self._packed = None     # matrix-core form of the training set (D >= 24), built on first use
         return self
 
     def _train(self) -> Tensor:
@@ -80,7 +81,14 @@ class DetectorKDE:
         return self._train_dev
 
     def score_samples_device(self, x: Tensor) -> Tensor:
-        return _hip.kde_score(self._train(), x.to(torch.float64), float(self.bandwidth))
+        train = self._train()
+        if train.shape[1] >= 24:
+            # pair distances as |x|^2 + |t|^2 - 2 x.t on the f64 matrix cores, online logsumexp (8 192 x 10 000 pairs:
+            # 0.33 / 0.44 / 0.98 ms at D = 32 / 64 / 256 against 0.57 / 1.83 / 21.5 ms for the direct kernels; a tie at 16)
+            if self._packed is None:
+                self._packed = _hip.kde_pack_train(train)
+            return _hip.kde_score_packed(self._packed, x.to(torch.float64), float(self.bandwidth))
+        return _hip.kde_score(train, x.to(torch.float64), float(self.bandwidth))
 
     def get_density_scores(self, test_embeddings):
         x = _hip.to_device(np.asarray(test_embeddings), torch.float64)

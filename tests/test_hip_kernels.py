@@ -458,3 +458,18 @@ def test_mc_stack_table_path_equals_register_kernel(hip, c, h, w, bs, p, n_mc, n
     assert rc == 0
     torch.cuda.synchronize()
     assert np.array_equal(a.cpu().numpy(), b.cpu().numpy(), equal_nan=True)
+
+
+@pytest.mark.parametrize("m,n,d,bw", [(300, 70, 100, 3.0), (1000, 257, 256, 6.0), (50, 5, 65, 2.0), (4097, 33, 512, 9.0)])
+def test_kde_matrix_core_path_equals_exact_differences(hip, m, n, d, bw):
+    """runia_kde_score_packed_f64 (|x|^2 + |t|^2 - 2 x.t on the f64 MFMA, online logsumexp) against the oracle's
+    exact-difference log-density and against the direct kernel."""
+    rng = np.random.default_rng(m + d)
+    train = rng.standard_normal((m, d))
+    x = rng.standard_normal((n, d)) * 1.1 + 0.1
+    td, xd = torch.from_numpy(train).cuda(), torch.from_numpy(x).cuda()
+    got = hip.kde_score_packed(hip.kde_pack_train(td), xd, bw).cpu().numpy()
+    exp = oracle.kde_score(train, x, bw)
+    assert np.abs(got - exp).max() / max(1.0, np.abs(exp).max()) < 1e-11
+    direct = hip.kde_score(td, xd, bw).cpu().numpy()
+    assert np.abs(got - direct).max() < 1e-9

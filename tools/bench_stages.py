@@ -127,7 +127,19 @@ s = _hip.kde_score(tr, x)
 m = 512
 cpu = cpu_rate(lambda: oracle.kde_score(tr.cpu().numpy(), x[:m].cpu().numpy()), m)
 err = rel(s[:m].cpu().numpy(), oracle.kde_score(tr.cpu().numpy(), x[:m].cpu().numpy()))
-add("KDE / LaRED (a9)", f"{N} x train {Mt}x{D} f64", "rows", N, ms, "mfma_f64", 3.0 * Mt * D, cpu, f"numpy brute force, {m} rows", err)
+add("KDE / LaRED (a9), direct", f"{N} x train {Mt}x{D} f64", "rows", N, ms, "mfma_f64", 3.0 * Mt * D, cpu, f"numpy brute force, {m} rows", err)
+# LaRED at PCA-256: pair distances on the f64 matrix cores (DetectorKDE takes this path for D >= 24)
+D = 256
+tr = torch.randn(Mt, D, dtype=torch.float64, device=dev, generator=g)
+x = torch.randn(N, D, dtype=torch.float64, device=dev, generator=g) * 1.05
+kst = _hip.kde_pack_train(tr)
+bw = 8.0
+ms = gpu_ms(lambda: _hip.kde_score_packed(kst, x, bw))
+s = _hip.kde_score_packed(kst, x, bw)
+m = 256
+cpu = cpu_rate(lambda: oracle.kde_score(tr.cpu().numpy(), x[:m].cpu().numpy(), bw), m)
+err = rel(s[:m].cpu().numpy(), oracle.kde_score(tr.cpu().numpy(), x[:m].cpu().numpy(), bw))
+add("KDE / LaRED (a9), matrix cores", f"{N} x train {Mt}x{D} f64", "rows", N, ms, "mfma_f64", 2.0 * Mt * D, cpu, f"numpy brute force, {m} rows", err)
 
 # ---- cfg2 stages ----------------------------------------------------------------------------------------
 N, NMC, C, H, W, NP = 10_000, 16, 512, 4, 4, 256
