@@ -389,19 +389,22 @@ def row_sqnorm(x: torch.Tensor) -> torch.Tensor:
 
 
 def kde_pack_train(train: torch.Tensor):
-    """Setup-time state of ``kde_score_packed``: (pack(train^T), squared row norms, M, D)."""
+    """Setup-time state of ``kde_score_packed``: (pack(train_c^T), squared row norms of train_c, M, D, mean) with
+    train_c = train - mean(train).  Distances are translation invariant; centring keeps |x|^2 + |t|^2 - 2 x.t
+    well conditioned when the embeddings sit far from the origin."""
     assert train.is_cuda and train.dtype == torch.float64 and train.dim() == 2
-    train = train.contiguous()
-    return pack_weights(train.t().contiguous()), row_sqnorm(train), int(train.shape[0]), int(train.shape[1])
+    mean = train.mean(dim=0)
+    tc = (train - mean).contiguous()
+    return pack_weights(tc.t().contiguous()), row_sqnorm(tc), int(train.shape[0]), int(train.shape[1]), mean
 
 
 def kde_score_packed(state, x: torch.Tensor, bandwidth: float = 1.0) -> torch.Tensor:
     """Gaussian-KDE log-density [N] f64 of x [N, D] f64 against a packed training set (matrix-core path)."""
     lib = load_library()
     require_gpu()
-    packed, tn, m, d = state
+    packed, tn, m, d, mean = state
     assert x.is_cuda and x.dtype == torch.float64 and x.dim() == 2 and x.shape[1] == d
-    x = x.contiguous()
+    x = (x - mean).contiguous()
     n = x.shape[0]
     out = torch.empty((n,), dtype=torch.float64, device=x.device)
     ws = torch.empty((max(n, 1),), dtype=torch.float64, device=x.device)

@@ -473,3 +473,6 @@ def test_kde_matrix_core_path_equals_exact_differences(hip, m, n, d, bw):
     assert np.abs(got - exp).max() / max(1.0, np.abs(exp).max()) < 1e-11
     direct = hip.kde_score(td, xd, bw).cpu().numpy()
     assert np.abs(got - direct).max() < 1e-9
+    # embeddings far from the origin: the training mean is removed at setup, so the norm expansion stays exact
+    far = hip.kde_score_packed(hip.kde_pack_train(td + 1.0e4), xd + 1.0e4, bw).cpu().numpy()
+    assert np.abs(far - exp).max() / max(1.0, np.abs(exp).max()) < 1e-9
