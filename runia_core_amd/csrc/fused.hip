@@ -840,7 +840,7 @@ extern "C" int runia_mc_entropy_f32(const float* x, const float* rnd, int64_t ra
 }
 
 extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k) {
-  if (k != 5) return 0;
+  if (k != 5 || k >= n_mc) return 0;
   const bool hw = (H == 4 && W == 4);
   if (hw && n_mc > 4 && n_mc <= 32) return 1;
   if (n_mc > 8 && n_mc <= 16 && ((H == 2 && W == 2) || (H == 7 && W == 7) || (H == 8 && W == 8))) return 1;

@@ -57,6 +57,18 @@ def test_library_exports_every_header_symbol():
 
 
 @pytest.mark.skipif(not no_gpu, reason="CPU-only behaviour")
+def test_fused_sampler_shape_query_needs_no_gpu():
+    """runia_mc_entropy_supported is a pure host query: the shapes the fused sampler + entropy covers, and k < n_mc."""
+    from runia_core_amd import _hip
+
+    lib = _hip.load_library()
+    assert lib.runia_mc_entropy_supported(4, 4, 16, 5) == 1 and lib.runia_mc_entropy_supported(8, 8, 12, 5) == 1
+    assert lib.runia_mc_entropy_supported(4, 4, 5, 5) == 0      # k-th neighbour needs k < n_mc
+    assert lib.runia_mc_entropy_supported(5, 5, 16, 5) == 0 and lib.runia_mc_entropy_supported(4, 4, 16, 3) == 0
+    assert lib.runia_mc_entropy_workspace_bytes(10, 4, 4, 16) == 10 * (16 * 18) * 4
+    assert lib.runia_proj_sq_workspace_bytes(100) == 1600
+
+
 def test_product_path_fails_loudly_without_gpu():
     with pytest.raises(_hip.RuniaHipError, match="no CPU fallback"):
         _hip.require_gpu()
