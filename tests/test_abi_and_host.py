@@ -69,6 +69,35 @@ def test_fused_sampler_shape_query_needs_no_gpu():
     assert lib.runia_proj_sq_workspace_bytes(100) == 1600
 
 
+def test_argument_checks_come_before_any_launch():
+    """Bad shapes, null pointers and short workspaces are refused with the documented codes before anything touches the
+    device - so these calls are safe on a box without a GPU."""
+    from runia_core_amd import _hip
+
+    lib = _hip.load_library()
+    P = 4096  # any non-null address: never dereferenced on these paths
+    INVALID, WORKSPACE = -1, -4
+    # fused sampler + entropy
+    assert lib.runia_mc_entropy_f32(P, P, 256, P, None, None, None, 0, 10, 8, 4, 4, 16, 0.5, 2, 5, 1e-5, None) == WORKSPACE
+    assert lib.runia_mc_entropy_f32(P, P, 256, P, None, None, P, 64, 10, 8, 4, 4, 16, 0.5, 2, 5, 1e-5, None) == WORKSPACE
+    assert lib.runia_mc_entropy_f32(P, P, 256, P, None, None, P, 1 << 20, 10, 8, 5, 5, 16, 0.5, 2, 5, 1e-5, None) == INVALID
+    assert lib.runia_mc_entropy_f32(P, None, 256, P, None, None, P, 1 << 20, 10, 8, 4, 4, 16, 0.5, 2, 5, 1e-5, None) == INVALID
+    assert lib.runia_mc_entropy_f32(None, P, 256, P, None, None, P, 1 << 20, 10, 8, 4, 4, 16, 0.5, 2, 5, 1e-5, None) == INVALID
+    assert lib.runia_mc_entropy_f32(P, P, 256, P, None, None, P, 1 << 20, 0, 8, 4, 4, 16, 0.5, 2, 5, 1e-5, None) == 0  # empty batch
+    assert lib.runia_mc_mask_table_f32(P, 256, P + 4, 1 << 20, 10, 4, 4, 16, 0.5, 2, None) == WORKSPACE  # misaligned
+    assert lib.runia_mc_stack_table_f32(P, P, 256, P, P, 8, 10, 8, 4, 4, 16, 0.5, 2, None) == WORKSPACE
+    # folded LaREM score
+    assert lib.runia_proj_sq_score_f64(None, P, P, P, None, 0, 10, 512, 256, None) == INVALID
+    assert lib.runia_proj_sq_score_f64(P, P, P, P, None, 0, 0, 512, 256, None) == 0
+    assert lib.runia_proj_sq_accumulate_f64(P, P, P, None, 10, 512, 256, None) == INVALID
+    # matrix-core KDE
+    assert lib.runia_kde_score_packed_f64(P, P, P, P, None, 0, 100, 10, 32, 1.0, None) == WORKSPACE
+    assert lib.runia_kde_score_packed_f64(P, P, P, P, P, 80, 100, 10, 32, 0.0, None) == INVALID
+    # kNN
+    assert lib.runia_knn_kth_f32(P, P, P, None, 0, 10, 100, 32, 5, None) == WORKSPACE
+    assert lib.runia_error_string(WORKSPACE) and lib.runia_error_string(INVALID)
+
+
 def test_product_path_fails_loudly_without_gpu():
     with pytest.raises(_hip.RuniaHipError, match="no CPU fallback"):
         _hip.require_gpu()
