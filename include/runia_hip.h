@@ -53,6 +53,12 @@ int runia_mc_stack_f32(const float* x, const float* rand, int64_t rand_image_str
                        int64_t N, int C, int H, int W, int n_mc, double drop_prob, int block_size,
                        runia_stream_t stream);
 
+/* layer_type "FC" / "RPN" of the same module (feature_extraction/abstract_classes.py:95-99: no fullmean, each drop
+ * layer's output is flattened):  out [N*n_mc, C*H*W] f32 = ((x * bm) * numel) / sum(bm), image-major. */
+int runia_mc_drop_flat_f32(const float* x, const float* rand, int64_t rand_image_stride, float* out,
+                           int64_t N, int C, int H, int W, int n_mc, double drop_prob, int block_size,
+                           runia_stream_t stream);
+
 /* ---- a2  Kozachenko-Leonenko kNN entropy --------------------------------- *
  * Replaces the loops of get_dl_h_z / single_image_entropy_calculation
  * (evaluation/entropy.py:20-93) over entropy_estimators.continuous.get_h(col, k,

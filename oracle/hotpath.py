@@ -25,6 +25,7 @@ __all__ = [
     "kl_entropy_per_dim_vectorized",
     "kl_entropy_joint_vectorized",
     "dropblock_block_mask",
+    "torch_cpu_sum_lastdim",
     "mc_stack",
     "pca_transform",
     "empirical_precision",
@@ -161,7 +162,9 @@ def kl_entropy_joint_vectorized(z: np.ndarray, n_mc: int, k: int | None = None) 
 
 # --------------------------------------------------------------------------
 # a1  MC-dropout latent stacking (feature_extraction/abstract_classes.py:81-101)
-#     PARITY UNPINNED for the mask path (dropblock==0.3.0 absent, see __init__).
+#     Pinned by tests/golden/ref_sampler.npz: outputs of the reference's own
+#     MCSamplerModule.forward (loaded by path, tools/make_goldens_r2.py); the only
+#     restated piece is the third-party DropBlock2D layer (dropblock==0.3.0, absent).
 # --------------------------------------------------------------------------
 def dropblock_block_mask(rand: np.ndarray, drop_prob: float, block_size: int) -> np.ndarray:
     """``dropblock.DropBlock2D`` block mask (dropblock==0.3.0,
@@ -188,25 +191,78 @@ def dropblock_block_mask(rand: np.ndarray, drop_prob: float, block_size: int) ->
     return (1.0 - pooled).astype(np.float32)
 
 
-def mc_stack(x: np.ndarray, rand: np.ndarray, drop_prob: float, block_size: int) -> np.ndarray:
-    """``MCSamplerModule.forward`` for ``layer_type="Conv"``
-    (feature_extraction/abstract_classes.py:91-101 + ``fullmean``,
-    feature_extraction/utils.py:88-92).  ``x`` is ``(1,C,H,W)`` f32, ``rand`` is
-    ``(n_mc,H,W)`` — the uniform draw of each drop layer in ``ModuleList`` order.
-    Returns ``(n_mc, C)`` f32."""
+def torch_cpu_sum_lastdim(a: np.ndarray) -> np.ndarray:
+    """f32 sum over the last axis in the order of ``torch.sum`` / ``torch.mean`` on a CPU tensor whose reduced
+    dimension is contiguous (ATen ``SumKernel.cpp`` ``cascade_sum``; what ``get_mean_or_fullmean_ls_sample``,
+    feature_extraction/utils.py:88-92, runs when the sampler sits on the host as in the reference's tests):
+
+    * n < 8: four interleaved partial sums ``p[k] = a[k] (+ a[4+k] ...)``, the remainder added to ``p[0]``, then
+      ``((p0 + p1) + p2) + p3``  -  for 4 <= n < 8 the chain a0, a4, .., a[n-1], a1, a2, a3;
+    * n >= 8: 8-lane vector partials (four of them interleaved over the 8-element chunks), the scalar remainder
+      summed first, then the 8 lanes added to it one by one.
+
+    Verified against torch itself for every n in 1..69 (tests/test_oracle_goldens.py).  The cascade levels that ATen
+    adds for rows of >= 512 elements are not restated."""
+    a = np.asarray(a, dtype=np.float32)
+    n = a.shape[-1]
+    lead = a.shape[:-1]
+    f = np.float32
+    if n < 8:
+        s = n // 4
+        p = [np.zeros(lead, f) for _ in range(4)]
+        for k in range(4):
+            for j in range(s):
+                p[k] = (p[k] + a[..., j * 4 + k]).astype(f)
+        for i in range(s * 4, n):
+            p[0] = (p[0] + a[..., i]).astype(f)
+        for k in range(1, 4):
+            p[0] = (p[0] + p[k]).astype(f)
+        return p[0]
+    vs = n // 8
+    vec = a[..., : vs * 8].reshape(lead + (vs, 8))
+    p = [np.zeros(lead + (8,), f) for _ in range(4)]
+    s = vs // 4
+    for k in range(4):
+        for j in range(s):
+            p[k] = (p[k] + vec[..., j * 4 + k, :]).astype(f)
+    for i in range(s * 4, vs):
+        p[0] = (p[0] + vec[..., i, :]).astype(f)
+    for k in range(1, 4):
+        p[0] = (p[0] + p[k]).astype(f)
+    acc = np.zeros(lead, f)
+    for k in range(vs * 8, n):
+        acc = (acc + a[..., k]).astype(f)
+    for lane in range(8):
+        acc = (acc + p[0][..., lane]).astype(f)
+    return acc
+
+
+def mc_stack(x: np.ndarray, rand: np.ndarray, drop_prob: float, block_size: int, layer_type: str = "Conv") -> np.ndarray:
+    """``MCSamplerModule.forward`` (feature_extraction/abstract_classes.py:91-101): per drop layer
+    ``y = x * bm * numel / sum`` (dropblock==0.3.0), then for ``layer_type="Conv"`` the ``fullmean``
+    (mean over W, then over H; feature_extraction/utils.py:88-92), then ``reshape(1, -1)`` and ``cat``.
+    ``x`` is ``(1,C,H,W)`` f32, ``rand`` is ``(n_mc,H,W)`` - the uniform draw of each drop layer in
+    ``ModuleList`` order.  Returns ``(n_mc, C)`` f32 for ``"Conv"``, ``(n_mc, C*H*W)`` for ``"FC"`` / ``"RPN"``."""
     x = np.asarray(x, dtype=np.float32)
     assert x.ndim == 4 and x.shape[0] == 1
     n_mc = rand.shape[0]
-    out = np.empty((n_mc, x.shape[1]), dtype=np.float32)
+    _, c, h, w = x.shape
+    conv = layer_type == "Conv"
+    out = np.empty((n_mc, c if conv else c * h * w), dtype=np.float32)
+
+    def fullmean(y):  # (C,H,W) -> (C,)
+        rows = torch_cpu_sum_lastdim(y) / np.float32(w)
+        return torch_cpu_sum_lastdim(rows) / np.float32(h)
+
     if drop_prob == 0.0:
-        m = x.mean(axis=3, dtype=np.float32).mean(axis=2, dtype=np.float32)
-        out[:] = m
+        out[:] = fullmean(x[0]) if conv else x[0].reshape(-1)
         return out
     bm = dropblock_block_mask(rand, drop_prob, block_size)  # (n_mc,H,W)
     for s in range(n_mc):
         # published order: out = x * bm; out = out * bm.numel() / bm.sum()   (all f32)
-        y = (x[0] * bm[s][None]) * np.float32(bm[s].size) / np.float32(bm[s].sum(dtype=np.float32))
-        out[s] = y.mean(axis=2, dtype=np.float32).mean(axis=1, dtype=np.float32)
+        with np.errstate(invalid="ignore", divide="ignore"):
+            y = (x[0] * bm[s][None]) * np.float32(bm[s].size) / np.float32(bm[s].sum(dtype=np.float32))
+        out[s] = fullmean(y) if conv else y.reshape(-1)
     return out
 
 

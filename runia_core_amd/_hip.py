@@ -26,6 +26,10 @@ _SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p],
     ),
+    "runia_mc_drop_flat_f32": (
+        c_int,
+        [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p],
+    ),
     "runia_kl_entropy_per_dim_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_double, c_void_p]),
     "runia_kl_entropy_joint_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_double, c_void_p]),
     "runia_packed_weights_bytes": (c_size_t, [c_int64, c_int64]),
@@ -226,6 +230,37 @@ def mc_stack(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob
                 m, c, h, w, n_mc, float(drop_prob), int(block_size), _stream(),
             ),
             "runia_mc_stack_f32",
+        )
+        done += m
+    return out
+
+
+def mc_drop_flat(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob: float, block_size: int) -> torch.Tensor:
+    """``layer_type="FC"/"RPN"`` form of the sampler: x [N,C,H,W] f32 -> [N*n_mc, C*H*W] f32 (no fullmean)."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    x = x.contiguous()
+    n, c, h, w = x.shape
+    stride = 0
+    if rand is not None:
+        assert rand.is_cuda and rand.dtype == torch.float32
+        rand = rand.contiguous()
+        if rand.dim() == 4:
+            assert rand.shape == (n, n_mc, h, w)
+            stride = n_mc * h * w
+        else:
+            assert rand.shape == (n_mc, h, w)
+    e = c * h * w
+    out = torch.empty((n * n_mc, e), dtype=torch.float32, device=x.device)
+    done = 0
+    while done < n:
+        m = min(65535, n - done)
+        rp = None if rand is None else rand.data_ptr() + done * stride * 4
+        _check(
+            lib.runia_mc_drop_flat_f32(x.data_ptr() + done * e * 4, rp, stride, out.data_ptr() + done * n_mc * e * 4,
+                                       m, c, h, w, n_mc, float(drop_prob), int(block_size), _stream()),
+            "runia_mc_drop_flat_f32",
         )
         done += m
     return out

@@ -40,6 +40,57 @@ static inline int64_t runia_cu_count() {
   return cus;
 }
 
+// Summation order of torch.sum / torch.mean over a contiguous reduced dimension of a CPU f32 tensor (ATen
+// SumKernel.cpp, cascade_sum) - the order in which the reference's fullmean (feature_extraction/utils.py:88-92) adds
+// a row of the DropBlock output; restated in oracle/hotpath.py::torch_cpu_sum_lastdim and checked there against torch.
+//   n < 8 : partial sums p[k] = a[k] (+ a[4+k]), remainder into p[0], then ((p0+p1)+p2)+p3: for n < 16 this is ONE
+//           chain whose i-th term is torch_chain<N>(i):   n < 4: 0..n-1;  4 <= n < 8: 0, 4..n-1, 1, 2, 3;
+//   n == 8: 0..7;   9 <= n < 16: 8..n-1, 0..7.
+template <int N>
+__host__ __device__ constexpr int torch_chain(int i) {
+  static_assert(N >= 1 && N < 16, "single-chain range of the ATen row sum");
+  if (N < 4 || N == 8) return i;
+  if (N < 8) return i == 0 ? 0 : (i <= N - 4 ? i + 3 : i - (N - 4));
+  return i < N - 8 ? 8 + i : i - (N - 8);
+}
+
+// The same order for a run-time length (rows of < 512 elements; ATen adds cascade levels beyond that): term(i) is
+// the i-th element of the row.
+template <class F>
+__device__ __forceinline__ float torch_row_sum(F term, int n) {
+  if (n < 8) {
+    float p0 = 0.f, p1 = 0.f, p2 = 0.f, p3 = 0.f;
+    const int s = n >> 2;
+    if (s) { p0 += term(0); p1 += term(1); p2 += term(2); p3 += term(3); }
+    for (int i = 4 * s; i < n; ++i) p0 += term(i);
+    p0 += p1; p0 += p2; p0 += p3;
+    return p0;
+  }
+  const int vs = n >> 3, s = vs >> 2;
+  float p[4][8];
+#pragma unroll
+  for (int k = 0; k < 4; ++k)
+#pragma unroll
+    for (int l = 0; l < 8; ++l) p[k][l] = 0.f;
+  for (int j = 0; j < s; ++j)
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int l = 0; l < 8; ++l) p[k][l] += term((j * 4 + k) * 8 + l);
+  for (int i = 4 * s; i < vs; ++i)
+#pragma unroll
+    for (int l = 0; l < 8; ++l) p[0][l] += term(i * 8 + l);
+#pragma unroll
+  for (int k = 1; k < 4; ++k)
+#pragma unroll
+    for (int l = 0; l < 8; ++l) p[0][l] += p[k][l];
+  float acc = 0.f;
+  for (int k = vs * 8; k < n; ++k) acc += term(k);
+#pragma unroll
+  for (int l = 0; l < 8; ++l) acc += p[0][l];
+  return acc;
+}
+
 __device__ __forceinline__ double kInfD() { return __builtin_inf(); }
 
 __device__ __forceinline__ float wave_max_f32(float v) {

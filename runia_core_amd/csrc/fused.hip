@@ -335,10 +335,12 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
           for (int k2 = 0; k2 < HT / 2; ++k2) {
             const f2* qq = q2 + k2 * WT;
             const float* mm = m + 2 * k2 * WT;
-            f2 acc = qq[0] * (f2){mm[0], mm[1]};
+            f2 acc = qq[0] * (f2){mm[0], mm[1]};  // torch_chain<WT>(0) == 0
 #pragma unroll
-            for (int xw = 1; xw < WT; ++xw)
+            for (int xi = 1; xi < WT; ++xi) {  // the row in torch's CPU summation order (common.hpp)
+              const int xw = torch_chain<WT>(xi);
               acc = __builtin_elementwise_fma(qq[xw], (f2){mm[2 * xw], mm[2 * xw + 1]}, acc);
+            }
             if constexpr (hw_pow2) {
               // scaled once below
             } else if constexpr (w_pow2) {
@@ -351,17 +353,22 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
           }
           col = rows[0];
 #pragma unroll
-          for (int y = 1; y < HT; ++y) col += rows[y];
+          for (int yi = 1; yi < HT; ++yi) col += rows[torch_chain<HT>(yi)];
         } else {
-          col = 0.f;
+          float rm[HT];
 #pragma unroll
           for (int y = 0; y < HT; ++y) {
             float rowsum = q[y * WT] * m[y * WT];
 #pragma unroll
-            for (int xw = 1; xw < WT; ++xw) rowsum = fmaf(q[y * WT + xw], m[y * WT + xw], rowsum);
-            const float rm = w_pow2 ? rowsum * rW : div_newton(rowsum, (float)WT, rW);
-            col = (y == 0) ? rm : col + rm;
+            for (int xi = 1; xi < WT; ++xi) {
+              const int xw = torch_chain<WT>(xi);
+              rowsum = fmaf(q[y * WT + xw], m[y * WT + xw], rowsum);
+            }
+            rm[y] = w_pow2 ? rowsum * rW : div_newton(rowsum, (float)WT, rW);
           }
+          col = rm[0];
+#pragma unroll
+          for (int yi = 1; yi < HT; ++yi) col += rm[torch_chain<HT>(yi)];
         }
         if constexpr (hw_pow2 && PAIRS) znew[g] = col * (rW * rH);
         else znew[g] = h_pow2 ? col * rH : div_newton(col, (float)HT, rH);

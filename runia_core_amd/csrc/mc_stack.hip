@@ -72,15 +72,18 @@ __global__ __launch_bounds__(256) void mc_stack_kernel(const float* __restrict__
   for (int s = 0; s < n_mc; ++s) {
     const float* b = bm + s * HW;
     const float den = scale[s];
-    float col = 0.f;
-    for (int y = 0; y < H; ++y) {
-      float rowsum = 0.f;
-      for (int xw = 0; xw < W; ++xw) {
-        const float q = (xc[y * W + xw] * (float)HW) / den;
-        rowsum += (b[y * W + xw] != 0.f) ? q : 0.f;
-      }
-      col += rowsum / (float)W;
-    }
+    // mean over W then over H, each row added in torch's CPU order (common.hpp::torch_row_sum)
+    const float col = torch_row_sum(
+        [&](int y) {
+          const float rowsum = torch_row_sum(
+              [&](int xw) {
+                const float q = (xc[y * W + xw] * (float)HW) / den;
+                return (b[y * W + xw] != 0.f) ? q : 0.f;
+              },
+              W);
+          return rowsum / (float)W;
+        },
+        H);
     o[(int64_t)s * C] = (den == 0.f) ? NAN : col / (float)H;
   }
 }
@@ -168,21 +171,83 @@ __global__ __launch_bounds__(256) void mc_stack_small_kernel(const float* __rest
   for (int s = 0; s < n_mc; ++s) {
     const unsigned long long bits = keep_bits[s];
     const float den = msum[s], r = mrcp[s];
-    float col = 0.f;
+    float rm[HT];
 #pragma unroll
     for (int y = 0; y < HT; ++y) {
       float rowsum = 0.f;
 #pragma unroll
-      for (int xw = 0; xw < WT; ++xw) {
-        const int p = y * WT + xw;
+      for (int xi = 0; xi < WT; ++xi) {  // the row in torch's CPU summation order
+        const int p = y * WT + torch_chain<WT>(xi);
         const float q = div_newton(u[p], den, r);
         rowsum += ((bits >> p) & 1ull) ? q : 0.f;
       }
-      col += w_pow2 ? rowsum * rW : div_newton(rowsum, (float)WT, rW);
+      rm[y] = w_pow2 ? rowsum * rW : div_newton(rowsum, (float)WT, rW);
     }
+    float col = 0.f;
+#pragma unroll
+    for (int yi = 0; yi < HT; ++yi) col += rm[torch_chain<HT>(yi)];
     float res = h_pow2 ? col * rH : div_newton(col, (float)HT, rH);
     if (den == 0.f) res = NAN;  // every position dropped: 0 * numel / 0 upstream
     o[(int64_t)s * C] = res;
+  }
+}
+
+
+// ---- layer_type "FC" / "RPN" (feature_extraction/abstract_classes.py:95-99): no fullmean, every drop layer's
+// output y = ((x * bm) * numel) / sum is flattened: out[img*n_mc + s][c*HW + p].  Write-bound (n_mc outputs per
+// input element); one workgroup per (image, slab of 1024 elements), block masks built once per workgroup in LDS.
+__global__ __launch_bounds__(256) void mc_drop_flat_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ rnd, int64_t rand_stride,
+                                                            float* __restrict__ out, int C, int H, int W, int n_mc,
+                                                            float gamma, int block_size, int identity) {
+  extern __shared__ float lds[];  // bm [n_mc][HW] then mask sums [n_mc]
+  const int HW = H * W;
+  float* bm = lds;
+  float* msum = lds + n_mc * HW;
+  const int tid = threadIdx.x;
+  const int64_t img = blockIdx.y;
+  const float* r = rnd ? rnd + img * rand_stride : nullptr;
+  const int pad = block_size / 2;
+  for (int i = tid; i < n_mc * HW; i += 256) {
+    float keep = 1.f;
+    if (!identity) {
+      const int s = i / HW, p = i - s * HW;
+      const int y = p / W, xw = p - y * W;
+      bool dropped = false;
+      for (int dy = 0; dy < block_size && !dropped; ++dy) {
+        const int yy = y - pad + dy;
+        if (yy < 0 || yy >= H) continue;
+        for (int dx = 0; dx < block_size; ++dx) {
+          const int xx = xw - pad + dx;
+          if (xx < 0 || xx >= W) continue;
+          if (r[s * HW + yy * W + xx] < gamma) { dropped = true; break; }
+        }
+      }
+      keep = dropped ? 0.f : 1.f;
+    }
+    bm[i] = keep;
+  }
+  __syncthreads();
+  {
+    const int lane = tid & 63, wave = tid >> 6;
+    for (int s = wave; s < n_mc; s += 4) {
+      float acc = 0.f;
+      for (int p = lane; p < HW; p += 64) acc += bm[s * HW + p];
+      acc = wave_sum_f32(acc);  // exact: small integer counts
+      if (lane == 0) msum[s] = acc;
+    }
+  }
+  __syncthreads();
+  const int64_t E = (int64_t)C * HW;
+  const float* xi = x + img * E;
+  float* oi = out + img * n_mc * E;
+  for (int64_t e = (int64_t)blockIdx.x * 1024 + tid; e < E && e < ((int64_t)blockIdx.x + 1) * 1024; e += 256) {
+    const float v = xi[e];
+    const int p = (int)(e % HW);
+    for (int s = 0; s < n_mc; ++s) {
+      // identity layers (eval mode / drop_prob 0) return x itself upstream, not x * numel / numel
+      oi[(int64_t)s * E + e] = identity ? v : ((v * bm[s * HW + p]) * (float)HW) / msum[s];
+    }
   }
 }
 
@@ -217,5 +282,25 @@ extern "C" int runia_mc_stack_f32(const float* x, const float* rnd, int64_t rand
 #undef RUNIA_MC_SMALL
   mc_stack_kernel<<<grid, 256, shmem, as_stream(stream)>>>(x, rnd, rand_image_stride, out, C, H, W, n_mc,
                                                           gamma, block_size, identity);
+  return runia_check_launch();
+}
+
+extern "C" int runia_mc_drop_flat_f32(const float* x, const float* rnd, int64_t rand_image_stride, float* out,
+                                      int64_t N, int C, int H, int W, int n_mc, double drop_prob, int block_size,
+                                      runia_stream_t stream) {
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0 || n_mc < 1 || n_mc > kMaxMC || block_size < 1 ||
+      (int64_t)H * W > kMaxHW || (N > 0 && (!x || !out)))
+    return RUNIA_E_INVALID;
+  const int identity = (drop_prob == 0.0);
+  if (!identity && !rnd) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (N > 65535) return RUNIA_E_INVALID;  // grid.y limit; callers batch above this
+  const float gamma = (float)(drop_prob / (double)(block_size * block_size));
+  const size_t shmem = ((size_t)n_mc * H * W + n_mc) * sizeof(float);
+  if (shmem > 64 * 1024) return RUNIA_E_INVALID;
+  const int64_t E = (int64_t)C * H * W;
+  dim3 grid((unsigned)((E + 1023) / 1024), (unsigned)N);
+  mc_drop_flat_kernel<<<grid, 256, shmem, as_stream(stream)>>>(x, rnd, rand_image_stride, out, C, H, W, n_mc, gamma,
+                                                              block_size, identity);
   return runia_check_launch();
 }

@@ -50,21 +50,25 @@ class MCSamplerModule(torch.nn.Module):
         )
 
     def draw(self, batch: int, h: int, w: int, device, generator=None) -> torch.Tensor:
-        """Uniform draws of the drop layers: ``(batch, mc_samples, h, w)``; image-major, one
-        ``torch.rand(1, h, w)`` per layer on the CPU generator exactly as upstream draws them."""
-        draws = [torch.rand(1, h, w, generator=generator) for _ in range(batch * self.mc_samples)]
-        return torch.cat(draws).reshape(batch, self.mc_samples, h, w).to(device)
+        """Uniform draws of the drop layers: ``(batch, mc_samples, h, w)``, image-major, in the reference's
+        random stream: upstream every drop layer calls ``torch.rand(1, h, w)`` on the CPU default generator, in
+        ``ModuleList`` order, image after image.  The CPU uniform kernel consumes the generator element by element,
+        so ONE ``torch.rand(batch * mc_samples, h, w)`` call yields the same values in the same order
+        (``tests/test_abi_and_host.py::test_draw_is_the_sequential_cpu_stream``) at 1/60 of the cost of the loop."""
+        return torch.rand(batch * self.mc_samples, h, w, generator=generator).reshape(batch, self.mc_samples, h, w).to(device)
 
     def forward(self, latent_rep: torch.Tensor, rand: torch.Tensor = None) -> torch.Tensor:
         """``(N, C, H, W)`` -> ``(N * mc_samples, C)`` (the reference is called with N = 1).
         ``rand`` optionally supplies the uniform draws (device tensor)."""
-        if self.layer_type != "Conv":
-            raise NotImplementedError("MCSamplerModule: only layer_type='Conv' is on the MI355X hot path")
         assert latent_rep.dim() == 4, "latent representation must be (N, C, H, W)"
         x = _hip.to_device(latent_rep, torch.float32)
         n, _, h, w = x.shape
         active = self.training and self.drop_prob != 0.0
         if active and rand is None:
             rand = self.draw(n, h, w, x.device)
+        if self.layer_type != "Conv":
+            # "FC" / "RPN": no fullmean, each drop layer's output is flattened (reference :95-99)
+            return _hip.mc_drop_flat(x, rand if active else None, self.mc_samples, self.drop_prob if active else 0.0,
+                                     self.block_size)
         return _hip.mc_stack(x, rand if active else None, self.mc_samples, self.drop_prob if active else 0.0,
                              self.block_size)

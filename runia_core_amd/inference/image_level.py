@@ -78,7 +78,7 @@ class LaRExInference(ProbabilisticInferenceModule):
         if rand is None and active:
             rand = self.mc_sampler.draw(x.shape[0], x.shape[2], x.shape[3], x.device)
         pipe = self._pipe()
-        if pipe._md_state() is not None:
+        if pipe._md_state() is not None and self.layer_type == "Conv":
             # LaREM: sampler + entropy and PCA + score as two fused launches (same arithmetic as the stages below)
             return pipe.score_latents(x, rand if active else None).cpu().numpy()
         h = pipe.entropy(self.mc_sampler(x, rand=rand))

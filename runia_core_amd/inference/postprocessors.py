@@ -59,7 +59,12 @@ def _np_dtype_to_torch(a) -> torch.dtype:
 class DetectorKDE:
     """Gaussian kernel density estimate of the training embeddings (LaRED).  Holds the
     training set on the device; ``get_density_scores`` is the exact log-density
-    ``logsumexp_i(-|x-x_i|^2 / 2h^2) - log N - D log h - (D/2) log 2 pi``."""
+    ``logsumexp_i(-|x-x_i|^2 / 2h^2) - log N - D log h - (D/2) log 2 pi``.
+
+    DIVERGENCE FROM THE REFERENCE above D ~ 20: the reference's sklearn ``KernelDensity`` tree returns the rounding
+    residue of its log-space node bounds there, not the density (+34 nats at D = 64, +260 at D = 256; its AUROC drops to
+    0.63-0.65 where the definition gives 0.91-0.996).  Scores and AUROC / FPR@95 therefore differ from the reference by
+    construction; up to D ~ 20 they agree at 1e-5.  Numbers and tests: INTEGRATION.md "Known divergences"."""
 
     def __init__(self, train_embeddings, save_path=None, kernel="gaussian", bandwidth=1.0) -> None:
         if kernel != "gaussian":
@@ -97,7 +102,8 @@ class DetectorKDE:
 
 @register_postprocessor("KDE", postprocessor_input=["latent_space_means"])
 class KDELatentSpace(Postprocessor):
-    """LaRED: kernel-density score of latent representations."""
+    """LaRED: kernel-density score of latent representations (exact log-density; see :class:`DetectorKDE` for the
+    documented divergence from the reference's sklearn tree above D ~ 20)."""
 
     def __init__(self, cfg=None):
         super().__init__(cfg)

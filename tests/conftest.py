@@ -59,3 +59,24 @@ def rel_err(got, ref):
     got = np.asarray(got, dtype=np.float64)
     ref = np.asarray(ref, dtype=np.float64)
     return float(np.max(np.abs(got - ref) / np.maximum(1.0, np.abs(ref)))) if ref.size else 0.0
+
+
+def kde_hd_inputs(d, seed):
+    """Seeded inputs of tests/golden/ref_kde_hd.npz (same recipe as tools/make_goldens_r2.py::kde_hd_inputs; only the
+    reference's scores are stored, the embeddings are regenerated and verified by checksum)."""
+    g = np.random.default_rng(seed)
+    scale = 0.8 + 0.4 * g.random(d)
+    train = g.standard_normal((3000, d)) * scale
+    ind = g.standard_normal((600, d)) * scale
+    ood = g.standard_normal((600, d)) * scale * 1.15 + 0.35
+    return train, ind, ood
+
+
+# What the reference's LaRED (KDELatentSpace -> sklearn KernelDensity tree) returned on those inputs, against the exact
+# log-density (measured in the build container, tools/make_goldens_r2.py --only kde_hd; quoted in INTEGRATION.md):
+#   D    max |ref - exact|   AUROC ref / exact      FPR@95 ref / exact
+KDE_HD_MEASURED = {
+    16: dict(max_abs=2.9e-7, auroc=(0.78705835, 0.78705835), fpr95=(0.66166669, 0.66166669)),
+    64: dict(max_abs=34.3, auroc=(0.63099998, 0.91174167), fpr95=(0.63166666, 0.36333334)),
+    256: dict(max_abs=260.2, auroc=(0.64546669, 0.99583334), fpr95=(0.54166669, 0.01333333)),
+}

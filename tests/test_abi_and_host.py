@@ -269,3 +269,20 @@ def test_metrics_host_goldens(ref_vectors):
     assert abs(r["aupr"].values[0] - aupr) < 1e-7
     _, ml = rc.evaluation.get_auroc_results("test", ind, ood, True)
     assert set(ml) == {"auroc", "aupr", "fpr_95"}
+
+
+def test_draw_is_the_sequential_cpu_stream():
+    """MCSamplerModule.draw makes ONE torch.rand call; upstream makes one torch.rand(1, H, W) per drop layer
+    (dropblock==0.3.0, called from /root/reference/runia_core/feature_extraction/abstract_classes.py:93).  Same
+    generator stream, value for value - global generator and an explicit one."""
+    from runia_core_amd.feature_extraction.abstract_classes import MCSamplerModule
+
+    for (b, n_mc, h, w) in [(3, 16, 2, 2), (5, 16, 4, 4), (2, 16, 7, 7), (2, 8, 8, 8), (3, 12, 5, 6), (1, 16, 14, 14), (64, 16, 4, 4)]:
+        m = MCSamplerModule(mc_samples=n_mc, block_size=2, drop_prob=0.5)
+        torch.manual_seed(5)
+        seq = torch.cat([torch.rand(1, h, w) for _ in range(b * n_mc)]).reshape(b, n_mc, h, w)
+        torch.manual_seed(5)
+        assert torch.equal(m.draw(b, h, w, "cpu"), seq)
+        g = torch.Generator().manual_seed(9)
+        seq = torch.cat([torch.rand(1, h, w, generator=g) for _ in range(b * n_mc)]).reshape(b, n_mc, h, w)
+        assert torch.equal(m.draw(b, h, w, "cpu", generator=torch.Generator().manual_seed(9)), seq)

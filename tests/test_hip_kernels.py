@@ -296,6 +296,54 @@ def test_mc_stack_vs_oracle(hip, c, h, w, bs, p, n_mc, n):
         assert np.array_equal(got_s[0], got[0])
 
 
+SAMPLER_CASES = ["c4x4_bs2", "c4x4_bs2_mc32", "c7x7_bs3", "c8x8_bs8", "c8x8_bs4", "c2x2_bs1", "c2x2_dead",
+                 "c4x4_bs3_mc8", "c5x6_bs2", "c4x4_p0", "fc4x4_bs2", "rpn7x7_bs3"]
+
+
+@pytest.mark.parametrize("name", SAMPLER_CASES)
+def test_mc_stack_reference_run_fixture(hip, name):
+    """The kernels against what the reference's own MCSamplerModule.forward returned (tests/golden/ref_sampler.npz,
+    tools/make_goldens_r2.py): bit for bit, every kernel that serves the shape (register kernel, keep-flag table
+    path, generic kernel, flattened "FC"/"RPN" kernel), NaN of a fully dropped map included."""
+    g = load_npz("ref_sampler.npz")
+    n_mc, bs, p, lt, _ = g[f"{name}_params"]
+    n_mc, bs, p, lt = int(n_mc), int(bs), float(p), int(lt)
+    x, draws, ref = dev(g[f"{name}_x"], torch.float32), dev(g[f"{name}_draws"], torch.float32), g[f"{name}_out"]
+    _, c, h, w = x.shape
+    if lt != 0:
+        got = hip.mc_drop_flat(x, draws if p > 0 else None, n_mc, p, bs).cpu().numpy()
+        assert np.array_equal(got, ref, equal_nan=True)
+        return
+    got = hip.mc_stack(x, draws if p > 0 else None, n_mc, p, bs).cpu().numpy()       # table path where supported
+    assert np.array_equal(got, ref, equal_nan=True)
+    lib = hip.load_library()
+    out = torch.empty((n_mc, c), dtype=torch.float32, device="cuda")
+    rc = lib.runia_mc_stack_f32(x.data_ptr(), draws.data_ptr() if p > 0 else None, 0, out.data_ptr(), 1, c, h, w, n_mc,
+                                p, bs, torch.cuda.current_stream().cuda_stream)      # register / generic kernel
+    assert rc == 0
+    assert np.array_equal(out.cpu().numpy(), ref, equal_nan=True)
+    # batch of 3 copies with per-image draws: every image reproduces the fixture
+    got3 = hip.mc_stack(x.repeat(3, 1, 1, 1), draws[None].repeat(3, 1, 1, 1) if p > 0 else None, n_mc, p, bs).cpu().numpy()
+    assert np.array_equal(got3.reshape(3, n_mc, c)[2], ref, equal_nan=True)
+
+
+def test_sampler_module_layer_types(hip):
+    """MCSamplerModule drop-in: "Conv" -> (n_mc, C), "FC"/"RPN" -> (n_mc, C*H*W); eval mode = identity layers."""
+    from runia_core_amd.feature_extraction.abstract_classes import MCSamplerModule
+
+    g = load_npz("ref_sampler.npz")
+    for name, lt in (("c4x4_bs2", "Conv"), ("fc4x4_bs2", "FC"), ("rpn7x7_bs3", "RPN"), ("c7x7_bs3", "Conv")):
+        n_mc, bs, p, _, seed = g[f"{name}_params"]
+        m = MCSamplerModule(mc_samples=int(n_mc), block_size=int(bs), drop_prob=float(p), layer_type=lt)
+        m.train()
+        torch.manual_seed(int(seed))  # the module draws from the CPU default generator exactly as upstream
+        got = m(torch.from_numpy(g[f"{name}_x"])).cpu().numpy()
+        assert np.array_equal(got, g[f"{name}_out"], equal_nan=True), name
+    m = MCSamplerModule(mc_samples=4, block_size=2, drop_prob=0.5)
+    m.eval()
+    assert np.array_equal(m(torch.from_numpy(g["eval_x"])).cpu().numpy(), g["eval_out"])
+
+
 # ---------------- full chain on pre-stacked samples -------------------------------------------------------------
 def test_larem_chain_unfused(hip):
     rng = np.random.default_rng(77)

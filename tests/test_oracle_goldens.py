@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import oracle
-from conftest import generate_test_data, load_npz, rel_err
+from conftest import KDE_HD_MEASURED, kde_hd_inputs, generate_test_data, load_npz, rel_err
 
 
 def _lists(ref_vectors, key):
@@ -236,6 +236,32 @@ def test_kde_reference_tree_residue_quirk():
     assert (np.abs(ref - exact) > 1e-3).any()  # the quirk is real at D=64
 
 
+@pytest.mark.parametrize("d", [16, 64, 256])
+def test_kde_high_dim_reference_run_fixture(d):
+    """tests/golden/ref_kde_hd.npz: the REFERENCE'S LaRED scores (KDELatentSpace -> sklearn KernelDensity) for an InD
+    and an OOD set at D = 16, 64, 256.  At D = 16 the oracle (exact log-density) reproduces them to 1e-5; at
+    D = 64 / 256 sklearn's tree returns the floating-point residue of its log-space node bounds
+    (`logsubexp` cancellation in _binary_tree.pxi.tp::_kde_single_breadthfirst), not the density: it over-estimates by
+    tens to hundreds of nats and its AUROC collapses (0.63 / 0.65 against 0.91 / 0.996 for the definition).  That
+    residue is rounding noise of the host's libm exp/log - no other implementation can reproduce it - so the oracle,
+    like the kernels, implements the definition, and the measured gap is asserted here and quoted in INTEGRATION.md."""
+    g = load_npz("ref_kde_hd.npz")
+    train, ind, ood = kde_hd_inputs(d, int(g[f"d{d}_seed"]))
+    assert np.allclose([np.abs(train).sum(), np.abs(ind).sum(), np.abs(ood).sum()], g[f"d{d}_checksum"], rtol=1e-12)
+    ref_i, ref_o = g[f"d{d}_ref_ind"], g[f"d{d}_ref_ood"]
+    ex_i, ex_o = oracle.kde_score(train, ind), oracle.kde_score(train, ood)
+    m = KDE_HD_MEASURED[d]
+    assert np.all(ref_i >= ex_i - 1e-9) and np.all(ref_o >= ex_o - 1e-9)  # the tree can only over-estimate
+    a_ref, a_ex = oracle.auroc_fpr95_aupr(ref_i, ref_o), oracle.auroc_fpr95_aupr(ex_i, ex_o)
+    assert abs(a_ref[0] - m["auroc"][0]) < 1e-6 and abs(a_ex[0] - m["auroc"][1]) < 1e-6
+    assert abs(a_ref[1] - m["fpr95"][0]) < 1e-6 and abs(a_ex[1] - m["fpr95"][1]) < 1e-6
+    gap = max(np.abs(ref_i - ex_i).max(), np.abs(ref_o - ex_o).max())
+    if d == 16:
+        assert rel_err(ex_i, ref_i) < 1e-5 and rel_err(ex_o, ref_o) < 1e-5 and a_ref == a_ex
+    else:
+        assert 0.5 * m["max_abs"] < gap < 2 * m["max_abs"]
+
+
 # ---------------- a10 threshold ----------------------------------------------------------
 def test_threshold_fixture():
     g = load_npz("ref_threshold.npz")
@@ -271,7 +297,43 @@ def test_metrics_postprocessors_reference_goldens(ref_vectors):
     assert abs(a - kde_auroc) < 1e-7 and abs(f - kde_fpr) < 1e-7 and abs(p - kde_aupr) < 1e-7
 
 
-# ---------------- a1 mc_stack (restatement self-consistency; parity unpinned) -------------
+# ---------------- a1 mc_stack: pinned by the reference's own MCSamplerModule.forward ------------------------
+SAMPLER_CASES = ["c4x4_bs2", "c4x4_bs2_mc32", "c7x7_bs3", "c8x8_bs8", "c8x8_bs4", "c2x2_bs1", "c2x2_dead",
+                 "c4x4_bs3_mc8", "c5x6_bs2", "c4x4_p0", "fc4x4_bs2", "rpn7x7_bs3"]
+
+
+@pytest.mark.parametrize("name", SAMPLER_CASES)
+def test_mc_stack_reference_run_fixture(name):
+    """tests/golden/ref_sampler.npz holds what /root/reference/runia_core/feature_extraction/abstract_classes.py's
+    MCSamplerModule.forward returned (tools/make_goldens_r2.py: the file is loaded by path; only the third-party
+    DropBlock2D layer, absent from the image, is restated).  The oracle reproduces it BIT FOR BIT, including the
+    summation order of the reference's torch fullmean on the host, the NaN of a fully dropped map and the flattened
+    "FC" / "RPN" outputs."""
+    g = load_npz("ref_sampler.npz")
+    n_mc, bs, p, lt, _ = g[f"{name}_params"]
+    got = oracle.mc_stack(g[f"{name}_x"], g[f"{name}_draws"], float(p), int(bs), ["Conv", "FC", "RPN"][int(lt)])
+    assert got.shape == g[f"{name}_out"].shape and got.shape[0] == int(n_mc)
+    assert np.array_equal(got, g[f"{name}_out"], equal_nan=True)
+    if name == "c2x2_dead":
+        assert np.isnan(g[f"{name}_out"]).any()
+
+
+def test_mc_stack_eval_mode_fixture():
+    g = load_npz("ref_sampler.npz")
+    x = g["eval_x"]
+    got = oracle.mc_stack(x, np.zeros((4, 4, 4), np.float32), 0.0, 2)
+    assert np.array_equal(got, g["eval_out"])
+
+
+def test_torch_cpu_sum_order_restatement():
+    """oracle.torch_cpu_sum_lastdim is the order torch.sum uses on a contiguous CPU row (ATen cascade_sum)."""
+    rng = np.random.default_rng(0)
+    for n in list(range(1, 41)) + [48, 49, 56, 63, 64, 65]:
+        a = rng.standard_normal((50, n)).astype(np.float32)
+        exp = torch.from_numpy(a).reshape(50, 1, 1, n).sum(dim=3).numpy().ravel()
+        assert np.array_equal(oracle.torch_cpu_sum_lastdim(a), exp), n
+
+
 def test_mc_stack_matches_torch_composition():
     """dropblock is absent; check the restatement against the same algebra written
     with torch ops (max_pool2d) as the published DropBlock2D does it."""
