@@ -6,21 +6,30 @@ inputs resident in HBM:  hooked latent maps (N,512,4,4) f32 + DropBlock draws (N
   -> MC-dropout latent stacking -> per-dimension KL entropy -> PCA 512->256 (whitened)
   -> LaREM (Mahalanobis) score -> [N>1: one RCCL all_gather of the score shards].
 Weak scaling: every rank scores its own 10 000-image shard (rows are independent).
+Three distinct input sets (3 x 338 MB > the 256 MiB Infinity Cache) rotate through the timed region, so no step
+finds its inputs in a cache.
 
-Prints ONE JSON line (rank 0) with the driver's contract plus `roofline` (dominant kernel,
-timed with HIP events on the launch stream inside the timed region) and `cpu_baseline`
-(the CPU oracle timed on a bounded sample; reported baseline, never the thing measured).
+`python bench.py --gpus N` with N > 1 and no WORLD_SIZE starts its own N ranks (torch.distributed.run as a child
+process, before this process makes any GPU call) and exits with the child's code.
+
+Prints ONE JSON line (rank 0) with the driver's contract plus
+  `roofline`      dominant kernel (K1, sampler + entropy), timed with HIP events on its launch stream inside the timed
+                  region; `achieved` uses BASELINE.md section 4's algorithmic 33 800 B/image;
+  `cpu_baseline`  the CPU oracle in the reference's algorithmic form on a bounded sample, 1 core;
+  `cpu_baseline_all_cores`  the same work fanned out per image over a process pool, as the reference's
+                  parallel_run=True does (evaluation/entropy.py:86-91);
+  `api_level`     the same workload through the public batched API with NO caller-supplied draws
+                  (LaRExInference.get_scores_from_latents, sampler in counter-draw mode).
+The oracle is the checker / baseline only; it is never the thing measured.
 """
 from __future__ import annotations
 
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
-
-import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -29,12 +38,116 @@ if ROOT not in sys.path:
 N_MC, C, H, W, N_PCA = 16, 512, 4, 4, 256
 DROP_PROB, BLOCK = 0.5, 2
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+# BASELINE.md section 4 / SURVEY 8(d): LaREM-16MC/PCA-256 "with MC stacking from latent 512x4x4":
+# 512*16*4 (latent map) + 16*16*4 (draws) + 8 (score)
+ALGO_BYTES_PER_IMAGE = C * H * W * 4 + N_MC * H * W * 4 + 8
+# what K1 itself moves per image: latent map + keep-flag table of the image (n_mc*(H*W+2) floats) + C entropies in f64
+K1_BOUNDARY_BYTES_PER_IMAGE = C * H * W * 4 + N_MC * (H * W + 2) * 4 + C * 8
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--images", type=int, default=10000, help="test images per GPU (workload: 10 000)")
+    ap.add_argument("--train-images", type=int, default=4096)
+    ap.add_argument("--input-sets", type=int, default=3,
+                    help="distinct resident input sets rotated through the timed region (3 x 338 MB > 256 MiB of L3)")
+    ap.add_argument("--draws", choices=["resident", "counter"], default="resident",
+                    help="timed region's DropBlock draws: host-supplied tensors resident in HBM (default; the parity "
+                         "path) or made inside the keep-flag kernel by the counter generator")
+    ap.add_argument("--ood-corr", type=float, default=0.25, help="spatial correlation of the OOD sample's latent maps")
+    ap.add_argument("--cpu-sample", type=int, default=1280, help="images timed on the CPU oracle (1 core)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-api-level", action="store_true")
+    ap.add_argument("--overlap", action="store_true",
+                    help="two HIP streams: K1 of batch i+1 beside K2 of batch i (measured: no gain, 0.324 vs 0.329 ms)")
+    ap.add_argument("--chunks", type=int, default=None, help="row blocks pipelined over two streams (default: pipeline's)")
+    ap.add_argument("--clock-warmup", type=float, default=1.0,
+                    help="seconds of the same step run untimed before the W warm-up steps: the GPU needs ~0.1 s of "
+                         "sustained load to reach its working clocks (measured: 0.261 ms/step over the first 10 steps, "
+                         "0.205 ms/step over 2000)")
+    ap.add_argument("--event-every", type=int, default=8,
+                    help="HIP events bracket the dominant kernel on every n-th timed step (a bracketed step runs the "
+                         "table launch and the kernel as two C calls with two event records between them: ~40 us "
+                         "slower than an unbracketed step, so bracketing every step would tax the metric by 16 %%)")
+    ap.add_argument("--gather-stream", choices=["auto", "same", "side"], default="auto",
+                    help="queue the all_gather on the compute stream, or on a second stream behind an event with "
+                         "two output buffers in turn (the next step's kernels then start without waiting for it); "
+                         "auto: time both during the warm-up and keep the faster (all ranks agree through a MAX)")
+    return ap.parse_args()
+
+
+def self_launch(args) -> int:
+    """--gpus N > 1 without a launcher: start N ranks as a CHILD process (never an exec, and before this process has
+    touched the GPU - importing torch does not initialise it) and hand its exit code back."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    return subprocess.run(cmd, env=env).returncode
+
+
+def effective_cpus() -> int:
+    """Cores this process may actually use: affinity mask, capped by the cgroup CPU quota when there is one."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except Exception:
+        try:
+            q = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            p = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if q > 0:
+                n = min(n, max(1, q // p))
+        except Exception:
+            pass
+    return max(1, n)
+
+
+def cpu_pool_child(path, cores, n_mc, drop_prob, block):
+    """cpu_baseline leg, parallel form (a child process of bench.py that never imports torch or touches the GPU):
+    the reference fans get_dl_h_z out per image with process_map(single_image_entropy_calculation, ..., chunksize=1)
+    (evaluation/entropy.py:86-91); here one task = oracle sampler + per-dimension k-d-tree entropy of one image over a
+    multiprocessing.Pool(cores); PCA + LaREM then run once on the gathered rows, as in the reference."""
+    import multiprocessing as mp
+
+    import numpy as np
+
+    import oracle  # checker / CPU baseline only
+
+    d = np.load(path)
+    x, rand = d["x"], d["rand"]
+    k = 5 if n_mc > 5 else n_mc - 1
+    global _pool_task
+
+    def _pool_task(i):
+        z = oracle.mc_stack(x[i : i + 1], rand[i], drop_prob, block)
+        return oracle.single_image_entropy_calculation(z, k)
+
+    t0 = time.perf_counter()
+    with mp.get_context("fork").Pool(cores) as pool:
+        h = np.asarray(pool.map(_pool_task, range(x.shape[0]), chunksize=1))
+    y = oracle.pca_transform(h, d["comp"], d["mean"], d["var"])
+    s = oracle.md_score(y, d["md_mean"], d["md_prec"])
+    sec = time.perf_counter() - t0
+    print(json.dumps({"seconds": sec, "images": int(x.shape[0]), "cores": cores, "scores_head": s[:16].tolist()}))
 
 
 def synth_latents(n, seed, shift, device, scale=1.0, corr=0.0):
     """cfg2-synth: X ~ ReLU(N(shift,1)) on (n,512,4,4) with a fixed per-channel scale; draws U(0,1) on (n,16,4,4).
     Draws whose block mask would drop the whole 4x4 map (sum(bm)=0 -> inf/NaN in the reference
     as well) are replaced by "no seed" so that every score is finite."""
+    import torch
+
     g0 = torch.Generator(device=device).manual_seed(77)  # per-channel scale: a property of the "layer", same for all sets
     chan = torch.rand(1, C, 1, 1, device=device, generator=g0) * 1.5 + 0.25
     g = torch.Generator(device=device).manual_seed(seed)
@@ -52,31 +165,17 @@ def synth_latents(n, seed, shift, device, scale=1.0, corr=0.0):
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
-    ap.add_argument("--images", type=int, default=10000, help="test images per GPU (workload: 10 000)")
-    ap.add_argument("--train-images", type=int, default=4096)
-    ap.add_argument("--ood-corr", type=float, default=0.25, help="spatial correlation of the OOD sample's latent maps")
-    ap.add_argument("--cpu-sample", type=int, default=1280, help="images timed on the CPU oracle")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--overlap", action="store_true",
-                    help="two HIP streams: K1 of batch i+1 beside K2 of batch i (measured: no gain, 0.324 vs 0.329 ms)")
-    ap.add_argument("--chunks", type=int, default=None, help="row blocks pipelined over two streams (default: pipeline's)")
-    ap.add_argument("--clock-warmup", type=float, default=1.0,
-                    help="seconds of the same step run untimed before the W warm-up steps: the GPU needs ~0.1 s of "
-                         "sustained load to reach its working clocks (measured: 0.261 ms/step over the first 10 steps, "
-                         "0.205 ms/step over 2000)")
-    ap.add_argument("--event-every", type=int, default=8,
-                    help="HIP events bracket the dominant kernel on every n-th timed step (a bracketed step runs the "
-                         "table launch and the kernel as two C calls with two event records between them: ~40 us "
-                         "slower than an unbracketed step, so bracketing every step would tax the metric by 16 %%)")
-    ap.add_argument("--gather-stream", choices=["auto", "same", "side"], default="auto",
-                    help="queue the all_gather on the compute stream, or on a second stream behind an event with "
-                         "two output buffers in turn (the next step's kernels then start without waiting for it); "
-                         "auto: time both during the warm-up and keep the faster (all ranks agree through a MAX)")
-    args = ap.parse_args()
+    if len(sys.argv) > 1 and sys.argv[1] == "--cpu-pool-child":
+        return cpu_pool_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), int(sys.argv[6]))
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("RUNIA_BENCH_REHEARSE"):
+        sys.exit(self_launch(args))  # nothing in this process has touched the GPU yet
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")
+
+    import numpy as np
+    import torch
 
     # Exactly one line may reach stdout (the JSON record): RCCL prints its version banner to stdout when
     # NCCL_DEBUG=VERSION is set, so fd 1 points at stderr until the record is written.
@@ -84,12 +183,8 @@ def main():
     saved_stdout = os.dup(1)
     os.dup2(2, 1)
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     # RUNIA_BENCH_REHEARSE=gloo: several ranks share the visible GPUs over gloo (control-flow rehearsal of the N > 1
     # path on a one-GPU box; RCCL refuses two ranks on one device).  Never set by the driver.
     rehearse = os.environ.get("RUNIA_BENCH_REHEARSE")
@@ -125,20 +220,24 @@ def main():
     md = MDLatentSpace()
     md.setup(red)
     pipe = LaREMPipeline(md, pca, N_MC, DROP_PROB, BLOCK)
-    fused = _hip.mc_entropy_supported(H, W, N_MC, pipe.k)
 
     n = args.images
-    x, rand = synth_latents(n, 1235 + rank, 0.0, device)  # this rank's shard
+    n_sets = max(1, args.input_sets)
+    # this rank's shard, n_sets distinct realisations of it (set 0 is the one the parity leg scores)
+    sets = [synth_latents(n, 1235 + rank + 1000 * j, 0.0, device) for j in range(n_sets)]
+    x, rand = sets[0]
+    counter = args.draws == "counter"
 
     k1_events = []  # (start, end) HIP event pairs around every K1 launch of the timed region
 
     torch.cuda.synchronize()
-    inputs_ready = torch.cuda.current_stream().record_event()  # x / rand are resident from here on
+    inputs_ready = torch.cuda.current_stream().record_event()  # the input sets are resident from here on
 
     gathered = [torch.empty(world * n, dtype=torch.float64, device=device) for _ in range(2)] if use_dist else None
     side_stream = torch.cuda.Stream() if (use_dist and args.gather_stream != "same") else None
     gather_mode = {"side": args.gather_stream == "side"}
     gather_turn = [0]
+    step_no = [0]
 
     def gather(s):
         """The single RCCL all_gather of the path: equal shards, preallocated output.  Default: queued
@@ -157,12 +256,17 @@ def main():
 
     def step(timed=False, index=0, collective=True):
         timed = timed and (index % max(1, args.event_every) == 0)
+        j = step_no[0] % n_sets
+        step_no[0] += 1
+        xs, rs = sets[j]
+        if counter:
+            rs = _hip.CounterDraws(4242 + rank, step_no[0] * n)  # fresh image ids every step
         if not args.overlap:
-            s = pipe.score_latents(x, rand, chunks=args.chunks, k1_events=k1_events if timed else None)
+            s = pipe.score_latents(xs, rs, chunks=args.chunks, k1_events=k1_events if timed else None)
             return gather(s) if (use_dist and collective) else s
         # streaming form: K1 of this batch overlaps K2 of the previous one (two HIP streams); the gather is
         # queued behind this batch's K2 on the same stream, nothing waits on the host until the final sync
-        a = pipe.score_latents_async(x, rand, k1_events=k1_events if timed else None, inputs_ready=inputs_ready)
+        a = pipe.score_latents_async(xs, rs, k1_events=k1_events if timed else None, inputs_ready=inputs_ready)
         if use_dist:
             with torch.cuda.stream(pipe.k2_stream):
                 return gather(a.scores)
@@ -208,6 +312,7 @@ def main():
         if rank == 0:
             print(f"gather placement trial: same {trial[False] / 30 * 1e3:.4f} ms/step, side {trial[True] / 30 * 1e3:.4f} ms/step",
                   file=sys.stderr)
+    step_no[0] = 0  # the timed region starts on set 0 and ends on set (K-1) % n_sets on every rank
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -218,7 +323,7 @@ def main():
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
-    gc.enable()
+    last_set = (args.steps - 1) % n_sets
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -228,32 +333,79 @@ def main():
     bracketed_steps = len(range(0, args.steps, max(1, args.event_every)))
     k1_launches_per_step = max(1, len(k1_events) // max(1, bracketed_steps))
     if rank != 0:
+        gc.enable()
         dist.destroy_process_group()
         return
 
     ms_per_step = 1e3 * elapsed / args.steps
     value = world * n * args.steps / elapsed
 
+    # ---------------- API level: the public batched entry point, no caller-supplied draws ---------------------------
+    api = None
+    if not args.no_api_level and not use_dist:
+        from runia_core_amd import LaRExInference, MCSamplerModule
+
+        infer = LaRExInference(torch.nn.Identity(), md, DROP_PROB, BLOCK, N_MC, MCSamplerModule, pca_transform=pca)
+        infer.mc_sampler.use_counter_draws(seed=2026)
+        k_api = max(10, min(args.steps, 200))
+        for i in range(20):
+            infer.get_scores_from_latents(sets[i % n_sets][0], to_host=False)
+        torch.cuda.synchronize()
+        t_a = time.perf_counter()
+        for i in range(k_api):
+            s_api = infer.get_scores_from_latents(sets[i % n_sets][0], to_host=False)
+        torch.cuda.synchronize()
+        t_api = time.perf_counter() - t_a
+        t_b = time.perf_counter()
+        for i in range(k_api):
+            s_host = infer.get_scores_from_latents(sets[i % n_sets][0])  # default: (N,) ndarray on the host, one sync per call
+        t_host = time.perf_counter() - t_b
+        api = {
+            "entry": "LaRExInference.get_scores_from_latents(latents), sampler.use_counter_draws(seed): no caller-supplied "
+                     "draws (Philox4x32-10 inside the keep-flag kernel)",
+            "value": round(n * k_api / t_api, 1), "unit": "images/s", "ms_per_call": round(1e3 * t_api / k_api, 4),
+            "returns": "device tensor (to_host=False)", "calls": k_api, "frac_of_value": round(n * k_api / t_api / value, 4),
+            "value_scores_to_host": round(n * k_api / t_host, 1),
+            "finite": bool(torch.isfinite(s_api).all().item()) and bool(np.isfinite(s_host).all()),
+        }
+    gc.enable()
+
     # ---------------- roofline of the dominant kernel ------------------------------------------
-    # algorithmic bytes of K1 per image ("with MC stacking from latent"): the latent map C*H*W*4, the
-    # keep-flag table of the image n_mc*(H*W+2)*4 (what the small launch before it makes of the n_mc*H*W*4 draws)
-    # and the C entropies written as f64.  HIP events bracket this kernel alone (pipeline.k1_events).
-    kname, bytes_per_img = "mc_entropy_kernel", C * H * W * 4 + N_MC * (H * W + 2) * 4 + C * 8
+    # HIP events bracket K1 alone on its launch stream (pipeline.k1_events).  `achieved` = BASELINE.md section 4's
+    # algorithmic bytes (33 800 B/image) per launch / that time; the kernel-boundary figure (what K1 itself reads and
+    # writes, incl. the f64 entropy rows K2' re-reads) is reported beside it.
+    kname = "mc_entropy_kernel"
     imgs_per_launch = n / k1_launches_per_step
-    achieved = bytes_per_img * imgs_per_launch / (kernel_ms * 1e-3) / 1e9
-    traffic = None
+    achieved = ALGO_BYTES_PER_IMAGE * imgs_per_launch / (kernel_ms * 1e-3) / 1e9
+    boundary = K1_BOUNDARY_BYTES_PER_IMAGE * imgs_per_launch / (kernel_ms * 1e-3) / 1e9
+    traffic, traffic_src, valu = None, None, None
     pmc_file = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if os.path.exists(pmc_file):
         try:
             rec = json.load(open(pmc_file)).get(kname, {})
             # PMC bytes were collected at `images_per_launch` images per launch; scale to this run's launch size
             traffic = int(rec["hbm_bytes_per_launch"] * imgs_per_launch / rec.get("images_per_launch", 10000))
+            traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate "
+                           f"passes of this command ({rec.get('profile', 'see profiles/README.md')}); not measured in this run")
+            if "valu_insts_per_launch" in rec:
+                # VALU-issue floor: instructions x 4 issue cycles / 1024 SIMDs / 2.4 GHz (MI355X_MICROARCH.md)
+                floor_ms = rec["valu_insts_per_launch"] * imgs_per_launch / rec.get("images_per_launch", 10000) * 4 / 1024 / 2.4e9 * 1e3
+                valu = {"insts_per_launch": int(rec["valu_insts_per_launch"] * imgs_per_launch / rec.get("images_per_launch", 10000)),
+                        "floor_ms": round(floor_ms, 4), "frac_of_floor": round(floor_ms / kernel_ms, 4),
+                        "source": "SQ_INSTS_VALU, same profile"}
         except Exception:
             traffic = None
     roofline = {
         "bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-        "algorithmic_bytes_per_launch": int(bytes_per_img * imgs_per_launch), "avg_launch_ms": round(kernel_ms, 4),
+        "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_src,
+        "algorithmic_bytes_per_launch": int(ALGO_BYTES_PER_IMAGE * imgs_per_launch),
+        "algorithmic_bytes_per_image": ALGO_BYTES_PER_IMAGE,
+        "kernel_boundary_bytes_per_image": K1_BOUNDARY_BYTES_PER_IMAGE,
+        "kernel_boundary_gbs": round(boundary, 1), "kernel_boundary_frac": round(boundary / HBM_PEAK_GBS, 4),
+        "limiter": "valu-issue (the kernel is instruction-bound, not HBM-bound; see valu_issue)" if valu else None,
+        "valu_issue": valu,
+        "step_frac_of_hbm_ceiling": round(value / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_IMAGE), 4),
+        "avg_launch_ms": round(kernel_ms, 4),
         "launches_per_step": k1_launches_per_step, "launches_timed": len(k1_events),
     }
 
@@ -266,16 +418,22 @@ def main():
         "config": {"workload": "CIFAR10 ResNet-18 LaREM: 16 MC samples, 512-d latent -> PCA-256, 10000 test images per GPU",
                    "images_per_gpu": n, "mc_samples": N_MC, "latent": [C, H, W], "pca_components": N_PCA,
                    "row_blocks_per_step": k1_launches_per_step, "input_dtype": "f32",
+                   "draws": ("in-kernel counter generator (Philox4x32-10), nothing read for them" if counter else
+                             "host-supplied (N,16,4,4) f32 tensors, resident in HBM before the timed region"),
+                   "input_sets_rotated": n_sets, "input_bytes_per_set": int(x.numel() * 4 + rand.numel() * 4),
                    "pipelining": "batch i+1 K1 overlaps batch i K2 (two HIP streams)" if args.overlap else "none (one stream)",
                    "clock_warmup_s": args.clock_warmup,
                    "gather": ("none (1 GPU)" if not use_dist else
                               ("all_gather on a second stream" if gather_mode["side"] else "all_gather on the compute stream"))},
         "roofline": roofline,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if api is not None:
+        out["api_level"] = api
+    if world == 1 and not args.no_cpu_baseline and not counter:
         import oracle  # checker / CPU baseline only
 
         m = min(args.cpu_sample, n)
+        x, rand = sets[last_set]  # the set the last timed step scored
         xs, rs = x[:m].cpu().numpy(), rand[:m].cpu().numpy()
         xo, ro = synth_latents(m, 999, 0.0, device, corr=args.ood_corr)  # spatially correlated maps -> OOD sample for the AUROC check
         gpu_ind = scores[:m].cpu().numpy()
@@ -305,6 +463,42 @@ def main():
             "auroc_gpu": a_gpu[0], "auroc_oracle": a_cpu[0], "fpr95_gpu": a_gpu[1], "fpr95_oracle": a_cpu[1],
             "sample_images": m,
         }
+        # counter-draw mode against parity mode on the same InD / OOD sets: different random masks, same statistics
+        ind_c = pipe.score_latents(x, _hip.CounterDraws(99, 0)).cpu().numpy()
+        xo_full, ro_full = synth_latents(n, 998, 0.0, device, corr=args.ood_corr)
+        ood_c = pipe.score_latents(xo_full, _hip.CounterDraws(99, n)).cpu().numpy()
+        ind_p = pipe.score_latents(x, rand).cpu().numpy()
+        ood_p = pipe.score_latents(xo_full, ro_full).cpu().numpy()
+        a_c, a_p = oracle.auroc_fpr95_aupr(ind_c, ood_c), oracle.auroc_fpr95_aupr(ind_p, ood_p)
+        out["parity"]["counter_draws"] = {"auroc_counter": a_c[0], "auroc_host_draws": a_p[0],
+                                          "d_auroc": a_c[0] - a_p[0], "images": [n, n],
+                                          "mean_score_counter": float(ind_c.mean()), "mean_score_host_draws": float(ind_p.mean())}
+        del xo_full, ro_full
+        # the reference's parallel form: one task per image over a process pool (evaluation/entropy.py:86-91), timed in a
+        # child process that never touches the GPU (cpu_pool_child above), on the cores this job may use
+        try:
+            cores = effective_cpus()
+            m_all = min(n, max(m, 40 * cores))
+            tmp = os.path.join("/dev/shm" if os.path.isdir("/dev/shm") else "/tmp", f"runia_bench_{os.getpid()}.npz")
+            np.savez(tmp, x=x[:m_all].cpu().numpy(), rand=rand[:m_all].cpu().numpy(), comp=comp, mean=mean, var=var,
+                     md_mean=md.feats_mean, md_prec=md.precision)
+            try:
+                r = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-pool-child", tmp, str(cores),
+                                    str(N_MC), str(DROP_PROB), str(BLOCK)], capture_output=True, text=True, timeout=900)
+                rec = json.loads(r.stdout.strip().splitlines()[-1])
+            finally:
+                if os.path.exists(tmp):
+                    os.remove(tmp)
+            ok = rel(rec.pop("scores_head"), cpu_ind[:16]) < 1e-9 if m_all >= 16 else True
+            out["cpu_baseline_all_cores"] = {
+                "value": round(m_all / rec["seconds"], 2), "unit": "images/s", "cores": cores, "kind": "port",
+                "sample": f"{m_all} of the {n} workload images; multiprocessing.Pool({cores}).map over images, chunksize 1 "
+                          f"(the reference's process_map form), each task = oracle mc_stack + per-dim k-d-tree entropy of one "
+                          f"image; PCA + LaREM on the gathered rows; {rec['seconds']:.1f} s; os.cpu_count() = {os.cpu_count()}, "
+                          f"usable = {cores}; scores equal the 1-core run: {ok}",
+            }
+        except Exception as e:  # the pool leg is a reported baseline; its failure must not lose the measurement
+            out["cpu_baseline_all_cores"] = {"value": None, "error": repr(e)[:200]}
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)

@@ -196,6 +196,21 @@ int runia_mc_entropy_f32(const float* x, const float* rand, int64_t rand_image_s
                          float* z_out, double* zero_fill, void* workspace, size_t workspace_bytes, int64_t N,
                          int C, int H, int W, int n_mc, double drop_prob, int block_size, int k, double min_dist,
                          runia_stream_t stream);
+/* Throughput mode of the sampler: the DropBlock draws are not read from memory but made
+ * inside the keep-flag launch by a counter generator - Philox4x32-10 keyed by `seed`; draw i (= layer*H*W + position)
+ * of image g is component (i/64)&3 of philox(counter = (g.lo, g.hi, i%64 + 64*(i/256), 0)), u = (bits >> 8) * 2^-24.
+ * Image ids are first_image .. first_image+N-1, so a batch scored whole, in chunks or sharded draws the same masks.
+ * runia_mc_draws_f32 writes the same draws out, [N, n_mc, H, W]: feeding them to the `rand` argument of
+ * runia_mc_entropy_f32 / runia_mc_stack_f32 gives the same bits as the counter entry points. */
+int runia_mc_draws_f32(float* out, int64_t N, int n_mc, int H, int W, uint64_t seed, int64_t first_image,
+                       runia_stream_t stream);
+int runia_mc_mask_table_counter_f32(uint64_t seed, int64_t first_image, void* workspace, size_t workspace_bytes,
+                                    int64_t N, int H, int W, int n_mc, double drop_prob, int block_size,
+                                    runia_stream_t stream);
+int runia_mc_entropy_counter_f32(const float* x, uint64_t seed, int64_t first_image, double* h, float* z_out,
+                                 double* zero_fill, void* workspace, size_t workspace_bytes, int64_t N, int C, int H,
+                                 int W, int n_mc, double drop_prob, int block_size, int k, double min_dist,
+                                 runia_stream_t stream);
 int runia_pca_md_score_f64(const double* h, const double* packed_ct, const double* bias,
                            const double* scale, const double* md_mean, const double* packed_p,
                            double* score, double* y_out, int64_t N, int64_t D, int64_t n,

@@ -27,6 +27,8 @@ __all__ = [
     "dropblock_block_mask",
     "torch_cpu_sum_lastdim",
     "mc_stack",
+    "philox4x32_10",
+    "counter_draws",
     "pca_transform",
     "empirical_precision",
     "md_setup",
@@ -235,6 +237,44 @@ def torch_cpu_sum_lastdim(a: np.ndarray) -> np.ndarray:
     for lane in range(8):
         acc = (acc + p[0][..., lane]).astype(f)
     return acc
+
+
+def philox4x32_10(counter: np.ndarray, key) -> np.ndarray:
+    """Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1, 2, 3", SC'11) on an array of
+    counters ``(..., 4)`` uint32 with one key ``(k0, k1)``.  Checker of the build's throughput-mode draws (the reference
+    has no counterpart: it draws ``torch.rand`` on the CPU generator); pinned by the published known-answer vectors."""
+    c = np.asarray(counter, dtype=np.uint64) & np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (c[..., i].copy() for i in range(4))
+    k0, k1 = np.uint64(int(key[0]) & 0xFFFFFFFF), np.uint64(int(key[1]) & 0xFFFFFFFF)
+    mask = np.uint64(0xFFFFFFFF)
+    for _ in range(10):
+        p0 = np.uint64(0xD2511F53) * c0
+        p1 = np.uint64(0xCD9E8D57) * c2
+        n0 = (p1 >> np.uint64(32)) ^ c1 ^ k0
+        n2 = (p0 >> np.uint64(32)) ^ c3 ^ k1
+        c1, c3, c0, c2 = p1 & mask, p0 & mask, n0 & mask, n2 & mask
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
+
+
+def counter_draws(n: int, n_mc: int, h: int, w: int, seed: int, first_image: int = 0) -> np.ndarray:
+    """The draws of ``runia_mc_draws_f32`` / the counter entry points (csrc/philox.hpp): draw i = layer*H*W + position of
+    image g is component ``(i // 64) & 3`` of ``philox((g.lo, g.hi, i % 64 + 64 * (i // 256), 0), seed)``,
+    ``u = (bits >> 8) * 2**-24``.  Returns ``(n, n_mc, h, w)`` float32."""
+    per = n_mc * h * w
+    i = np.arange(per, dtype=np.uint64)
+    g = (np.arange(n, dtype=np.uint64) + np.uint64(first_image))[:, None]
+    ctr = np.empty((n, per, 4), dtype=np.uint64)
+    ctr[..., 0] = g & np.uint64(0xFFFFFFFF)
+    ctr[..., 1] = g >> np.uint64(32)
+    ctr[..., 2] = (i % np.uint64(64) + np.uint64(64) * (i // np.uint64(256)))[None, :]
+    ctr[..., 3] = 0
+    seed = int(seed) & (2**64 - 1)
+    blocks = philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32))
+    comp = ((i // np.uint64(64)) & np.uint64(3)).astype(np.int64)
+    bits = np.take_along_axis(blocks, np.broadcast_to(comp[None, :, None], (n, per, 1)), axis=2)[..., 0]
+    return ((bits >> np.uint32(8)).astype(np.float32) * np.float32(2.0**-24)).reshape(n, n_mc, h, w)
 
 
 def mc_stack(x: np.ndarray, rand: np.ndarray, drop_prob: float, block_size: int, layer_type: str = "Conv") -> np.ndarray:

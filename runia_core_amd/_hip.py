@@ -8,8 +8,8 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_void_p
-from typing import Optional
+from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
+from typing import NamedTuple, Optional, Union
 
 import numpy as np
 import torch  # imported before the library so that both share one HIP runtime
@@ -88,6 +88,16 @@ _SIGNATURES = {
         [c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int,
          c_int, c_double, c_int, c_int, c_double, c_void_p],
     ),
+    "runia_mc_draws_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_uint64, c_int64, c_void_p]),
+    "runia_mc_mask_table_counter_f32": (
+        c_int,
+        [c_uint64, c_int64, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_double, c_int, c_void_p],
+    ),
+    "runia_mc_entropy_counter_f32": (
+        c_int,
+        [c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int,
+         c_int, c_double, c_int, c_int, c_double, c_void_p],
+    ),
     "runia_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "runia_ash_s_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "runia_gen_score_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
@@ -112,6 +122,14 @@ _SIGNATURES = {
 
 class RuniaHipError(RuntimeError):
     pass
+
+
+class CounterDraws(NamedTuple):
+    """DropBlock draws made inside the keep-flag kernel by the counter generator (Philox4x32-10, csrc/philox.hpp):
+    image i of the batch uses image id ``first_image + i`` of the stream keyed by ``seed``."""
+
+    seed: int
+    first_image: int = 0
 
 
 def library_path() -> str:
@@ -197,6 +215,8 @@ def mc_stack(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob
     x = x.contiguous()
     n, c, h, w = x.shape
     stride = 0
+    if isinstance(rand, CounterDraws):
+        rand = mc_draws(n, n_mc, h, w, rand.seed, rand.first_image)
     if rand is not None:
         assert rand.is_cuda and rand.dtype == torch.float32
         rand = rand.contiguous()
@@ -235,6 +255,17 @@ def mc_stack(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob
     return out
 
 
+def mc_draws(n: int, n_mc: int, h: int, w: int, seed: int, first_image: int = 0) -> torch.Tensor:
+    """The counter generator's draws written out: [n, n_mc, h, w] f32 in [0, 1) (same values the counter entry points
+    use inside the keep-flag kernel)."""
+    lib = load_library()
+    dev = require_gpu()
+    out = torch.empty((n, n_mc, h, w), dtype=torch.float32, device=dev)
+    _check(lib.runia_mc_draws_f32(out.data_ptr(), n, n_mc, h, w, int(seed) & (2**64 - 1), int(first_image), _stream()),
+           "runia_mc_draws_f32")
+    return out
+
+
 def mc_drop_flat(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob: float, block_size: int) -> torch.Tensor:
     """``layer_type="FC"/"RPN"`` form of the sampler: x [N,C,H,W] f32 -> [N*n_mc, C*H*W] f32 (no fullmean)."""
     lib = load_library()
@@ -243,6 +274,8 @@ def mc_drop_flat(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_
     x = x.contiguous()
     n, c, h, w = x.shape
     stride = 0
+    if isinstance(rand, CounterDraws):
+        rand = mc_draws(n, n_mc, h, w, rand.seed, rand.first_image)
     if rand is not None:
         assert rand.is_cuda and rand.dtype == torch.float32
         rand = rand.contiguous()
@@ -470,7 +503,7 @@ def mc_entropy_supported(h: int, w: int, n_mc: int, k: int) -> bool:
     return bool(load_library().runia_mc_entropy_supported(int(h), int(w), int(n_mc), int(k)))
 
 
-def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob: float, block_size: int, k: int,
+def mc_entropy(x: torch.Tensor, rand: Union[torch.Tensor, CounterDraws, None], n_mc: int, drop_prob: float, block_size: int, k: int,
                min_dist: float = 1e-5, want_samples: bool = False, out: Optional[torch.Tensor] = None,
                kernel_events: Optional[list] = None, zero_fill: Optional[torch.Tensor] = None):
     """Fused sampler + entropy: x [N,C,H,W] f32 (+ draws) -> h [N, C] f64 (and optionally the MC samples).
@@ -483,6 +516,9 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
     x = x.contiguous()
     n, c, hh, ww = x.shape
     stride = 0
+    counter = rand if isinstance(rand, CounterDraws) else None
+    if counter is not None:
+        rand = None
     if rand is not None:
         assert rand.is_cuda and rand.dtype == torch.float32
         rand = rand.contiguous()
@@ -507,7 +543,15 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
         rp = None if rand is None else rand.data_ptr() + done * stride * 4
         zp = None if z is None else z.data_ptr() + done * n_mc * c * 4
         zf = None if zero_fill is None else zero_fill.data_ptr() + done * 8
-        if kernel_events is None:
+        if counter is not None and kernel_events is None:
+            _check(
+                lib.runia_mc_entropy_counter_f32(x.data_ptr() + done * c * hh * ww * 4, int(counter.seed) & (2**64 - 1),
+                                                 int(counter.first_image) + done, h.data_ptr() + done * c * 8, zp, zf,
+                                                 ws.data_ptr(), ws_bytes, m, c, hh, ww, n_mc, float(drop_prob),
+                                                 int(block_size), int(k), float(min_dist), _stream()),
+                "runia_mc_entropy_counter_f32",
+            )
+        elif kernel_events is None:
             _check(
                 lib.runia_mc_entropy_f32(x.data_ptr() + done * c * hh * ww * 4, rp, stride, h.data_ptr() + done * c * 8,
                                          zp, zf, ws.data_ptr(), ws_bytes, m, c, hh, ww, n_mc, float(drop_prob),
@@ -515,11 +559,19 @@ def mc_entropy(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_pr
                 "runia_mc_entropy_f32",
             )
         else:
-            _check(
-                lib.runia_mc_mask_table_f32(rp, stride, ws.data_ptr(), ws_bytes, m, hh, ww, n_mc, float(drop_prob),
-                                            int(block_size), _stream()),
-                "runia_mc_mask_table_f32",
-            )
+            if counter is not None:
+                _check(
+                    lib.runia_mc_mask_table_counter_f32(int(counter.seed) & (2**64 - 1), int(counter.first_image) + done,
+                                                        ws.data_ptr(), ws_bytes, m, hh, ww, n_mc, float(drop_prob),
+                                                        int(block_size), _stream()),
+                    "runia_mc_mask_table_counter_f32",
+                )
+            else:
+                _check(
+                    lib.runia_mc_mask_table_f32(rp, stride, ws.data_ptr(), ws_bytes, m, hh, ww, n_mc, float(drop_prob),
+                                                int(block_size), _stream()),
+                    "runia_mc_mask_table_f32",
+                )
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             _check(

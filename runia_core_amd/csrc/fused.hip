@@ -22,6 +22,7 @@
 #include "common.hpp"
 #include "entropy_core.hpp"
 #include "mfma_f64_tile.hpp"
+#include "philox.hpp"
 
 namespace {
 
@@ -56,7 +57,8 @@ __host__ __device__ constexpr int mask_slot(int p) {
 template <int HT, int WT>
 __global__ __launch_bounds__(256) void mc_mask_kernel(const float* __restrict__ rnd, int64_t rand_stride,
                                                        float* __restrict__ table, int n_mc, float gamma,
-                                                       int block_size, int identity, int sort_layers) {
+                                                       int block_size, int identity, int sort_layers,
+                                                       uint64_t seed, int64_t first_image) {
   constexpr int HW = HT * WT;
   __shared__ float draws[kMaxMC * HW];
   __shared__ unsigned keep_lo[kMaxMC], keep_hi[kMaxMC];
@@ -68,8 +70,12 @@ __global__ __launch_bounds__(256) void mc_mask_kernel(const float* __restrict__ 
   float* out = table + img * (int64_t)(n_mc * (HW + 2));
   if (tid < n_mc) { keep_lo[tid] = 0u; keep_hi[tid] = 0u; }
   if (!identity) {
-    const float* r = rnd + img * rand_stride;
-    for (int i = tid; i < n_mc * HW; i += 256) draws[i] = r[i];
+    if (rnd) {
+      const float* r = rnd + img * rand_stride;
+      for (int i = tid; i < n_mc * HW; i += 256) draws[i] = r[i];
+    } else {  // counter mode: the draws are a function of (seed, image, index), philox.hpp
+      for (int i = tid; i < n_mc * HW; i += 256) draws[i] = runia_philox::draw(seed, (uint64_t)(first_image + img), i);
+    }
   }
   __syncthreads();
   // one thread per (drop layer, position): max-pool window of the seed mask, keep bit ORed into the layer's mask
@@ -152,7 +158,8 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
                                                                            int64_t rand_stride,
                                                                            float* __restrict__ table, int64_t N,
                                                                            int n_mc, float gamma, int block_size,
-                                                                           int identity, int sort_layers) {
+                                                                           int identity, int sort_layers,
+                                                                           uint64_t rng_seed, int64_t first_image) {
   constexpr int HW = HT * WT;
   static_assert(64 % HW == 0 && NP <= 64, "one drop layer per 64-bit word");
   constexpr int LPW = 64 / HW;                 // layers per ballot word
@@ -163,11 +170,23 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
   if (img >= N) return;  // wave-uniform
   float d[WORDS];
   if (!identity) {
-    const float* r = rnd + img * rand_stride;
+    if (rnd) {
+      const float* r = rnd + img * rand_stride;
 #pragma unroll
-    for (int t = 0; t < WORDS; ++t) {
-      const int i = lane + 64 * t;
-      d[t] = (i < n_mc * HW) ? r[i] : 1.0f;
+      for (int t = 0; t < WORDS; ++t) {
+        const int i = lane + 64 * t;
+        d[t] = (i < n_mc * HW) ? r[i] : 1.0f;
+      }
+    } else {  // counter mode (philox.hpp): this lane's words 4q .. 4q+3 are the four components of one Philox block
+#pragma unroll
+      for (int q = 0; q < (WORDS + 3) / 4; ++q) {
+        const runia_philox::u4 b = runia_philox::lane_block(rng_seed, (uint64_t)(first_image + img), lane, q);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const int t = 4 * q + j;
+          if (t < WORDS) d[t] = (lane + 64 * t < n_mc * HW) ? runia_philox::component(b, j) : 1.0f;
+        }
+      }
     }
   }
   unsigned long long seed = 0ull;  // this lane's layer (lane = layer index)
@@ -707,15 +726,23 @@ extern "C" int runia_pca_md_score_f64(const double* h, const double* packed_ct, 
 namespace {
 template <int HH, int WW, int NPP>
 void launch_mask(const float* rnd, int64_t rand_image_stride, float* table, int64_t N, int n_mc, float gamma,
-                 int block_size, int identity, int sort_layers, hipStream_t s) {
+                 int block_size, int identity, int sort_layers, uint64_t seed, int64_t first_image, hipStream_t s) {
   if constexpr (64 % (HH * WW) == 0) {
     mc_mask_bits_kernel<HH, WW, NPP><<<(unsigned)((N + kMaskBitsWaves - 1) / kMaskBitsWaves), 64 * kMaskBitsWaves, 0,
                                        s>>>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity,
-                                            sort_layers);
+                                            sort_layers, seed, first_image);
   } else {
     mc_mask_kernel<HH, WW><<<(unsigned)N, 256, 0, s>>>(rnd, rand_image_stride, table, n_mc, gamma, block_size,
-                                                       identity, sort_layers);
+                                                       identity, sort_layers, seed, first_image);
   }
+}
+
+// explicit draws of the counter generator, [N, n_mc, H, W] (tests; callers that want the values themselves)
+__global__ void mc_draws_kernel(float* __restrict__ out, int64_t N, int per_image, uint64_t seed, int64_t first_image) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= N * per_image) return;
+  const int64_t img = i / per_image;
+  out[i] = runia_philox::draw(seed, (uint64_t)(first_image + img), (int)(i - img * per_image));
 }
 }  // namespace
 
@@ -739,19 +766,20 @@ static int mc_args_ok(int64_t N, int H, int W, int n_mc, const void* workspace, 
 
 static int mc_mask_table(const float* rnd, int64_t rand_image_stride, void* workspace, size_t workspace_bytes,
                          int64_t N, int H, int W, int n_mc, double drop_prob, int block_size, int sort_layers,
-                         runia_stream_t stream) {
+                         runia_stream_t stream, bool counter = false, uint64_t seed = 0, int64_t first_image = 0) {
   if (block_size < 1) return RUNIA_E_INVALID;
   if (int rc = mc_args_ok(N, H, W, n_mc, workspace, workspace_bytes)) return rc;
   if (N == 0) return RUNIA_OK;
   const int identity = (drop_prob == 0.0);
-  if (!identity && !rnd) return RUNIA_E_INVALID;
+  if (!identity && !rnd && !counter) return RUNIA_E_INVALID;
+  if (counter) rnd = nullptr;
   float* table = reinterpret_cast<float*>(workspace);
   const float gamma = (float)(drop_prob / (double)(block_size * block_size));
   hipStream_t s = as_stream(stream);
 #define RUNIA_MCE(HH, WW, NPP, KK)                                                                          \
   if (H == HH && W == WW && n_mc <= NPP && n_mc > NPP / 2) {                                                \
     launch_mask<HH, WW, NPP>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity,           \
-                             sort_layers, s);                                                               \
+                             sort_layers, seed, first_image, s);                                            \
     return runia_check_launch();                                                                            \
   }
   RUNIA_MCE_SHAPES(RUNIA_MCE)
@@ -841,6 +869,46 @@ extern "C" int runia_mc_entropy_f32(const float* x, const float* rnd, int64_t ra
   if (!(((((uintptr_t)x) & 15) == 0) || (H * W) % 4 != 0)) return RUNIA_E_INVALID;  // before anything is launched
   if (int rc = runia_mc_mask_table_f32(rnd, rand_image_stride, workspace, workspace_bytes, N, H, W, n_mc, drop_prob,
                                        block_size, stream))
+    return rc;
+  return runia_mc_entropy_from_table_f32(x, workspace, workspace_bytes, h, z_out, zero_fill, N, C, H, W, n_mc, k,
+                                         min_dist, stream);
+}
+
+// ---- throughput mode: the DropBlock draws come from the counter generator inside K0 (philox.hpp) ----------------
+extern "C" int runia_mc_draws_f32(float* out, int64_t N, int n_mc, int H, int W, uint64_t seed, int64_t first_image,
+                                  runia_stream_t stream) {
+  if (N < 0 || n_mc < 1 || H <= 0 || W <= 0 || first_image < 0 || (int64_t)n_mc * H * W > (1 << 20))
+    return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!out) return RUNIA_E_INVALID;
+  const int64_t total = N * n_mc * H * W;
+  if ((total + 255) / 256 > 0x7fffffffLL) return RUNIA_E_INVALID;
+  mc_draws_kernel<<<(unsigned)((total + 255) / 256), 256, 0, as_stream(stream)>>>(out, N, n_mc * H * W, seed,
+                                                                                first_image);
+  return runia_check_launch();
+}
+
+extern "C" int runia_mc_mask_table_counter_f32(uint64_t seed, int64_t first_image, void* workspace,
+                                               size_t workspace_bytes, int64_t N, int H, int W, int n_mc,
+                                               double drop_prob, int block_size, runia_stream_t stream) {
+  if (first_image < 0) return RUNIA_E_INVALID;
+  return mc_mask_table(nullptr, 0, workspace, workspace_bytes, N, H, W, n_mc, drop_prob, block_size, 1, stream, true,
+                       seed, first_image);
+}
+
+extern "C" int runia_mc_entropy_counter_f32(const float* x, uint64_t seed, int64_t first_image, double* h,
+                                            float* z_out, double* zero_fill, void* workspace, size_t workspace_bytes,
+                                            int64_t N, int C, int H, int W, int n_mc, double drop_prob,
+                                            int block_size, int k, double min_dist, runia_stream_t stream) {
+  if (N < 0 || C <= 0 || H <= 0 || W <= 0 || n_mc < 2 || n_mc > kMaxMC || block_size < 1 || k < 1 || k >= n_mc ||
+      first_image < 0)
+    return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!x || !h || N > 65535) return RUNIA_E_INVALID;
+  if (!runia_mc_entropy_supported(H, W, n_mc, k)) return RUNIA_E_INVALID;
+  if (!(((((uintptr_t)x) & 15) == 0) || (H * W) % 4 != 0)) return RUNIA_E_INVALID;  // before anything is launched
+  if (int rc = runia_mc_mask_table_counter_f32(seed, first_image, workspace, workspace_bytes, N, H, W, n_mc,
+                                               drop_prob, block_size, stream))
     return rc;
   return runia_mc_entropy_from_table_f32(x, workspace, workspace_bytes, h, z_out, zero_fill, N, C, H, W, n_mc, k,
                                          min_dist, stream);

@@ -39,6 +39,8 @@ def gather_scores(local: torch.Tensor, n_rows: int, group=None) -> torch.Tensor:
     world, _ = _world(group)
     if not (dist.is_available() and dist.is_initialized()):
         return local
+    if local.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"gather_scores: score shards must be float32 or float64 on every rank, got {local.dtype}")
     per = -(-n_rows // world) if n_rows > 0 else 0
     if local.numel() == per and local.is_contiguous():
         buf = local  # even split: no padding copy
@@ -97,8 +99,11 @@ class ShardedPostprocessor:
         a, b = shard_bounds(n, world, rank)
         kw = {k: (v[a:b] if hasattr(v, "__len__") and not isinstance(v, str) and len(v) == n else v)
               for k, v in kwargs.items()}
-        local = self.postprocessor.postprocess(test_data[a:b], **kw) if b > a else np.zeros(0)
-        local = torch.from_numpy(np.ascontiguousarray(local))
+        # An empty tail shard still goes through the postprocessor (its kernels return at once for N == 0) so that
+        # the shard carries the dtype the scorer returns - f32 for energy / msp / knn / cMD / gen / GMM / ddu: every rank
+        # must enter the one all_gather with the same element size.
+        local = np.ascontiguousarray(self.postprocessor.postprocess(test_data[a:b], **kw)).reshape(-1)
+        local = torch.from_numpy(local)
         backend = dist.get_backend(self.group) if world > 1 else None
         if backend == "nccl":
             local = local.to(self.device or torch.device("cuda", torch.cuda.current_device()))

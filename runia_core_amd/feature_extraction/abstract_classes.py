@@ -48,6 +48,31 @@ class MCSamplerModule(torch.nn.Module):
         self.drop_blocks = torch.nn.ModuleList(
             [DropBlockSpec(block_size=block_size, drop_prob=drop_prob) for _ in range(self.mc_samples)]
         )
+        # Source of the DropBlock draws.  "cpu" (default): the reference's stream - torch.rand on the CPU default
+        # generator, uploaded (parity mode).  "counter": Philox4x32-10 inside the keep-flag kernel, keyed by
+        # `counter_seed`, image ids advancing with every call (throughput mode: no host RNG, no upload; statistically
+        # equivalent, not the same stream) - see use_counter_draws().
+        self.draw_source = "cpu"
+        self.counter_seed = 0
+        self._next_image = 0
+
+    def use_counter_draws(self, seed: int = 0, first_image: int = 0) -> "MCSamplerModule":
+        """Switch to in-kernel counter-based draws (additive API; the reference has only the CPU stream)."""
+        self.draw_source, self.counter_seed, self._next_image = "counter", int(seed), int(first_image)
+        return self
+
+    def use_cpu_draws(self) -> "MCSamplerModule":
+        self.draw_source = "cpu"
+        return self
+
+    def next_draws(self, batch: int, h: int, w: int, device):
+        """Draws of the next ``batch`` images from the configured source: a device tensor ``(batch, n_mc, h, w)`` in
+        "cpu" mode, a ``_hip.CounterDraws`` ticket in "counter" mode (the kernel makes the draws itself)."""
+        if self.draw_source == "counter":
+            ticket = _hip.CounterDraws(self.counter_seed, self._next_image)
+            self._next_image += int(batch)
+            return ticket
+        return self.draw(batch, h, w, device)
 
     def draw(self, batch: int, h: int, w: int, device, generator=None) -> torch.Tensor:
         """Uniform draws of the drop layers: ``(batch, mc_samples, h, w)``, image-major, in the reference's
@@ -65,7 +90,7 @@ class MCSamplerModule(torch.nn.Module):
         n, _, h, w = x.shape
         active = self.training and self.drop_prob != 0.0
         if active and rand is None:
-            rand = self.draw(n, h, w, x.device)
+            rand = self.next_draws(n, h, w, x.device)
         if self.layer_type != "Conv":
             # "FC" / "RPN": no fullmean, each drop layer's output is flattened (reference :95-99)
             return _hip.mc_drop_flat(x, rand if active else None, self.mc_samples, self.drop_prob if active else 0.0,

@@ -70,20 +70,25 @@ class LaRExInference(ProbabilisticInferenceModule):
             latent_rep = layer_hook.output
         return output, self.get_scores_from_latents(latent_rep)
 
-    def get_scores_from_latents(self, latents: torch.Tensor, rand: torch.Tensor = None) -> np.ndarray:
+    def get_scores_from_latents(self, latents: torch.Tensor, rand: torch.Tensor = None, to_host: bool = True):
         """Additive batched entry point: hooked activations ``(N, C, H, W)`` -> ``(N,)`` scores.
-        ``rand`` ``(N, n_mc, H, W)`` supplies the DropBlock draws (default: the sampler's CPU-generator stream)."""
+        ``rand`` ``(N, n_mc, H, W)`` supplies the DropBlock draws (default: the sampler's source - the reference's
+        CPU-generator stream, or in-kernel counter draws after ``self.mc_sampler.use_counter_draws(seed)``).
+        ``to_host=False`` returns the device tensor (stream-ordered, no synchronisation)."""
         x = _hip.to_device(latents, torch.float32)
         active = self.mc_sampler.training and self.drop_block_prob != 0.0
         if rand is None and active:
-            rand = self.mc_sampler.draw(x.shape[0], x.shape[2], x.shape[3], x.device)
+            rand = self.mc_sampler.next_draws(x.shape[0], x.shape[2], x.shape[3], x.device)
         pipe = self._pipe()
         if pipe._md_state() is not None and self.layer_type == "Conv":
             # LaREM: sampler + entropy and PCA + score as two fused launches (same arithmetic as the stages below)
-            return pipe.score_latents(x, rand if active else None).cpu().numpy()
+            s = pipe.score_latents(x, rand if active else None)
+            return s.cpu().numpy() if to_host else s
         h = pipe.entropy(self.mc_sampler(x, rand=rand))
         if self.pca_transform:
             h = device_pca_for(self.pca_transform).transform_device(h)
+        if not to_host and hasattr(self.postprocessor, "postprocess_device"):
+            return self.postprocessor.postprocess_device(h)
         return _score_rows_device(self.postprocessor, h)
 
     @record_time

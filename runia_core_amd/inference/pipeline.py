@@ -161,9 +161,11 @@ class LaREMPipeline:
         """Pre-stacked MC samples ``(N * n_mc, D)`` f32 (device) -> scores ``(N,)`` f64 (device)."""
         return self.score_entropies(self.entropy(z))
 
-    def score_latents(self, latents: Tensor, rand: Optional[Tensor], chunks: Optional[int] = None,
+    def score_latents(self, latents: Tensor, rand, chunks: Optional[int] = None,
                       k1_events: Optional[list] = None) -> Tensor:
         """Hooked activations ``(N, C, H, W)`` + uniform draws ``(N, n_mc, H, W)`` -> scores ``(N,)``.
+        ``rand`` may also be a ``_hip.CounterDraws(seed, first_image)``: the draws are then made inside the keep-flag
+        kernel by the counter generator (throughput mode; nothing is read from memory for them).
 
         Large LaREM batches are cut into ``chunks`` row blocks pipelined over two HIP streams: the sampler +
         entropy kernel (vector ALUs) of block i+1 runs beside the PCA + LaREM kernel (matrix cores) of block i.
@@ -174,7 +176,8 @@ class LaREMPipeline:
         chunks = self.overlap_chunks if chunks is None else int(chunks)
         md = self._md_state()
         fused = _hip.mc_entropy_supported(hh, ww, self.n_mc, self.k) and md is not None
-        if not fused or chunks <= 1 or n < 2048 * chunks or (rand is not None and rand.dim() != 4):
+        counter = isinstance(rand, _hip.CounterDraws)
+        if not fused or chunks <= 1 or n < 2048 * chunks or (rand is not None and not counter and rand.dim() != 4):
             folded = self._folded_state() if (fused and self.fold_weights) else None
             if folded is not None and (self.pca is None or latents.shape[1] == self.pca.n_features):
                 # K1 clears the score vector on its way, K2' adds the two column halves of each row into it: no
@@ -184,7 +187,7 @@ class LaREMPipeline:
                 return _hip.proj_sq_accumulate(h, *folded, out=scores)
             return self.score_entropies(self.entropy_from_latents(latents, rand, k1_events if fused else None))
         latents = latents.contiguous()
-        if rand is not None:
+        if rand is not None and not counter:
             rand = rand.contiguous()
         mean, packed_p = md
         main = torch.cuda.current_stream()
@@ -201,7 +204,8 @@ class LaREMPipeline:
         for a in range(0, n, per):
             b = min(a + per, n)
             with torch.cuda.stream(s_k1):
-                _hip.mc_entropy(latents[a:b], None if rand is None else rand[a:b], self.n_mc, drop, self.block_size,
+                r_ab = None if rand is None else (_hip.CounterDraws(rand.seed, rand.first_image + a) if counter else rand[a:b])
+                _hip.mc_entropy(latents[a:b], r_ab, self.n_mc, drop, self.block_size,
                                 self.k, MIN_DIST, out=h[a:b], kernel_events=k1_events)
                 ready = s_k1.record_event()
             s_k2.wait_event(ready)
@@ -253,7 +257,7 @@ class LaREMPipeline:
         ring["free"][slot] = done
         # keep the caller's tensors alive for the side streams (caching-allocator stream safety)
         latents.record_stream(s_k1)
-        if rand is not None:
+        if isinstance(rand, Tensor):
             rand.record_stream(s_k1)
         scores.record_stream(s_k2)
         return AsyncScores(scores, done)

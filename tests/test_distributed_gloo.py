@@ -41,6 +41,13 @@ class _RowSum:
         return s
 
 
+class _RowSum32(_RowSum):
+    """A scorer that returns float32, as energy / msp / knn / cMD / gen / GMM / ddu do; handles zero rows."""
+
+    def postprocess(self, x, **kwargs):
+        return np.asarray(x, dtype=np.float32).sum(axis=1, dtype=np.float32)
+
+
 def _worker(rank, world, port, n_rows, out_dir):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
@@ -56,8 +63,9 @@ def _worker(rank, world, port, n_rows, out_dir):
         a, b = shard_bounds(n_rows, world, rank)
         local = torch.arange(a, b, dtype=torch.float32)
         g32 = gather_scores(local, n_rows)
+        full32 = ShardedPostprocessor(_RowSum32()).postprocess(rows.astype(np.float32))  # empty tail shard keeps f32
         np.savez(os.path.join(out_dir, f"r{rank}.npz"), full=full.numpy(), full2=full2, mean=state["mean"],
-                 g32=g32.numpy(), thr=sp.threshold)
+                 g32=g32.numpy(), thr=sp.threshold, full32=full32)
     finally:
         dist.destroy_process_group()
 
@@ -73,6 +81,8 @@ def test_sharded_scoring_world2_gloo(tmp_path, n_rows):
         assert np.array_equal(g["full"], exp)
         assert np.array_equal(g["full2"], exp + np.arange(n_rows))
         assert np.array_equal(g["g32"], np.arange(n_rows, dtype=np.float32))
+        assert g["full32"].dtype == np.float32 and g["full32"].shape == (n_rows,)
+        assert np.array_equal(g["full32"], rows.astype(np.float32).sum(axis=1, dtype=np.float32))
         if n_rows:
             assert np.array_equal(g["mean"], rows.mean(0))
         assert float(g["thr"]) == 1.5

@@ -112,3 +112,96 @@ def test_cfg4_per_proposal_entropy_and_larem(hip):
     s2 = hip.pca_md_score(h[10_000:10_700].contiguous(), hip.pack_weights(dev(comp.T)), dev((mean.reshape(1, -1) @ comp.T).ravel()),
                           dev(np.sqrt(var)), dev(md_mean.ravel()), hip.pack_weights(dev(prec)), n)
     assert torch.equal(s2, s[10_000:10_700])
+
+
+# ---------------- fused LaREM path (K0 + K1 + K2') at full size and at the launch boundaries -------------------------
+def _larem_state(hip, seed=0, c=512, n=256):
+    from runia_core_amd.dimensionality_reduction import DevicePCA
+    from runia_core_amd.inference import LaREMPipeline, MDLatentSpace
+
+    rng = np.random.default_rng(seed)
+    comp = np.linalg.qr(rng.standard_normal((c, n)))[0].T
+    pca_mean, var = rng.standard_normal(c), rng.random(n) + 0.05
+    a = rng.standard_normal((n, n))
+    md = MDLatentSpace()
+    md.feats_mean, md.precision, md._setup_flag = rng.standard_normal((1, n)) * 0.1, a @ a.T / n + np.eye(n), True
+    return LaREMPipeline(md, DevicePCA(comp, pca_mean, var, True), 16, 0.5, 2), (comp, pca_mean, var, md.feats_mean, md.precision)
+
+
+def _latents(n, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.relu(torch.randn(n, 512, 4, 4, device="cuda", generator=g))
+    rand = torch.rand(n, 16, 4, 4, device="cuda", generator=g)
+    rand[:, :, 0, 0] = rand[:, :, 0, 0].clamp_min(0.2)  # no fully dropped map: every score finite
+    return x, rand
+
+
+@pytest.mark.parametrize("n", [10_000, 10_003, 65_535, 65_536, 70_001])
+def test_fused_larem_from_latents_sizes_and_boundaries(hip, n):
+    """score_latents at the bench size, at N % 8 != 0 (the XCD-aware workgroup order rounds the grid up to 8 images), at
+    the C entry's 65 535-image limit, one beyond it and well beyond it (host chunk loop): sampled rows against the
+    oracle, slices against the whole (rows are independent, so a shard scores the same bits as within the batch)."""
+    pipe, (comp, pmean, var, mdm, prec) = _larem_state(hip)
+    x, rand = _latents(n, 100 + n % 97)
+    s = pipe.score_latents(x, rand)
+    assert s.shape == (n,) and s.dtype == torch.float64 and bool(torch.isfinite(s).all())
+    idx = np.r_[0:6, n // 2 - 3 : n // 2 + 3, n - 6 : n]
+    if n > 65_540:
+        idx = np.r_[idx, 65_530:65_540]  # both sides of the host chunk boundary
+    idx = np.unique(idx)
+    z = np.concatenate([oracle.mc_stack(x[i : i + 1].cpu().numpy(), rand[i].cpu().numpy(), 0.5, 2) for i in idx])
+    exp, _ = oracle.larem_pipeline(z, 16, comp, pmean, var, mdm, prec)
+    assert rel_err(s[idx].cpu().numpy(), exp) < 1e-9
+    for a, b in ((0, 1000), (n // 2 - 123, n // 2 + 1001), (n - 777, n)):
+        assert torch.equal(pipe.score_latents(x[a:b].contiguous(), rand[a:b].contiguous()), s[a:b]), (a, b)
+    # counter-draw mode: chunks and shards line up through the image ids
+    from runia_core_amd._hip import CounterDraws
+
+    sc = pipe.score_latents(x, CounterDraws(5, 1_000_000))
+    assert bool(torch.isfinite(sc).all() | True)  # a fully dropped map is NaN by definition; equality below is the check
+    a, b = n - 3333, n - 1
+    part = pipe.score_latents(x[a:b].contiguous(), CounterDraws(5, 1_000_000 + a))
+    assert torch.equal(torch.nan_to_num(part, nan=1.0), torch.nan_to_num(sc[a:b], nan=1.0))
+
+
+def test_sharded_postprocessor_real_kernels_nccl_world1(hip):
+    """ShardedPostprocessor over a world-size-1 RCCL group with the real kernels behind it: f64 (LaREM, Mahalanobis) and
+    f32 (Energy, kNN) scorers, uneven row counts, and the empty-input case (dtype kept)."""
+    import socket
+
+    import torch.distributed as dist
+
+    from runia_core_amd.distributed import ShardedPostprocessor, shard_bounds
+    from runia_core_amd.inference import Energy, KNNLatentSpace, MDLatentSpace
+
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    try:
+        rng = np.random.default_rng(3)
+        train = rng.standard_normal((500, 48))
+        md = MDLatentSpace()
+        md.setup(train)
+        knn = KNNLatentSpace()
+        knn.setup(train.astype(np.float32))
+        en = Energy(flip_sign=False)
+        en.setup(rng.standard_normal((100, 10)).astype(np.float32))
+        for rows in (1, 7, 1001):
+            xt = rng.standard_normal((rows, 48))
+            assert np.array_equal(ShardedPostprocessor(md).postprocess(xt), md.postprocess(xt))
+            g32 = ShardedPostprocessor(knn).postprocess(xt.astype(np.float32))
+            assert g32.dtype == np.float32 and np.array_equal(g32, knn.postprocess(xt.astype(np.float32)))
+            lg = rng.standard_normal((rows, 10)).astype(np.float32)
+            assert np.array_equal(ShardedPostprocessor(en).postprocess(lg), en.postprocess(lg))
+        # what a rank with an empty tail shard does (N = 9 on 8 ranks: rank 5.. get no rows): zero rows through the
+        # real postprocessors keep their dtypes
+        a, b = shard_bounds(9, 8, 7)
+        assert a == b
+        assert md.postprocess(np.zeros((0, 48))).dtype == np.float64
+        assert knn.postprocess(np.zeros((0, 48), np.float32)).dtype == np.float32
+        assert en.postprocess(np.zeros((0, 10), np.float32)).dtype == np.float32
+        assert ShardedPostprocessor(en).postprocess(np.zeros((0, 10), np.float32)).shape == (0,)
+    finally:
+        dist.destroy_process_group()

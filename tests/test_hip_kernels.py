@@ -344,6 +344,38 @@ def test_sampler_module_layer_types(hip):
     assert np.array_equal(m(torch.from_numpy(g["eval_x"])).cpu().numpy(), g["eval_out"])
 
 
+# ---------------- throughput-mode draws (counter generator inside the keep-flag kernel) ---------------------------
+@pytest.mark.parametrize("n,n_mc,h,w,first", [(5, 16, 4, 4, 0), (3, 16, 7, 7, 10), (2, 12, 8, 8, 2**33), (300, 32, 4, 4, 65530),
+                                              (4, 16, 2, 2, 1)])
+def test_counter_draws_equal_oracle(hip, n, n_mc, h, w, first):
+    got = hip.mc_draws(n, n_mc, h, w, seed=0xDEADBEEF12345, first_image=first).cpu().numpy()
+    assert np.array_equal(got, oracle.counter_draws(n, n_mc, h, w, 0xDEADBEEF12345, first))
+
+
+@pytest.mark.parametrize("c,h,w,bs,p,n_mc,n", [(512, 4, 4, 2, 0.5, 16, 33), (64, 4, 4, 2, 0.4, 32, 9), (48, 8, 8, 3, 0.4, 12, 5),
+                                               (40, 7, 7, 3, 0.4, 16, 5), (64, 2, 2, 1, 0.3, 16, 7)])
+def test_counter_mode_equals_explicit_draws(hip, c, h, w, bs, p, n_mc, n):
+    """In-kernel draws (runia_mc_entropy_counter_f32) == the parity path fed with the same generator's explicit draws
+    (runia_mc_draws_f32 -> runia_mc_entropy_f32), bit for bit; chunks and shards line up through first_image."""
+    torch.manual_seed(c)
+    x = torch.relu(torch.randn(n, c, h, w)).cuda()
+    seed, first = 77, 1000
+    explicit = hip.mc_draws(n, n_mc, h, w, seed, first)
+    h_par = hip.mc_entropy(x, explicit, n_mc, p, bs, 5)
+    h_ctr = hip.mc_entropy(x, hip.CounterDraws(seed, first), n_mc, p, bs, 5)
+    assert torch.equal(torch.nan_to_num(h_ctr, nan=-7.0), torch.nan_to_num(h_par, nan=-7.0))
+    # two-call form (bench's bracketed step) and a shifted chunk
+    ev = []
+    h_ev = hip.mc_entropy(x, hip.CounterDraws(seed, first), n_mc, p, bs, 5, kernel_events=ev)
+    assert torch.equal(torch.nan_to_num(h_ev, nan=-7.0), torch.nan_to_num(h_par, nan=-7.0)) and len(ev) == 1
+    h_tail = hip.mc_entropy(x[2:].contiguous(), hip.CounterDraws(seed, first + 2), n_mc, p, bs, 5)
+    assert torch.equal(torch.nan_to_num(h_tail, nan=-7.0), torch.nan_to_num(h_par[2:], nan=-7.0))
+    # sampler alone
+    z_ctr = hip.mc_stack(x, hip.CounterDraws(seed, first), n_mc, p, bs)
+    z_par = hip.mc_stack(x, explicit, n_mc, p, bs)
+    assert torch.equal(torch.nan_to_num(z_ctr, nan=-7.0), torch.nan_to_num(z_par, nan=-7.0))
+
+
 # ---------------- full chain on pre-stacked samples -------------------------------------------------------------
 def test_larem_chain_unfused(hip):
     rng = np.random.default_rng(77)

@@ -262,6 +262,38 @@ def test_kde_high_dim_reference_run_fixture(d):
         assert 0.5 * m["max_abs"] < gap < 2 * m["max_abs"]
 
 
+# ---------------- throughput-mode draws: Philox4x32-10 known answers + uniformity --------------------------------
+def test_philox_known_answer_vectors():
+    """Random123's published kat_vectors for philox4x32-10 (the generator behind runia_mc_*_counter_f32)."""
+    kat = [([0, 0, 0, 0], [0, 0], [0x6627E8D5, 0xE169C58D, 0xBC57AC4C, 0x9B00DBD8]),
+           ([0xFFFFFFFF] * 4, [0xFFFFFFFF] * 2, [0x408F276D, 0x41C83B0E, 0xA20BC7C6, 0x6D5451FD]),
+           ([0x243F6A88, 0x85A308D3, 0x13198A2E, 0x03707344], [0xA4093822, 0x299F31D0],
+            [0xD16CFE09, 0x94FDCCEB, 0x5001E420, 0x24126EA1])]
+    for ctr, key, exp in kat:
+        assert np.array_equal(oracle.philox4x32_10(np.array(ctr), key), np.array(exp, dtype=np.uint32))
+
+
+def test_counter_draws_are_uniform_and_independent():
+    d = oracle.counter_draws(4000, 16, 4, 4, seed=2026, first_image=0)
+    assert d.dtype == np.float32 and d.min() >= 0.0 and d.max() < 1.0
+    flat = d.ravel()
+    n = flat.size
+    assert abs(flat.mean() - 0.5) < 4 * (1 / 12) ** 0.5 / n**0.5
+    hist = np.histogram(flat, bins=64, range=(0, 1))[0]
+    chi2 = ((hist - n / 64) ** 2 / (n / 64)).sum()
+    assert chi2 < 63 + 5 * (2 * 63) ** 0.5                      # 5 sigma of chi^2(63)
+    gamma = 0.125
+    p = (flat < gamma).mean()
+    assert abs(p - gamma) < 5 * (gamma * (1 - gamma) / n) ** 0.5
+    # neighbouring positions, neighbouring layers and neighbouring images are uncorrelated
+    for a, b in ((d[:, :, :, :-1], d[:, :, :, 1:]), (d[:, :-1], d[:, 1:]), (d[:-1], d[1:])):
+        r = np.corrcoef(a.ravel(), b.ravel())[0, 1]
+        assert abs(r) < 5 / a.size**0.5
+    # a stream is a function of (seed, image id): chunks line up, seeds differ
+    assert np.array_equal(oracle.counter_draws(10, 16, 4, 4, 2026, 100), d[100:110])
+    assert not np.array_equal(oracle.counter_draws(10, 16, 4, 4, 2027, 100), d[100:110])
+
+
 # ---------------- a10 threshold ----------------------------------------------------------
 def test_threshold_fixture():
     g = load_npz("ref_threshold.npz")
