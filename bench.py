@@ -348,9 +348,12 @@ def main():
         infer = LaRExInference(torch.nn.Identity(), md, DROP_PROB, BLOCK, N_MC, MCSamplerModule, pca_transform=pca)
         infer.mc_sampler.use_counter_draws(seed=2026)
         k_api = max(10, min(args.steps, 200))
-        for i in range(20):
-            infer.get_scores_from_latents(sets[i % n_sets][0], to_host=False)
-        torch.cuda.synchronize()
+        infer.get_scores_from_latents(sets[0][0], to_host=False)  # folds the weights (host eigh): the GPU idles meanwhile
+        t_spin = time.perf_counter()
+        while time.perf_counter() - t_spin < args.clock_warmup:   # ... so bring the clocks back up, as before the main region
+            for i in range(50):
+                infer.get_scores_from_latents(sets[i % n_sets][0], to_host=False)
+            torch.cuda.synchronize()
         t_a = time.perf_counter()
         for i in range(k_api):
             s_api = infer.get_scores_from_latents(sets[i % n_sets][0], to_host=False)
@@ -366,7 +369,9 @@ def main():
             "value": round(n * k_api / t_api, 1), "unit": "images/s", "ms_per_call": round(1e3 * t_api / k_api, 4),
             "returns": "device tensor (to_host=False)", "calls": k_api, "frac_of_value": round(n * k_api / t_api / value, 4),
             "value_scores_to_host": round(n * k_api / t_host, 1),
-            "finite": bool(torch.isfinite(s_api).all().item()) and bool(np.isfinite(s_host).all()),
+            # a drop layer that removes the whole map is 0 * numel / 0 = NaN upstream as well; the resident draw sets
+            # of the main region were cleaned of such layers, the generator's stream is not
+            "nan_scores_in_last_call": int(np.isnan(s_host).sum()),
         }
     gc.enable()
 
@@ -469,10 +474,14 @@ def main():
         ood_c = pipe.score_latents(xo_full, _hip.CounterDraws(99, n)).cpu().numpy()
         ind_p = pipe.score_latents(x, rand).cpu().numpy()
         ood_p = pipe.score_latents(xo_full, ro_full).cpu().numpy()
-        a_c, a_p = oracle.auroc_fpr95_aupr(ind_c, ood_c), oracle.auroc_fpr95_aupr(ind_p, ood_p)
+        a_c = oracle.auroc_fpr95_aupr(ind_c[np.isfinite(ind_c)], ood_c[np.isfinite(ood_c)])
+        a_p = oracle.auroc_fpr95_aupr(ind_p, ood_p)
+        fin = np.isfinite(ind_c)
         out["parity"]["counter_draws"] = {"auroc_counter": a_c[0], "auroc_host_draws": a_p[0],
                                           "d_auroc": a_c[0] - a_p[0], "images": [n, n],
-                                          "mean_score_counter": float(ind_c.mean()), "mean_score_host_draws": float(ind_p.mean())}
+                                          "auroc_standard_error": float((a_p[0] * (1 - a_p[0]) / n) ** 0.5),
+                                          "mean_score_counter": float(ind_c[fin].mean()), "nan_scores_counter": int((~fin).sum()),
+                                          "mean_score_host_draws": float(ind_p.mean())}
         del xo_full, ro_full
         # the reference's parallel form: one task per image over a process pool (evaluation/entropy.py:86-91), timed in a
         # child process that never touches the GPU (cpu_pool_child above), on the cores this job may use

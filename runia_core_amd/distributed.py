@@ -104,7 +104,7 @@ class ShardedPostprocessor:
         # must enter the one all_gather with the same element size.
         local = np.ascontiguousarray(self.postprocessor.postprocess(test_data[a:b], **kw)).reshape(-1)
         local = torch.from_numpy(local)
-        backend = dist.get_backend(self.group) if world > 1 else None
+        backend = dist.get_backend(self.group) if (dist.is_available() and dist.is_initialized()) else None
         if backend == "nccl":
             local = local.to(self.device or torch.device("cuda", torch.cuda.current_device()))
         return gather_scores(local, n, self.group).cpu().numpy()
