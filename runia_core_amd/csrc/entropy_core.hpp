@@ -53,6 +53,37 @@ __device__ __forceinline__ void sort_asc(float (&v)[NP]) {
   }
 }
 
+// log(f) and the binary exponent e of a positive, finite, normal x = f * 2^e with f in [sqrt(1/2), sqrt(2)):
+// log(f) = 2 atanh(s), s = (f-1)/(f+1), |s| <= 0.1716, odd series to s^21 (next term < 3e-17); plain f64 operations,
+// ~35 instructions against ~75 of the library log (which carries double-double terms this sum does not need: the
+// result enters h as (log(f) + e ln 2) / n_mc, absolute error ~2e-16).
+__device__ __forceinline__ double log_mantissa(double x, int& e_out) {
+  int e;
+  double f = frexp(x, &e);                      // [0.5, 1)
+  const bool low = f < 0.70710678118654752440;
+  f = low ? f + f : f;
+  e_out = low ? e - 1 : e;
+  const double num = f - 1.0, den = f + 1.0;
+  double r = __builtin_amdgcn_rcp(den);
+  r = fma(fma(-den, r, 1.0), r, r);
+  r = fma(fma(-den, r, 1.0), r, r);
+  double q = num * r;
+  q = fma(fma(-den, q, num), r, q);             // (f-1)/(f+1) to ~0.5 ulp
+  const double t = q * q;
+  double p = 1.0 / 21.0;
+  p = fma(p, t, 1.0 / 19.0);
+  p = fma(p, t, 1.0 / 17.0);
+  p = fma(p, t, 1.0 / 15.0);
+  p = fma(p, t, 1.0 / 13.0);
+  p = fma(p, t, 1.0 / 11.0);
+  p = fma(p, t, 1.0 / 9.0);
+  p = fma(p, t, 1.0 / 7.0);
+  p = fma(p, t, 1.0 / 5.0);
+  p = fma(p, t, 1.0 / 3.0);
+  const double q2 = q + q;
+  return fma(q2 * t, p, q2);
+}
+
 // sum_i log(2*max(eps_i, min_dist)) over the first n entries of one ascending column (entries >= n are +inf
 // pads; FULL promises n == NP and removes every run-time guard).
 //   eps_i = k-th-nearest-neighbour distance of rank i = min_j max(v[i]-v[i-j], v[i+K-j]-v[i]),  j = 0..K,
@@ -96,7 +127,9 @@ __device__ __forceinline__ double column_log_sum(const float (&vs)[NP], int n, d
     mant *= m;
     esum += ex;
   }
-  return log(mant) + (double)(esum + (FULL ? NP : n)) * 0.69314718055994530942;  // + n: the factors 2 of log(2*eps)
+  int em;
+  const double lf = log_mantissa(mant, em);
+  return fma((double)(esum + em + (FULL ? NP : n)), 0.69314718055994530942, lf);  // + n: the factors 2 of log(2*eps)
 }
 
 }  // namespace runia_entropy

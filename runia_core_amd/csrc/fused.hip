@@ -23,6 +23,7 @@
 #include "entropy_core.hpp"
 #include "mfma_f64_tile.hpp"
 #include "philox.hpp"
+#include "div_consts.hpp"
 
 namespace {
 
@@ -31,6 +32,23 @@ using namespace runia_mfma;
 
 constexpr int kMaxMC = 64;
 typedef float f2 __attribute__((ext_vector_type(2)));
+
+// Keep-flag table of one image (K0 -> K1), n_mc*(HW+2) floats:
+//   n_mc records of HW floats: 0.0 where the drop layer removes the position, 2^-a where it keeps it, with the layer's
+//     mask sum written as sum = 2^a * m (m odd).  The DropBlock rescale x * numel / sum = (x * numel / m) * 2^-a and a
+//     power-of-two factor commutes with every rounding that follows (products, row sums, means), so it rides on the
+//     flags for free;  positions in K1's operand order (mask_slot);
+//   n_mc floats zh = RN(1/m) and n_mc floats zl = RN(1/m - zh): the layer's quotients are q = fma(u, zh, u * zl),
+//     the correctly rounded u / m in two instructions (div_consts.hpp, proven by tools/verify_div_constants.py).
+//     A layer that drops the whole map has zh = NaN (0 * numel / 0 upstream).
+// Drop layers are sorted by m (layers that share m share their quotients; m = 1 - sums 1, 2, 4, 8, 16, ... - needs none).
+__device__ __forceinline__ void layer_consts(int cnt, int& m, float& flag, float& zh, float& zl) {
+  const int a = cnt ? __ffs(cnt) - 1 : 0;
+  m = cnt >> a;
+  flag = __uint_as_float((unsigned)(127 - a) << 23);  // 2^-a
+  zh = cnt ? __uint_as_float(runia_div::kDivHi[(m - 1) >> 1]) : NAN;
+  zl = cnt ? __uint_as_float(runia_div::kDivLo[(m - 1) >> 1]) : 0.f;
+}
 
 __device__ __forceinline__ float div_newton(float u, float den, float r) {
   const float q = u * r;
@@ -63,7 +81,7 @@ __global__ __launch_bounds__(256) void mc_mask_kernel(const float* __restrict__ 
   __shared__ float draws[kMaxMC * HW];
   __shared__ unsigned keep_lo[kMaxMC], keep_hi[kMaxMC];
   __shared__ unsigned long long keep_bits[kMaxMC], sbits[kMaxMC];
-  __shared__ float msum[kMaxMC];
+  __shared__ float msum[kMaxMC], sflag[kMaxMC];
   const int tid = threadIdx.x;
   const int64_t img = blockIdx.x;
   const int pad = block_size / 2;
@@ -103,10 +121,13 @@ __global__ __launch_bounds__(256) void mc_mask_kernel(const float* __restrict__ 
   if (tid < n_mc) {
     const unsigned long long bits = ((unsigned long long)keep_hi[tid] << 32) | keep_lo[tid];
     keep_bits[tid] = bits;
-    msum[tid] = (float)__popcll(bits);
+    int m;
+    float fl, zh, zl;
+    layer_consts(__popcll(bits), m, fl, zh, zl);
+    msum[tid] = (float)(m ? m : 127);  // sort key: the odd part of the mask sum (fully dropped maps last)
   }
   __syncthreads();
-  if (tid < n_mc) {  // counting sort of the drop layers by mask sum (stable)
+  if (tid < n_mc) {  // counting sort of the drop layers by the odd part of their mask sum (stable)
     const float mine = msum[tid];
     int rank = 0;
     for (int j = 0; j < n_mc; ++j) {
@@ -115,13 +136,17 @@ __global__ __launch_bounds__(256) void mc_mask_kernel(const float* __restrict__ 
     }
     if (!sort_layers) rank = tid;  // table in the order of the draws (runia_mc_stack_table_f32)
     sbits[rank] = keep_bits[tid];
-    out[n_mc * HW + rank] = mine;
-    out[n_mc * (HW + 1) + rank] = 1.0f / mine;
+    int m;
+    float fl, zh, zl;
+    layer_consts(__popcll(keep_bits[tid]), m, fl, zh, zl);
+    sflag[rank] = fl;
+    out[n_mc * HW + rank] = zh;
+    out[n_mc * (HW + 1) + rank] = zl;
   }
   __syncthreads();
   for (int i = tid; i < n_mc * HW; i += 256) {
     const int s = i / HW, p = i - s * HW;
-    out[s * HW + mask_slot<HT, WT>(p)] = (float)((sbits[s] >> p) & 1ull);
+    out[s * HW + mask_slot<HT, WT>(p)] = ((sbits[s] >> p) & 1ull) ? sflag[s] : 0.f;
   }
 }
 
@@ -211,11 +236,15 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
   }
   const unsigned long long keep = ~dropped & FULL;
   const int cnt = __popcll(keep);
-  int rank = 0;  // stable counting sort of the drop layers by mask sum
+  int m;
+  float flag, zh, zl;
+  layer_consts(cnt, m, flag, zh, zl);
+  const int key = m ? m : 127;  // fully dropped maps last
+  int rank = 0;  // stable counting sort of the drop layers by the odd part of their mask sum
 #pragma unroll
   for (int j = 0; j < NP; ++j) {
-    const int o = __shfl(cnt, j, 64);
-    rank += (j < n_mc) && ((o < cnt) || (o == cnt && j < lane));
+    const int o = __shfl(key, j, 64);
+    rank += (j < n_mc) && ((o < key) || (o == key && j < lane));
   }
   if (!sort_layers) rank = lane;  // table in the order of the draws (runia_mc_stack_table_f32)
   if (lane >= n_mc) return;
@@ -225,18 +254,18 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
 #pragma unroll
     for (int c = 0; c < HW / 4; ++c) {
       float4 v;
-      v.x = (float)((keep >> slot_position<HT, WT>(4 * c)) & 1ull);
-      v.y = (float)((keep >> slot_position<HT, WT>(4 * c + 1)) & 1ull);
-      v.z = (float)((keep >> slot_position<HT, WT>(4 * c + 2)) & 1ull);
-      v.w = (float)((keep >> slot_position<HT, WT>(4 * c + 3)) & 1ull);
+      v.x = ((keep >> slot_position<HT, WT>(4 * c)) & 1ull) ? flag : 0.f;
+      v.y = ((keep >> slot_position<HT, WT>(4 * c + 1)) & 1ull) ? flag : 0.f;
+      v.z = ((keep >> slot_position<HT, WT>(4 * c + 2)) & 1ull) ? flag : 0.f;
+      v.w = ((keep >> slot_position<HT, WT>(4 * c + 3)) & 1ull) ? flag : 0.f;
       reinterpret_cast<float4*>(rec)[c] = v;
     }
   } else {
 #pragma unroll
-    for (int q = 0; q < HW; ++q) rec[q] = (float)((keep >> slot_position<HT, WT>(q)) & 1ull);
+    for (int q = 0; q < HW; ++q) rec[q] = ((keep >> slot_position<HT, WT>(q)) & 1ull) ? flag : 0.f;
   }
-  out[n_mc * HW + rank] = (float)cnt;
-  out[n_mc * (HW + 1) + rank] = 1.0f / (float)cnt;
+  out[n_mc * HW + rank] = zh;
+  out[n_mc * (HW + 1) + rank] = zl;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -274,8 +303,8 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
   if (zero_fill && c == 0) zero_fill[img] = 0.0;  // the accumulator of the score launch that follows (optional)
   if (c >= C) return;
   const float* mk = table + img * (int64_t)(n_mc * (HW + 2));  // wave-uniform
-  const float* dens = mk + n_mc * HW;
-  const float* rcps = dens + n_mc;
+  const float* zhs = mk + n_mc * HW;
+  const float* zls = zhs + n_mc;
   float u[HW];
   {
     // 16-byte loads at a 4*HW-byte lane stride: measured faster than staging the block's contiguous run
@@ -294,8 +323,9 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
   }
   constexpr bool w_pow2 = (WT & (WT - 1)) == 0, h_pow2 = (HT & (HT - 1)) == 0;
   // Power-of-two scalings are exact and commute with rounding (no overflow / underflow at feature-map magnitudes),
-  // so they are moved to where they cost least: (x*numel)/sum = x/(sum/numel) when numel = H*W is a power of two, and
-  // mean_H(mean_W(.)) = (sum over the map in the upstream order) * (1/(H*W)) when H and W are.
+  // so they are moved to where they cost nothing: with sum(bm) = 2^a * m, (x*numel)/sum = (x*numel/m) * 2^-a, the
+  // factor 2^-a sits on the keep flags (K0), and when numel = H*W is a power of two it cancels against the 1/(H*W) of
+  // mean_H(mean_W(.)): the sample is the plain sum of the quotients x/m over the kept positions, in upstream order.
   constexpr bool hw_pow2 = w_pow2 && h_pow2;
   if constexpr (!hw_pow2) {
 #pragma unroll
@@ -305,8 +335,12 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
   float z[NP];
   float q[PAIRS ? 1 : HW];   // quotients (x*numel)/sum ...
   f2 q2[PAIRS ? HW / 2 : 1];  // ... as row pairs in mask_slot order when H is even
-  float cur_den = -1.f;
-  bool bad = false;
+  float cur_zh = 1.0f;  // quotients start out as x / 1 (the m = 1 group comes first in the sorted table)
+#pragma unroll
+  for (int p = 0; p < HW; ++p) {
+    if constexpr (PAIRS) q2[mask_slot<HT, WT>(p) >> 1][mask_slot<HT, WT>(p) & 1] = u[p];
+    else q[p] = u[p];
+  }
   // G drop layers per trip of a rolled loop: G*HW keep flags live in SGPRs at a time (a fully unrolled loop
   // lets the compiler hoist all n_mc*HW scalar loads and spill them).  z is a shift register: constant indices
   // only, and the sample order is irrelevant to the sort that follows.
@@ -324,8 +358,8 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int sc = FULL ? s0 + g : ((s0 + g < n_mc) ? s0 + g : n_mc - 1);
-      dg[g] = dens[sc];
-      rg[g] = rcps[sc];
+      dg[g] = zhs[sc];
+      rg[g] = zls[sc];
 #pragma unroll
       for (int p = 0; p < HW; ++p) mg[g][p] = mk[sc * HW + p];
     }
@@ -334,17 +368,15 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
       const int s = s0 + g;
       znew[g] = INFINITY;
       if (FULL || s < n_mc) {
-        const float den = dg[g];
-        if (den != cur_den) {  // wave-uniform: every thread of the block works on the same image
-          const float r = hw_pow2 ? rg[g] * (float)HW : rg[g];
-          const float dd = hw_pow2 ? den * (1.0f / (float)HW) : den;
+        const float zh = dg[g], zl = rg[g];
+        if (zh != cur_zh) {  // wave-uniform: every thread of the block works on the same image
 #pragma unroll
           for (int p = 0; p < HW; ++p) {
-            const float qv = div_newton(u[p], dd, r);
+            const float qv = fmaf(u[p], zh, u[p] * zl);  // u / m, correctly rounded (div_consts.hpp)
             if constexpr (PAIRS) q2[mask_slot<HT, WT>(p) >> 1][mask_slot<HT, WT>(p) & 1] = qv;
             else q[p] = qv;
           }
-          cur_den = den;
+          cur_zh = zh;
         }
         const float* m = mg[g];
         float col;
@@ -389,11 +421,10 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
 #pragma unroll
           for (int yi = 1; yi < HT; ++yi) col += rm[torch_chain<HT>(yi)];
         }
-        if constexpr (hw_pow2 && PAIRS) znew[g] = col * (rW * rH);
+        if constexpr (hw_pow2 && PAIRS) znew[g] = col;
         else znew[g] = h_pow2 ? col * rH : div_newton(col, (float)HT, rH);
-        bad = bad || (den == 0.f);
-        if (z_out)  // optional copy of the MC samples (drop-layer order is the mask-sum order; tests only)
-          z_out[(img * n_mc + s) * (int64_t)C + c] = (den == 0.f) ? NAN : znew[g];
+        if (z_out)  // optional copy of the MC samples (drop-layer order is the table's; tests only)
+          z_out[(img * n_mc + s) * (int64_t)C + c] = znew[g];
       }
     }
 #pragma unroll
@@ -402,9 +433,16 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
     for (int g = 0; g < G; ++g) z[g] = znew[g];
   }
   if constexpr (ENTROPY) {
+    // A NaN sample - a fully dropped map (0*numel/0 upstream), a NaN or infinite activation - makes the entropy NaN
+    // upstream; the min/max sort below would silently drop it, so it is caught here: a sum is NaN iff a term is
+    // (+inf pads of a short column cannot cancel: the samples are finite otherwise).
+    float nan_probe = z[0];
+#pragma unroll
+    for (int s = 1; s < NP; ++s) nan_probe += z[s];
+    const bool bad = nan_probe != nan_probe;
     sort_asc<NP>(z);
     double res = const_term + inv_n * column_log_sum<NP, K, FULL>(z, n_mc, min_dist);
-    if (bad) res = NAN;  // a fully dropped map is 0*numel/0 = NaN upstream
+    if (bad) res = NAN;
     h[img * C + c] = res;
   }
 }
