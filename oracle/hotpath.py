@@ -423,13 +423,17 @@ def normalizer(x: np.ndarray) -> np.ndarray:
     return x / (np.linalg.norm(x, ord=2, axis=-1, keepdims=True) + 1e-10)
 
 
-def knn_kth_score(bank_normed: np.ndarray, queries: np.ndarray, k: int, chunk: int = 256) -> np.ndarray:
+def knn_kth_score(bank_normed: np.ndarray, queries: np.ndarray, k: int, chunk: int = 256, normalize: bool = True) -> np.ndarray:
     """``faiss.IndexFlatL2.add(bank); search(normalizer(q), k)`` then ``-D[:, -1]``
     (faiss-gpu==1.7.2, /root/reference/requirements.txt:4; call sites
     inference/postprocessors.py:396-397,419,850-851,878).  Published behaviour:
     squared L2 in float32, results sorted ascending, tail filled with FLT_MAX when
     ``k > ntotal``.  The reference searches one query at a time, for which faiss
-    accumulates ``sum((q-b)^2)`` directly (no norm expansion)."""
+    accumulates ``sum((q-b)^2)`` directly (no norm expansion).  faiss keeps a max-heap
+    initialised with FLT_MAX and inserts a distance only if it compares SMALLER than the
+    heap top (``CMax::cmp``), so a NaN or infinite distance is never inserted: it counts
+    as the FLT_MAX fill.  ``normalize=False`` skips the reference's ``normalizer`` on the
+    queries (checks of the raw ``runia_knn_kth_f32`` entry point)."""
     bank = np.ascontiguousarray(bank_normed, dtype=np.float32)
     m = bank.shape[0]
     n = queries.shape[0]
@@ -438,9 +442,11 @@ def knn_kth_score(bank_normed: np.ndarray, queries: np.ndarray, k: int, chunk: i
         out[:] = -np.float32(FLT_MAX)
         return out
     for s in range(0, n, chunk):
-        q = normalizer(queries[s : s + chunk])
+        q = normalizer(queries[s : s + chunk]) if normalize else queries[s : s + chunk]
         q = np.ascontiguousarray(np.asarray(q).astype(np.float32))
-        d = ((q[:, None, :] - bank[None, :, :]) ** 2).sum(axis=2, dtype=np.float32)
+        with np.errstate(invalid="ignore", over="ignore"):
+            d = ((q[:, None, :] - bank[None, :, :]) ** 2).sum(axis=2, dtype=np.float32)
+        d = np.where(np.isfinite(d), d, np.float32(FLT_MAX)).astype(np.float32)
         out[s : s + chunk] = -np.partition(d, k - 1, axis=1)[:, k - 1]
     return out
 

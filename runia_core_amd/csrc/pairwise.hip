@@ -32,7 +32,7 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict
     s = wave_sum_f32(s);
     if (lane == 0) {
       out[row] = s;
-      if (max_bits) atomicMax(max_bits, __float_as_uint(s));
+      if (max_bits && s < INFINITY) atomicMax(max_bits, __float_as_uint(s));  // NaN / inf rows do not set the range
     }
   }
 }
@@ -119,7 +119,9 @@ __global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__
         if (row < Q && col < M) {
           if constexpr (EPI == EPI_DIST) {
             const float d = (qn[row] + bnv) - 2.0f * acc[a][b][r];
-            dist[row * M + col] = fmaxf(d, 0.f);
+            // faiss keeps a max-heap initialised with FLT_MAX and inserts a distance only if it compares smaller: a NaN
+            // or infinite distance is never inserted, i.e. it counts as FLT_MAX (fmaxf alone would turn NaN into 0)
+            dist[row * M + col] = (d == d) ? fminf(fmaxf(d, 0.f), kFltMax) : kFltMax;
           } else {
             dist[row * M + col] = acc[a][b][r] + bnv;
           }
@@ -133,7 +135,7 @@ __global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__
 // faiss's one-query path accumulates sum((q-b)^2) directly; so every bank row whose approximate distance lies within
 // +-kRefineDelta of the selected value is re-measured with exact f32 differences and the k-th order statistic is
 // re-taken among them (rows below the window keep their rank; a copied bank row gives exactly 0 again).
-constexpr float kRefineDelta = 2e-5f;
+constexpr float kRefineRel = 5e-6f;  // refinement half-window relative to the row's range bound (2e-5 for unit vectors)
 constexpr int kMaxCand = 512;
 
 // Selection in two histogram passes.  The raw float bits of a row of distances share their top 8-9 bits (L2-normalised
@@ -142,7 +144,12 @@ constexpr int kMaxCand = 512;
 // linearly onto a 24-bit key over the row's range bound (sqrt|q|^2 + sqrt(max|b|^2))^2, 12 bits per pass, 4096
 // counters (1.03 ms, three reads).  A key bin is range / 2^24 wide; the refinement window (never narrower than two
 // bins) then restores the exact k-th value.
-__global__ __launch_bounds__(256) void kth_select_range_kernel(const float* __restrict__ dist, const float* __restrict__ q,
+// Every row is written on every path: -FLT_MAX for a query whose norm is not finite (all its distances are
+// incomparable, faiss returns its FLT_MAX fill), the approximate value before the refinement starts, the exact value
+// after it.  A window holding more than kMaxCand candidates (duplicated bank rows, distances crowded into a few key
+// bins by an outlier norm) takes the exact slow path: candidates are re-measured in place in the distance row (marked
+// by the sign bit) and the wanted order statistic is taken by an 8-bit radix select over their bit patterns.
+__global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict__ dist, const float* __restrict__ q,
                                                                 const float* __restrict__ bank,
                                                                 const float* __restrict__ qn,
                                                                 const unsigned* __restrict__ bn_max_bits,
@@ -156,8 +163,13 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(const float* __re
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float bmax = __uint_as_float(*bn_max_bits);
   for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
-    const float* drow = dist + row * M;
-    const float sq = sqrtf(qn[row]) + sqrtf(bmax);
+    float* drow = dist + row * M;
+    const float qnorm = qn[row];
+    if (!(qnorm < INFINITY)) {  // NaN or infinite query: every distance is FLT_MAX (wave-uniform branch)
+      if (tid == 0) score[row] = -kFltMax;
+      continue;
+    }
+    const float sq = sqrtf(qnorm) + sqrtf(bmax);
     const float range = sq * sq * 1.000001f + 1e-30f;
     const float scale = 16777216.0f / range;
     unsigned bin1 = 0, rank = (unsigned)k;
@@ -199,9 +211,14 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(const float* __re
       rank = sel_rank;
     }
     const unsigned key_sel = (bin1 << 12) | sel_bin;
+    if (key_sel == 16777215u) {  // the k-th distance is a FLT_MAX fill (fewer than k comparable bank rows)
+      if (tid == 0) score[row] = -kFltMax;
+      continue;
+    }
     const float approx = ((float)key_sel + 0.5f) / scale;
+    if (tid == 0) score[row] = -approx;  // never left unwritten; replaced by the exact value below
     // ---- refinement window (never narrower than two key bins) ----
-    const float delta = fmaxf(kRefineDelta, 2.0f / scale);
+    const float delta = fmaxf(kRefineRel * range, 2.0f / scale);
     const float lo = approx - delta, hi = approx + delta;
     unsigned below = 0;
     for (int64_t m = tid; m < M; m += 256) {
@@ -216,11 +233,54 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(const float* __re
     atomicAdd(&n_below, below);
     __syncthreads();
     const unsigned nc = n_cand;
-    if (nc > (unsigned)kMaxCand) {  // pathological tie cluster: keep the approximate value
-      if (tid == 0) score[row] = -approx;
+    const int want = k - (int)n_below;  // 1-based rank inside the window; 1 <= want <= nc by construction
+    if (want < 1 || (unsigned)want > nc) continue;  // (cannot happen; the approximate value stays)
+    const float* qr = q + row * D;
+    if (nc > (unsigned)kMaxCand) {
+      // exact slow path: re-measure every candidate in place (sign bit = "exact"), then radix-select among them
+      for (int64_t m = wave; m < M; m += 4) {
+        const float d = drow[m];  // wave-uniform
+        if (d >= lo && d <= hi) {
+          const float* br = bank + m * D;
+          float acc = 0.f;
+          for (int64_t i = lane; i < D; i += 64) {
+            const float df = qr[i] - br[i];
+            acc = fmaf(df, df, acc);
+          }
+          acc = wave_sum_f32(acc);
+          if (lane == 0) drow[m] = __uint_as_float(__float_as_uint(acc) | 0x80000000u);
+        }
+      }
+      __threadfence_block();
+      __syncthreads();
+      unsigned prefix = 0u, r = (unsigned)want;
+      for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0u;
+        __syncthreads();
+        const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int64_t m = tid; m < M; m += 256) {
+          const unsigned b = __float_as_uint(drow[m]);
+          if ((b & 0x80000000u) && (((b & 0x7FFFFFFFu) & himask) == prefix))
+            atomicAdd(&hist[((b & 0x7FFFFFFFu) >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned d8 = 0;
+          for (; d8 < 255; ++d8) {
+            if (r <= hist[d8]) break;
+            r -= hist[d8];
+          }
+          sel_bin = d8;
+          sel_rank = r;
+        }
+        __syncthreads();
+        prefix |= sel_bin << shift;
+        r = sel_rank;
+        __syncthreads();
+      }
+      if (tid == 0) score[row] = -__uint_as_float(prefix);
       continue;
     }
-    const float* qr = q + row * D;
     for (unsigned c = wave; c < nc; c += 4) {
       const float* br = bank + (int64_t)cand_idx[c] * D;
       float acc = 0.f;
@@ -232,7 +292,6 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(const float* __re
       if (lane == 0) cand_d[c] = acc;
     }
     __syncthreads();
-    const int want = k - (int)n_below;  // 1-based, 1 <= want <= nc by construction of the window
     for (unsigned c = tid; c < nc; c += 256) {
       const float dc = cand_d[c];
       int less = 0, leq = 0;

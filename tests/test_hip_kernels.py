@@ -256,6 +256,69 @@ def test_knn_k_larger_than_bank(hip):
     assert np.array_equal(got, np.full(10, -oracle.FLT_MAX, dtype=np.float32))
 
 
+def test_knn_adversarial_inputs_through_the_raw_entry(hip):
+    """runia_knn_kth_f32 called directly (no normaliser in front) on data built to break a histogram select:
+    1 000 copies of one bank row with k on and around the tie boundary, un-normalised rows spanning six orders of
+    magnitude, an outlier norm that crowds every other distance into a few key bins, NaN / infinite query and bank rows.
+    Every row must be written on every path (the output buffer is pre-filled with a sentinel) and equal the oracle."""
+    rng = np.random.default_rng(11)
+    d = 96
+    # (1) duplicated bank rows: the refinement window holds > 512 candidates -> exact slow path
+    base = rng.standard_normal((300, d)).astype(np.float32)
+    dup = np.repeat(base[:1], 1000, axis=0)
+    bank = np.concatenate([dup, base[1:]]).astype(np.float32)
+    q = np.concatenate([base[:1] + 0.01 * rng.standard_normal((6, d)).astype(np.float32),
+                        rng.standard_normal((10, d)).astype(np.float32)])
+    for k in (1, 2, 500, 999, 1000, 1001, 1100):
+        sentinel = torch.full((q.shape[0],), 123.0, device="cuda")
+        ws_bytes = hip.load_library().runia_knn_workspace_bytes(q.shape[0], bank.shape[0], d, k)
+        ws = torch.empty(ws_bytes // 4, dtype=torch.float32, device="cuda")
+        qd, bd = dev(q, torch.float32), dev(bank, torch.float32)
+        rc = hip.load_library().runia_knn_kth_f32(qd.data_ptr(), bd.data_ptr(), sentinel.data_ptr(), ws.data_ptr(), ws_bytes,
+                                                  q.shape[0], bank.shape[0], d, k, torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        got = sentinel.cpu().numpy()
+        assert not (got == 123.0).any(), f"k={k}: a row was left unwritten"
+        assert rel_err(got, oracle.knn_kth_score(bank, q, k, normalize=False)) < 1e-5, k
+    # (2) un-normalised, wide-range rows
+    scale = 10.0 ** rng.uniform(-3, 3, size=(2000, 1))
+    bank2 = (rng.standard_normal((2000, d)) * scale).astype(np.float32)
+    q2 = (rng.standard_normal((64, d)) * 10.0 ** rng.uniform(-3, 3, size=(64, 1))).astype(np.float32)
+    for k in (1, 50, 1999):
+        got = hip.knn_kth(dev(q2, torch.float32), dev(bank2, torch.float32), k).cpu().numpy()
+        assert rel_err(got, oracle.knn_kth_score(bank2, q2, k, normalize=False)) < 1e-5, k
+    # (3) one outlier norm: the range bound is set by it, all other distances share a handful of key bins
+    bank3 = rng.standard_normal((3000, d)).astype(np.float32) * 1e-2
+    bank3[7] = 1e4
+    q3 = rng.standard_normal((32, d)).astype(np.float32) * 1e-2
+    for k in (1, 50, 2999, 3000):
+        got = hip.knn_kth(dev(q3, torch.float32), dev(bank3, torch.float32), k).cpu().numpy()
+        assert rel_err(got, oracle.knn_kth_score(bank3, q3, k, normalize=False)) < 1e-5, k
+    # (4) NaN / infinite rows: faiss never inserts an incomparable distance -> they count as its FLT_MAX fill
+    bank4 = rng.standard_normal((200, d)).astype(np.float32)
+    bank4[3, 5] = np.nan
+    bank4[9, 0] = np.inf
+    q4 = rng.standard_normal((8, d)).astype(np.float32)
+    q4[1, 2] = np.nan
+    q4[5, :] = np.inf
+    for k in (1, 50, 198, 199, 200):
+        got = hip.knn_kth(dev(q4, torch.float32), dev(bank4, torch.float32), k).cpu().numpy()
+        exp = oracle.knn_kth_score(bank4, q4, k, normalize=False)
+        assert got[1] == -oracle.FLT_MAX and got[5] == -oracle.FLT_MAX
+        assert np.isfinite(got).all() and rel_err(got, exp) < 1e-5, k
+    # through the postprocessor: a NaN feature row scores -FLT_MAX, the others are untouched
+    from runia_core_amd.inference import KNNLatentSpace
+
+    knn = KNNLatentSpace()
+    knn.setup(rng.standard_normal((500, 32)).astype(np.float32))
+    xt = rng.standard_normal((20, 32)).astype(np.float32)
+    clean = knn.postprocess(xt)
+    xt2 = xt.copy()
+    xt2[4, 0] = np.nan
+    dirty = knn.postprocess(xt2)
+    assert dirty[4] == -oracle.FLT_MAX and np.array_equal(np.delete(dirty, 4), np.delete(clean, 4))
+
+
 def test_knn_all_baselines_mean(hip, ref_vectors):
     from test_oracle_goldens import _all_baselines_inputs
 

@@ -44,6 +44,14 @@ __global__ void bench(float* out, unsigned long long* cyc) {
       if constexpr (KIND == 17) asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
       if constexpr (KIND == 18) asm volatile("v_cmp_lt_f64 vcc, %0, %1" : : "v"(d[i]), "v"(db) : "vcc");
       if constexpr (KIND == 19) asm volatile("v_cndmask_b32 %0, %0, %1, vcc" : "+v"(a[i]) : "v"(b) : "vcc");
+      if constexpr (KIND == 20) asm volatile("v_min_u32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if constexpr (KIND == 21) asm volatile("v_max_i32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if constexpr (KIND == 22) asm volatile("v_or_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if constexpr (KIND == 23) asm volatile("v_xor_b32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if constexpr (KIND == 24) asm volatile("v_sub_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if constexpr (KIND == 25) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+      if constexpr (KIND == 26) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[i]) : "v"(d[i]));
+      if constexpr (KIND == 27) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -70,8 +78,10 @@ int run(const char* name, float* buf, unsigned long long* cyc) {
     float ms; CHECK(hipEventElapsedTime(&ms, e0, e1));
     unsigned long long c; CHECK(hipMemcpy(&c, cyc, 8, hipMemcpyDeviceToHost));
     // in-kernel cycles of one wave for ITER*16 instructions; per SIMD `wps` waves ran concurrently
+    // in-kernel shader cycles of one wave for its ITER*16 instructions; `wps` waves share the SIMD, so the SIMD retires one
+    // instruction every c / (ITER*16*wps) cycles once it is saturated (wps >= 2)
     const double per_instr_per_simd = (double)c / (double)(ITER * 16) / wps;
-    printf("  wps=%d: %5.2f cyc/instr/SIMD (%.3f ms)", wps, per_instr_per_simd, ms);
+    printf("  wps=%d: %5.2f (%.3f ms)", wps, per_instr_per_simd, ms);
   }
   printf("\n");
   return 0;
@@ -86,5 +96,7 @@ int main() {
   run<4>("v_add_f64", buf, cyc); run<5>("v_max_f64", buf, cyc); run<6>("v_min_f64", buf, cyc); run<7>("v_mul_f64", buf, cyc);
   run<8>("v_fma_f64", buf, cyc); run<9>("v_cvt_f64_f32", buf, cyc); run<14>("v_log_f32", buf, cyc); run<15>("v_rcp_f64", buf, cyc);
   run<16>("v_frexp_mant_f64", buf, cyc); run<18>("v_cmp_lt_f64", buf, cyc); run<19>("v_cndmask_b32", buf, cyc);
+  run<20>("v_min_u32", buf, cyc); run<21>("v_max_i32", buf, cyc); run<27>("v_min3_u32", buf, cyc); run<22>("v_or_b32", buf, cyc);
+  run<23>("v_xor_b32", buf, cyc); run<24>("v_sub_f32", buf, cyc); run<25>("v_mul_f32", buf, cyc); run<26>("v_cvt_f32_f64", buf, cyc);
   return 0;
 }
