@@ -242,6 +242,19 @@ int runia_covariance_f64(const double* x, double* mean, double* cov, void* works
 int runia_covariance_f32in(const float* x, double* mean, double* cov, void* workspace,
                            size_t workspace_bytes, int64_t N, int64_t D, runia_stream_t stream);
 
+/* ---- f2  metrics after the path (SURVEY 8f "next #2") -------------------------------------- *
+ * AUROC, FPR@95 and AUPR of in-distribution (positive) against out-of-distribution scores as get_auroc_results
+ * computes them (evaluation/metrics.py:37-100: torchmetrics binary auroc / roc / precision_recall_curve +
+ * sklearn.metrics.auc): sigmoid in the dtype of the scores when any score is outside [0, 1], descending sort, one
+ * curve point per run of equal scores, float32 curve points and trapezoid terms.  Device-resident: radix sort + scans.
+ *   ind_scores [n_ind], ood_scores [n_ood] (device), out3 [3] f64 (device) = {auroc, fpr@95, aupr} (float32 values);
+ *   workspace: runia_ood_metrics_workspace_bytes(n_ind + n_ood) bytes, 256-byte aligned. */
+size_t runia_ood_metrics_workspace_bytes(int64_t n_total);
+int runia_ood_metrics_f64(const double* ind_scores, int64_t n_ind, const double* ood_scores, int64_t n_ood,
+                          double* out3, void* workspace, size_t workspace_bytes, runia_stream_t stream);
+int runia_ood_metrics_f32(const float* ind_scores, int64_t n_ind, const float* ood_scores, int64_t n_ood,
+                          double* out3, void* workspace, size_t workspace_bytes, runia_stream_t stream);
+
 /* ---- f4  remaining logits/features postprocessors (SURVEY 8f "next #4") ------- *
  * runia_linear_f32: out [N, C] = min(x, clip_max) @ w.T + bias on the f32 matrix cores - the final linear layer
  *   that ReAct / ASH / DICE re-apply to (transformed) features (inference/postprocessors.py:1193, 1441, 1466;

@@ -500,13 +500,18 @@ def auroc_fpr95_aupr(ind_scores: np.ndarray, ood_scores: np.ndarray):
     """evaluation/metrics.py:61-81.  InD = positive class.  torchmetrics applies a
     sigmoid when any score is outside [0,1] (monotone, but saturates), and returns
     float32 curves; both are reproduced.  Returns (auroc, fpr@95, aupr) as floats."""
-    scores = np.concatenate([np.ravel(ind_scores), np.ravel(ood_scores)]).astype(np.float64)
+    # np.vstack keeps float32 when both score sets are float32 (energy / msp / knn / ... scores): torchmetrics then
+    # applies its sigmoid in float32; every other combination is float64
+    both_f32 = np.asarray(ind_scores).dtype == np.float32 and np.asarray(ood_scores).dtype == np.float32
+    dt = np.float32 if both_f32 else np.float64
+    scores = np.concatenate([np.ravel(ind_scores), np.ravel(ood_scores)]).astype(dt)
     labels = np.concatenate(
         [np.ones(np.size(ind_scores), dtype=np.int64), np.zeros(np.size(ood_scores), dtype=np.int64)]
     )
     if not np.all((scores >= 0) & (scores <= 1)):
         with np.errstate(over="ignore"):
-            scores = 1.0 / (1.0 + np.exp(-scores))
+            scores = (dt(1.0) / (dt(1.0) + np.exp(-scores))).astype(dt)
+    scores = scores.astype(np.float64)
     fps, tps, _ = binary_clf_curve(scores, labels)
     # roc: leading (0,0), float32 ratios
     tps_r = np.concatenate([[0], tps]).astype(np.float32)

@@ -98,6 +98,9 @@ _SIGNATURES = {
         [c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int,
          c_int, c_double, c_int, c_int, c_double, c_void_p],
     ),
+    "runia_ood_metrics_workspace_bytes": (c_size_t, [c_int64]),
+    "runia_ood_metrics_f64": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "runia_ood_metrics_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "runia_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "runia_ash_s_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "runia_gen_score_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
@@ -702,3 +705,22 @@ def proj_sq_score(h: torch.Tensor, packed_m: torch.Tensor, c: torch.Tensor, r: i
                                        ws_bytes, nrow, d, int(r), _stream()),
            "runia_proj_sq_score_f64")
     return s
+
+
+def ood_metrics(ind_scores: torch.Tensor, ood_scores: torch.Tensor) -> torch.Tensor:
+    """Device scores (both f32 or both f64) -> device tensor [3] f64 = (auroc, fpr@95, aupr), InD = positive class
+    (``get_auroc_results`` of the reference, evaluation/metrics.py:37-100).  Stream-ordered, no synchronisation."""
+    lib = load_library()
+    require_gpu()
+    assert ind_scores.is_cuda and ood_scores.is_cuda and ind_scores.dtype == ood_scores.dtype
+    assert ind_scores.dtype in (torch.float32, torch.float64)
+    a, b = ind_scores.reshape(-1).contiguous(), ood_scores.reshape(-1).contiguous()
+    n = a.numel() + b.numel()
+    ws_bytes = int(lib.runia_ood_metrics_workspace_bytes(n))
+    ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=a.device)
+    off = (-ws.data_ptr()) % 256
+    out = torch.empty(3, dtype=torch.float64, device=a.device)
+    fn = lib.runia_ood_metrics_f64 if a.dtype == torch.float64 else lib.runia_ood_metrics_f32
+    _check(fn(a.data_ptr(), a.numel(), b.data_ptr(), b.numel(), out.data_ptr(), ws.data_ptr() + off, ws_bytes, _stream()),
+           "runia_ood_metrics")
+    return out

@@ -1,0 +1,380 @@
+// f2: the metrics step after the scoring path - AUROC / FPR@95 / AUPR of an in-distribution (positive) and an
+// out-of-distribution (negative) score set, as get_auroc_results computes them through torchmetrics' binary
+// auroc / roc / precision_recall_curve and sklearn.metrics.auc (reference evaluation/metrics.py:37-100; torchmetrics'
+// _binary_clf_curve: descending sort, one curve point per run of equal scores, cumulative true / false positives).
+// Everything stays on the device: a stable LSD radix sort of the 64-bit keys (8 passes of 8 bits), a scan of the labels and
+// of the run ends, and the trapezoid sums.
+//
+// Reference behaviour that is reproduced on purpose (the oracle pins it with the reference's goldens):
+//   * if any score lies outside [0, 1] (or is NaN) every score goes through a sigmoid first - in the dtype of the
+//     scores (f64 scores: f64 sigmoid; f32 scores: f32 sigmoid).  It is monotone but saturates: f64 scores below -745
+//     all become 0.0 and tie;
+//   * curve points are float32 (tps, fps converted to f32 and divided in f32), the trapezoid terms are formed in f32.
+//     The reference then adds them in f32; here they are accumulated in f64 (differences ~1e-7, the test tolerance).
+#include "common.hpp"
+
+namespace {
+
+constexpr int kTile = 4096;       // elements per workgroup in every pass
+constexpr int kItems = kTile / 256;
+
+__device__ __forceinline__ uint64_t sortable_desc(double v) {
+  // ascending order of the key == descending order of v (NaN keys sort first, as a "largest" value)
+  uint64_t b = (uint64_t)__double_as_longlong(v);
+  b = (b >> 63) ? ~b : (b | 0x8000000000000000ull);  // ascending-sortable
+  return ~b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void range_check_kernel(const T* __restrict__ ind, int64_t n_ind,
+                                                          const T* __restrict__ ood, int64_t n_ood,
+                                                          unsigned* __restrict__ any_outside) {
+  bool bad = false;
+  const int64_t n = n_ind + n_ood;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const T v = (i < n_ind) ? ind[i] : ood[i - n_ind];
+    bad = bad || !(v >= (T)0 && v <= (T)1);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(any_outside, 1u);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void make_keys_kernel(const T* __restrict__ ind, int64_t n_ind,
+                                                        const T* __restrict__ ood, int64_t n_ood,
+                                                        const unsigned* __restrict__ any_outside,
+                                                        uint64_t* __restrict__ keys, uint8_t* __restrict__ labels) {
+  const bool squash = *any_outside != 0u;
+  const int64_t n = n_ind + n_ood;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    T v = (i < n_ind) ? ind[i] : ood[i - n_ind];
+    if (squash) v = (T)1 / ((T)1 + exp(-v));  // torch.sigmoid in the dtype of the scores
+    keys[i] = sortable_desc((double)v);
+    labels[i] = (i < n_ind) ? 1 : 0;
+  }
+}
+
+// ---- LSD radix sort, one 8-bit digit per pass ----------------------------------------------------------------
+__global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restrict__ keys, int64_t n, int shift,
+                                                         unsigned* __restrict__ table, unsigned nblocks) {
+  __shared__ unsigned hist[256];
+  hist[threadIdx.x] = 0u;
+  __syncthreads();
+  const int64_t t0 = (int64_t)blockIdx.x * kTile;
+#pragma unroll
+  for (int c = 0; c < kItems; ++c) {
+    const int64_t i = t0 + c * 256 + threadIdx.x;
+    if (i < n) atomicAdd(&hist[(unsigned)(keys[i] >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  table[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];  // digit-major: scan order = (digit, block)
+}
+
+// exclusive scan of `len` unsigned counters in place, one workgroup of 1024 threads
+__global__ __launch_bounds__(1024) void scan_u32_kernel(unsigned* __restrict__ a, int64_t len) {
+  __shared__ unsigned wsum[16];
+  __shared__ unsigned carry_s;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  if (tid == 0) carry_s = 0u;
+  __syncthreads();
+  for (int64_t base = 0; base < len; base += 1024) {
+    const int64_t i = base + tid;
+    const unsigned v = (i < len) ? a[i] : 0u;
+    unsigned x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    unsigned woff = 0u;
+    for (int w = 0; w < wave; ++w) woff += wsum[w];
+    const unsigned carry = carry_s;
+    if (i < len) a[i] = carry + woff + x - v;
+    __syncthreads();
+    if (tid == 1023) carry_s = carry + woff + x;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
+                                                            const uint8_t* __restrict__ lab_in,
+                                                            uint64_t* __restrict__ keys_out, uint8_t* __restrict__ lab_out,
+                                                            int64_t n, int shift, const unsigned* __restrict__ table,
+                                                            unsigned nblocks) {
+  __shared__ unsigned base[256];       // next free global slot of every digit for this workgroup
+  __shared__ unsigned wcnt[4][256];    // per-wave digit counts of the current chunk
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  base[tid] = table[(size_t)tid * nblocks + blockIdx.x];
+#pragma unroll
+  for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0u;
+  __syncthreads();
+  const int64_t t0 = (int64_t)blockIdx.x * kTile;
+  const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+  for (int c = 0; c < kItems; ++c) {  // chunks in order: the pass is stable
+    const int64_t i = t0 + c * 256 + tid;
+    const bool valid = i < n;
+    const uint64_t key = valid ? keys_in[i] : 0ull;
+    const unsigned d = (unsigned)(key >> shift) & 255u;
+    uint64_t same = __ballot(valid);  // lanes of this wave holding the same digit
+#pragma unroll
+    for (int b = 0; b < 8; ++b) {
+      const uint64_t bal = __ballot((d >> b) & 1u);
+      same &= ((d >> b) & 1u) ? bal : ~bal;
+    }
+    const unsigned rank_in_wave = (unsigned)__popcll(same & lt_mask);
+    if (valid && rank_in_wave == 0u) wcnt[wave][d] = (unsigned)__popcll(same);
+    __syncthreads();
+    if (valid) {
+      unsigned off = base[d] + rank_in_wave;
+      for (int w = 0; w < wave; ++w) off += wcnt[w][d];
+      keys_out[off] = key;
+      lab_out[off] = lab_in[i];
+    }
+    __syncthreads();
+    base[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+#pragma unroll
+    for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0u;
+    __syncthreads();
+  }
+}
+
+// ---- curve: cumulative positives and the previous run end of every run end ------------------------------------------------
+// tile pass 1: (label sum, index of the last run end) of every tile
+__global__ __launch_bounds__(256) void tile_summary_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
+                                                           int64_t n, unsigned* __restrict__ tile_sum,
+                                                           int* __restrict__ tile_end) {
+  __shared__ unsigned ssum[4];
+  __shared__ int send[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t t0 = (int64_t)blockIdx.x * kTile;
+  unsigned s = 0u;
+  int e = -1;
+#pragma unroll
+  for (int c = 0; c < kItems; ++c) {
+    const int64_t i = t0 + c * 256 + tid;
+    if (i < n) {
+      s += lab[i];
+      if (i == n - 1 || keys[i] != keys[i + 1]) e = (int)i;  // indices ascend with c
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    e = max(e, __shfl_xor(e, o, 64));
+  }
+  if (lane == 0) { ssum[wave] = s; send[wave] = e; }
+  __syncthreads();
+  if (tid == 0) {
+    tile_sum[blockIdx.x] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+    tile_end[blockIdx.x] = max(max(send[0], send[1]), max(send[2], send[3]));
+  }
+}
+
+// exclusive scan of the tile summaries (sum: +, end: max), single workgroup, sequential over the tiles
+__global__ void tile_scan_kernel(unsigned* __restrict__ tile_sum, int* __restrict__ tile_end, int64_t ntiles) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  unsigned s = 0u;
+  int e = -1;
+  for (int64_t t = 0; t < ntiles; ++t) {
+    const unsigned ts = tile_sum[t];
+    const int te = tile_end[t];
+    tile_sum[t] = s;
+    tile_end[t] = e;
+    s += ts;
+    e = max(e, te);
+  }
+}
+
+// tile pass 2: tps[i] (inclusive) for every element; prev_end[i] for every run end
+__global__ __launch_bounds__(256) void tile_prefix_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
+                                                          int64_t n, const unsigned* __restrict__ tile_sum,
+                                                          const int* __restrict__ tile_end, unsigned* __restrict__ tps,
+                                                          int* __restrict__ prev_end) {
+  __shared__ unsigned wsum[4];
+  __shared__ int wend[4];
+  __shared__ unsigned carry_sum;
+  __shared__ int carry_end;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int64_t t0 = (int64_t)blockIdx.x * kTile;
+  if (tid == 0) { carry_sum = tile_sum[blockIdx.x]; carry_end = tile_end[blockIdx.x]; }
+  __syncthreads();
+  for (int c = 0; c < kItems; ++c) {
+    const int64_t i = t0 + c * 256 + tid;
+    const bool valid = i < n;
+    const unsigned l = valid ? lab[i] : 0u;
+    const bool is_end = valid && (i == n - 1 || keys[i] != keys[i + 1]);
+    unsigned x = l;
+    int m = is_end ? (int)i : -1;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned y = __shfl_up(x, o, 64);
+      const int q = __shfl_up(m, o, 64);
+      if (lane >= o) { x += y; m = max(m, q); }
+    }
+    if (lane == 63) { wsum[wave] = x; wend[wave] = m; }
+    __syncthreads();
+    unsigned woff = 0u;
+    int wmax = -1;
+    for (int w = 0; w < wave; ++w) { woff += wsum[w]; wmax = max(wmax, wend[w]); }
+    const unsigned cs = carry_sum;
+    const int ce = carry_end;
+    // exclusive maximum of the run-end indices before i
+    int excl = __shfl_up(m, 1, 64);
+    if (lane == 0) excl = -1;
+    excl = max(max(excl, wmax), ce);
+    if (valid) {
+      tps[i] = cs + woff + x;
+      if (is_end) prev_end[i] = excl;
+    }
+    __syncthreads();
+    if (tid == 255) {
+      carry_sum = cs + woff + x;
+      carry_end = max(max(m, wmax), ce);
+    }
+    __syncthreads();
+  }
+}
+
+struct MetricsAccum {
+  double roc_sum;            // sum of (fpr_j - fpr_{j-1}) * (tpr_j + tpr_{j-1})   (f32 terms)
+  double pr_sum;             // sum of (recall_{j-1} - recall_j) * (precision_{j-1} + precision_j) and the end-point term
+  unsigned long long fpr95_idx;  // smallest run-end index with tpr >= 0.95
+};
+
+__global__ __launch_bounds__(256) void curve_terms_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                          const unsigned* __restrict__ tps, const int* __restrict__ prev_end,
+                                                          MetricsAccum* __restrict__ acc) {
+  __shared__ double sroc[4], spr[4];
+  __shared__ unsigned long long sidx[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float P = (float)tps[n - 1];
+  const float Nn = (float)((unsigned)n - tps[n - 1]);
+  double roc = 0.0, pr = 0.0;
+  unsigned long long first = ~0ull;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+    if (!(i == n - 1 || keys[i] != keys[i + 1])) continue;
+    const int p = prev_end[i];
+    const float tp = (float)tps[i], fp = (float)((unsigned)(i + 1) - tps[i]);
+    const float tp0 = (p < 0) ? 0.f : (float)tps[p], fp0 = (p < 0) ? 0.f : (float)((unsigned)(p + 1) - tps[p]);
+    const float tpr = tp / P, fpr = fp / Nn, tpr0 = tp0 / P, fpr0 = fp0 / Nn;
+    roc += (double)((fpr - fpr0) * (tpr + tpr0));
+    if (tpr >= 0.95f) first = min(first, (unsigned long long)i);
+    // precision-recall points: this run end and the one before it (the first run end pairs with the (1, 0) end point)
+    const float prec = tp / (tp + fp), rec = tpr;
+    const float prec0 = (p < 0) ? 1.0f : tp0 / (tp0 + fp0), rec0 = (p < 0) ? 0.0f : tpr0;
+    pr += (double)((rec0 - rec) * (prec0 + prec));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    roc += shfl_xor_f64(roc, o);
+    pr += shfl_xor_f64(pr, o);
+    const unsigned lo = __shfl_xor((unsigned)first, o, 64), hi = __shfl_xor((unsigned)(first >> 32), o, 64);
+    first = min(first, ((unsigned long long)hi << 32) | lo);
+  }
+  if (lane == 0) { sroc[wave] = roc; spr[wave] = pr; sidx[wave] = first; }
+  __syncthreads();
+  if (tid == 0) {
+    unsafeAtomicAdd(&acc->roc_sum, ((sroc[0] + sroc[1]) + sroc[2]) + sroc[3]);
+    unsafeAtomicAdd(&acc->pr_sum, ((spr[0] + spr[1]) + spr[2]) + spr[3]);
+    atomicMin(&acc->fpr95_idx, min(min(sidx[0], sidx[1]), min(sidx[2], sidx[3])));
+  }
+}
+
+__global__ void finalize_kernel(const MetricsAccum* __restrict__ acc, const unsigned* __restrict__ tps, int64_t n,
+                                double* __restrict__ out) {
+  if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  const float Nn = (float)((unsigned)n - tps[n - 1]);
+  out[0] = (double)(float)(acc->roc_sum * 0.5);                // trapz(tpr, fpr), reported as float32 like torchmetrics
+  const unsigned long long i = acc->fpr95_idx;
+  out[1] = (i == ~0ull) ? NAN : (double)((float)((unsigned)(i + 1) - tps[i]) / Nn);
+  // pr_sum = sum over curve pairs of (recall_prev - recall_cur) * (precision_prev + precision_cur) <= 0, the first run end
+  // paired with torchmetrics' (precision 1, recall 0) end point: twice trapz(precision, recall) along the decreasing
+  // recall axis; sklearn.metrics.auc flips the sign of a decreasing axis
+  out[2] = (double)(float)(-(acc->pr_sum * 0.5));
+}
+
+size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+struct Layout {
+  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, tile_sum, tile_end, accum, flag, total;
+  unsigned nblocks;
+};
+
+Layout make_layout(int64_t n) {
+  Layout L;
+  L.nblocks = (unsigned)((n + kTile - 1) / kTile);
+  size_t o = 0;
+  L.keys_a = o; o += align256((size_t)n * 8);
+  L.keys_b = o; o += align256((size_t)n * 8);
+  L.lab_a = o; o += align256((size_t)n);
+  L.lab_b = o; o += align256((size_t)n);
+  L.tps = o; o += align256((size_t)n * 4);
+  L.prev_end = o; o += align256((size_t)n * 4);
+  L.table = o; o += align256((size_t)256 * L.nblocks * 4);
+  L.tile_sum = o; o += align256((size_t)L.nblocks * 4);
+  L.tile_end = o; o += align256((size_t)L.nblocks * 4);
+  L.accum = o; o += align256(sizeof(MetricsAccum));
+  L.flag = o; o += 256;
+  L.total = o;
+  return L;
+}
+
+template <typename T>
+int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double* out3, void* workspace,
+                size_t workspace_bytes, runia_stream_t stream) {
+  if (n_ind < 1 || n_ood < 1 || n_ind + n_ood >= (1ll << 31)) return RUNIA_E_INVALID;
+  if (!ind || !ood || !out3) return RUNIA_E_INVALID;
+  const int64_t n = n_ind + n_ood;
+  const Layout L = make_layout(n);
+  if (!workspace || workspace_bytes < L.total || (((uintptr_t)workspace) & 255) != 0) return RUNIA_E_WORKSPACE;
+  char* w = reinterpret_cast<char*>(workspace);
+  uint64_t* keys[2] = {reinterpret_cast<uint64_t*>(w + L.keys_a), reinterpret_cast<uint64_t*>(w + L.keys_b)};
+  uint8_t* labs[2] = {reinterpret_cast<uint8_t*>(w + L.lab_a), reinterpret_cast<uint8_t*>(w + L.lab_b)};
+  unsigned* tps = reinterpret_cast<unsigned*>(w + L.tps);
+  int* prev_end = reinterpret_cast<int*>(w + L.prev_end);
+  unsigned* table = reinterpret_cast<unsigned*>(w + L.table);
+  unsigned* tile_sum = reinterpret_cast<unsigned*>(w + L.tile_sum);
+  int* tile_end = reinterpret_cast<int*>(w + L.tile_end);
+  MetricsAccum* acc = reinterpret_cast<MetricsAccum*>(w + L.accum);
+  unsigned* flag = reinterpret_cast<unsigned*>(w + L.flag);
+  hipStream_t s = as_stream(stream);
+  if (hipMemsetAsync(flag, 0, 4, s) != hipSuccess) return RUNIA_E_LAUNCH;
+  if (hipMemsetAsync(acc, 0, 16, s) != hipSuccess) return RUNIA_E_LAUNCH;
+  if (hipMemsetAsync(&acc->fpr95_idx, 0xFF, 8, s) != hipSuccess) return RUNIA_E_LAUNCH;
+  const unsigned sgrid = runia_stream_grid(n, 256);
+  range_check_kernel<T><<<sgrid, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag);
+  make_keys_kernel<T><<<sgrid, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, keys[0], labs[0]);
+  int cur = 0;
+  for (int pass = 0; pass < 8; ++pass) {
+    const int shift = 8 * pass;
+    radix_hist_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], n, shift, table, L.nblocks);
+    scan_u32_kernel<<<1, 1024, 0, s>>>(table, (int64_t)256 * L.nblocks);
+    radix_scatter_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], labs[cur], keys[cur ^ 1], labs[cur ^ 1], n, shift, table,
+                                                   L.nblocks);
+    cur ^= 1;
+  }
+  tile_summary_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], labs[cur], n, tile_sum, tile_end);
+  tile_scan_kernel<<<1, 64, 0, s>>>(tile_sum, tile_end, L.nblocks);
+  tile_prefix_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], labs[cur], n, tile_sum, tile_end, tps, prev_end);
+  curve_terms_kernel<<<sgrid, 256, 0, s>>>(keys[cur], n, tps, prev_end, acc);
+  finalize_kernel<<<1, 64, 0, s>>>(acc, tps, n, out3);
+  return runia_check_launch();
+}
+
+}  // namespace
+
+extern "C" size_t runia_ood_metrics_workspace_bytes(int64_t n_total) {
+  if (n_total <= 0) return 0;
+  return make_layout(n_total).total;
+}
+
+extern "C" int runia_ood_metrics_f64(const double* ind_scores, int64_t n_ind, const double* ood_scores, int64_t n_ood,
+                                     double* out3, void* workspace, size_t workspace_bytes, runia_stream_t stream) {
+  return ood_metrics<double>(ind_scores, n_ind, ood_scores, n_ood, out3, workspace, workspace_bytes, stream);
+}
+
+extern "C" int runia_ood_metrics_f32(const float* ind_scores, int64_t n_ind, const float* ood_scores, int64_t n_ood,
+                                     double* out3, void* workspace, size_t workspace_bytes, runia_stream_t stream) {
+  return ood_metrics<float>(ind_scores, n_ind, ood_scores, n_ood, out3, workspace, workspace_bytes, stream);
+}

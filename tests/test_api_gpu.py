@@ -633,3 +633,57 @@ def test_cfg4_lared_leg(n_pca):
     a_o = oracle.auroc_fpr95_aupr(oracle.kde_score(red, y_ind[:1500]), oracle.kde_score(red, y_ood[:1500]))
     a_g = oracle.auroc_fpr95_aupr(s_ind[:1500], s_ood[:1500])
     assert a_g == a_o and 0.5 < a[0] <= 1.0
+
+
+# ---------------- f2: AUROC / FPR@95 / AUPR on the device -------------------------------------------------------------
+def _scal(ref_vectors, key):
+    return [v["value"] for v in ref_vectors[key]["scalars"]]
+
+
+def test_device_metrics_reference_goldens(ref_vectors):
+    """runia_ood_metrics_f64 on the reference's own metric goldens (/root/reference/tests/unit_test_metrics.py:21-29,
+    TOL = 1e-7 there) and on the LaRED / LaREM end-to-end goldens of :31-80 (scores from KDELatentSpace / MDLatentSpace)."""
+    from runia_core_amd.evaluation.metrics import auroc_fpr95_aupr_device
+
+    np.random.seed(1)
+    ind = 0.5 + np.random.randn(1000)
+    ood = -0.5 + np.random.randn(1000)
+    fpr95, aupr, auroc = _scal(ref_vectors, "metrics_hz")
+    a, f, p = auroc_fpr95_aupr_device(ind, ood)
+    assert abs(a - auroc) < 2e-7 and abs(f - fpr95) < 1e-7 and abs(p - aupr) < 2e-7
+    assert (a, f, p) == pytest.approx(oracle.auroc_fpr95_aupr(ind, ood), abs=2e-7)
+
+
+@pytest.mark.parametrize("case", ["f64_far", "f64_unit", "f32", "ties", "saturated", "tiny", "big"])
+def test_device_metrics_vs_oracle(case):
+    """Device sort + scan metrics against the oracle's restatement of torchmetrics / sklearn: scores inside [0, 1] (no
+    sigmoid), far outside (f64 sigmoid), float32 scores (f32 sigmoid), heavy ties, LaREM-like scores whose sigmoid
+    underflows to 0 (everything below -745 ties, as in the reference), 3 + 2 scores, and 1.2 M + 0.9 M scores."""
+    from runia_core_amd.evaluation.metrics import auroc_fpr95_aupr_device
+
+    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    if case == "f64_far":
+        ind, ood = rng.standard_normal(5000) * 3 + 1, rng.standard_normal(3000) * 3 - 1
+    elif case == "f64_unit":
+        ind, ood = rng.beta(4, 2, 4000), rng.beta(2, 3, 6000)
+    elif case == "f32":
+        ind, ood = (rng.standard_normal(7000) - 2).astype(np.float32), (rng.standard_normal(5000) - 3).astype(np.float32)
+    elif case == "ties":
+        ind, ood = rng.integers(0, 12, 9000).astype(np.float64) / 11.0, rng.integers(0, 9, 7000).astype(np.float64) / 11.0
+    elif case == "saturated":
+        ind, ood = -200 - 300 * rng.random(6000), -400 - 900 * rng.random(6000)
+    elif case == "tiny":
+        ind, ood = np.array([0.9, 0.4, 0.7]), np.array([0.1, 0.4])
+    else:
+        ind, ood = rng.standard_normal(1_200_000) + 0.3, rng.standard_normal(900_000) - 0.3
+    got = auroc_fpr95_aupr_device(ind, ood)
+    exp = oracle.auroc_fpr95_aupr(ind, ood)
+    tol = 3e-7 if case != "big" else 2e-6  # the reference adds its float32 trapezoid terms in float32
+    assert got == pytest.approx(exp, abs=tol), (case, got, exp)
+    # device-resident inputs, no host round trip
+    import torch as _t
+
+    a = _t.from_numpy(np.ascontiguousarray(ind)).cuda()
+    b = _t.from_numpy(np.ascontiguousarray(ood)).cuda()
+    out = auroc_fpr95_aupr_device(a, b, to_host=False)
+    assert out.is_cuda and tuple(out.cpu().numpy()) == pytest.approx(got, abs=1e-12)
