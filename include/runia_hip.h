@@ -242,6 +242,25 @@ int runia_covariance_f64(const double* x, double* mean, double* cov, void* works
 int runia_covariance_f32in(const float* x, double* mean, double* cov, void* workspace,
                            size_t workspace_bytes, int64_t N, int64_t D, runia_stream_t stream);
 
+/* Symmetric eigen-decomposition without a vendor solver: two-sided cyclic Jacobi, f64, parallel ordering.  What
+ * scipy.linalg.pinvh (EmpiricalCovariance.fit, inference/postprocessors.py:213-220, inference/funcs.py:52-66), the
+ * "covariance_eigh" / "full" PCA fit (dimensionality_reduction.py:70-71) and eigen_score (llm_uncertainty/scores.py:49-66)
+ * need.  runia_eigh_init_f64: V = I, matrix norm.  runia_eigh_sweep_f64: ONE sweep in place (A -> J^T A J, V -> V J);
+ * `rotations` (device, unsigned) grows by the number of rotations applied - the caller repeats the call until a sweep adds
+ * none (typically 8-10 sweeps), then diag(A) holds the eigenvalues and the columns of V the eigenvectors.
+ * A, V [n, n] f64 row-major (A symmetric, overwritten); workspace: runia_eigh_workspace_bytes(n), 16-byte aligned. */
+size_t runia_eigh_workspace_bytes(int64_t n);
+int runia_eigh_init_f64(const double* A, double* V, int64_t n, void* workspace, size_t workspace_bytes,
+                        runia_stream_t stream);
+int runia_eigh_sweep_f64(double* A, double* V, int64_t n, void* workspace, size_t workspace_bytes,
+                         unsigned* rotations, runia_stream_t stream);
+/* C [M, N] = A [M, K] * B  (B [K, N], or B [N, K] read transposed when transpose_b != 0); f64, setup-time sizes. */
+int runia_matmul_f64(const double* A, const double* B, double* C, int64_t M, int64_t N, int64_t K, int transpose_b,
+                     runia_stream_t stream);
+/* f4: Gram form of eigen_score's covariance: G [n, n] = Ec Ec^T / denom with Ec = E - column means, E [n, H] f32
+ * (torch.cov(E.T) is Ec^T Ec / (n-1), [H, H] of rank < n: its non-zero spectrum is that of G). */
+int runia_centred_gram_f32(const float* E, double* G, int64_t n, int64_t H, double denom, runia_stream_t stream);
+
 /* ---- f2  metrics after the path (SURVEY 8f "next #2") -------------------------------------- *
  * AUROC, FPR@95 and AUPR of in-distribution (positive) against out-of-distribution scores as get_auroc_results
  * computes them (evaluation/metrics.py:37-100: torchmetrics binary auroc / roc / precision_recall_curve +

@@ -101,6 +101,11 @@ _SIGNATURES = {
     "runia_ood_metrics_workspace_bytes": (c_size_t, [c_int64]),
     "runia_ood_metrics_f64": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "runia_ood_metrics_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "runia_eigh_workspace_bytes": (c_size_t, [c_int64]),
+    "runia_eigh_init_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "runia_eigh_sweep_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "runia_matmul_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "runia_centred_gram_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
     "runia_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "runia_ash_s_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "runia_gen_score_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
@@ -179,6 +184,17 @@ def require_gpu() -> torch.device:
             "The scoring hot path runs only as HIP kernels on MI355X; there is no CPU fallback."
         )
     return torch.device("cuda", torch.cuda.current_device())
+
+
+def array_fingerprint(a):
+    """Cheap identity of a fitted array (address, shape, dtype): reassigning or refitting gives a new array, so caches of
+    device copies keyed on it are rebuilt instead of going stale.  (In-place edits of the same buffer are not seen.)"""
+    if a is None:
+        return None
+    if isinstance(a, torch.Tensor):
+        return ("t", a.data_ptr(), tuple(a.shape), str(a.dtype))
+    a = np.asarray(a)
+    return ("n", a.__array_interface__["data"][0], a.shape, a.dtype.str)
 
 
 def _check(rc: int, what: str) -> None:
@@ -724,3 +740,59 @@ def ood_metrics(ind_scores: torch.Tensor, ood_scores: torch.Tensor) -> torch.Ten
     _check(fn(a.data_ptr(), a.numel(), b.data_ptr(), b.numel(), out.data_ptr(), ws.data_ptr() + off, ws_bytes, _stream()),
            "runia_ood_metrics")
     return out
+
+
+def eigh(a: torch.Tensor, max_sweeps: int = 30):
+    """Symmetric eigen-decomposition on the device (Jacobi sweeps of ``runia_eigh_sweep_f64`` until one applies no
+    rotation): a [n, n] f64 -> (eigenvalues [n] ascending, eigenvectors [n, n] as columns), like ``numpy.linalg.eigh``.
+    Setup-time: reads one counter back per sweep."""
+    lib = load_library()
+    require_gpu()
+    assert a.is_cuda and a.dtype == torch.float64 and a.dim() == 2 and a.shape[0] == a.shape[1]
+    n = a.shape[0]
+    work = ((a + a.T) * 0.5).contiguous()  # exactly symmetric input
+    v = torch.empty_like(work)
+    ws_bytes = int(lib.runia_eigh_workspace_bytes(n))
+    ws = torch.empty(ws_bytes + 16, dtype=torch.uint8, device=a.device)
+    off = (-ws.data_ptr()) % 16
+    count = torch.zeros(1, dtype=torch.int32, device=a.device)
+    _check(lib.runia_eigh_init_f64(work.data_ptr(), v.data_ptr(), n, ws.data_ptr() + off, ws_bytes, _stream()), "runia_eigh_init_f64")
+    done = 0
+    for _ in range(max_sweeps):
+        _check(lib.runia_eigh_sweep_f64(work.data_ptr(), v.data_ptr(), n, ws.data_ptr() + off, ws_bytes, count.data_ptr(),
+                                        _stream()), "runia_eigh_sweep_f64")
+        total = int(count.item())
+        if total == done:
+            break
+        done = total
+    else:
+        raise RuniaHipError(f"runia_eigh_sweep_f64 did not converge in {max_sweeps} sweeps (n = {n})")
+    w = torch.diagonal(work).clone()
+    order = torch.argsort(w)
+    return w[order], v[:, order].contiguous()
+
+
+def matmul_f64(a: torch.Tensor, b: torch.Tensor, transpose_b: bool = False) -> torch.Tensor:
+    lib = load_library()
+    require_gpu()
+    assert a.is_cuda and b.is_cuda and a.dtype == torch.float64 and b.dtype == torch.float64
+    a, b = a.contiguous(), b.contiguous()
+    m, k = a.shape
+    n = b.shape[0] if transpose_b else b.shape[1]
+    assert (b.shape[1] if transpose_b else b.shape[0]) == k
+    c = torch.empty((m, n), dtype=torch.float64, device=a.device)
+    _check(lib.runia_matmul_f64(a.data_ptr(), b.data_ptr(), c.data_ptr(), m, n, k, 1 if transpose_b else 0, _stream()),
+           "runia_matmul_f64")
+    return c
+
+
+def centred_gram(e: torch.Tensor, denom: float) -> torch.Tensor:
+    """e [n, H] f32 -> Gram matrix [n, n] f64 of the column-centred rows, divided by ``denom``."""
+    lib = load_library()
+    require_gpu()
+    assert e.is_cuda and e.dtype == torch.float32 and e.dim() == 2
+    e = e.contiguous()
+    n, h = e.shape
+    g = torch.empty((n, n), dtype=torch.float64, device=e.device)
+    _check(lib.runia_centred_gram_f32(e.data_ptr(), g.data_ptr(), n, h, float(denom), _stream()), "runia_centred_gram_f32")
+    return g

@@ -58,20 +58,32 @@ class DevicePCA:
 _device_pca_cache: "weakref.WeakKeyDictionary" = weakref.WeakKeyDictionary()
 
 
+def _pca_fingerprint(pca) -> tuple:
+    """Cheap identity of the fitted state a DevicePCA was built from: a PCA object that is refitted (or whose attributes
+    are reassigned) gets new arrays, so the cached device copy is rebuilt instead of silently going stale."""
+    def ident(a):
+        a = np.asarray(a) if a is not None else None
+        return None if a is None else (a.__array_interface__["data"][0], a.shape, a.dtype.str)
+
+    return (ident(pca.components_), ident(getattr(pca, "mean_", None)), ident(pca.explained_variance_),
+            bool(getattr(pca, "whiten", False)))
+
+
 def device_pca_for(pca_transform) -> DevicePCA:
     if isinstance(pca_transform, DevicePCA):
         return pca_transform
+    fp = _pca_fingerprint(pca_transform)
     try:
         cached = _device_pca_cache.get(pca_transform)
     except TypeError:
         cached = None
-    if cached is None:
-        cached = DevicePCA.from_sklearn(pca_transform)
+    if cached is None or cached[0] != fp:
+        cached = (fp, DevicePCA.from_sklearn(pca_transform))
         try:
             _device_pca_cache[pca_transform] = cached
         except TypeError:
             pass
-    return cached
+    return cached[1]
 
 
 def apply_pca_ds(train_samples: np.ndarray, test_samples: np.ndarray, nro_components: int = 16,
@@ -87,7 +99,16 @@ def apply_pca_ds(train_samples: np.ndarray, test_samples: np.ndarray, nro_compon
 
 def apply_pca_ds_split(samples: np.ndarray, nro_components: int = 16, svd_solver: str = "randomized",
                        whiten: bool = True) -> Tuple[np.ndarray, "PCA"]:  # noqa: F821
-    """Fit a PCA on one dataset split; return (reduced samples, fitted sklearn PCA)."""
+    """Fit a PCA on one dataset split; return (reduced samples, fitted sklearn PCA).
+    With ``runia_core_amd.config.device_fit`` and an exact solver (``"covariance_eigh"`` / ``"full"``) the fit runs on the
+    GPU (``device_fit.pca_fit_device``) and a ``FittedPCA`` with the same public attributes is returned."""
+    from . import config
+
+    if config.device_fit and svd_solver in ("covariance_eigh", "full") and isinstance(nro_components, int):
+        from .device_fit import pca_fit_device
+
+        fitted = pca_fit_device(samples, nro_components, whiten)
+        return apply_pca_transform(samples, fitted), fitted
     from sklearn.decomposition import PCA
 
     pca_dim_red = PCA(n_components=nro_components, svd_solver=svd_solver, whiten=whiten)

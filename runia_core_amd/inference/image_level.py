@@ -52,11 +52,18 @@ class LaRExInference(ProbabilisticInferenceModule):
         self.mc_sampler.to(self.device)
         self.mc_sampler.train()
         self._pipeline = None
+        self._pipeline_key = None
 
     def _pipe(self) -> LaREMPipeline:
-        if self._pipeline is None:
-            self._pipeline = LaREMPipeline(self.postprocessor, self.pca_transform, self.mcd_samples_nro,
-                                           self.drop_block_prob, self.drop_block_size)
+        # the pipeline is rebuilt when the postprocessor / PCA objects (or the PCA's fitted arrays) are replaced
+        pca = self.pca_transform
+        key = (id(self.postprocessor), id(pca),
+               None if pca is None or not hasattr(pca, "components_") else _hip.array_fingerprint(pca.components_),
+               self.mcd_samples_nro, self.drop_block_prob, self.drop_block_size)
+        if self._pipeline is None or self._pipeline_key != key:
+            self._pipeline = LaREMPipeline(self.postprocessor, pca, self.mcd_samples_nro, self.drop_block_prob,
+                                           self.drop_block_size)
+            self._pipeline_key = key
         return self._pipeline
 
     def get_score(self, input_image, layer_hook):

@@ -67,6 +67,7 @@ class LaREMPipeline:
         # K2 (`runia_pca_md_score_f64`), which also materialises the projection in LDS.
         self.fold_weights = True
         self._folded = None
+        self._folded_fp = None
 
     # -- stages ---------------------------------------------------------------------
     def stack(self, latents: Tensor, rand: Optional[Tensor]) -> Tensor:
@@ -99,8 +100,11 @@ class LaREMPipeline:
     def _folded_state(self):
         """(packed M^T, c, r) with M = W diag(1/scale) C, c = W (-bias/scale - mu), precision = W^T W; None when the
         precision matrix is not positive semi-definite to rounding (then the two-stage kernel is used)."""
-        if self._folded is None:
-            pp = self.postprocessor
+        pp = self.postprocessor
+        fp = (_hip.array_fingerprint(pp.precision), _hip.array_fingerprint(pp.feats_mean),
+              None if self.pca is None else id(self.pca))
+        if self._folded is None or self._folded_fp != fp:
+            self._folded_fp = fp
             prec = np.asarray(pp.precision, dtype=np.float64)
             lam, vec = np.linalg.eigh((prec + prec.T) * 0.5)
             top = float(np.abs(lam).max()) if lam.size else 0.0

@@ -155,9 +155,11 @@ class MDLatentSpace(Postprocessor):
             warnings.warn("MDPostprocessor already trained")
 
     def _device_state(self):
-        if self._dev is None:
+        # rebuilt when precision / feats_mean are reassigned after first use (the reference reads the live attributes)
+        fp = (_hip.array_fingerprint(self.precision), _hip.array_fingerprint(self.feats_mean))
+        if self._dev is None or self._dev.get("fp") != fp:
             packed = _hip.pack_weights(_hip.to_device(np.asarray(self.precision, dtype=np.float64), torch.float64))
-            self._dev = {"packed_p": packed, "mean": {}}
+            self._dev = {"packed_p": packed, "mean": {}, "fp": fp}
         return self._dev
 
     def _mean(self, dtype: torch.dtype) -> Tensor:

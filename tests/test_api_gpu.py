@@ -687,3 +687,95 @@ def test_device_metrics_vs_oracle(case):
     b = _t.from_numpy(np.ascontiguousarray(ood)).cuda()
     out = auroc_fpr95_aupr_device(a, b, to_host=False)
     assert out.is_cuda and tuple(out.cpu().numpy()) == pytest.approx(got, abs=1e-12)
+
+
+# ---------------- f1 / f4: Jacobi eigen-solver, pinvh, PCA fit, eigen_score ----------------------------------------------
+@pytest.mark.parametrize("n", [1, 2, 3, 10, 33, 64, 257])
+def test_jacobi_eigh_vs_numpy(n):
+    from runia_core_amd import _hip
+
+    rng = np.random.default_rng(n)
+    a = rng.standard_normal((n, n))
+    a = a @ a.T + np.diag(rng.random(n))
+    if n > 3:  # rank-deficient block + repeated eigenvalues
+        a[:, -2] = a[:, -3]
+        a[-2, :] = a[-3, :]
+    w, v = _hip.eigh(torch.from_numpy(a).cuda())
+    w, v = w.cpu().numpy(), v.cpu().numpy()
+    w_ref = np.linalg.eigvalsh(a)
+    scale = max(1.0, np.abs(w_ref).max())
+    assert np.abs(w - w_ref).max() < 1e-12 * scale
+    assert np.abs(v.T @ v - np.eye(n)).max() < 1e-12
+    assert np.abs(a @ v - v * w).max() < 1e-11 * scale
+
+
+def test_device_fit_pinvh_and_pca_without_vendor_solver(monkeypatch):
+    """config.device_fit: MDLatentSpace.setup (covariance on the matrix cores + Jacobi pinvh, rank-deficient unit case
+    included) against the reference-run fixtures, and apply_pca_ds_split(svd_solver="covariance_eigh") against sklearn."""
+    from sklearn.decomposition import PCA
+
+    import runia_core_amd.config as cfg
+
+    monkeypatch.setattr(cfg, "device_fit", True)
+    g = load_npz("ref_md.npz")
+    for name in ("unit", "baselines"):
+        md = MDLatentSpace()
+        md.setup(g[f"{name}_train"])
+        scale = np.abs(g[f"{name}_precision"]).max()
+        assert np.abs(md.precision - g[f"{name}_precision"]).max() < 1e-8 * scale
+        assert rel_err(md.postprocess(g[f"{name}_test"]), g[f"{name}_scores"]) < 1e-6
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal((3000, 96)) * (0.3 + rng.random(96)) + rng.standard_normal(96)
+    red, fitted = rc.apply_pca_ds_split(x, 24, svd_solver="covariance_eigh")
+    ref = PCA(n_components=24, svd_solver="covariance_eigh", whiten=True).fit(x)
+    assert np.abs(fitted.components_ - ref.components_).max() < 1e-9
+    assert np.abs(fitted.explained_variance_ - ref.explained_variance_).max() < 1e-10
+    assert np.abs(fitted.mean_ - ref.mean_).max() < 1e-12
+    assert rel_err(red, ref.transform(x)) < 1e-8
+    xt = rng.standard_normal((50, 96))
+    assert rel_err(rc.apply_pca_transform(xt, fitted), ref.transform(xt)) < 1e-8
+    assert rel_err(fitted.transform(xt), ref.transform(xt)) < 1e-8
+
+
+def test_eigen_score_reference_golden():
+    """/root/reference/tests/unit_test_llm_uncertainty.py:69-92: seeded synthetic hidden states, golden
+    -6.775187082486514 at the reference's own tolerance 1e-6; alpha dependence; device inputs."""
+    from runia_core_amd.llm_uncertainty import eigen_score
+
+    np.random.seed(42)
+    torch.manual_seed(42)
+    hs = tuple(tuple(torch.randn(1, 10, 768) for _ in range(20)) for _ in range(5))
+    s = eigen_score(hs, alpha=1e-3)
+    assert isinstance(s, float) and abs(s - (-6.775187082486514)) < 1e-6
+    # the definition, in float64 on the host
+    e = hs[-1][15].squeeze().double().numpy()
+    cov = np.cov(e.T)
+    sv = np.linalg.svd(cov + 1e-3 * np.eye(768), compute_uv=False)
+    assert abs(s - float(np.mean(np.log(sv)))) < 1e-9
+    hs2 = tuple(tuple(torch.randn(1, 5, 64) for _ in range(20)) for _ in range(3))
+    s1, s2 = eigen_score(hs2, alpha=1e-3), eigen_score(hs2, alpha=1e-2)
+    assert abs(s1 - s2) > 1e-3 and eigen_score(hs2) == s1
+    hs_dev = tuple(tuple(t.cuda() for t in layer) for layer in hs2)
+    assert abs(eigen_score(hs_dev) - s1) < 1e-12
+
+
+def test_refit_invalidates_device_caches():
+    """Fitted-state caches follow the live attributes: refitting the same sklearn PCA object, or reassigning
+    precision / feats_mean, must change the scores."""
+    from sklearn.decomposition import PCA
+
+    rng = np.random.default_rng(8)
+    x1, x2 = rng.standard_normal((400, 20)), rng.standard_normal((400, 20)) * 2 + 1
+    xt = rng.standard_normal((30, 20))
+    pca = PCA(n_components=5, whiten=True).fit(x1)
+    y1 = rc.apply_pca_transform(xt, pca)
+    pca.fit(x2)
+    y2 = rc.apply_pca_transform(xt, pca)
+    assert rel_err(y2, pca.transform(xt)) < 1e-9 and np.abs(y1 - y2).max() > 1e-3
+    md = MDLatentSpace()
+    md.setup(x1)
+    s1 = md.postprocess(xt)
+    md.precision = md.precision * 4.0
+    assert rel_err(md.postprocess(xt), 4.0 * s1) < 1e-12
+    md.feats_mean = md.feats_mean + 1.0
+    assert np.abs(md.postprocess(xt) - 4.0 * s1).max() > 1e-3
