@@ -242,6 +242,16 @@ int runia_covariance_f64(const double* x, double* mean, double* cov, void* works
 int runia_covariance_f32in(const float* x, double* mean, double* cov, void* workspace,
                            size_t workspace_bytes, int64_t N, int64_t D, runia_stream_t stream);
 
+/* ---- f3  the step in front of the sampler for object-level inference ------------------------ *
+ * torchvision.ops.roi_align as the reference calls it (feature_extraction/object_level.py:283-292, 340-349):
+ *   input [B, C, H, W] f32, boxes [K, 4] f32 (x1, y1, x2, y2 in image pixels), batch_idx [K] int32 (NULL when B == 1),
+ *   out [K, C, PH, PW] f32; bins average sampling_ratio^2 bilinear samples (ceil(roi / pooled) per axis when
+ *   sampling_ratio <= 0); aligned != 0 shifts the box by -0.5 pixel.  The output is the (N, C, H, W) input of
+ *   runia_mc_entropy_f32 / runia_mc_stack_f32: roi_align -> per-ROI MC DropBlock -> entropy with no host round trip. */
+int runia_roi_align_f32(const float* input, const float* boxes, const int* batch_idx, float* out, int64_t K, int64_t B,
+                        int C, int H, int W, int PH, int PW, double spatial_scale, int sampling_ratio, int aligned,
+                        runia_stream_t stream);
+
 /* Symmetric eigen-decomposition without a vendor solver: two-sided cyclic Jacobi, f64, parallel ordering.  What
  * scipy.linalg.pinvh (EmpiricalCovariance.fit, inference/postprocessors.py:213-220, inference/funcs.py:52-66), the
  * "covariance_eigh" / "full" PCA fit (dimensionality_reduction.py:70-71) and eigen_score (llm_uncertainty/scores.py:49-66)

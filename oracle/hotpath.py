@@ -27,6 +27,8 @@ __all__ = [
     "dropblock_block_mask",
     "torch_cpu_sum_lastdim",
     "mc_stack",
+    "roi_align",
+    "rois_mc_entropy",
     "philox4x32_10",
     "counter_draws",
     "pca_transform",
@@ -304,6 +306,78 @@ def mc_stack(x: np.ndarray, rand: np.ndarray, drop_prob: float, block_size: int,
             y = (x[0] * bm[s][None]) * np.float32(bm[s].size) / np.float32(bm[s].sum(dtype=np.float32))
         out[s] = fullmean(y) if conv else y.reshape(-1)
     return out
+
+
+# --------------------------------------------------------------------------
+# f3  roi_align in front of the per-ROI sampler (feature_extraction/object_level.py:283-292, 340-349)
+#     torchvision is absent from the image: restated from its published algorithm; PARITY UNPINNED for this function
+#     (the reference's own per-ROI glue around it is pinned by tests/golden/ref_roi.npz with this restatement plugged in).
+# --------------------------------------------------------------------------
+def roi_align(x: np.ndarray, boxes: np.ndarray, output_size, spatial_scale: float = 1.0, sampling_ratio: int = -1,
+              aligned: bool = False) -> np.ndarray:
+    """``torchvision.ops.roi_align(x, [boxes], output_size, spatial_scale, sampling_ratio, aligned)`` for one image
+    ``x (1, C, H, W)`` f32, ``boxes (K, 4)`` xyxy -> ``(K, C, PH, PW)`` f32 (float32 arithmetic, samples added row by row)."""
+    x = np.asarray(x, dtype=np.float32)
+    boxes = np.asarray(boxes, dtype=np.float32)
+    _, c, h, w = x.shape
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+    f = np.float32
+    out = np.zeros((boxes.shape[0], c, ph, pw), dtype=np.float32)
+    off = f(0.5) if aligned else f(0.0)
+    sc = f(spatial_scale)
+
+    def bilinear(yy, xx):
+        if yy < -1.0 or yy > h or xx < -1.0 or xx > w:
+            return np.zeros(c, dtype=np.float32)
+        yy = max(yy, f(0.0))
+        xx = max(xx, f(0.0))
+        yl, xl = int(yy), int(xx)
+        if yl >= h - 1:
+            yh = yl = h - 1
+            yy = f(yl)
+        else:
+            yh = yl + 1
+        if xl >= w - 1:
+            xh = xl = w - 1
+            xx = f(xl)
+        else:
+            xh = xl + 1
+        ly, lx = f(yy - f(yl)), f(xx - f(xl))
+        hy, hx = f(f(1.0) - ly), f(f(1.0) - lx)
+        w1, w2, w3, w4 = f(hy * hx), f(hy * lx), f(ly * hx), f(ly * lx)
+        return ((w1 * x[0, :, yl, xl] + w2 * x[0, :, yl, xh]) + w3 * x[0, :, yh, xl]) + w4 * x[0, :, yh, xh]
+
+    for k, bx in enumerate(boxes):
+        x1, y1, x2, y2 = (f(f(v * sc) - off) for v in bx)
+        rw, rh = f(x2 - x1), f(y2 - y1)
+        if not aligned:
+            rw, rh = max(rw, f(1.0)), max(rh, f(1.0))
+        bh, bw = f(rh / f(ph)), f(rw / f(pw))
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rh / ph))
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rw / pw))
+        count = f(max(gh * gw, 1))
+        for i in range(ph):
+            for j in range(pw):
+                acc = np.zeros(c, dtype=np.float32)
+                for iy in range(gh):
+                    yy = f(f(y1 + f(f(i) * bh)) + f(f(f(iy) + f(0.5)) * bh) / f(gh))
+                    for ix in range(gw):
+                        xx = f(f(x1 + f(f(j) * bw)) + f(f(f(ix) + f(0.5)) * bw) / f(gw))
+                        acc = (acc + bilinear(yy, xx)).astype(np.float32)
+                out[k, :, i, j] = acc / count
+    return out
+
+
+def rois_mc_entropy(feature_maps, output_sizes, boxes, img_shape, sampling_ratio, rand, drop_prob, block_size) -> np.ndarray:
+    """``_dropblock_rois_get_entropy`` (feature_extraction/object_level.py:312-367): roi_align of every hooked layer
+    (spatial_scale = W_feat / W_img, aligned), concatenation along channels, ``mc_sampler(roi[None])`` per detection,
+    ``get_dl_h_z(...)[1]``.  ``rand`` ``(K, n_mc, PH, PW)``: the DropBlock draws, detection-major.  Returns ``(K, C_total)``."""
+    rois = [roi_align(fm, boxes, output_sizes[i], fm.shape[3] / img_shape[1], sampling_ratio, True)
+            for i, fm in enumerate(feature_maps)]
+    rois = np.concatenate(rois, axis=1) if len(rois) > 1 else rois[0]
+    n_mc = rand.shape[1]
+    z = np.concatenate([mc_stack(rois[k : k + 1], rand[k], drop_prob, block_size) for k in range(rois.shape[0])])
+    return kl_entropy_per_dim_vectorized(z, n_mc)
 
 
 # --------------------------------------------------------------------------

@@ -106,6 +106,11 @@ _SIGNATURES = {
     "runia_eigh_sweep_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "runia_matmul_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "runia_centred_gram_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
+    "runia_roi_align_f32": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_double, c_int, c_int,
+         c_void_p],
+    ),
     "runia_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "runia_ash_s_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "runia_gen_score_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
@@ -796,3 +801,23 @@ def centred_gram(e: torch.Tensor, denom: float) -> torch.Tensor:
     g = torch.empty((n, n), dtype=torch.float64, device=e.device)
     _check(lib.runia_centred_gram_f32(e.data_ptr(), g.data_ptr(), n, h, float(denom), _stream()), "runia_centred_gram_f32")
     return g
+
+
+def roi_align(x: torch.Tensor, boxes: torch.Tensor, output_size, spatial_scale: float = 1.0, sampling_ratio: int = -1,
+              aligned: bool = False, batch_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``torchvision.ops.roi_align``: x [B, C, H, W] f32, boxes [K, 4] f32 (xyxy) -> [K, C, PH, PW] f32 (device)."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    x = x.contiguous()
+    boxes = boxes.to(device=x.device, dtype=torch.float32).contiguous()
+    b, c, h, w = x.shape
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+    k = boxes.shape[0]
+    if batch_idx is not None:
+        batch_idx = batch_idx.to(device=x.device, dtype=torch.int32).contiguous()
+    out = torch.empty((k, c, ph, pw), dtype=torch.float32, device=x.device)
+    _check(lib.runia_roi_align_f32(x.data_ptr(), boxes.data_ptr(), _ptr(batch_idx), out.data_ptr(), k, b, c, h, w, int(ph),
+                                   int(pw), float(spatial_scale), int(sampling_ratio), 1 if aligned else 0, _stream()),
+           "runia_roi_align_f32")
+    return out

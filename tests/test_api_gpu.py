@@ -779,3 +779,63 @@ def test_refit_invalidates_device_caches():
     assert rel_err(md.postprocess(xt), 4.0 * s1) < 1e-12
     md.feats_mean = md.feats_mean + 1.0
     assert np.abs(md.postprocess(xt) - 4.0 * s1).max() > 1e-3
+
+
+# ---------------- f3: roi_align -> per-ROI MC DropBlock -> entropy on the device ---------------------------------------
+@pytest.mark.parametrize("name", ["p7", "p4x2", "p8_adaptive"])
+def test_per_roi_entropy_reference_run_fixture(name):
+    """runia_core_amd.feature_extraction.object_level._dropblock_rois_get_entropy (same signature as the reference's)
+    against what the reference's own function returned (tests/golden/ref_roi.npz): roi_align kernel + fused sampler /
+    entropy kernels; the module's CPU-generator draws are the reference's stream (detection after detection)."""
+    from runia_core_amd import MCSamplerModule
+    from runia_core_amd.feature_extraction.object_level import _dropblock_rois_get_entropy, _reduce_features_to_rois, roi_align
+
+    g = load_npz("ref_roi.npz")
+    n_rep, osz, ih, iw, sr, n_mc, bs, p, seed = g[f"{name}_params"]
+    n_rep, osz, sr, n_mc, bs = int(n_rep), int(osz), int(sr), int(n_mc), int(bs)
+    fms = [torch.from_numpy(g[f"{name}_fm{i}"]).cuda() for i in range(n_rep)]
+    boxes = torch.from_numpy(g[f"{name}_boxes"])
+    sampler = MCSamplerModule(mc_samples=n_mc, block_size=bs, drop_prob=float(p), layer_type="Conv")
+    sampler.train()
+    torch.manual_seed(int(seed))
+    ent = _dropblock_rois_get_entropy(fms, (osz,) * n_rep, boxes, (int(ih), int(iw)), sr, n_rep, n_mc, sampler)
+    assert isinstance(ent, torch.Tensor) and ent.dtype == torch.float32 and not ent.is_cuda
+    ref = g[f"{name}_entropy"]
+    assert ent.shape == ref.shape and np.abs(ent.numpy() - ref).max() < 2e-5
+    # explicit draws = the fixture's
+    ent2 = _dropblock_rois_get_entropy(fms, (osz,) * n_rep, boxes, (int(ih), int(iw)), sr, n_rep, n_mc, sampler,
+                                       rand=torch.from_numpy(g[f"{name}_draws"]).cuda())
+    assert torch.equal(ent, ent2)
+    # roi_align kernel against the oracle's restatement (float32, same sample order; fma contraction may differ by ulps)
+    for i, fm in enumerate(fms):
+        r = roi_align(fm, [boxes], osz, fm.shape[3] / iw, sr, True).cpu().numpy()
+        exp = oracle.roi_align(g[f"{name}_fm{i}"], g[f"{name}_boxes"], osz, fm.shape[3] / iw, sr, True)
+        assert np.allclose(r, exp, rtol=2e-6, atol=2e-6)
+    means, stds = _reduce_features_to_rois(fms, (osz,) * n_rep, boxes, (int(ih), int(iw)), sr, n_rep, boxes.shape[0], True)
+    assert np.allclose(torch.cat(means).cpu().numpy(), g[f"{name}_means"], rtol=1e-5, atol=1e-6)
+    assert np.allclose(torch.cat(stds).cpu().numpy(), g[f"{name}_stds"], rtol=1e-4, atol=1e-6)
+
+
+def test_cfg4_per_roi_path_at_size():
+    """Config 4 shape end to end on the device: 100 proposals per image on a 256-channel 50x80 feature map, 7x7 ROI
+    bins, 16 MC DropBlock layers (counter draws) -> (100, 256) entropies per image; rows are independent of the other
+    boxes in the call, and equal the unfused chain (roi_align -> mc_stack -> entropy)."""
+    from runia_core_amd import MCSamplerModule, _hip
+    from runia_core_amd.feature_extraction.object_level import _dropblock_rois_get_entropy, roi_align
+
+    g = torch.Generator(device="cuda").manual_seed(3)
+    fm = torch.relu(torch.randn(1, 256, 50, 80, device="cuda", generator=g))
+    k = 100
+    xy = torch.rand(k, 2, generator=torch.Generator().manual_seed(1)) * torch.tensor([400.0, 250.0])
+    wh = 30 + torch.rand(k, 2, generator=torch.Generator().manual_seed(2)) * torch.tensor([200.0, 120.0])
+    boxes = torch.cat([xy, xy + wh], dim=1)
+    sampler = MCSamplerModule(mc_samples=16, block_size=3, drop_prob=0.4).train().use_counter_draws(seed=9)
+    ent = _dropblock_rois_get_entropy([fm], (7,), boxes, (400, 640), 2, 1, 16, sampler)
+    assert ent.shape == (k, 256) and bool(torch.isfinite(ent).all())
+    sampler.use_counter_draws(seed=9)  # same stream again
+    part = _dropblock_rois_get_entropy([fm], (7,), boxes[:10], (400, 640), 2, 1, 16, sampler)
+    assert torch.equal(part, ent[:10])
+    rois = roi_align(fm, [boxes], 7, 80 / 640, 2, True)
+    z = _hip.mc_stack(rois, _hip.CounterDraws(9, 0), 16, 0.4, 3)
+    h = _hip.kl_entropy_per_dim(z, 16, 5).to(torch.float32).cpu()
+    assert float((h - ent).abs().max()) < 1e-6

@@ -262,6 +262,29 @@ def test_kde_high_dim_reference_run_fixture(d):
         assert 0.5 * m["max_abs"] < gap < 2 * m["max_abs"]
 
 
+# ---------------- f3: per-ROI sampler path, pinned by the reference's own glue ---------------------------------------
+ROI_CASES = ["p7", "p4x2", "p8_adaptive"]
+
+
+@pytest.mark.parametrize("name", ROI_CASES)
+def test_rois_mc_entropy_reference_run_fixture(name):
+    """tests/golden/ref_roi.npz: what /root/reference/runia_core/feature_extraction/object_level.py's
+    _dropblock_rois_get_entropy and _reduce_features_to_rois returned (loaded by path, tools/make_goldens_r2.py; the
+    absent third-party calls inside - torchvision roi_align, DropBlock2D, get_h - restated).  The oracle chain reproduces
+    the entropies (returned as float32 by the reference) and the ROI means."""
+    g = load_npz("ref_roi.npz")
+    n_rep, osz, ih, iw, sr, n_mc, bs, p, _ = g[f"{name}_params"]
+    fms = [g[f"{name}_fm{i}"] for i in range(int(n_rep))]
+    got = oracle.rois_mc_entropy(fms, [int(osz)] * int(n_rep), g[f"{name}_boxes"], (int(ih), int(iw)), int(sr),
+                                 g[f"{name}_draws"], float(p), int(bs))
+    ref = g[f"{name}_entropy"]
+    assert got.shape == ref.shape and ref.dtype == np.float32
+    assert np.abs(got - ref).max() < 2e-6  # float32 cast of the reference's float64 entropies
+    rois = [oracle.roi_align(fm, g[f"{name}_boxes"], int(osz), fm.shape[3] / iw, int(sr), True) for fm in fms]
+    means = np.concatenate([r.mean(axis=(2, 3)) for r in rois], axis=1)
+    assert np.allclose(means, g[f"{name}_means"], rtol=1e-5, atol=1e-6)
+
+
 # ---------------- throughput-mode draws: Philox4x32-10 known answers + uniformity --------------------------------
 def test_philox_known_answer_vectors():
     """Random123's published kat_vectors for philox4x32-10 (the generator behind runia_mc_*_counter_f32)."""

@@ -176,7 +176,120 @@ def gen_kde_hd():
     np.savez_compressed(os.path.join(OUT, "ref_kde_hd.npz"), **cases)
 
 
-SECTIONS = {"sampler": gen_sampler, "kde_hd": gen_kde_hd}
+def _roi_align_torch(input, boxes, output_size, spatial_scale=1.0, sampling_ratio=-1, aligned=False):
+    """torchvision.ops.roi_align restated from its published algorithm (torchvision is absent): float32, bins average
+    sampling_ratio^2 bilinear samples, aligned shifts by -0.5, out-of-map samples (more than one pixel) contribute 0."""
+    import math
+
+    x = input.detach().cpu().numpy().astype(np.float32)
+    bx = (boxes[0] if isinstance(boxes, (list, tuple)) else boxes).detach().cpu().numpy().astype(np.float32)
+    _, c, h, w = x.shape
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+    f = np.float32
+    out = np.zeros((bx.shape[0], c, ph, pw), np.float32)
+    off = f(0.5) if aligned else f(0.0)
+
+    def bil(yy, xx):
+        if yy < -1.0 or yy > h or xx < -1.0 or xx > w:
+            return np.zeros(c, np.float32)
+        yy, xx = max(yy, f(0)), max(xx, f(0))
+        yl, xl = int(yy), int(xx)
+        if yl >= h - 1:
+            yh = yl = h - 1; yy = f(yl)
+        else:
+            yh = yl + 1
+        if xl >= w - 1:
+            xh = xl = w - 1; xx = f(xl)
+        else:
+            xh = xl + 1
+        ly, lx = f(yy - f(yl)), f(xx - f(xl))
+        hy, hx = f(f(1) - ly), f(f(1) - lx)
+        return ((f(hy * hx) * x[0, :, yl, xl] + f(hy * lx) * x[0, :, yl, xh]) + f(ly * hx) * x[0, :, yh, xl]) + f(ly * lx) * x[0, :, yh, xh]
+
+    for k, b in enumerate(bx):
+        x1, y1, x2, y2 = (f(f(v * f(spatial_scale)) - off) for v in b)
+        rw, rh = f(x2 - x1), f(y2 - y1)
+        if not aligned:
+            rw, rh = max(rw, f(1)), max(rh, f(1))
+        bh, bw = f(rh / f(ph)), f(rw / f(pw))
+        gh = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rh / ph))
+        gw = sampling_ratio if sampling_ratio > 0 else int(math.ceil(rw / pw))
+        cnt = f(max(gh * gw, 1))
+        for i in range(ph):
+            for j in range(pw):
+                acc = np.zeros(c, np.float32)
+                for iy in range(gh):
+                    yy = f(f(y1 + f(f(i) * bh)) + f(f(f(iy) + f(0.5)) * bh) / f(gh))
+                    for ix in range(gw):
+                        xx = f(f(x1 + f(f(j) * bw)) + f(f(f(ix) + f(0.5)) * bw) / f(gw))
+                        acc = (acc + bil(yy, xx)).astype(np.float32)
+                out[k, :, i, j] = acc / cnt
+    return torch.from_numpy(out)
+
+
+def _get_h(x, k=1, norm="max", min_dist=0.0):
+    """entropy_estimators==0.0.1 continuous.get_h restated from its published algorithm (the package is absent; pinned by
+    the reference's entropy goldens in tests/test_oracle_goldens.py)."""
+    from scipy.spatial import cKDTree
+    from scipy.special import digamma
+
+    x = np.asarray(x, dtype=np.float64)
+    if x.ndim == 1:
+        x = x.reshape(-1, 1)
+    n, d = x.shape
+    assert norm == "max"
+    dist = cKDTree(x).query(x, k + 1, eps=0, p=np.inf)[0][:, -1].copy()
+    dist[dist < min_dist] = min_dist
+    return -digamma(k) + digamma(n) + (d / float(n)) * np.sum(np.log(2 * dist))
+
+
+def gen_roi():
+    """The reference's own per-ROI glue (_dropblock_rois_get_entropy, _reduce_features_to_rois of
+    feature_extraction/object_level.py, loaded by path) on seeded feature maps and boxes, with the three absent third-party
+    pieces it calls restated (torchvision.ops.roi_align, dropblock.DropBlock2D, entropy_estimators get_h)."""
+    ee = types.ModuleType("entropy_estimators")
+    cont = types.ModuleType("entropy_estimators.continuous")
+    cont.get_h = _get_h
+    ee.continuous = cont
+    sys.modules["entropy_estimators"], sys.modules["entropy_estimators.continuous"] = ee, cont
+    sys.modules["torchvision.ops"].roi_align = _roi_align_torch
+    import runia_core.feature_extraction.abstract_classes as fac
+    import runia_core.feature_extraction.object_level as fol
+
+    cases = {}
+    specs = [  # name, [(C, Hf, Wf)], output sizes, img (H, W), K boxes, sampling_ratio, n_mc, bs, p, seed
+        ("p7", [(24, 25, 40)], (7,), (200, 320), 6, 2, 16, 3, 0.4, 71),
+        ("p4x2", [(16, 50, 80), (8, 25, 40)], (4, 4), (400, 640), 5, 2, 16, 2, 0.5, 72),
+        ("p8_adaptive", [(12, 32, 32)], (8,), (256, 256), 4, -1, 12, 4, 0.3, 73),
+    ]
+    for name, maps, osz, img, k, sr, n_mc, bs, p, seed in specs:
+        g = np.random.default_rng(seed)
+        fms = [np.maximum(g.standard_normal((1, c, h, w)), 0).astype(np.float32) for (c, h, w) in maps]
+        x1 = g.uniform(-10, img[1] * 0.6, k); y1 = g.uniform(-10, img[0] * 0.6, k)
+        bw = g.uniform(20, img[1] * 0.5, k); bh = g.uniform(20, img[0] * 0.5, k)
+        boxes = np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float32)
+        sampler = fac.MCSamplerModule(mc_samples=n_mc, block_size=bs, drop_prob=p, layer_type="Conv")
+        sampler.train()
+        ph = osz[0]
+        torch.manual_seed(seed)
+        draws = torch.cat([torch.rand(1, ph, ph) for _ in range(k * n_mc)]).reshape(k, n_mc, ph, ph).numpy()
+        torch.manual_seed(seed)
+        ent = fol._dropblock_rois_get_entropy([torch.from_numpy(f) for f in fms], osz, torch.from_numpy(boxes), img, sr,
+                                              len(fms), n_mc, sampler).numpy()
+        means, stds = fol._reduce_features_to_rois([torch.from_numpy(f) for f in fms], osz, torch.from_numpy(boxes), img, sr,
+                                                    len(fms), k, return_stds=True)
+        for i, f in enumerate(fms):
+            cases[f"{name}_fm{i}"] = f
+        cases[f"{name}_boxes"], cases[f"{name}_draws"] = boxes, draws
+        cases[f"{name}_entropy"] = ent
+        cases[f"{name}_means"] = torch.cat(means).numpy()
+        cases[f"{name}_stds"] = torch.cat(stds).numpy()
+        cases[f"{name}_params"] = np.array([len(fms), osz[0], img[0], img[1], sr, n_mc, bs, p, seed], dtype=np.float64)
+        print(f"  roi {name}: entropy {ent.shape} finite {np.isfinite(ent).all()}")
+    np.savez_compressed(os.path.join(OUT, "ref_roi.npz"), **cases)
+
+
+SECTIONS = {"sampler": gen_sampler, "kde_hd": gen_kde_hd, "roi": gen_roi}
 
 
 def main():
