@@ -90,40 +90,44 @@ def normalizer(x):
     return out.reshape(arr.shape)
 
 
+_GMM_JITTERS = (0.0,) + tuple(10.0 ** e for e in range(-20, 0))
+
+
 def gmm_fit(embeddings: torch.Tensor, labels: torch.Tensor, num_classes: int):
-    """Class-wise Gaussians (reference ``inference/funcs.py:265-344``): per-class mean and covariance
-    ``x_c^T x_c / (n_c - 1)`` in float32, classes without samples dropped, and the smallest jitter of
-    ``[0, 1e-20, ..., 1e-1]`` for which ``torch.distributions.MultivariateNormal`` accepts ``cov + jitter * I``
-    (its float32 Cholesky must succeed).  Setup-time host fit with the reference's own torch calls.
+    """Class-wise Gaussians behind ``GMMLatentSpace`` / ``DDU`` (what the reference's ``gmm_fit`` returns,
+    ``inference/funcs.py:265-344``): per-class mean, per-class covariance of the centred rows divided by
+    ``max(n_c, 2) - 1``, classes without samples left out, and the smallest jitter of ``0, 1e-20, ..., 1e-1`` whose
+    ``cov + jitter * I`` has a float32 Cholesky factor.
+
+    Setup-time host fit in float32 torch like the reference, restructured: the class statistics come from one one-hot
+    contraction over all classes at once, and the jitter ladder is walked with ``torch.linalg.cholesky_ex`` (status codes
+    instead of exceptions); the factor found is handed to ``MultivariateNormal(scale_tril=...)`` - the same factor the
+    reference's ``covariance_matrix=`` construction computes internally.
 
     Returns ``(MultivariateNormal, jitter)``."""
-    jitters = [0] + [10**exp for exp in range(-20, 0, 1)]
-
-    def centered_cov(x):
-        n = x.shape[0]
-        if n == 1:
-            n += 1
-        return 1 / (n - 1) * x.t().mm(x)
-
     with torch.no_grad():
-        means = torch.stack([torch.mean(embeddings[labels == c], dim=0) for c in range(num_classes)])
-        covs = torch.stack([centered_cov(embeddings[labels == c] - means[c]) for c in range(num_classes)])
-        keep = ~torch.any(means.isnan(), dim=1)
-        if not bool(keep.all()):
-            means, covs = means[keep], covs[keep]
-        gmm, jitter_eps = None, None
-        for jitter_eps in jitters:
-            try:
-                jitter = jitter_eps * torch.eye(covs.shape[1], device=covs.device).unsqueeze(0)
-                gmm = torch.distributions.MultivariateNormal(loc=means, covariance_matrix=(covs + jitter))
-            except RuntimeError as e:
-                if "cholesky" in str(e):
-                    continue
-            except ValueError as e:
-                if "found invalid values" in str(e):
-                    continue
-            break
-    return gmm, jitter_eps
+        x = embeddings.to(torch.float32)
+        lab = labels.to(torch.long).reshape(-1)
+        member = torch.nn.functional.one_hot(lab.clamp(0, num_classes - 1), num_classes).to(x.dtype)
+        member = member * ((lab >= 0) & (lab < num_classes)).to(x.dtype).unsqueeze(1)      # (N, C)
+        counts = member.sum(dim=0)                                                           # (C,)
+        present = counts > 0
+        means = (member.t() @ x) / counts.clamp_min(1.0).unsqueeze(1)                        # (C, D)
+        centred = x - means[lab.clamp(0, num_classes - 1)]                                   # every row minus its class mean
+        denom = (counts.clamp_min(2.0) - 1.0).reshape(-1, 1, 1)
+        covs = torch.einsum("nc,ni,nj->cij", member, centred, centred) / denom               # (C, D, D)
+        means, covs = means[present], covs[present]
+        eye = torch.eye(covs.shape[-1], dtype=covs.dtype, device=covs.device)
+        chosen, factor = _GMM_JITTERS[-1], None
+        for jitter in _GMM_JITTERS:
+            tril, info = torch.linalg.cholesky_ex(covs + jitter * eye)
+            if int(info.abs().max()) == 0 and bool(torch.isfinite(tril).all()):
+                chosen, factor = jitter, tril
+                break
+        if factor is None:  # nothing on the ladder is positive definite: same outcome as the reference's last attempt
+            factor = torch.linalg.cholesky(covs + chosen * eye)
+        gmm = torch.distributions.MultivariateNormal(loc=means, scale_tril=factor)
+    return gmm, (0 if chosen == 0.0 else chosen)
 
 
 class GmmState:

@@ -839,3 +839,38 @@ def test_cfg4_per_roi_path_at_size():
     z = _hip.mc_stack(rois, _hip.CounterDraws(9, 0), 16, 0.4, 3)
     h = _hip.kl_entropy_per_dim(z, 16, 5).to(torch.float32).cpu()
     assert float((h - ent).abs().max()) < 1e-6
+
+
+def test_fast_mcd_samples_extractor_batched():
+    """FastMCDSamplesExtractor.get_ls_samples (reference feature_extraction/image_level.py:127-249) over a dataloader with
+    batches of 1 and of 3 images: the same MC samples as the oracle's MCSamplerModule.forward per image with the
+    reference's draw stream (one torch.rand(1, H, W) per sample, image after image), gt labels and raw predictions."""
+    from runia_core_amd import Hook
+    from runia_core_amd.feature_extraction import FastMCDSamplesExtractor
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 12, 3, padding=1), torch.nn.ReLU(), torch.nn.AdaptiveAvgPool2d(4)).cuda().eval()
+    hook = Hook(net[2])
+    imgs = torch.randn(7, 3, 16, 16)
+    labels = torch.arange(7)
+    for bs in (1, 3):
+        loader = [(imgs[i : i + bs], labels[i : i + bs]) for i in range(0, 7, bs)]
+        ex = FastMCDSamplesExtractor(net, [hook], torch.device("cuda"), "Conv", "fullmean", return_raw_predictions=True,
+                                     mcd_nro_samples=16, dropblock_probs=0.5, dropblock_sizes=2, return_gt_labels=True)
+        torch.manual_seed(123)
+        res = ex.get_ls_samples(loader)
+        z = res["latent_space_means"]
+        assert z.is_cuda and z.shape == (7 * 16, 12) and res["raw_preds"].shape == (7, 12, 4, 4)
+        assert res["gt_labels"].numel() == 7
+        with torch.no_grad():
+            lat = net(imgs.cuda()).cpu().numpy()
+        torch.manual_seed(123)
+        draws = torch.cat([torch.rand(1, 4, 4) for _ in range(7 * 16)]).reshape(7, 16, 4, 4).numpy()
+        exp = np.concatenate([oracle.mc_stack(lat[i : i + 1], draws[i], 0.5, 2) for i in range(7)])
+        if bs == 1:
+            assert np.array_equal(z.cpu().numpy(), exp, equal_nan=True)
+        else:  # batches draw per batch: the stream is the same, image after image
+            assert np.array_equal(z.cpu().numpy(), exp, equal_nan=True)
+    with pytest.raises(NotImplementedError):
+        FastMCDSamplesExtractor(net, [hook], torch.device("cuda"), "Conv", "mean", mcd_nro_samples=4, dropblock_probs=0.5,
+                                dropblock_sizes=2)
