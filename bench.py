@@ -169,7 +169,7 @@ def main():
         return cpu_pool_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), int(sys.argv[6]))
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not os.environ.get("RUNIA_BENCH_REHEARSE"):
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(self_launch(args))  # nothing in this process has touched the GPU yet
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}")

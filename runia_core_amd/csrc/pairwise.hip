@@ -37,14 +37,15 @@ __global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict
   }
 }
 
-// stage a [rows x 32] K-chunk of a K-contiguous matrix into LDS (zero filled outside the matrix)
-__device__ __forceinline__ void stage_chunk(const float* __restrict__ src, int64_t row0, int64_t nrows, int64_t D,
-                                            int64_t k0, float (*dst)[KP], int tid, bool vec,
-                                            float clip_max = INFINITY) {
-  const int row = tid >> 1, half = tid & 1;  // 128 rows x 2 halves of 16 floats
+// stage a [rows x 32] K-chunk of a K-contiguous matrix into LDS (zero filled outside the matrix), in two halves so that
+// the global loads of chunk i+1 are in flight while the matrix cores work on chunk i:
+//   load_chunk : global -> 16 registers per thread (128 rows x 2 halves of 16 floats)
+//   store_chunk: registers -> LDS
+__device__ __forceinline__ void load_chunk(const float* __restrict__ src, int64_t row0, int64_t nrows, int64_t D,
+                                           int64_t k0, float (&v)[16], int tid, bool vec) {
+  const int row = tid >> 1, half = tid & 1;
   const int64_t gr = row0 + row;
   const float* p = src + gr * D + k0 + half * 16;
-  float v[16];
   if (gr < nrows && vec && k0 + half * 16 + 16 <= D) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -55,10 +56,17 @@ __device__ __forceinline__ void stage_chunk(const float* __restrict__ src, int64
 #pragma unroll
     for (int j = 0; j < 16; ++j) v[j] = (gr < nrows && k0 + half * 16 + j < D) ? p[j] : 0.f;
   }
+}
+
+template <bool CLIP>
+__device__ __forceinline__ void store_chunk(const float (&v)[16], float (*dst)[KP], int tid, float clip_max = INFINITY) {
+  const int row = tid >> 1, half = tid & 1;
 #pragma unroll
-  for (int j = 0; j < 8; ++j)
-    *reinterpret_cast<float2*>(&dst[row][half * 16 + 2 * j]) =
-        make_float2(fminf(v[2 * j], clip_max), fminf(v[2 * j + 1], clip_max));
+  for (int j = 0; j < 8; ++j) {
+    // the clip (ReAct) costs two vector instructions per element: only the instantiation that clips pays for it
+    const float a = CLIP ? fminf(v[2 * j], clip_max) : v[2 * j], b = CLIP ? fminf(v[2 * j + 1], clip_max) : v[2 * j + 1];
+    *reinterpret_cast<float2*>(&dst[row][half * 16 + 2 * j]) = make_float2(a, b);
+  }
 }
 
 // EPI_DIST  : out[q, m] = max(0, |q|^2 + |b_m|^2 - 2 q.b_m)                  (kNN distances; qn = |q|^2, bn = |b|^2)
@@ -85,11 +93,18 @@ __global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__
     for (int b = 0; b < 2; ++b)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+  float ra[16], rb[16];
+  load_chunk(q, q0, Q, D, 0, ra, tid, vec);
+  load_chunk(bank, m0, M, D, 0, rb, tid, vec);
   for (int64_t k0 = 0; k0 < D; k0 += KCH) {
+    __syncthreads();  // every wave has finished reading the previous chunk
+    store_chunk<EPI == EPI_LINEAR>(ra, As, tid, clip_max);
+    store_chunk<false>(rb, Bs, tid);
     __syncthreads();
-    stage_chunk(q, q0, Q, D, k0, As, tid, vec, EPI == EPI_LINEAR ? clip_max : INFINITY);
-    stage_chunk(bank, m0, M, D, k0, Bs, tid, vec);
-    __syncthreads();
+    if (k0 + KCH < D) {  // next chunk's loads fly while the matrix cores consume this one
+      load_chunk(q, q0, Q, D, k0 + KCH, ra, tid, vec);
+      load_chunk(bank, m0, M, D, k0 + KCH, rb, tid, vec);
+    }
 #pragma unroll
     for (int s = 0; s < KCH / 4; ++s) {
       float2 av[2], bv[2];
@@ -144,11 +159,85 @@ constexpr int kMaxCand = 512;
 // linearly onto a 24-bit key over the row's range bound (sqrt|q|^2 + sqrt(max|b|^2))^2, 12 bits per pass, 4096
 // counters (1.03 ms, three reads).  A key bin is range / 2^24 wide; the refinement window (never narrower than two
 // bins) then restores the exact k-th value.
+// Fast path (one read of the row instead of three): the k-th smallest of ANY subset of the row is an upper bound of the
+// row's k-th smallest, so the k-th smallest of a strided sample of 2048 entries (selected in LDS) gives a threshold tau;
+// one pass over the row collects the entries <= tau (about k * M / 2048 of them) into LDS and the selection and the
+// refinement window are taken among those.  Whenever that cannot be exact - more candidates than the LDS list holds
+// (ties, a sample that does not represent the row), a window reaching beyond tau - the three-read path runs instead.
 // Every row is written on every path: -FLT_MAX for a query whose norm is not finite (all its distances are
 // incomparable, faiss returns its FLT_MAX fill), the approximate value before the refinement starts, the exact value
 // after it.  A window holding more than kMaxCand candidates (duplicated bank rows, distances crowded into a few key
 // bins by an outlier norm) takes the exact slow path: candidates are re-measured in place in the distance row (marked
 // by the sign bit) and the wanted order statistic is taken by an 8-bit radix select over their bit patterns.
+constexpr int kSample = 2048;    // strided sample of the row (fast path)
+constexpr int kFastCap = 2048;   // candidates <= tau kept in LDS (the sample shares the buffer)
+
+// 24-bit linear key of a distance
+__device__ __forceinline__ unsigned dist_key(float d, float scale) {
+  const float kf = d * scale;
+  return (kf >= 16777215.0f) ? 16777215u : (unsigned)kf;
+}
+
+// rank-th smallest (1-based) 24-bit key among load(0..count-1): two 12-bit histogram passes, whole workgroup.
+// `vec4` (optional): the same values as a 16-byte aligned array of count/4 float4 (count % 4 == 0), read 16 bytes per
+// lane with two loads in flight.
+template <class Load>
+__device__ __forceinline__ unsigned hist_select24(Load load, int64_t count, unsigned rank, float scale, unsigned* hist,
+                                                  unsigned* part, unsigned* sel, int tid, const float4* vec4 = nullptr) {
+  unsigned bin1 = 0;
+  for (int pass = 0; pass < 2; ++pass) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) hist[tid * 16 + j] = 0u;
+    __syncthreads();
+    auto tally = [&](float d) {
+      const unsigned key = dist_key(d, scale);
+      if (pass == 0) atomicAdd(&hist[key >> 12], 1u);
+      else if ((key >> 12) == bin1) atomicAdd(&hist[key & 4095u], 1u);
+    };
+    if (vec4) {
+      const int64_t n4 = count >> 2;
+      int64_t m = tid;
+      for (; m + 256 < n4; m += 512) {
+        const float4 a = vec4[m], b = vec4[m + 256];
+        tally(a.x); tally(a.y); tally(a.z); tally(a.w);
+        tally(b.x); tally(b.y); tally(b.z); tally(b.w);
+      }
+      for (; m < n4; m += 256) {
+        const float4 a = vec4[m];
+        tally(a.x); tally(a.y); tally(a.z); tally(a.w);
+      }
+    } else {
+      for (int64_t m = tid; m < count; m += 256) tally(load(m));
+    }
+    __syncthreads();
+    unsigned ssum = 0;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) ssum += hist[tid * 16 + j];
+    part[tid] = ssum;
+    __syncthreads();
+    if (tid == 0) {
+      unsigned r = rank, t = 0;
+      for (; t < 255; ++t) {
+        if (r <= part[t]) break;
+        r -= part[t];
+      }
+      unsigned b = t * 16;
+      for (; b < t * 16 + 15; ++b) {
+        const unsigned c = hist[b];
+        if (r <= c) break;
+        r -= c;
+      }
+      sel[0] = b;
+      sel[1] = r;
+    }
+    __syncthreads();
+    if (pass == 0) bin1 = sel[0];
+    rank = sel[1];
+    __syncthreads();
+  }
+  return (bin1 << 12) | sel[0];
+}
+
 __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict__ dist, const float* __restrict__ q,
                                                                 const float* __restrict__ bank,
                                                                 const float* __restrict__ qn,
@@ -157,11 +246,17 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
                                                                 int64_t D, int k) {
   __shared__ unsigned hist[4096];
   __shared__ unsigned part[256];
-  __shared__ unsigned sel_bin, sel_rank, n_below, n_cand;
+  __shared__ unsigned sel[2];
+  __shared__ unsigned n_below, n_cand, n_fast;
   __shared__ int cand_idx[kMaxCand];
   __shared__ float cand_d[kMaxCand];
+  __shared__ float fast_d[kFastCap];  // first the strided sample (kSample <= kFastCap), then the candidates <= tau
+  __shared__ int fast_i[kFastCap];
+  static_assert(kSample <= kFastCap, "the sample lives in the candidate buffer");
+  float* samp = fast_d;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float bmax = __uint_as_float(*bn_max_bits);
+  const bool fast_ok = (M >= 4 * (int64_t)kSample) && (k <= kSample / 4);
   for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
     float* drow = dist + row * M;
     const float qnorm = qn[row];
@@ -172,65 +267,93 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
     const float sq = sqrtf(qnorm) + sqrtf(bmax);
     const float range = sq * sq * 1.000001f + 1e-30f;
     const float scale = 16777216.0f / range;
-    unsigned bin1 = 0, rank = (unsigned)k;
+    const float delta = fmaxf(kRefineRel * range, 2.0f / scale);  // refinement half-window, never narrower than two bins
+    const float4* drow4 = (((M & 3) == 0) && ((((uintptr_t)drow) & 15) == 0)) ? reinterpret_cast<const float4*>(drow) : nullptr;
     __syncthreads();
-    if (tid == 0) { n_below = 0u; n_cand = 0u; }
-    for (int pass = 0; pass < 2; ++pass) {
+    if (tid == 0) { n_below = 0u; n_cand = 0u; n_fast = 0u; }
+    bool windowed = false;
+    float approx = 0.f, lo = 0.f, hi = 0.f;
+    if (fast_ok) {
+      const int64_t stride = M / kSample;
 #pragma unroll
-      for (int j = 0; j < 16; ++j) hist[tid * 16 + j] = 0u;
+      for (int j = 0; j < kSample / 256; ++j) samp[tid + 256 * j] = drow[(int64_t)(tid + 256 * j) * stride];
       __syncthreads();
+      const unsigned key_s = hist_select24([&](int64_t m) { return samp[m]; }, kSample, (unsigned)k, scale, hist, part, sel, tid);
+      if (key_s < 16777214u) {
+        const float tau = ((float)key_s + 1.0f) / scale * 1.000001f;  // upper edge of the bin: >= k sample entries are <= tau
+        __syncthreads();  // the sample (in fast_d) has been consumed
+        auto keep = [&](float d, int64_t m) {
+          if (d <= tau) {
+            const unsigned slot = atomicAdd(&n_fast, 1u);
+            if (slot < (unsigned)kFastCap) { fast_d[slot] = d; fast_i[slot] = (int)m; }
+          }
+        };
+        if (drow4) {
+          const int64_t n4 = M >> 2;
+          int64_t m = tid;
+          for (; m + 768 < n4; m += 1024) {  // four 16-byte loads in flight per lane
+            const float4 a = drow4[m], b = drow4[m + 256], c = drow4[m + 512], e = drow4[m + 768];
+            keep(a.x, 4 * m); keep(a.y, 4 * m + 1); keep(a.z, 4 * m + 2); keep(a.w, 4 * m + 3);
+            keep(b.x, 4 * (m + 256)); keep(b.y, 4 * (m + 256) + 1); keep(b.z, 4 * (m + 256) + 2); keep(b.w, 4 * (m + 256) + 3);
+            keep(c.x, 4 * (m + 512)); keep(c.y, 4 * (m + 512) + 1); keep(c.z, 4 * (m + 512) + 2); keep(c.w, 4 * (m + 512) + 3);
+            keep(e.x, 4 * (m + 768)); keep(e.y, 4 * (m + 768) + 1); keep(e.z, 4 * (m + 768) + 2); keep(e.w, 4 * (m + 768) + 3);
+          }
+          for (; m < n4; m += 256) {
+            const float4 a = drow4[m];
+            keep(a.x, 4 * m); keep(a.y, 4 * m + 1); keep(a.z, 4 * m + 2); keep(a.w, 4 * m + 3);
+          }
+        } else {
+          for (int64_t m = tid; m < M; m += 256) keep(drow[m], m);
+        }
+        __syncthreads();
+        const unsigned nf = n_fast;
+        if (nf >= (unsigned)k && nf <= (unsigned)kFastCap) {
+          const unsigned key_f = hist_select24([&](int64_t m) { return fast_d[m]; }, nf, (unsigned)k, scale, hist, part, sel, tid);
+          approx = ((float)key_f + 0.5f) / scale;
+          lo = approx - delta;
+          hi = approx + delta;
+          if (key_f < 16777215u && hi <= tau) {  // every entry of the row inside the window is among the candidates
+            unsigned below = 0;
+            for (unsigned c = tid; c < nf; c += 256) {
+              const float d = fast_d[c];
+              if (d < lo) {
+                ++below;
+              } else if (d <= hi) {
+                const unsigned slot = atomicAdd(&n_cand, 1u);
+                if (slot < (unsigned)kMaxCand) cand_idx[slot] = fast_i[c];
+              }
+            }
+            atomicAdd(&n_below, below);
+            windowed = true;
+            if (tid == 0) score[row] = -approx;
+          }
+        }
+      }
+      __syncthreads();
+    }
+    if (!windowed) {  // three reads of the row
+      if (tid == 0) { n_below = 0u; n_cand = 0u; }
+      const unsigned key_sel = hist_select24([&](int64_t m) { return drow[m]; }, M, (unsigned)k, scale, hist, part, sel, tid, drow4);
+      if (key_sel == 16777215u) {  // the k-th distance is a FLT_MAX fill (fewer than k comparable bank rows)
+        if (tid == 0) score[row] = -kFltMax;
+        continue;
+      }
+      approx = ((float)key_sel + 0.5f) / scale;
+      if (tid == 0) score[row] = -approx;  // never left unwritten; replaced by the exact value below
+      lo = approx - delta;
+      hi = approx + delta;
+      unsigned below = 0;
       for (int64_t m = tid; m < M; m += 256) {
-        const float kf = drow[m] * scale;
-        const unsigned key = (kf >= 16777215.0f) ? 16777215u : (unsigned)kf;
-        if (pass == 0) atomicAdd(&hist[key >> 12], 1u);
-        else if ((key >> 12) == bin1) atomicAdd(&hist[key & 4095u], 1u);
-      }
-      __syncthreads();
-      unsigned ssum = 0;
-#pragma unroll
-      for (int j = 0; j < 16; ++j) ssum += hist[tid * 16 + j];
-      part[tid] = ssum;
-      __syncthreads();
-      if (tid == 0) {
-        unsigned r = rank, t = 0;
-        for (; t < 255; ++t) {
-          if (r <= part[t]) break;
-          r -= part[t];
+        const float d = drow[m];
+        if (d < lo) {
+          ++below;
+        } else if (d <= hi) {
+          const unsigned slot = atomicAdd(&n_cand, 1u);
+          if (slot < (unsigned)kMaxCand) cand_idx[slot] = (int)m;
         }
-        unsigned b = t * 16;
-        for (; b < t * 16 + 15; ++b) {
-          const unsigned c = hist[b];
-          if (r <= c) break;
-          r -= c;
-        }
-        sel_bin = b;
-        sel_rank = r;
       }
-      __syncthreads();
-      if (pass == 0) bin1 = sel_bin;
-      rank = sel_rank;
+      atomicAdd(&n_below, below);
     }
-    const unsigned key_sel = (bin1 << 12) | sel_bin;
-    if (key_sel == 16777215u) {  // the k-th distance is a FLT_MAX fill (fewer than k comparable bank rows)
-      if (tid == 0) score[row] = -kFltMax;
-      continue;
-    }
-    const float approx = ((float)key_sel + 0.5f) / scale;
-    if (tid == 0) score[row] = -approx;  // never left unwritten; replaced by the exact value below
-    // ---- refinement window (never narrower than two key bins) ----
-    const float delta = fmaxf(kRefineRel * range, 2.0f / scale);
-    const float lo = approx - delta, hi = approx + delta;
-    unsigned below = 0;
-    for (int64_t m = tid; m < M; m += 256) {
-      const float d = drow[m];
-      if (d < lo) {
-        ++below;
-      } else if (d <= hi) {
-        const unsigned slot = atomicAdd(&n_cand, 1u);
-        if (slot < (unsigned)kMaxCand) cand_idx[slot] = (int)m;
-      }
-    }
-    atomicAdd(&n_below, below);
     __syncthreads();
     const unsigned nc = n_cand;
     const int want = k - (int)n_below;  // 1-based rank inside the window; 1 <= want <= nc by construction
@@ -270,12 +393,12 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
             if (r <= hist[d8]) break;
             r -= hist[d8];
           }
-          sel_bin = d8;
-          sel_rank = r;
+          sel[0] = d8;
+          sel[1] = r;
         }
         __syncthreads();
-        prefix |= sel_bin << shift;
-        r = sel_rank;
+        prefix |= sel[0] << shift;
+        r = sel[1];
         __syncthreads();
       }
       if (tid == 0) score[row] = -__uint_as_float(prefix);

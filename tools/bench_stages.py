@@ -197,6 +197,62 @@ cfd = torch.from_numpy(cf).to(dev)
 ms = gpu_ms(lambda: _hip.proj_sq_score(h, pm, cfd, NP))
 add("K2' proj_sq (a4+a5 folded)", f"{N}x{C} f64", "rows", N, ms, "mfma_f64", 2.0 * C * NP + 2 * NP, float("nan"), "-", rel(_hip.proj_sq_score(h, pm, cfd, NP)[:2000].cpu().numpy(), oracle.md_score(ys, mdm, prec)))
 
+# ---- round 2: metrics step, setup-time fits, per-ROI path ---------------------------------------------------------------
+ind = torch.randn(1_000_000, dtype=torch.float64, device=dev, generator=g) + 0.4
+ood = torch.randn(1_000_000, dtype=torch.float64, device=dev, generator=g) - 0.4
+ms = gpu_ms(lambda: _hip.ood_metrics(ind, ood), reps=5)
+got = _hip.ood_metrics(ind, ood).cpu().numpy()
+m = 200_000
+t0 = time.perf_counter()
+exp = oracle.auroc_fpr95_aupr(ind[:m].cpu().numpy(), ood[:m].cpu().numpy())
+cpu = 2 * m / (time.perf_counter() - t0)
+got_s = _hip.ood_metrics(ind[:m].contiguous(), ood[:m].contiguous()).cpu().numpy()
+add("AUROC/FPR95/AUPR (f2)", "1M + 1M f64 scores", "scores", 2_000_000, ms, "hbm", 8 * (8 + 1) * 2 + 16, cpu,
+    f"numpy argsort + cumsum restatement of torchmetrics, {2 * m} scores", float(np.max(np.abs(got_s - np.array(exp)))))
+
+for n_e in (256, 512, 2048):
+    a_ = torch.randn(n_e, n_e, dtype=torch.float64, device=dev, generator=g)
+    a_ = a_ @ a_.T / n_e + torch.eye(n_e, dtype=torch.float64, device=dev)
+    t0 = time.perf_counter()
+    w_, v_ = _hip.eigh(a_)
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) * 1e3
+    t0 = time.perf_counter()
+    w_ref = np.linalg.eigvalsh(a_.cpu().numpy())
+    cpu = 1.0 / (time.perf_counter() - t0)
+    add("Jacobi eigh (f1)", f"{n_e}x{n_e} f64 symmetric", "matrices", 1, ms, "mfma_f64", 10 * 4.0 * n_e**3, cpu,
+        "numpy.linalg.eigvalsh (LAPACK, all host cores)", rel(w_.cpu().numpy(), w_ref))
+
+xr = torch.randn(50_000, 512, dtype=torch.float64, device=dev, generator=g) * (0.2 + torch.rand(512, dtype=torch.float64, device=dev, generator=g))
+from runia_core_amd.device_fit import pca_fit_device  # noqa: E402
+
+t0 = time.perf_counter()
+fit = pca_fit_device(xr.cpu().numpy(), 256)
+ms = (time.perf_counter() - t0) * 1e3
+from sklearn.decomposition import PCA as _PCA  # noqa: E402
+
+t0 = time.perf_counter()
+ref_fit = _PCA(n_components=256, svd_solver="covariance_eigh", whiten=True).fit(xr.cpu().numpy())
+cpu = 1.0 / (time.perf_counter() - t0)
+add("PCA fit covariance_eigh (f1)", "50000x512 f64 -> 256 (incl. H2D of the rows)", "fits", 1, ms, "mfma_f64", 2.0 * 50_000 * 512 * 512, cpu,
+    "sklearn PCA(svd_solver='covariance_eigh')", float(np.abs(fit.components_ - ref_fit.components_).max()))
+
+fm = torch.relu(torch.randn(1, 256, 50, 80, device=dev, generator=g))
+kb = 1000
+xy = torch.rand(kb, 2, device=dev, generator=g) * torch.tensor([400.0, 250.0], device=dev)
+wh = 30 + torch.rand(kb, 2, device=dev, generator=g) * torch.tensor([200.0, 120.0], device=dev)
+boxes = torch.cat([xy, xy + wh], dim=1)
+ms = gpu_ms(lambda: _hip.roi_align(fm, boxes, 7, 80 / 640, 2, True))
+rois = _hip.roi_align(fm, boxes, 7, 80 / 640, 2, True)
+mb = 4
+t0 = time.perf_counter()
+exp = oracle.roi_align(fm.cpu().numpy(), boxes[:mb].cpu().numpy(), 7, 80 / 640, 2, True)
+cpu = mb / (time.perf_counter() - t0)
+add("roi_align (f3)", f"{kb} boxes x 256 ch x 7x7, sampling 2", "boxes", kb, ms, "hbm", 256 * 49 * 4 * (1 + 4 * 4), cpu,
+    f"numpy restatement, {mb} boxes", rel(rois[:mb].cpu().numpy(), exp))
+ms = gpu_ms(lambda: _hip.mc_entropy(rois, _hip.CounterDraws(3, 0), 16, 0.4, 3, 5))
+add("per-ROI MC entropy 7x7 (f3)", f"{kb} ROIs x 256 ch x 7x7, 16 MC", "boxes", kb, ms, "hbm", 256 * 49 * 4 + 256 * 8, float("nan"), "-", 0.0)
+
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"host_cores": os.cpu_count(), "device": torch.cuda.get_device_name(0), "rows": rows},
           open(os.path.join(ROOT, "gpurun_out", "stages.json"), "w"), indent=1)
