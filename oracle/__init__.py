@@ -9,10 +9,13 @@ library and fails loudly when that library or a GPU is missing.
 Parity status: PINNED.  Every function here is checked (tests/test_oracle_goldens.py)
 against the golden vectors hard-coded in the reference's own unit tests and
 against fixtures produced by importing the reference's hot-path source files
-in the build container (tools/make_goldens.py -> tests/golden/*.npz).  The one
-exception is the DropBlock mask path (``mc_stack``): the third-party
-``dropblock==0.3.0`` package is absent from the image and the only value-level
-pin in the reference needs a dataset download, so that stage is
-"parity unpinned" (restated from the published algorithm).
+in the build container (tools/make_goldens.py, tools/make_goldens_r2.py -> tests/golden/*.npz).
+The sampler (``mc_stack``) is pinned since round 2 by outputs of the reference's own
+``MCSamplerModule.forward`` loaded by path (tests/golden/ref_sampler.npz; the only restated
+piece that runs there is the third-party ``dropblock==0.3.0`` layer, absent from the image).
+Unpinned: ``roi_align`` (torchvision is absent; restated from its published algorithm - the
+reference's per-ROI glue around it is pinned with that restatement plugged in,
+tests/golden/ref_roi.npz) and ``philox4x32_10`` / ``counter_draws`` (the build's own
+throughput-mode draws; checked against Random123's published known-answer vectors).
 """
 from .hotpath import *  # noqa: F401,F403
