@@ -26,7 +26,8 @@ using namespace runia_mfma;
 
 constexpr int BM = 32;  // rows per workgroup (2 row tiles of 16)
 
-enum Epilogue { EPI_PCA = 0, EPI_ROWDOT = 1, EPI_STORE = 2, EPI_ROWNORM = 3, EPI_KDE = 4 };
+enum Epilogue { EPI_PCA = 0, EPI_ROWDOT = 1, EPI_STORE = 2, EPI_ROWNORM = 3, EPI_KDE = 4, EPI_MAHA = 5 };
+constexpr int kMahaMaxClasses = 16;  // classes the fused Mahalanobis epilogue keeps in LDS
 
 struct GemmArgs {
   const void* x;        // [N, K] rows (TA), ld = ldx
@@ -42,6 +43,10 @@ struct GemmArgs {
   const double* rown;   // [N] squared norms of the rows of x
   const double* coln;   // [n] squared norms of the columns of B
   double alpha, addc;
+  // EPI_MAHA: out[row] = max_c -(t P t^T), t = fl(x - mu_c) in the input dtype (see maha_class_kernel for the algebra)
+  const void* class_mean;  // [C, K] (TA)
+  const double* mu_p;      // [C, K] f64 = class_mean @ P
+  int n_classes;
   // outputs
   double* out;          // EPI_PCA / EPI_STORE: [N, n] (ld = n); EPI_ROWDOT / EPI_ROWNORM / EPI_KDE: [N]
 };
@@ -93,6 +98,11 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   __shared__ double lds_a[2][BM][APITCH];
   __shared__ double lds_part[4][BM];
   __shared__ double lds_part2[(EPI == EPI_KDE) ? 4 : 1][BM];
+  // EPI_MAHA: per (wave, row, class) partial of sum_j (G_j - (mu_c P)_j)(2 t_j - a_j); every slot is owned by one lane
+  __shared__ double lds_cls[(EPI == EPI_MAHA) ? 4 * BM * kMahaMaxClasses : 1];
+  if constexpr (EPI == EPI_MAHA) {
+    for (int i = threadIdx.x; i < 4 * BM * kMahaMaxClasses; i += 256) lds_cls[i] = 0.0;
+  }
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -137,7 +147,52 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     }
 
     // ---- epilogue for this 256-column block ----
-    if constexpr (EPI == EPI_KDE) {
+    if constexpr (EPI == EPI_MAHA) {
+      // class terms of this 256-column block straight from the accumulators (G = X P never goes to memory):
+      // for every class c, row partial += (G_j - (mu_c P)_j) * (2 t_j - a_j) over the lane's 4 columns, reduced over the
+      // 16 lanes that share a row, added to the (wave, row, class) slot this lane group owns.  ~5 % of the block's MFMA time.
+      const TA* xg = reinterpret_cast<const TA*>(g.x);
+      const TA* mug = reinterpret_cast<const TA*>(g.class_mean);
+      TA xv[2][4][4];
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int64_t col = (ctbase + c) * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t row = r0 + 16 * a + lg + 4 * r;
+            xv[a][c][r] = (row < g.N && col < g.n) ? xg[row * g.ldx + col] : (TA)0;
+          }
+        }
+      for (int cls = 0; cls < g.n_classes; ++cls) {
+        TA mv[4];
+        double qv[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const int64_t col = (ctbase + c) * 16 + li;
+          mv[c] = (col < g.n) ? mug[(int64_t)cls * g.K + col] : (TA)0;
+          qv[c] = (col < g.n) ? g.mu_p[(int64_t)cls * g.K + col] : 0.0;
+        }
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            double part = 0.0;
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const double ad = (double)xv[a][c][r] - (double)mv[c];
+              const double td = (double)(TA)(xv[a][c][r] - mv[c]);
+              part = fma(acc[a][c][r] - qv[c], 2.0 * td - ad, part);  // zero beyond n: G = 0, q = 0
+            }
+            part += shfl_xor_f64(part, 1);
+            part += shfl_xor_f64(part, 2);
+            part += shfl_xor_f64(part, 4);
+            part += shfl_xor_f64(part, 8);
+            if (li == 0) lds_cls[(wave * BM + 16 * a + lg + 4 * r) * kMahaMaxClasses + cls] += part;
+          }
+      }
+    } else if constexpr (EPI == EPI_KDE) {
       // online logsumexp over this lane's 4 columns of the block, per accumulator row
 #pragma unroll
       for (int a = 0; a < 2; ++a)
@@ -194,6 +249,23 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     __syncthreads();  // all waves done with the last chunk before the next block restages LDS
   }
 
+  if constexpr (EPI == EPI_MAHA) {
+    __syncthreads();
+    if (tid < BM) {
+      const int64_t row = r0 + tid;
+      if (row < g.N) {
+        double best = -kInfD();
+        for (int cls = 0; cls < g.n_classes; ++cls) {
+          const double t = ((lds_cls[(0 * BM + tid) * kMahaMaxClasses + cls] + lds_cls[(1 * BM + tid) * kMahaMaxClasses + cls]) +
+                            lds_cls[(2 * BM + tid) * kMahaMaxClasses + cls]) + lds_cls[(3 * BM + tid) * kMahaMaxClasses + cls];
+          double sc = -t;
+          if (sc != sc) sc = -kInfD();  // NaN (class without training samples) -> -inf, as the reference
+          best = fmax(best, sc);
+        }
+        g.out[row] = best;
+      }
+    }
+  }
   if constexpr (EPI == EPI_KDE) {
     // merge the (max, sum) pairs of the 16 lanes that share a row, then of the four waves
 #pragma unroll
@@ -433,6 +505,14 @@ static int maha_impl(const TX* x, const TX* class_mean, const double* packed_p, 
   if (N < 0 || D <= 0 || C <= 0 || (N > 0 && (!x || !score)) || !class_mean || !packed_p || !mu_p)
     return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
+  if (C <= kMahaMaxClasses) {
+    // fused: the class terms are taken from the GEMM accumulators of every 256-column block; G = X P is never written
+    // (the two-launch form below spends 20 % of its time re-reading it per class).  The workspace is not touched.
+    GemmArgs g{};
+    g.x = x; g.ldx = D; g.packed = packed_p; g.N = N; g.K = D; g.n = D;
+    g.class_mean = class_mean; g.mu_p = mu_p; g.n_classes = C; g.out = score;
+    return launch_gemm<TX, EPI_MAHA>(g, as_stream(stream));
+  }
   const int64_t cap_rows = (int64_t)(workspace_bytes / ((size_t)D * sizeof(double)));
   if (!workspace || cap_rows < 1) return RUNIA_E_WORKSPACE;
   double* G = reinterpret_cast<double*>(workspace);
