@@ -1,3 +1,3 @@
-from .scores import eigen_score  # noqa: F401
+from .scores import eigen_score, semantic_entropy  # noqa: F401
 
-__all__ = ["eigen_score"]
+__all__ = ["eigen_score", "semantic_entropy"]

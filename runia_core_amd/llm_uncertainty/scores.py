@@ -15,13 +15,13 @@ clustering) is model glue and out of scope.
 from __future__ import annotations
 
 import math
-from typing import Tuple
+from typing import Dict, List, Tuple
 
 import torch
 
 from .. import _hip
 
-__all__ = ["eigen_score"]
+__all__ = ["eigen_score", "semantic_entropy"]
 
 
 def _construct_embedding_matrix(hidden_states: Tuple[torch.Tensor, ...], token_index: int = -1, layer_index: int = 15) -> torch.Tensor:
@@ -44,3 +44,46 @@ def eigen_score(hidden_states: Tuple[torch.Tensor, ...], alpha: float = 1e-3) ->
     top = torch.flip(lam, dims=(0,))[:k]
     total = float(torch.log(top + alpha).sum().item()) + (hidden - k) * math.log(alpha)
     return total / hidden
+
+
+def _entails_both_ways(model, tokenizer, a: str, b: str) -> bool:
+    """Bidirectional NLI check of two texts (reference ``llm_uncertainty/utils.py:11-43``): class 0 = contradiction, 1 =
+    neutral, 2 = entailment; equivalent unless either direction contradicts or both are neutral.  Both directions go
+    through the model in ONE batched forward pass."""
+    enc = tokenizer([a, b], [b, a], return_tensors="pt", padding=True)
+    enc = {k: v.to(model.device) for k, v in enc.items()}
+    with torch.no_grad():
+        verdicts = tuple(int(v) for v in torch.argmax(model(**enc).logits, dim=1).tolist())
+    return (0 not in verdicts) and verdicts != (1, 1)
+
+
+def _semantic_clustering(model, tokenizer, texts: List[str]) -> Dict[int, List[int]]:
+    """Greedy clustering of semantically equivalent texts (reference ``llm_uncertainty/utils.py:46-81``): every
+    unassigned text opens a cluster and collects the later unassigned texts that are equivalent to it."""
+    owner = [-1] * len(texts)
+    clusters: Dict[int, List[int]] = {}
+    for i in range(len(texts)):
+        if owner[i] >= 0:
+            continue
+        cid = len(clusters)
+        owner[i] = cid
+        clusters[cid] = [i]
+        for j in range(i + 1, len(texts)):
+            if owner[j] < 0 and _entails_both_ways(model, tokenizer, texts[i], texts[j]):
+                owner[j] = cid
+                clusters[cid].append(j)
+    return clusters
+
+
+def semantic_entropy(model, tokenizer, texts: List[str]) -> Tuple[float, Dict[int, List[int]]]:
+    """Discrete semantic entropy (reference ``llm_uncertainty/scores.py:88-118``; Kuhn et al. 2023): entropy of the
+    cluster-size distribution of the NLI clustering of ``texts``.  Host scalars: the cost is the NLI model's forward passes
+    (PyTorch-ROCm), there is no kernel work here.  Returns ``(entropy, clusters)``."""
+    clusters = _semantic_clustering(model, tokenizer, texts)
+    total = sum(len(v) for v in clusters.values())
+    entropy = 0.0
+    for members in clusters.values():
+        p = len(members) / total
+        if p > 0:
+            entropy -= p * math.log(p)
+    return float(entropy), clusters

@@ -286,3 +286,37 @@ def test_draw_is_the_sequential_cpu_stream():
         g = torch.Generator().manual_seed(9)
         seq = torch.cat([torch.rand(1, h, w, generator=g) for _ in range(b * n_mc)]).reshape(b, n_mc, h, w)
         assert torch.equal(m.draw(b, h, w, "cpu", generator=torch.Generator().manual_seed(9)), seq)
+
+
+def test_semantic_entropy_reference_goldens():
+    """/root/reference/tests/unit_test_llm_uncertainty.py:209-265 (clustering mocked as there): 1.0114042647073516 for
+    cluster sizes 3/2/1, 0 for one cluster, log(5) for five singletons; plus the greedy bidirectional-entailment clustering
+    itself against a stand-in NLI model."""
+    from unittest.mock import MagicMock, patch
+
+    import runia_core_amd.llm_uncertainty.scores as sc
+
+    with patch.object(sc, "_semantic_clustering", return_value={0: [0, 1, 2], 1: [3, 4], 2: [5]}):
+        e, cl = sc.semantic_entropy(MagicMock(), MagicMock(), ["t"] * 6)
+    assert isinstance(e, float) and abs(e - 1.0114042647073516) < 1e-6 and len(cl) == 3
+    with patch.object(sc, "_semantic_clustering", return_value={0: [0, 1, 2, 3]}):
+        assert abs(sc.semantic_entropy(MagicMock(), MagicMock(), ["t"] * 4)[0]) < 1e-6
+    with patch.object(sc, "_semantic_clustering", return_value={i: [i] for i in range(5)}):
+        assert abs(sc.semantic_entropy(MagicMock(), MagicMock(), ["t"] * 5)[0] - np.log(5)) < 1e-6
+
+    class _Tok:  # texts are "<group><variant>": same group = equivalent
+        def __call__(self, a, b, return_tensors=None, padding=None):
+            same = [float(x[0] == y[0]) for x, y in zip(a, b)]
+            return {"same": torch.tensor(same)}
+
+    class _Nli:
+        device = torch.device("cpu")
+
+        def __call__(self, same):
+            logits = torch.zeros(len(same), 3)
+            logits[:, 2] = same * 5          # entailment when the groups match
+            logits[:, 0] = (1 - same) * 5    # contradiction otherwise
+            return type("O", (), {"logits": logits})()
+
+    e, cl = sc.semantic_entropy(_Nli(), _Tok(), ["a1", "b1", "a2", "c1", "b2", "a3"])
+    assert cl == {0: [0, 2, 5], 1: [1, 4], 2: [3]} and abs(e - 1.0114042647073516) < 1e-12
