@@ -7,9 +7,10 @@
   matrix cores (``runia_covariance_*``),
 * ``scipy.linalg.pinvh`` to the hand-written Jacobi eigen-solver (``runia_eigh_*``, ``csrc/eigh.hip``) with SciPy's
   cut-off rule and a device matrix product,
-* the PCA fit of ``apply_pca_ds_split(..., svd_solver="covariance_eigh" | "full")`` to covariance + the same
-  eigen-solver + sklearn's sign convention (``svd_flip(u_based_decision=False)``).  The reference's default
-  ``svd_solver="randomized"`` stays the scikit-learn call: its result depends on draws from NumPy's global generator.
+* the PCA fit of ``apply_pca_ds_split`` to the device: ``svd_solver="covariance_eigh" | "full"`` = covariance + the same
+  eigen-solver + sklearn's sign convention (``svd_flip(u_based_decision=False)``); the reference's default
+  ``svd_solver="randomized"`` = sklearn's randomized range finder carried out in covariance space with the SAME random
+  test matrix (drawn from NumPy's global generator exactly as sklearn draws it), see ``pca_fit_randomized_device``.
 
 No vendor solver is involved.  The default (False) keeps the reference's own host calls, so fitted state is
 bit-identical to the reference.
@@ -21,7 +22,7 @@ import torch
 
 from . import _hip
 
-__all__ = ["empirical_precision_device", "pinvh_device", "pca_fit_device", "FittedPCA"]
+__all__ = ["empirical_precision_device", "pinvh_device", "pca_fit_device", "pca_fit_randomized_device", "FittedPCA"]
 
 
 def pinvh_device(cov: torch.Tensor) -> torch.Tensor:
@@ -84,3 +85,73 @@ def pca_fit_device(samples, n_components: int, whiten: bool = True) -> FittedPCA
     vt = vt * signs
     total = float(w.sum().item())
     return FittedPCA(vt[:n_components].cpu().numpy(), mean.cpu().numpy(), w[:n_components].cpu().numpy(), whiten, n, total)
+
+
+def _inv_sqrt_spd(t: torch.Tensor) -> torch.Tensor:
+    """``T^(-1/2)`` of a symmetric positive semi-definite matrix through the Jacobi solver; directions below the numerical
+    rank are dropped."""
+    w, v = _hip.eigh(t)
+    floor = w.max() * (t.shape[0] * torch.finfo(t.dtype).eps)
+    inv = torch.where(w > floor, 1.0 / torch.sqrt(w.clamp_min(floor)), torch.zeros_like(w))
+    return _hip.matmul_f64((v * inv).contiguous(), v, transpose_b=True)
+
+
+def _orthonormalise(y: torch.Tensor) -> torch.Tensor:
+    """Orthonormal basis of the column span of ``y`` (symmetric orthogonalisation ``y (y^T y)^(-1/2)``)."""
+    g = _hip.matmul_f64(y.T.contiguous(), y)
+    return _hip.matmul_f64(y, _inv_sqrt_spd(g))
+
+
+def pca_fit_randomized_device(samples, n_components: int, whiten: bool = True, n_oversamples: int = 10) -> FittedPCA:
+    """sklearn ``PCA(n_components, svd_solver="randomized").fit`` (what ``apply_pca_ds_split`` calls by default,
+    reference ``dimensionality_reduction.py:70-71``) on the GPU, reproducing sklearn's result for the same state of NumPy's
+    global generator.
+
+    sklearn (``utils/extmath.py::_randomized_svd``, tall data): Q = random normal ``(n_features, k + 10)``; ``n_iter`` times
+    Q <- normalise(M Q), Q <- normalise(M^T Q); Q <- qr(M Q); SVD of ``B = Q^T M``.  The normalisations only re-condition a
+    basis, so the outcome is a function of ``span(S^n_iter Omega)`` with ``S = M^T M``: every step is carried out on the
+    ``n_features x (k + 10)`` side with S alone - ONE pass over the data (the covariance kernel on the matrix cores), then
+    small products and Jacobi eigen-decompositions:
+        Z <- orth(S Z) x n_iter;  T = Z^T S Z;  C = T^(-1/2) (S Z)^T (S Z) T^(-1/2) = U diag(s^2) U^T;
+        Vt = diag(1/s) U^T T^(-1/2) (S Z)^T.
+    Agreement with sklearn: components to ~1e-11 on the test spectra (tests/test_api_gpu.py).  Data with fewer samples than
+    features (sklearn transposes the problem and draws a different matrix) is not covered: the caller falls back to sklearn."""
+    x = np.asarray(samples)
+    n, d = x.shape
+    if not 0 < n_components <= min(n, d):
+        raise ValueError(f"n_components={n_components} must be between 0 and min(n_samples, n_features)={min(n, d)}")
+    if n < d:
+        raise ValueError("pca_fit_randomized_device: n_samples < n_features is fitted by sklearn (transposed problem)")
+    size = min(n_components + n_oversamples, d)
+    omega = np.random.normal(size=(d, n_components + n_oversamples))[:, :size]  # the draw sklearn makes (random_state=None)
+    n_iter = 7 if n_components < 0.1 * min(n, d) else 4
+    xd = _hip.to_device(x, torch.float32 if x.dtype == np.float32 else torch.float64)
+    mean, cov = _hip.covariance(xd)           # bias = 1
+    s_mat = (cov * float(n)).contiguous()     # S = M^T M of the centred rows
+    z = _hip.to_device(omega, torch.float64)
+    for _ in range(n_iter):
+        z = _orthonormalise(_hip.matmul_f64(s_mat, z))
+    sz = _hip.matmul_f64(s_mat, z)                                      # (d, size)
+    t_ih = _inv_sqrt_spd(_hip.matmul_f64(z.T.contiguous(), sz))         # (Z^T S Z)^(-1/2)
+    szt = _hip.matmul_f64(sz, t_ih)                                     # S Z T^(-1/2)
+    w, u = _hip.eigh(_hip.matmul_f64(szt.T.contiguous(), szt))          # = B B^T of sklearn's B = Q^T M
+    w = torch.flip(w, dims=(0,)).clamp_min(0.0)
+    u = torch.flip(u, dims=(1,)).contiguous()
+    sing = torch.sqrt(w)
+    vt = _hip.matmul_f64(u.T.contiguous(), szt.T.contiguous())          # rows = s_i * v_i^T
+    vt = vt / sing.clamp_min(torch.finfo(torch.float64).tiny).unsqueeze(1)
+    idx = vt.abs().argmax(dim=1, keepdim=True)
+    signs = torch.sign(torch.gather(vt, 1, idx))
+    signs[signs == 0] = 1.0
+    vt = vt * signs
+    u = (u * signs.reshape(1, -1)).contiguous()  # svd_flip flips the columns of U with the rows of Vt
+    total_var = float(torch.diagonal(s_mat).sum().item()) / (n - 1.0)
+    fitted = FittedPCA(vt[:n_components].cpu().numpy(), mean.cpu().numpy(), (w[:n_components] / (n - 1.0)).cpu().numpy(),
+                       whiten, n, total_var)
+    fitted.svd_solver = "randomized"
+    # sklearn's fit_transform returns U (scaled), not transform(X): with an approximate SVD the two differ in the trailing
+    # components.  U = Q Uhat = M (Z T^(-1/2) Uhat), so the training rows are projected with that matrix instead of V.
+    proj = _hip.matmul_f64(_hip.matmul_f64(z, t_ih), u[:, :n_components].contiguous())       # (d, k)
+    scale = np.full(n_components, 1.0 / (n - 1.0)) if whiten else 1.0 / np.maximum(sing[:n_components].cpu().numpy(), 1e-300) ** 2
+    fitted._train_projection = (proj.T.contiguous().cpu().numpy(), scale)
+    return fitted

@@ -100,15 +100,26 @@ def apply_pca_ds(train_samples: np.ndarray, test_samples: np.ndarray, nro_compon
 def apply_pca_ds_split(samples: np.ndarray, nro_components: int = 16, svd_solver: str = "randomized",
                        whiten: bool = True) -> Tuple[np.ndarray, "PCA"]:  # noqa: F821
     """Fit a PCA on one dataset split; return (reduced samples, fitted sklearn PCA).
-    With ``runia_core_amd.config.device_fit`` and an exact solver (``"covariance_eigh"`` / ``"full"``) the fit runs on the
-    GPU (``device_fit.pca_fit_device``) and a ``FittedPCA`` with the same public attributes is returned."""
+    With ``runia_core_amd.config.device_fit`` the fit runs on the GPU - exact solvers through ``device_fit.pca_fit_device``,
+    the default ``"randomized"`` through ``device_fit.pca_fit_randomized_device`` (same draws from NumPy's global generator
+    as sklearn, same result) - and a ``FittedPCA`` with the same public attributes is returned."""
     from . import config
 
-    if config.device_fit and svd_solver in ("covariance_eigh", "full") and isinstance(nro_components, int):
-        from .device_fit import pca_fit_device
+    if config.device_fit and isinstance(nro_components, int):
+        from .device_fit import pca_fit_device, pca_fit_randomized_device
 
-        fitted = pca_fit_device(samples, nro_components, whiten)
-        return apply_pca_transform(samples, fitted), fitted
+        shape = np.shape(samples)
+        fitted = None
+        if svd_solver in ("covariance_eigh", "full"):
+            fitted = pca_fit_device(samples, nro_components, whiten)
+        elif svd_solver == "randomized" and len(shape) == 2 and shape[0] >= shape[1]:
+            fitted = pca_fit_randomized_device(samples, nro_components, whiten)  # consumes np.random like sklearn does
+        if fitted is not None:
+            if getattr(fitted, "_train_projection", None) is not None:
+                # randomized solver: sklearn's fit_transform is U * sqrt(n - 1) (or U * S), see pca_fit_randomized_device
+                proj, var = fitted._train_projection
+                return apply_pca_transform(samples, DevicePCA(proj, fitted.mean_, var, True)), fitted
+            return apply_pca_transform(samples, fitted), fitted
     from sklearn.decomposition import PCA
 
     pca_dim_red = PCA(n_components=nro_components, svd_solver=svd_solver, whiten=whiten)

@@ -874,3 +874,35 @@ def test_fast_mcd_samples_extractor_batched():
     with pytest.raises(NotImplementedError):
         FastMCDSamplesExtractor(net, [hook], torch.device("cuda"), "Conv", "mean", mcd_nro_samples=4, dropblock_probs=0.5,
                                 dropblock_sizes=2)
+
+
+def test_device_fit_randomized_pca_reproduces_sklearn(monkeypatch):
+    """apply_pca_ds_split with the reference's DEFAULT solver ("randomized") on the device: for the same state of NumPy's
+    global generator it returns sklearn's components / variances / transform (covariance-space range finder + Jacobi
+    eigen-solver, device_fit.pca_fit_randomized_device), and it leaves the generator in the same state as sklearn does."""
+    from sklearn.decomposition import PCA
+
+    import runia_core_amd.config as cfg
+
+    rng = np.random.default_rng(0)
+    n, d = 6000, 192
+    basis = np.linalg.qr(rng.standard_normal((d, d)))[0]
+    spec = np.exp(-np.arange(d) / 40.0) * 3 + 0.05
+    x = (rng.standard_normal((n, d)) * spec) @ basis.T + rng.standard_normal(d)
+    xt = (rng.standard_normal((64, d)) * spec) @ basis.T
+    for k in (96, 8):  # n_iter = 4 and n_iter = 7 in sklearn's rule
+        np.random.seed(7)
+        ref = PCA(n_components=k, svd_solver="randomized", whiten=True)
+        ref_red = ref.fit_transform(x)
+        after_ref = np.random.random()
+        monkeypatch.setattr(cfg, "device_fit", True)
+        np.random.seed(7)
+        red, fitted = rc.apply_pca_ds_split(x, k)  # default solver
+        after_dev = np.random.random()
+        monkeypatch.setattr(cfg, "device_fit", False)
+        assert fitted.svd_solver == "randomized" and after_dev == after_ref
+        assert np.abs(fitted.components_ - ref.components_).max() < 1e-8
+        assert np.abs(fitted.explained_variance_ / ref.explained_variance_ - 1).max() < 1e-9
+        assert np.abs(fitted.explained_variance_ratio_ - ref.explained_variance_ratio_).max() < 1e-10
+        assert rel_err(red, ref_red) < 1e-7
+        assert rel_err(rc.apply_pca_transform(xt, fitted), ref.transform(xt)) < 1e-7
