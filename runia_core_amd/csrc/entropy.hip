@@ -49,8 +49,14 @@ __global__ __launch_bounds__(256) void entropy_per_dim_kernel(const float* __res
     double out[VEC];
 #pragma unroll
     for (int q = 0; q < VEC; ++q) {
+      // a NaN sample makes the reference's entropy NaN; the min/max sort would drop it, so it is caught first (a sum is
+      // NaN iff a term is: the +inf pads of a short column cannot cancel finite samples)
+      float probe = v[q][0];
+#pragma unroll
+      for (int t = 1; t < NP; ++t) probe += v[q][t];
       sort_asc<NP>(v[q]);
       out[q] = const_term + inv_n * column_log_sum<NP, K>(v[q], n, min_dist);
+      if (probe != probe) out[q] = NAN;
     }
     double* dst = h + img * D + c * VEC;
     if constexpr (VEC == 4) {
@@ -75,8 +81,10 @@ __global__ __launch_bounds__(64) void entropy_per_dim_generic_kernel(const float
     const int64_t img = g / D;
     const int64_t c = g - img * D;
     const float* base = z + (img * n) * D + c;
+    bool has_nan = false;
     for (int s = 0; s < n; ++s) {  // insertion sort while loading
       const float x = base[(int64_t)s * D];
+      has_nan = has_nan || (x != x);
       int p = s;
       while (p > 0 && col[p - 1][t] > x) {
         col[p][t] = col[p - 1][t];
@@ -105,7 +113,7 @@ __global__ __launch_bounds__(64) void entropy_per_dim_generic_kernel(const float
         esum += e2;
       }
     }
-    h[img * D + c] = const_term + inv_n * (log(mant) + (double)esum * 0.69314718055994530942);
+    h[img * D + c] = has_nan ? NAN : const_term + inv_n * (log(mant) + (double)esum * 0.69314718055994530942);
   }
 }
 
@@ -145,8 +153,11 @@ __global__ __launch_bounds__(256) void entropy_joint_kernel(const float* __restr
       tb[q] = a + 1 + rem;
     }
   }
+  __shared__ int nan_seen;
   for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
     const float* base = z + img * n * D;
+    if (tid == 0) nan_seen = 0;  // ordered before the first staging pass by its barrier
+    bool my_nan = false;
     double best[kJointTasks];
 #pragma unroll
     for (int q = 0; q < kJointTasks; ++q) best[q] = 0.0;
@@ -156,7 +167,9 @@ __global__ __launch_bounds__(256) void entropy_joint_kernel(const float* __restr
       __syncthreads();
       for (int i = tid; i < n * w; i += 256) {
         const int s = i / w, j = i - s * w;
-        tile[s * TP + j] = (double)base[(int64_t)s * D + d0 + j];
+        const float xv = base[(int64_t)s * D + d0 + j];
+        my_nan = my_nan || (xv != xv);
+        tile[s * TP + j] = (double)xv;
       }
       __syncthreads();
       const int per = ((w + slices - 1) / slices + 3) & ~3;  // multiple of 4: slices start 32-byte aligned
@@ -189,6 +202,7 @@ __global__ __launch_bounds__(256) void entropy_joint_kernel(const float* __restr
         atomicMax(reinterpret_cast<unsigned long long*>(&dist[tb[q] * DP + ta[q]]), bits);
       }
     }
+    if (my_nan) nan_seen = 1;  // a NaN sample makes the reference's joint entropy NaN; fmax would drop it
     __syncthreads();
     // sample i: k-th smallest distance to the others (selection by counting, n <= 64)
     double logsum = 0.0;
@@ -213,7 +227,7 @@ __global__ __launch_bounds__(256) void entropy_joint_kernel(const float* __restr
     if (tid < 64) {
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) logsum += shfl_xor_f64(logsum, o);
-      if (tid == 0) h_mvn[img] = const_term + d_over_n * logsum;
+      if (tid == 0) h_mvn[img] = nan_seen ? NAN : const_term + d_over_n * logsum;
     }
     __syncthreads();
   }

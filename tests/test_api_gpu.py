@@ -906,3 +906,28 @@ def test_device_fit_randomized_pca_reproduces_sklearn(monkeypatch):
         assert np.abs(fitted.explained_variance_ratio_ - ref.explained_variance_ratio_).max() < 1e-10
         assert rel_err(red, ref_red) < 1e-7
         assert rel_err(rc.apply_pca_transform(xt, fitted), ref.transform(xt)) < 1e-7
+
+
+def test_larex_inference_fc_layer_type():
+    """LaRExInference with layer_type="FC": the sampler returns the flattened drop-layer outputs (C*H*W dims per sample,
+    reference feature_extraction/abstract_classes.py:95-99), entropies / PCA / LaREM follow; against the oracle chain."""
+    from runia_core_amd import LaRExInference, MCSamplerModule
+
+    rng = np.random.default_rng(4)
+    c, h, w, n_mc, n = 6, 4, 4, 16, 5
+    dflat = c * h * w
+    comp = np.linalg.qr(rng.standard_normal((dflat, 12)))[0].T
+    pca = type("P", (), {})()
+    pca.components_, pca.mean_, pca.explained_variance_, pca.whiten = comp, rng.standard_normal(dflat), rng.random(12) + 0.1, True
+    a = rng.standard_normal((12, 12))
+    md = MDLatentSpace()
+    md.feats_mean, md.precision, md._setup_flag = rng.standard_normal((1, 12)) * 0.1, a @ a.T / 12 + np.eye(12), True
+    inf = LaRExInference(torch.nn.Identity(), md, 0.5, 2, n_mc, MCSamplerModule, pca_transform=pca, layer_type="FC")
+    x = np.maximum(rng.standard_normal((n, c, h, w)), 0).astype(np.float32) + 0.1
+    rand = rng.random((n, n_mc, h, w)).astype(np.float32)
+    rand[:, :, 0, 0] = np.maximum(rand[:, :, 0, 0], 0.2)
+    s = inf.get_scores_from_latents(torch.from_numpy(x), rand=torch.from_numpy(rand).cuda())
+    z = np.concatenate([oracle.mc_stack(x[i : i + 1], rand[i], 0.5, 2, "FC") for i in range(n)])
+    assert z.shape == (n * n_mc, dflat)
+    exp, _ = oracle.larem_pipeline(z, n_mc, comp, pca.mean_, pca.explained_variance_, md.feats_mean, md.precision)
+    assert s.shape == (n,) and rel_err(s, exp) < 1e-9

@@ -407,6 +407,42 @@ def test_sampler_module_layer_types(hip):
     assert np.array_equal(m(torch.from_numpy(g["eval_x"])).cpu().numpy(), g["eval_out"])
 
 
+def test_nan_and_inf_activations_give_nan_entropies(hip):
+    """A NaN MC sample makes the reference's entropy NaN (its f64 tree query / log propagate it); the kernels' min/max sort
+    would silently drop it, so every entropy kernel probes for it: unfused per-dimension and joint kernels, generic-k
+    kernel, fused sampler + entropy (NaN / infinite activation, fully dropped map).  Clean columns are untouched."""
+    rng = np.random.default_rng(2)
+    n_img, n_mc, d = 5, 16, 40
+    z = rng.standard_normal((n_img * n_mc, d)).astype(np.float32)
+    clean = hip.kl_entropy_per_dim(dev(z, torch.float32), n_mc, 5).cpu().numpy()
+    cleanj = hip.kl_entropy_joint(dev(z, torch.float32), n_mc, 5).cpu().numpy()
+    z2 = z.copy()
+    z2[2 * n_mc + 3, 7] = np.nan
+    got = hip.kl_entropy_per_dim(dev(z2, torch.float32), n_mc, 5).cpu().numpy()
+    assert np.isnan(got[2, 7]) and np.isnan(got).sum() == 1
+    mask = np.ones_like(got, bool)
+    mask[2, 7] = False
+    assert np.array_equal(got[mask], clean[mask])
+    gj = hip.kl_entropy_joint(dev(z2, torch.float32), n_mc, 5).cpu().numpy()
+    assert np.isnan(gj[2]) and np.array_equal(np.delete(gj, 2), np.delete(cleanj, 2))
+    g3 = hip.kl_entropy_per_dim(dev(z2, torch.float32), n_mc, 3).cpu().numpy()  # generic-k kernel
+    assert np.isnan(g3[2, 7]) and np.isnan(g3).sum() == 1
+    # fused: NaN and infinite activations
+    x = np.maximum(rng.standard_normal((3, 24, 4, 4)), 0).astype(np.float32)
+    rand = rng.random((3, 16, 4, 4)).astype(np.float32)
+    rand[:, :, 0, 0] = np.maximum(rand[:, :, 0, 0], 0.2)
+    base = hip.mc_entropy(dev(x, torch.float32), dev(rand, torch.float32), 16, 0.5, 2, 5).cpu().numpy()
+    assert np.isfinite(base).all()
+    x2 = x.copy()
+    x2[1, 5, 2, 2] = np.nan
+    x2[2, 9, 0, 1] = np.inf
+    got = hip.mc_entropy(dev(x2, torch.float32), dev(rand, torch.float32), 16, 0.5, 2, 5).cpu().numpy()
+    assert np.isnan(got[1, 5]) and not np.isfinite(got[2, 9])
+    keep = np.ones_like(got, bool)
+    keep[1, 5] = keep[2, 9] = False
+    assert np.array_equal(got[keep], base[keep])
+
+
 # ---------------- throughput-mode draws (counter generator inside the keep-flag kernel) ---------------------------
 @pytest.mark.parametrize("n,n_mc,h,w,first", [(5, 16, 4, 4, 0), (3, 16, 7, 7, 10), (2, 12, 8, 8, 2**33), (300, 32, 4, 4, 65530),
                                               (4, 16, 2, 2, 1)])
