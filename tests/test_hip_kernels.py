@@ -319,6 +319,34 @@ def test_knn_adversarial_inputs_through_the_raw_entry(hip):
     assert dirty[4] == -oracle.FLT_MAX and np.array_equal(np.delete(dirty, 4), np.delete(clean, 4))
 
 
+@pytest.mark.parametrize("m", [9001, 12000, 20002])
+def test_knn_sampled_threshold_path_and_its_fallbacks(hip, m):
+    """Banks large enough for the one-read select (M >= 8192): 16-byte and scalar row loads (M % 4), k from 1 to the
+    path's limit and beyond it (k > 512 -> three-read path), a bank with 3 000 copies of one row (more candidates below
+    the sampled threshold than the LDS list holds -> three-read path, then the crowded-window slow path), rows whose
+    sample misrepresents the row (bank sorted by distance to the query)."""
+    rng = np.random.default_rng(m)
+    d = 48
+    bank = rng.standard_normal((m, d)).astype(np.float32)
+    bank /= np.linalg.norm(bank, axis=1, keepdims=True)
+    q = rng.standard_normal((12, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    for k in (1, 5, 50, 512, 513, 2000):
+        got = hip.knn_kth(dev(q, torch.float32), dev(bank, torch.float32), k).cpu().numpy()
+        assert rel_err(got, oracle.knn_kth_score(bank, q, k, normalize=False)) < 1e-5, (m, k)
+    dup = bank.copy()
+    dup[1000:4000] = dup[17]
+    for k in (1, 50, 2999, 3001):
+        got = hip.knn_kth(dev(q, torch.float32), dev(dup, torch.float32), k).cpu().numpy()
+        assert rel_err(got, oracle.knn_kth_score(dup, q, k, normalize=False)) < 1e-5, (m, k)
+    # bank ordered by distance to query 0: the strided sample still spans the row, the first rows do not
+    order = np.argsort(((bank - q[0]) ** 2).sum(1))
+    sorted_bank = np.ascontiguousarray(bank[order])
+    for k in (1, 50):
+        got = hip.knn_kth(dev(q, torch.float32), dev(sorted_bank, torch.float32), k).cpu().numpy()
+        assert rel_err(got, oracle.knn_kth_score(sorted_bank, q, k, normalize=False)) < 1e-5, (m, k)
+
+
 def test_knn_all_baselines_mean(hip, ref_vectors):
     from test_oracle_goldens import _all_baselines_inputs
 
