@@ -641,9 +641,11 @@ __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
 #pragma unroll
       for (int c = 0; c < NCT; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
     const double2* bp = reinterpret_cast<const double2*>(g.packed_m) + ctbase * 64 + lane;
-    double2 b0[NCT];
+    double2 bring[4][NCT];  // B fragments three k-step pairs ahead (mfma_chunk_ring)
 #pragma unroll
-    for (int c = 0; c < NCT; ++c) b0[c] = bp[c * 64];
+    for (int j = 0; j < 3; ++j)
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) bring[j][c] = bp[j * NT * 64 + c * 64];
     // staging: element q*256 + tid of the BM x KC chunk (a wave covers two 256-byte row segments per pass)
     double areg[PER_T];
     const int srow = tid / KC, skk = tid % KC;  // + 256/KC rows per q
@@ -662,7 +664,7 @@ __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
       for (int q = 0; q < PER_T; ++q) lds_a[(buf * BM + srow + q * (256 / KC)) * APITCH + skk] = areg[q];
       __syncthreads();
       if (ch + 1 < nchunks) load_a((ch + 1) * KC);
-      mfma_chunk<RT, NCT>(acc, lds_a + buf * BM * APITCH, APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
+      mfma_chunk_ring<RT, NCT>(acc, lds_a + buf * BM * APITCH, APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, bring);
       buf ^= 1;
     }
 #pragma unroll

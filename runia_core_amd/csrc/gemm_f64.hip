@@ -7,7 +7,7 @@
 // Layout.  The right-hand matrix B [K, n] is constant after setup(), so it is repacked
 // once into MFMA fragment order: for k-step pair s2 (8 k values) and 16-column tile ct,
 //   packed[((s2*NT + ct)*64 + lane)*2 + h] = B[8*s2 + 4*h + (lane>>4)][16*ct + (lane&15)]
-// (zero padded to K%32==0 plus one zero k-step pair, n%256==0; see mfma_f64_tile.hpp).  One wave-wide 16-byte load then yields the B operand
+// (zero padded to K%32==0 plus four zero k-step pairs, n%256==0; see mfma_f64_tile.hpp).  One wave-wide 16-byte load then yields the B operand
 // of two MFMA k-steps, fully coalesced (1 KiB per instruction, 4 KiB per wave per k-step pair)
 // and served by the XCD L2 (the whole matrix is <= a few MiB).
 // The left-hand rows stream from HBM exactly once: a 32-row x 32-k chunk is staged into LDS

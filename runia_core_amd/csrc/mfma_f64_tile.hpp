@@ -3,8 +3,8 @@
 // Packed weights.  A constant right-hand matrix B [K, n] is stored in MFMA fragment order:
 //   packed[((s2*NT + ct)*64 + lane)*2 + h] = B[8*s2 + 4*h + (lane>>4)][16*ct + (lane&15)]
 // for k-step pair s2 and 16-column tile ct (NT = n_pad/16).  K is zero padded to a multiple of 32 (= one staged
-// A chunk, so the MFMA loops carry no tail conditions) plus ONE extra all-zero k-step pair (so the B prefetch of
-// "the next pair" never needs a bounds check); n is zero padded to a multiple of 256.
+// A chunk, so the MFMA loops carry no tail conditions) plus FOUR extra all-zero k-step pairs (so the B prefetch of
+// up to three pairs beyond the last chunk never needs a bounds check); n is zero padded to a multiple of 256.
 //
 // v_mfma_f64_16x16x4_f64 fragment maps: A lane l -> A[l&15][l>>4]; B lane l -> B[l>>4][l&15];
 // C/D lane l, reg r -> C[(l>>4) + 4r][l&15].
@@ -19,7 +19,7 @@ constexpr int BN = 256;     // columns per workgroup pass: 4 waves x 4 tiles x 1
 
 __host__ __device__ inline int64_t n_padded(int64_t n) { return (n + BN - 1) / BN * BN; }
 __host__ __device__ inline int64_t k_padded(int64_t K) { return (K + KC - 1) / KC * KC; }        // multiple of 32
-__host__ __device__ inline int64_t packed_pairs(int64_t K) { return k_padded(K) / 8 + 1; }       // + 1 zero pair
+__host__ __device__ inline int64_t packed_pairs(int64_t K) { return k_padded(K) / 8 + 4; }       // + 4 zero pairs
 __host__ __device__ inline int64_t packed_elems(int64_t K, int64_t n) { return packed_pairs(K) * 8 * n_padded(n); }
 
 // Multiply-accumulate one 32-deep chunk: acc[a][c] += A[16a.., chunk] * B[chunk, this wave's 4 column tiles].
@@ -56,6 +56,36 @@ __device__ __forceinline__ void mfma_chunk(d4 (&acc)[RT][NCT], const double* a_t
       for (int c = 0; c < NCT; ++c) {
         const double2 bb = (s2 & 1) ? b1[c] : b0[c];
         const double bv = hh ? bb.y : bb.x;
+#pragma unroll
+        for (int a = 0; a < RT; ++a)
+          acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][2 * s2 + hh], bv, acc[a][c], 0, 0, 0);
+      }
+    }
+  }
+}
+
+// The same chunk product with the B fragments fetched THREE k-step pairs ahead (ring of four pair buffers, one per pair
+// of a chunk, indexed statically): with few MFMAs per pair (RT * NCT * 2 = 4 for the 16 x 128 tiles of K2') the one-pair
+// look-ahead of mfma_chunk is 256 matrix-pipe cycles, well under an L2 hit under load; three pairs are 768.
+//   b[j] : on entry pairs 0..2 of THIS chunk are in b[0..2]; on return b[0..2] hold pairs 0..2 of the next chunk.
+template <int RT, int NCT>
+__device__ __forceinline__ void mfma_chunk_ring(d4 (&acc)[RT][NCT], const double* a_tile, int pitch, int li, int lg,
+                                                const double2* __restrict__ bp, int64_t pair_stride,
+                                                double2 (&b)[4][NCT]) {
+  double av[RT][8];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) av[a][t] = a_tile[(16 * a + li) * pitch + 4 * t + lg];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) b[(s2 + 3) & 3][c] = bp[(s2 + 3) * pair_stride + c * 64];  // pair 3, then the next chunk's 0..2
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        const double bv = hh ? b[s2][c].y : b[s2][c].x;
 #pragma unroll
         for (int a = 0; a < RT; ++a)
           acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][2 * s2 + hh], bv, acc[a][c], 0, 0, 0);

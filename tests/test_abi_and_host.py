@@ -51,9 +51,9 @@ def test_library_exports_every_header_symbol():
     assert set(syms) <= exported
     assert lib.runia_abi_version() == 2
     assert lib.runia_error_string(-1).decode().startswith("invalid argument")
-    # K padded to a multiple of 32 plus one zero k-step pair (8 rows), n to a multiple of 256
-    assert lib.runia_packed_weights_bytes(512, 256) == (512 + 8) * 256 * 8
-    assert lib.runia_packed_weights_bytes(20, 10) == (32 + 8) * 256 * 8
+    # K padded to a multiple of 32 plus four zero k-step pairs (32 rows), n to a multiple of 256
+    assert lib.runia_packed_weights_bytes(512, 256) == (512 + 32) * 256 * 8
+    assert lib.runia_packed_weights_bytes(20, 10) == (32 + 32) * 256 * 8
 
 
 @pytest.mark.skipif(not no_gpu, reason="CPU-only behaviour")
