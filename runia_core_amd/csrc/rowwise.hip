@@ -62,6 +62,41 @@ __global__ __launch_bounds__(256) void lse_small_kernel(const float* __restrict_
   }
 }
 
+// ---- C <= 16 (10-class logits: BASELINE config 1 / the x10 leg of config 3): one row per lane straight from global
+// memory, the row in registers.  No LDS, no barrier: the lanes of a wave read 64 consecutive rows (64*C*4 contiguous
+// bytes), every load instruction of the row touches the same cache lines, so HBM sees each byte once.
+template <int CT>
+__global__ __launch_bounds__(256) void lse_tiny_kernel(const float* __restrict__ x, float* lse, float* msp, int64_t N) {
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < N; row += (int64_t)gridDim.x * 256) {
+    const float* p = x + row * CT;
+    float v[CT];
+    if constexpr (CT % 2 == 0) {
+      if ((((uintptr_t)x) & 7) == 0) {
+#pragma unroll
+        for (int j = 0; j < CT / 2; ++j) {
+          const float2 t = reinterpret_cast<const float2*>(p)[j];
+          v[2 * j] = t.x; v[2 * j + 1] = t.y;
+        }
+      } else {
+#pragma unroll
+        for (int j = 0; j < CT; ++j) v[j] = p[j];
+      }
+    } else {
+#pragma unroll
+      for (int j = 0; j < CT; ++j) v[j] = p[j];
+    }
+    float m = v[0];
+#pragma unroll
+    for (int j = 1; j < CT; ++j) m = fmaxf(m, v[j]);
+    const float m_raw = m;
+    if (m == INFINITY || m == -INFINITY) m = 0.f;
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) s += expf(v[j] - m);
+    finish_row(m_raw, m, s, lse, msp, row);
+  }
+}
+
 // ---- C > 64: one wave per row; the row stays in registers when it fits ----
 template <int NCH>  // float4 chunks per lane; NCH == 0 -> re-read the row (any C)
 __global__ __launch_bounds__(256) void lse_wave_kernel(const float* __restrict__ x, float* lse,
@@ -278,6 +313,17 @@ extern "C" int runia_row_lse_msp_f32(const float* logits, float* lse, float* msp
   if (N == 0) return RUNIA_OK;
   if (!logits || (!lse && !msp)) return RUNIA_E_INVALID;
   hipStream_t s = as_stream(stream);
+  if (C <= 16) {
+    const unsigned grid = runia_stream_grid(N, 256);
+#define RUNIA_LSE_TINY(CT) case CT: lse_tiny_kernel<CT><<<grid, 256, 0, s>>>(logits, lse, msp, N); break;
+    switch ((int)C) {
+      RUNIA_LSE_TINY(1) RUNIA_LSE_TINY(2) RUNIA_LSE_TINY(3) RUNIA_LSE_TINY(4) RUNIA_LSE_TINY(5) RUNIA_LSE_TINY(6)
+      RUNIA_LSE_TINY(7) RUNIA_LSE_TINY(8) RUNIA_LSE_TINY(9) RUNIA_LSE_TINY(10) RUNIA_LSE_TINY(11) RUNIA_LSE_TINY(12)
+      RUNIA_LSE_TINY(13) RUNIA_LSE_TINY(14) RUNIA_LSE_TINY(15) RUNIA_LSE_TINY(16)
+    }
+#undef RUNIA_LSE_TINY
+    return runia_check_launch();
+  }
   if (C <= 64) {
     const size_t shmem = (size_t)kSmallRows * C * sizeof(float);
     lse_small_kernel<<<runia_stream_grid(N, kSmallRows), 256, shmem, s>>>(logits, lse, msp, N, (int)C);
