@@ -649,7 +649,16 @@ __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
     // staging: element q*256 + tid of the BM x KC chunk (a wave covers two 256-byte row segments per pass)
     double areg[PER_T];
     const int srow = tid / KC, skk = tid % KC;  // + 256/KC rows per q
+    // interior row tile of a matrix whose width is a whole number of chunks (uniform over the workgroup): plain loads off
+    // one running pointer - predicated loads and 64-bit index arithmetic are vector instructions the matrix pipe waits for
+    const bool interior = (r0 + BM <= g.N) && (g.D % KC == 0);
+    const double* pa = g.h + (r0 + srow) * g.D + skk;
     auto load_a = [&](int64_t kc) {
+      if (interior) {
+#pragma unroll
+        for (int q = 0; q < PER_T; ++q) areg[q] = pa[(int64_t)q * (256 / KC) * g.D + kc];
+        return;
+      }
       const int64_t gk = kc + skk;
 #pragma unroll
       for (int q = 0; q < PER_T; ++q) {
