@@ -16,12 +16,25 @@ static inline int runia_check_launch() {
 
 static inline hipStream_t as_stream(runia_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
-// Grid for grid-stride streaming kernels: enough workgroups to fill 256 CUs several
-// times over, capped so that launch overhead stays flat (guide: Guideline 11).
+// Grid for thread-per-item streaming kernels: one trip per thread up to 2^20 workgroups (the kernels keep their
+// grid-stride loop for more).  A 4 096-workgroup cap used to sit here; a grid just above it left a second trip to a
+// fraction of the workgroups, and an address stream that follows the dispatch order reads faster (see below).
 static inline unsigned runia_stream_grid(int64_t work_items, int per_block) {
   int64_t blocks = (work_items + per_block - 1) / per_block;
-  const int64_t cap = 256 * 16;
+  const int64_t cap = 1 << 20;
   if (blocks > cap) blocks = cap;
+  if (blocks < 1) blocks = 1;
+  return (unsigned)blocks;
+}
+
+// Grid for one-wave-per-row kernels: every wave takes ONE row and consecutive waves take consecutive rows, so the
+// address stream follows the dispatch order.  Measured on the Energy shape (1 M x 1000 f32, tools/microbench/
+// stream_rows.hip): 6.5 TB/s with 8 waves per workgroup and no loop, 5.5-5.6 TB/s as a 4 096-workgroup grid-stride
+// loop (a flat float4 sweep of the same bytes reads 6.3 TB/s).  The kernels keep their loop for N beyond the grid limit.
+constexpr int kRowWaves = 8;  // waves (rows) per workgroup of the wave-per-row kernels
+static inline unsigned runia_rows_grid(int64_t rows, int waves = kRowWaves) {
+  int64_t blocks = (rows + waves - 1) / waves;
+  if (blocks > 0x7fffffffll) blocks = 0x7fffffffll;
   if (blocks < 1) blocks = 1;
   return (unsigned)blocks;
 }

@@ -347,7 +347,10 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
 #ifndef K1_GCAP
 #define K1_GCAP 128
 #endif
-  constexpr int G = (K1_GCAP / HW < 1) ? 1 : ((K1_GCAP / HW > NP) ? NP : K1_GCAP / HW);
+  // (a run-time n_mc adds the clamped indices to the scalar side: with 8 layers per trip that instantiation spilled
+  // scalar registers to vector lanes - 254 v_readlane / v_writelane; 4 per trip do not)
+  constexpr int GCAP = FULL ? K1_GCAP : K1_GCAP / 2;
+  constexpr int G = (GCAP / HW < 1) ? 1 : ((GCAP / HW > NP) ? NP : GCAP / HW);
 #pragma unroll
   for (int s = 0; s < NP; ++s) z[s] = INFINITY;
 #pragma unroll 1

@@ -22,10 +22,10 @@ typedef float f32x16 __attribute__((ext_vector_type(16)));
 constexpr int TQ = 128, TB = 128, KCH = 32, KP = 34;
 
 // squared row norms; max_bits (optional): running maximum of the norms as an unsigned bit pattern (norms are >= 0)
-__global__ __launch_bounds__(256) void row_sqnorm_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                          int64_t N, int64_t D, unsigned* __restrict__ max_bits) {
+__global__ __launch_bounds__(64 * kRowWaves) void row_sqnorm_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                                    int64_t N, int64_t D, unsigned* __restrict__ max_bits) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+  for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += (int64_t)gridDim.x * kRowWaves) {
     const float* p = x + row * D;
     float s = 0.f;
     for (int64_t i = lane; i < D; i += 64) s = fmaf(p[i], p[i], s);
@@ -592,12 +592,12 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
   float* bn = qn + qc;
   unsigned* bn_max = reinterpret_cast<unsigned*>(bn + M);
   if (hipMemsetAsync(bn_max, 0, sizeof(unsigned), s) != hipSuccess) return RUNIA_E_LAUNCH;
-  row_sqnorm_kernel<<<runia_stream_grid(M, 4), 256, 0, s>>>(bank, bn, M, D, bn_max);
+  row_sqnorm_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(bank, bn, M, D, bn_max);
   int rc = runia_check_launch();
   if (rc != RUNIA_OK) return rc;
   for (int64_t r0 = 0; r0 < N; r0 += qc) {
     const int64_t rows = (N - r0 < qc) ? (N - r0) : qc;
-    row_sqnorm_kernel<<<runia_stream_grid(rows, 4), 256, 0, s>>>(q + r0 * D, qn, rows, D, nullptr);
+    row_sqnorm_kernel<<<runia_rows_grid(rows), 64 * kRowWaves, 0, s>>>(q + r0 * D, qn, rows, D, nullptr);
     dim3 grid((unsigned)((M + TB - 1) / TB), (unsigned)((rows + TQ - 1) / TQ));
     knn_dist_kernel<EPI_DIST><<<grid, 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D, INFINITY);
     kth_select_range_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(dist, q + r0 * D, bank, qn, bn_max,

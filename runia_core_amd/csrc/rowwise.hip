@@ -99,12 +99,12 @@ __global__ __launch_bounds__(256) void lse_tiny_kernel(const float* __restrict__
 
 // ---- C > 64: one wave per row; the row stays in registers when it fits ----
 template <int NCH>  // float4 chunks per lane; NCH == 0 -> re-read the row (any C)
-__global__ __launch_bounds__(256) void lse_wave_kernel(const float* __restrict__ x, float* lse,
-                                                        float* msp, int64_t N, int64_t C) {
+__global__ __launch_bounds__(64 * kRowWaves) void lse_wave_kernel(const float* __restrict__ x, float* lse,
+                                                                  float* msp, int64_t N, int64_t C) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int64_t wave_stride = (int64_t)gridDim.x * 4;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += wave_stride) {
+  const int64_t wave_stride = (int64_t)gridDim.x * kRowWaves;
+  for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += wave_stride) {
     const float* p = x + row * C;
     float m = -INFINITY, s = 0.f, m_raw;
     if constexpr (NCH > 0) {
@@ -136,30 +136,36 @@ __global__ __launch_bounds__(256) void lse_wave_kernel(const float* __restrict__
   }
 }
 
-// ---- normalizer: y = x / (||x||_2 + 1e-10), f32, one wave per row ----
-__global__ __launch_bounds__(256) void l2_normalize_kernel(const float* __restrict__ x,
-                                                            float* __restrict__ y, int64_t N, int64_t D) {
+// ---- normalizer: y = x / (||x||_2 + 1e-10), f32, one wave per row; the row stays in registers when it fits ----
+template <int NCH>  // float4 chunks per lane; NCH == 0 -> re-read the row (any D)
+__global__ __launch_bounds__(64 * kRowWaves) void l2_normalize_kernel(const float* __restrict__ x,
+                                                                      float* __restrict__ y, int64_t N, int64_t D) {
   const int lane = threadIdx.x & 63;
   const int wave = threadIdx.x >> 6;
-  const int64_t wave_stride = (int64_t)gridDim.x * 4;
-  const bool vec = ((D & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)y) & 15) == 0);
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += wave_stride) {
+  const int64_t wave_stride = (int64_t)gridDim.x * kRowWaves;
+  for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += wave_stride) {
     const float* p = x + row * D;
     float* q = y + row * D;
     float ss = 0.f;
-    if (vec) {
+    if constexpr (NCH > 0) {
       const float4* p4 = reinterpret_cast<const float4*>(p);
-      const int64_t n4 = D >> 2;
-      for (int64_t i = lane; i < n4; i += 64) {
-        float4 v = p4[i];
-        ss += (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+      float4* q4 = reinterpret_cast<float4*>(q);
+      const int n4 = (int)(D >> 2);
+      float4 v[NCH];
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int i = lane + 64 * c;
+        v[c] = (i < n4) ? p4[i] : make_float4(0.f, 0.f, 0.f, 0.f);
       }
+#pragma unroll
+      for (int c = 0; c < NCH; ++c)
+        if (lane + 64 * c < n4) ss += (v[c].x * v[c].x + v[c].y * v[c].y) + (v[c].z * v[c].z + v[c].w * v[c].w);
       ss = wave_sum_f32(ss);
       const float den = sqrtf(ss) + 1e-10f;
-      float4* q4 = reinterpret_cast<float4*>(q);
-      for (int64_t i = lane; i < n4; i += 64) {
-        float4 v = p4[i];
-        q4[i] = make_float4(v.x / den, v.y / den, v.z / den, v.w / den);
+#pragma unroll
+      for (int c = 0; c < NCH; ++c) {
+        const int i = lane + 64 * c;
+        if (i < n4) q4[i] = make_float4(v[c].x / den, v[c].y / den, v[c].z / den, v[c].w / den);
       }
     } else {
       for (int64_t i = lane; i < D; i += 64) ss += p[i] * p[i];
@@ -199,10 +205,10 @@ __device__ __forceinline__ unsigned kth_largest_key(const unsigned (&key)[NV], i
 // ASH-S for 2-D activations (reference inference/funcs.py:234-261): keep the k = n - round(n*p/100) largest entries
 // of each row, zero the rest, multiply by exp(sum(row) / sum(kept)).  Ties at the threshold are kept in index order.
 template <int NV>
-__global__ __launch_bounds__(256) void ash_s_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t N,
+__global__ __launch_bounds__(64 * kRowWaves) void ash_s_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t N,
                                                      int D, int k) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+  for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += (int64_t)gridDim.x * kRowWaves) {
     const float* p = x + row * D;
     float v[NV];
     unsigned key[NV];
@@ -252,10 +258,10 @@ __global__ __launch_bounds__(256) void ash_s_kernel(const float* __restrict__ x,
 // GEN (reference inference/funcs.py:347-375 on softmax(logits)): -sum over the M largest probabilities of
 // p^gamma * (1-p)^gamma, f32.
 template <int NV>
-__global__ __launch_bounds__(256) void gen_kernel(const float* __restrict__ logits, float* __restrict__ score,
+__global__ __launch_bounds__(64 * kRowWaves) void gen_kernel(const float* __restrict__ logits, float* __restrict__ score,
                                                    int64_t N, int C, int M, float gamma) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  for (int64_t row = (int64_t)blockIdx.x * 4 + wave; row < N; row += (int64_t)gridDim.x * 4) {
+  for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += (int64_t)gridDim.x * kRowWaves) {
     const float* p = logits + row * C;
     float v[NV];
     float m = -INFINITY;
@@ -329,26 +335,36 @@ extern "C" int runia_row_lse_msp_f32(const float* logits, float* lse, float* msp
     lse_small_kernel<<<runia_stream_grid(N, kSmallRows), 256, shmem, s>>>(logits, lse, msp, N, (int)C);
     return runia_check_launch();
   }
-  const unsigned grid = runia_stream_grid(N, 4);
+  const unsigned grid = runia_rows_grid(N);
+  constexpr int kT = 64 * kRowWaves;
   const bool vec = ((C & 3) == 0) && ((((uintptr_t)logits) & 15) == 0);
   const int64_t n4 = C >> 2;
   if (vec && n4 <= 64)
-    lse_wave_kernel<1><<<grid, 256, 0, s>>>(logits, lse, msp, N, C);
+    lse_wave_kernel<1><<<grid, kT, 0, s>>>(logits, lse, msp, N, C);
   else if (vec && n4 <= 128)
-    lse_wave_kernel<2><<<grid, 256, 0, s>>>(logits, lse, msp, N, C);
+    lse_wave_kernel<2><<<grid, kT, 0, s>>>(logits, lse, msp, N, C);
   else if (vec && n4 <= 256)
-    lse_wave_kernel<4><<<grid, 256, 0, s>>>(logits, lse, msp, N, C);
+    lse_wave_kernel<4><<<grid, kT, 0, s>>>(logits, lse, msp, N, C);
   else if (vec && n4 <= 512)
-    lse_wave_kernel<8><<<grid, 256, 0, s>>>(logits, lse, msp, N, C);
+    lse_wave_kernel<8><<<grid, kT, 0, s>>>(logits, lse, msp, N, C);
   else
-    lse_wave_kernel<0><<<grid, 256, 0, s>>>(logits, lse, msp, N, C);
+    lse_wave_kernel<0><<<grid, kT, 0, s>>>(logits, lse, msp, N, C);
   return runia_check_launch();
 }
 
 extern "C" int runia_l2_normalize_f32(const float* x, float* y, int64_t N, int64_t D, runia_stream_t stream) {
   if (N < 0 || D <= 0 || (N > 0 && (!x || !y))) return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
-  l2_normalize_kernel<<<runia_stream_grid(N, 4), 256, 0, as_stream(stream)>>>(x, y, N, D);
+  const unsigned grid = runia_rows_grid(N);
+  constexpr int kT = 64 * kRowWaves;
+  hipStream_t s = as_stream(stream);
+  const bool vec = ((D & 3) == 0) && ((((uintptr_t)x) & 15) == 0) && ((((uintptr_t)y) & 15) == 0);
+  const int64_t n4 = D >> 2;
+  if (vec && n4 <= 64) l2_normalize_kernel<1><<<grid, kT, 0, s>>>(x, y, N, D);
+  else if (vec && n4 <= 128) l2_normalize_kernel<2><<<grid, kT, 0, s>>>(x, y, N, D);
+  else if (vec && n4 <= 256) l2_normalize_kernel<4><<<grid, kT, 0, s>>>(x, y, N, D);
+  else if (vec && n4 <= 512) l2_normalize_kernel<8><<<grid, kT, 0, s>>>(x, y, N, D);
+  else l2_normalize_kernel<0><<<grid, kT, 0, s>>>(x, y, N, D);
   return runia_check_launch();
 }
 
@@ -361,12 +377,13 @@ extern "C" int runia_ash_s_f32(const float* x, float* y, int64_t N, int64_t D, i
   const double frac = (double)D * (double)percentile / 100.0;
   int k = (int)D - (int)nearbyint(frac);
   if (k == 0) k = (int)D;  // NumPy: x[:, -0:] is the whole row, i.e. nothing is pruned at percentile 100
-  const unsigned grid = runia_stream_grid(N, 4);
+  const unsigned grid = runia_rows_grid(N);
+  constexpr int kT = 64 * kRowWaves;
   hipStream_t s = as_stream(stream);
-  if (D <= 512) ash_s_kernel<8><<<grid, 256, 0, s>>>(x, y, N, (int)D, k);
-  else if (D <= 1024) ash_s_kernel<16><<<grid, 256, 0, s>>>(x, y, N, (int)D, k);
-  else if (D <= 2048) ash_s_kernel<32><<<grid, 256, 0, s>>>(x, y, N, (int)D, k);
-  else ash_s_kernel<64><<<grid, 256, 0, s>>>(x, y, N, (int)D, k);
+  if (D <= 512) ash_s_kernel<8><<<grid, kT, 0, s>>>(x, y, N, (int)D, k);
+  else if (D <= 1024) ash_s_kernel<16><<<grid, kT, 0, s>>>(x, y, N, (int)D, k);
+  else if (D <= 2048) ash_s_kernel<32><<<grid, kT, 0, s>>>(x, y, N, (int)D, k);
+  else ash_s_kernel<64><<<grid, kT, 0, s>>>(x, y, N, (int)D, k);
   return runia_check_launch();
 }
 
@@ -375,12 +392,13 @@ extern "C" int runia_gen_score_f32(const float* logits, float* score, int64_t N,
   if (N < 0 || C <= 0 || C > 4096 || M < 1) return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
   if (!logits || !score) return RUNIA_E_INVALID;
-  const unsigned grid = runia_stream_grid(N, 4);
+  const unsigned grid = runia_rows_grid(N);
+  constexpr int kT = 64 * kRowWaves;
   hipStream_t s = as_stream(stream);
   const float g = (float)gamma;
-  if (C <= 64) gen_kernel<1><<<grid, 256, 0, s>>>(logits, score, N, (int)C, M, g);
-  else if (C <= 256) gen_kernel<4><<<grid, 256, 0, s>>>(logits, score, N, (int)C, M, g);
-  else if (C <= 1024) gen_kernel<16><<<grid, 256, 0, s>>>(logits, score, N, (int)C, M, g);
-  else gen_kernel<64><<<grid, 256, 0, s>>>(logits, score, N, (int)C, M, g);
+  if (C <= 64) gen_kernel<1><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g);
+  else if (C <= 256) gen_kernel<4><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g);
+  else if (C <= 1024) gen_kernel<16><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g);
+  else gen_kernel<64><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g);
   return runia_check_launch();
 }
