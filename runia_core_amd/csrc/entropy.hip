@@ -233,6 +233,192 @@ __global__ __launch_bounds__(256) void entropy_joint_kernel(const float* __restr
   }
 }
 
+// ---- joint entropy, register form (n <= 32, D a multiple of the vector width, aligned rows) --------------------
+// One workgroup per image, one thread per VEC adjacent dims: the thread reads its dims of ALL n samples straight from
+// global memory (16-byte loads, 1 KB of a sample row per wave-instruction), promotes them to f64 once, and forms the
+// partial Chebyshev distance of every sample pair over its own dims in registers (VEC subtractions + VEC-1 maxima per
+// pair; the LDS form above reads both rows of a pair from LDS for every pair - 16 bytes of LDS traffic per pair and
+// dim, which is what bounded it).  Sixteen pair maxima at a time are then reduced over the wave by a halving exchange:
+// lanes i and i^32 split the 16 slots between them (v_permlane32_swap + v_max_f64 per slot kept), then i^16
+// (v_permlane16_swap), i^8 and i^4 (DPP row rotations), leaving one slot per lane quad; two quad-permute butterfly
+// steps finish it.  ~65 vector instructions per 16 pairs instead of 16 x 6 x 3, none through the LDS crossbar.
+// Distances are maxima of exact differences: the same bits as the LDS form whatever the order.  The k-th neighbour of
+// a sample is entry k-1 of its sorted row of distances (60-comparator network on f64 registers; the counting selection
+// of the LDS form is 2 n^2 dependent LDS reads per sample).
+// 10 000 images x 16 samples x 512 dims: 0.477 ms (LDS form) -> 0.132 ms; 8 samples x 2048 dims reads 6.0 TB/s.
+#ifndef JOINT_VEC16
+#define JOINT_VEC16 4
+#endif
+template <int NP> constexpr int joint_vec() { return NP <= 8 ? 4 : (NP <= 16 ? JOINT_VEC16 : 2); }
+__host__ __device__ constexpr int joint_pair_a(int np, int p) {
+  int a = 0;
+  while (p >= np - 1 - a) { p -= np - 1 - a; ++a; }
+  return a;
+}
+__host__ __device__ constexpr int joint_pair_b(int np, int p) {
+  int a = 0;
+  while (p >= np - 1 - a) { p -= np - 1 - a; ++a; }
+  return a + 1 + p;
+}
+
+__device__ __forceinline__ double max_f64(double a, double b) {  // IEEE maxNum, no canonicalisation of the operands
+  double r;
+  asm("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ double max_abs_f64(double m, double d) {  // max(m, |d|)
+  double r;
+  asm("v_max_f64 %0, %1, |%2|" : "=v"(r) : "v"(m), "v"(d));
+  return r;
+}
+__device__ __forceinline__ double max_abs2_f64(double a, double b) {  // max(|a|, |b|)
+  double r;
+  asm("v_max_f64 %0, |%1|, |%2|" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+// DPP move of an f64 (two 32-bit moves): lanes whose bank (group of four lanes in a row of 16) is in BANKS take the
+// value the pattern CTRL brings them, the others keep `old`.  Vector-ALU latency, no trip through the LDS crossbar.
+constexpr int kDppQuadXor1 = 0xB1, kDppQuadXor2 = 0x4E;          // quad_perm:[1,0,3,2], [2,3,0,1]
+constexpr int kDppRowRor4 = 0x124, kDppRowRor8 = 0x128, kDppRowRor12 = 0x12C;  // lane i <- lane (i - n) mod 16 of its row
+template <int CTRL, int BANKS = 0xf>
+__device__ __forceinline__ double dpp_f64(double old, double v) {
+  const int lo = __builtin_amdgcn_update_dpp(__double2loint(old), __double2loint(v), CTRL, 0xf, BANKS, false);
+  const int hi = __builtin_amdgcn_update_dpp(__double2hiint(old), __double2hiint(v), CTRL, 0xf, BANKS, false);
+  return __hiloint2double(hi, lo);
+}
+// lanes i, i+32: the lower lane ends with max over both of slot `a`, the upper lane with that of slot `b` (in `a`)
+__device__ __forceinline__ void halve32(double& a, const double b) {
+  const auto lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = max_f64(__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1]));
+}
+__device__ __forceinline__ void halve16(double& a, const double b) {  // the same for lanes i, i+16 (rows of 16 lanes)
+  const auto lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(a), (unsigned)__double2loint(b), false, false);
+  const auto hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(a), (unsigned)__double2hiint(b), false, false);
+  a = max_f64(__hiloint2double((int)hi[0], (int)lo[0]), __hiloint2double((int)hi[1], (int)lo[1]));
+}
+// 16 per-lane values -> their maxima over the wave; lane L ends with slot (L >> 2) & 15 (all four lanes of a quad)
+__device__ __forceinline__ double wave_max16(double (&v)[16], int lane) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) halve32(v[j], v[j + 8]);
+#pragma unroll
+  for (int j = 0; j < 4; ++j) halve16(v[j], v[j + 4]);
+  const bool u8 = (lane & 8) != 0, u4 = (lane & 4) != 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {  // lanes i, i ^ 8: a rotation of the row by 8 is that exchange
+    const double send = u8 ? v[j] : v[j + 2], keep = u8 ? v[j + 2] : v[j];
+    v[j] = max_f64(keep, dpp_f64<kDppRowRor8>(send, send));
+  }
+  {  // lanes i, i ^ 4: banks 1 and 3 take lane i - 4, banks 0 and 2 lane i + 4 (= i - 12 in the row)
+    const double send = u4 ? v[0] : v[1], keep = u4 ? v[1] : v[0];
+    double recv = dpp_f64<kDppRowRor4, 0xA>(send, send);
+    recv = dpp_f64<kDppRowRor12, 0x5>(recv, send);
+    v[0] = max_f64(keep, recv);
+  }
+  double r = v[0];
+  r = max_f64(r, dpp_f64<kDppQuadXor2>(r, r));
+  r = max_f64(r, dpp_f64<kDppQuadXor1>(r, r));
+  return r;
+}
+
+template <int NP>
+__global__ __launch_bounds__(256) void entropy_joint_reg_kernel(const float* __restrict__ z,
+                                                                 double* __restrict__ h_mvn, int64_t N, int n,
+                                                                 int64_t D, int k, double min_dist,
+                                                                 double const_term, double d_over_n) {
+  constexpr int VEC = joint_vec<NP>();
+  constexpr int NPAIRS = NP * (NP - 1) / 2, NGROUPS = (NPAIRS + 15) / 16;
+  constexpr int DP = NP + 1;
+  typedef float fvec __attribute__((ext_vector_type(VEC)));
+  __shared__ double dist[NP * DP];
+  __shared__ double red[4 * NGROUPS * 16];  // per wave: the reduced pair maxima, [group][slot]
+  __shared__ int nan_seen;
+  const int tid = threadIdx.x, lane = tid & 63;
+  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
+    const float* base = z + img * n * D;
+    for (int i = tid; i < NP * DP; i += blockDim.x) dist[i] = 0.0;
+    if (tid == 0) nan_seen = 0;
+    bool my_nan = false;
+    double acc[NGROUPS];
+#pragma unroll
+    for (int g = 0; g < NGROUPS; ++g) acc[g] = 0.0;
+    for (int64_t d0 = 0; d0 < D; d0 += (int64_t)blockDim.x * VEC) {
+      // No predicates: a lane past the end of the row re-reads dims 0.., a sample slot past n re-reads sample n-1.
+      // Maxima are idempotent (a dim counted twice changes nothing) and pairs with a slot >= n are never read back.
+      const int64_t dd = d0 + (int64_t)tid * VEC;
+      const int64_t d = (dd < D) ? dd : 0;  // D % VEC == 0
+      double x[NP][VEC];
+#pragma unroll
+      for (int s = 0; s < NP; ++s) {
+        const int sc = (s < n) ? s : n - 1;  // wave-uniform
+        const fvec t = *reinterpret_cast<const fvec*>(base + (int64_t)sc * D + d);
+#pragma unroll
+        for (int q = 0; q < VEC; ++q) {
+          my_nan = my_nan || (t[q] != t[q]);
+          x[s][q] = (double)t[q];
+        }
+      }
+      {
+        // pairs (a, b), a < b, in row-major order; sixteen at a time go through the wave reduction.  Both loops unroll
+        // fully, so the pair counter and every register index are compile-time constants.
+        double v[16];
+        int p = 0;
+#pragma unroll
+        for (int a = 0; a < NP - 1; ++a) {
+#pragma unroll
+          for (int b = a + 1; b < NP; ++b) {
+            double m = max_abs2_f64(x[a][0] - x[b][0], x[a][1] - x[b][1]);
+#pragma unroll
+            for (int q = 2; q < VEC; ++q) m = max_abs_f64(m, x[a][q] - x[b][q]);
+            v[p & 15] = m;
+            if ((p & 15) == 15 || p == NPAIRS - 1) {
+#pragma unroll
+              for (int j = (p & 15) + 1; j < 16; ++j) v[j] = 0.0;  // short last group: 0 is neutral (distances >= 0)
+              acc[p >> 4] = max_f64(acc[p >> 4], wave_max16(v, lane));
+            }
+            ++p;
+          }
+        }
+      }
+    }
+    if ((lane & 3) == 0) {
+#pragma unroll
+      for (int g = 0; g < NGROUPS; ++g) red[(tid >> 6) * (NGROUPS * 16) + 16 * g + (lane >> 2)] = acc[g];
+    }
+    __syncthreads();  // dist zeroed, red written
+    for (int p = tid; p < NPAIRS; p += blockDim.x) {
+      int a = 0, rem = p;
+      while (rem >= NP - 1 - a) { rem -= NP - 1 - a; ++a; }
+      const int b = a + 1 + rem;
+      if (b < n) {
+        double m = red[p];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = fmax(m, red[w * (NGROUPS * 16) + p]);
+        dist[a * DP + b] = m;
+        dist[b * DP + a] = m;
+      }
+    }
+    if (my_nan) nan_seen = 1;  // a NaN sample makes the reference's joint entropy NaN; the maxima would drop it
+    __syncthreads();
+    double logsum = 0.0;
+    if (tid < NP) {  // sample slot i: its row of distances into registers, sorted there; the k-th smallest is entry k-1
+      double r[NP];
+#pragma unroll
+      for (int c = 0; c < NP; ++c) r[c] = (c < n && c != tid) ? dist[tid * DP + c] : kInf;
+      sort_asc<NP>(r);
+      double kth = r[0];
+#pragma unroll
+      for (int c = 1; c < NP - 1; ++c) kth = (c == k - 1) ? r[c] : kth;
+      if (tid < n) logsum = log(2.0 * fmax(kth, min_dist));
+    }
+    if (tid < 64) {
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) logsum += shfl_xor_f64(logsum, o);
+      if (tid == 0) h_mvn[img] = nan_seen ? NAN : const_term + d_over_n * logsum;
+    }
+    __syncthreads();
+  }
+}
+
 int next_pow2(int n) {
   int p = 4;
   while (p < n) p <<= 1;
@@ -294,6 +480,20 @@ extern "C" int runia_kl_entropy_joint_f32(const float* z, double* h_mvn, int64_t
   if (N == 0) return RUNIA_OK;
   const double ct = digamma_diff(n_mc, k);
   const double d_over_n = (double)D / (double)n_mc;
+  hipStream_t s = as_stream(stream);
+  {
+    // register form: rows of whole, aligned vectors (the LDS form below takes everything else)
+    const int vec = n_mc <= 8 ? 4 : (n_mc <= 16 ? JOINT_VEC16 : 2);
+    if (n_mc <= 32 && D % vec == 0 && ((uintptr_t)z) % (4 * vec) == 0) {
+      const int64_t lanes = (D / vec + 63) / 64 * 64;
+      const unsigned threads = (unsigned)(lanes < 256 ? lanes : 256);
+      const unsigned grid = (unsigned)(N < 0x7fffffffll ? N : 0x7fffffffll);
+      if (n_mc <= 8) entropy_joint_reg_kernel<8><<<grid, threads, 0, s>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n);
+      else if (n_mc <= 16) entropy_joint_reg_kernel<16><<<grid, threads, 0, s>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n);
+      else entropy_joint_reg_kernel<32><<<grid, threads, 0, s>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n);
+      return runia_check_launch();
+    }
+  }
   const size_t lds = ((size_t)n_mc * (kJointChunk + 2) + (size_t)n_mc * (n_mc + 1)) * sizeof(double);  // <= 99 KB
   static bool attr_set = false;
   if (!attr_set) {
@@ -303,6 +503,6 @@ extern "C" int runia_kl_entropy_joint_f32(const float* z, double* h_mvn, int64_t
     attr_set = true;
   }
   const unsigned grid = (unsigned)(N < 65535 ? N : 65535);
-  entropy_joint_kernel<<<grid, 256, lds, as_stream(stream)>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n);
+  entropy_joint_kernel<<<grid, 256, lds, s>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n);
   return runia_check_launch();
 }

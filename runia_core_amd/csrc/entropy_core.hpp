@@ -17,12 +17,19 @@ __device__ __forceinline__ void cswap(float& a, float& b) {
   a = lo;
   b = hi;
 }
+__device__ __forceinline__ void cswap(double& a, double& b) {
+  double lo, hi;
+  asm("v_min_f64 %0, %1, %2" : "=v"(lo) : "v"(a), "v"(b));
+  asm("v_max_f64 %0, %1, %2" : "=v"(hi) : "v"(a), "v"(b));
+  a = lo;
+  b = hi;
+}
 
 // Ascending sort of NP (power of two) registers.  NP = 16: the 60-comparator, 10-layer network (the best
 // known size); other sizes: Batcher's odd-even merge sort (19 / 191 / 543 comparators for 8 / 32 / 64).
 // Both were checked with the 0-1 principle (all 2^16 inputs; 2e6 random 0-1 vectors for 32 and 64).
-template <int NP>
-__device__ __forceinline__ void sort_asc(float (&v)[NP]) {
+template <int NP, typename T>
+__device__ __forceinline__ void sort_asc(T (&v)[NP]) {
   if constexpr (NP == 16) {
 #define RUNIA_CX(a, b) cswap(v[a], v[b]);
     RUNIA_CX(0, 13) RUNIA_CX(1, 12) RUNIA_CX(2, 15) RUNIA_CX(3, 14) RUNIA_CX(4, 8) RUNIA_CX(5, 6) RUNIA_CX(7, 11) RUNIA_CX(9, 10)

@@ -68,7 +68,10 @@ def test_entropy_generic_k(hip, n_mc, k):
     assert np.abs(got - oracle.kl_entropy_per_dim_vectorized(z, n_mc, k)).max() < 1e-11
 
 
-@pytest.mark.parametrize("n_mc,d,n_img", [(16, 512, 5), (3, 20, 40), (6, 300, 3), (33, 17, 2), (64, 130, 2)])
+@pytest.mark.parametrize("n_mc,d,n_img", [(16, 512, 5), (3, 20, 40), (6, 300, 3), (33, 17, 2), (64, 130, 2),
+                                          # register form: short sample sets, rows shorter than a wave, several chunks
+                                          (12, 512, 4), (16, 4, 9), (16, 2048, 3), (16, 1028, 2), (8, 64, 7), (5, 12, 6),
+                                          (32, 130, 3), (20, 1024, 2), (9, 1500, 2), (2, 8, 5), (16, 510, 3)])
 def test_entropy_joint_vs_oracle(hip, n_mc, d, n_img):
     rng = np.random.default_rng(n_mc * 7 + d)
     z = rng.standard_normal((n_img * n_mc, d)).astype(np.float32)
@@ -76,6 +79,11 @@ def test_entropy_joint_vs_oracle(hip, n_mc, d, n_img):
     got = hip.kl_entropy_joint(dev(z, torch.float32), n_mc, k).cpu().numpy()
     exp = oracle.kl_entropy_joint_vectorized(z, n_mc, k)[:, 0]
     assert rel_err(got, exp) < 1e-11
+    # a view that starts 4 bytes into the buffer takes the LDS form (unaligned rows): same bits
+    buf = torch.empty(z.size + 1, dtype=torch.float32, device="cuda")
+    buf[1:] = dev(z, torch.float32).reshape(-1)
+    off = hip.kl_entropy_joint(buf[1:].view(z.shape), n_mc, k).cpu().numpy()
+    assert np.array_equal(off, got)
 
 
 # ---------------- a7 energy / msp -----------------------------------------------------

@@ -2,6 +2,8 @@ import sys, os
 sys.path.insert(0, os.getcwd())
 import torch
 from runia_core_amd import _hip
+if os.environ.get('RUNIA_LIB'):
+    _hip._LIB_PATH = os.environ['RUNIA_LIB']
 torch.manual_seed(0)
 for (N, n_mc, D) in ((10000, 16, 512), (10000, 16, 256), (2000, 32, 512), (4000, 8, 2048)):
     z = torch.randn(N * n_mc, D, device="cuda")
