@@ -25,20 +25,33 @@ rows = []
 
 
 def gpu_ms(fn, reps=7):
+    """Median time of one call in steady state.  Short stages are timed as back-to-back batches of calls (~3 ms per
+    batch) between one pair of events: a lone 50 us launch bracketed by events and a host synchronisation measures the
+    launch gap and an idling GPU's clocks, not the kernel (the MD stage read 0.216 ms that way; its kernel takes 0.052)."""
+    fn()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    fn()
+    e1.record()
+    torch.cuda.synchronize()
+    inner = int(max(1, min(200, 3.0 / max(e0.elapsed_time(e1), 1e-3))))
     # warm the stage up for ~0.25 s first: after an idle spell (a CPU-oracle timing, a gen-2 GC pass) the GPU takes
     # tens of ms of sustained load to return to its working clocks
     t0 = time.perf_counter()
     while time.perf_counter() - t0 < 0.25:
-        fn()
+        for _ in range(inner):
+            fn()
         torch.cuda.synchronize()
     ts = []
     for _ in range(reps):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        fn()
+        for _ in range(inner):
+            fn()
         e1.record()
         torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1))
+        ts.append(e0.elapsed_time(e1) / inner)
     return float(np.median(ts))
 
 
