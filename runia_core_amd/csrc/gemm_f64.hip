@@ -72,28 +72,36 @@ __device__ __forceinline__ double sub_promote(TA x, TS m) {
   else return (double)x - (double)m;
 }
 
-template <typename TA, typename TS>
-__device__ __forceinline__ void load_a_regs(const GemmArgs& g, int64_t r0, int64_t kc, int tid, double (&r)[4]) {
-  const int row = tid >> 3;          // 0..31
-  const int kk = (tid & 7) * 4;      // 0,4,...,28
+template <typename TA, typename TS, int RT>
+__device__ __forceinline__ void load_a_regs(const GemmArgs& g, int64_t r0, int64_t kc, int tid, double (&r)[2 * RT]) {
+  constexpr int PER = 2 * RT;              // elements per thread of the (16*RT) x 32 chunk: 4 (32 rows) or 2 (16 rows)
+  constexpr int TPR = KC / PER;            // threads per row: 8 or 16
+  const int row = tid / TPR;               // 0 .. 16*RT-1
+  const int kk = (tid % TPR) * PER;
   const int64_t gr = r0 + row;
   const int64_t gk = kc + kk;
   const TA* x = reinterpret_cast<const TA*>(g.x);
   // interior chunk of an aligned matrix (the common case; the condition is uniform over the workgroup): one 16-byte load
-  // (two for f64 rows) instead of four predicated scalar loads - vector instructions do not overlap the matrix pipe
-  if (!g.sub && r0 + BM <= g.N && kc + KC <= g.K && (g.ldx & 3) == 0 && (((uintptr_t)g.x) & 15) == 0) {
-    if constexpr (sizeof(TA) == 4) {
+  // (two for f64 rows of a 32-row tile) instead of predicated scalar loads - vector instructions do not overlap the
+  // matrix pipe
+  if (!g.sub && r0 + 16 * RT <= g.N && kc + KC <= g.K && (g.ldx & 3) == 0 && (((uintptr_t)g.x) & 15) == 0) {
+    if constexpr (sizeof(TA) == 4 && PER == 4) {
       const float4 v = *reinterpret_cast<const float4*>(x + gr * g.ldx + gk);
       r[0] = (double)v.x; r[1] = (double)v.y; r[2] = (double)v.z; r[3] = (double)v.w;
+    } else if constexpr (sizeof(TA) == 4) {
+      const float2 v = *reinterpret_cast<const float2*>(x + gr * g.ldx + gk);
+      r[0] = (double)v.x; r[1] = (double)v.y;
     } else {
-      const double2 a = *reinterpret_cast<const double2*>(x + gr * g.ldx + gk);
-      const double2 b = *reinterpret_cast<const double2*>(x + gr * g.ldx + gk + 2);
-      r[0] = a.x; r[1] = a.y; r[2] = b.x; r[3] = b.y;
+#pragma unroll
+      for (int q = 0; q < PER; q += 2) {
+        const double2 a = *reinterpret_cast<const double2*>(x + gr * g.ldx + gk + q);
+        r[q] = a.x; r[q + 1] = a.y;
+      }
     }
     return;
   }
 #pragma unroll
-  for (int q = 0; q < 4; ++q) {
+  for (int q = 0; q < PER; ++q) {
     double v = 0.0;
     if (gr < g.N && gk + q < g.K) {
       const TA xv = x[gr * g.ldx + gk + q];
@@ -106,8 +114,9 @@ __device__ __forceinline__ void load_a_regs(const GemmArgs& g, int64_t r0, int64
 // One workgroup = 32 rows x all n columns (256 at a time); wave w owns the 64-column slice w of each pass.
 // The rows stream from HBM once per 256-column pass through a double-buffered 32x32 LDS chunk; the packed
 // weights come from L2 one k-step pair ahead (mfma_chunk).
-template <typename TA, typename TS, int EPI>
+template <typename TA, typename TS, int EPI, int RT = 2>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
+  constexpr int BM = 16 * RT;  // rows per workgroup (shadows the file-level default of 32)
   __shared__ double lds_a[2][BM][APITCH];
   __shared__ double lds_part[4][BM];
   __shared__ double lds_part2[(EPI == EPI_KDE) ? 4 : 1][BM];
@@ -125,18 +134,18 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   const int64_t nchunks = k_padded(g.K) / KC;
   const int64_t r0 = (int64_t)blockIdx.x * BM;
 
-  double rowdot[2][4];   // EPI_KDE: running sum of exp(. - rowmax)
-  double rowmax[2][4];   // EPI_KDE only
+  double rowdot[RT][4];   // EPI_KDE: running sum of exp(. - rowmax)
+  double rowmax[RT][4];   // EPI_KDE only
 #pragma unroll
-  for (int a = 0; a < 2; ++a)
+  for (int a = 0; a < RT; ++a)
 #pragma unroll
     for (int r = 0; r < 4; ++r) { rowdot[a][r] = 0.0; rowmax[a][r] = -kInfD(); }
 
   for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
     const int64_t ctbase = cb * 16 + wave * 4;
-    d4 acc[2][4];
+    d4 acc[RT][4];
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < RT; ++a)
 #pragma unroll
       for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
     const double2* bp = reinterpret_cast<const double2*>(g.packed) + ctbase * 64 + lane;
@@ -144,18 +153,19 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
 #pragma unroll
     for (int c = 0; c < 4; ++c) b0[c] = bp[c * 64];
 
-    double areg[4];
-    load_a_regs<TA, TS>(g, r0, 0, tid, areg);
+    double areg[2 * RT];
+    load_a_regs<TA, TS, RT>(g, r0, 0, tid, areg);
     int buf = 0;
     for (int64_t ch = 0; ch < nchunks; ++ch) {
       {
-        const int row = tid >> 3, kk = (tid & 7) * 4;
+        constexpr int PER = 2 * RT, TPR = KC / PER;
+        const int row = tid / TPR, kk = (tid % TPR) * PER;
 #pragma unroll
-        for (int q = 0; q < 4; ++q) lds_a[buf][row][kk + q] = areg[q];
+        for (int q = 0; q < PER; ++q) lds_a[buf][row][kk + q] = areg[q];
       }
       __syncthreads();
-      if (ch + 1 < nchunks) load_a_regs<TA, TS>(g, r0, (ch + 1) * KC, tid, areg);
-      mfma_chunk<2>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
+      if (ch + 1 < nchunks) load_a_regs<TA, TS, RT>(g, r0, (ch + 1) * KC, tid, areg);
+      mfma_chunk<RT>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
       buf ^= 1;
     }
 
@@ -166,9 +176,9 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
       // 16 lanes that share a row, added to the (wave, row, class) slot this lane group owns.  ~5 % of the block's MFMA time.
       const TA* xg = reinterpret_cast<const TA*>(g.x);
       const TA* mug = reinterpret_cast<const TA*>(g.class_mean);
-      TA xv[2][4][4];
+      TA xv[RT][4][4];
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < RT; ++a)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
           const int64_t col = (ctbase + c) * 16 + li;
@@ -188,7 +198,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
           qv[c] = (col < g.n) ? g.mu_p[(int64_t)cls * g.K + col] : 0.0;
         }
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < RT; ++a)
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
             double part = 0.0;
@@ -208,7 +218,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     } else if constexpr (EPI == EPI_KDE) {
       // online logsumexp over this lane's 4 columns of the block, per accumulator row
 #pragma unroll
-      for (int a = 0; a < 2; ++a)
+      for (int a = 0; a < RT; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int64_t row = r0 + 16 * a + lg + 4 * r;
@@ -232,7 +242,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
         }
     } else
 #pragma unroll
-    for (int a = 0; a < 2; ++a) {
+    for (int a = 0; a < RT; ++a) {
 #pragma unroll
       for (int c = 0; c < 4; ++c) {
         const int64_t col = (ctbase + c) * 16 + li;
@@ -282,7 +292,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   if constexpr (EPI == EPI_KDE) {
     // merge the (max, sum) pairs of the 16 lanes that share a row, then of the four waves
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < RT; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double m = rowmax[a][r], sm = rowdot[a][r];
@@ -313,7 +323,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   }
   if constexpr (EPI == EPI_ROWDOT || EPI == EPI_ROWNORM) {
 #pragma unroll
-    for (int a = 0; a < 2; ++a)
+    for (int a = 0; a < RT; ++a)
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
         double v = rowdot[a][r];
@@ -350,10 +360,18 @@ __global__ __launch_bounds__(256) void row_sqnorm_f64_kernel(const double* __res
   if (lane == 0) out[row] = s;
 }
 
+// 32-row tiles halve the L2 traffic of the packed weights but need several tiles per CU to balance: below 4 per CU the
+// 16-row instantiation runs (N = 10 000: 313 tiles of 32 rows are 1.2 rounds on 256 CUs - PCA transform 75 us, MD
+// 51 us; 625 tiles of 16 rows: 59 and 33 us; LaRED 8 192 x 10 000 x 256: 0.94 -> 0.88 ms).  A row's bits do not depend on
+// the tile height (tests/test_full_size_gpu.py).
 template <typename TA, int EPI, typename TS = double>
 int launch_gemm(const GemmArgs& g, hipStream_t s) {
   const int64_t tiles = (g.N + BM - 1) / BM;
   if (tiles > 0x7fffffff) return RUNIA_E_INVALID;
+  if (EPI != EPI_MAHA && tiles < 4 * runia_cu_count()) {
+    gemm_rows_kernel<TA, TS, EPI, 1><<<(unsigned)((g.N + 15) / 16), 256, 0, s>>>(g);
+    return runia_check_launch();
+  }
   gemm_rows_kernel<TA, TS, EPI><<<(unsigned)tiles, 256, 0, s>>>(g);
   return runia_check_launch();
 }

@@ -114,6 +114,45 @@ def test_cfg4_per_proposal_entropy_and_larem(hip):
     assert torch.equal(s2, s[10_000:10_700])
 
 
+def test_row_gemm_stages_tile_height_does_not_change_bits(hip):
+    """The row GEMM kernel (PCA transform, MD, ViM norm, KDE on the matrix cores) runs 16-row tiles below four tiles per
+    CU and 32-row tiles above (40 000 rows here: 32-row tiles).  A row's result must not depend on that: slices scored on
+    their own (16-row tiles) equal the same rows of the whole batch bit for bit, ragged ends included; sampled rows are
+    checked against the oracle."""
+    n_rows, d, n = 40_003, 512, 256
+    g = torch.Generator(device="cuda").manual_seed(9)
+    h = torch.randn(n_rows, d, dtype=torch.float64, device="cuda", generator=g)
+    rng = np.random.default_rng(3)
+    comp = np.linalg.qr(rng.standard_normal((d, n)))[0].T
+    mean, var = rng.standard_normal(d), rng.random(n) + 0.1
+    a = rng.standard_normal((n, n))
+    prec = a @ a.T / n + np.eye(n)
+    md_mean = rng.standard_normal((1, n)) * 0.1
+    dev = lambda v: torch.from_numpy(np.ascontiguousarray(v)).cuda()  # noqa: E731
+    pct, bias, scale = hip.pack_weights(dev(comp.T)), dev((mean.reshape(1, -1) @ comp.T).ravel()), dev(np.sqrt(var))
+    pp, mdm = hip.pack_weights(dev(prec)), dev(md_mean.ravel())
+    y = hip.pca_transform(h, pct, bias, scale, n)
+    s = hip.md_score(y, mdm, pp)
+    for lo, hi in ((0, 700), (17_001, 17_050), (39_990, n_rows)):
+        y_part = hip.pca_transform(h[lo:hi].contiguous(), pct, bias, scale, n)
+        assert torch.equal(y_part, y[lo:hi])
+        assert torch.equal(hip.md_score(y_part, mdm, pp), s[lo:hi])
+    idx = np.r_[0:24, 20_000:20_024, n_rows - 24:n_rows]
+    y_exp = oracle.pca_transform(h[idx].cpu().numpy(), comp, mean, var)
+    assert rel_err(y[idx].cpu().numpy(), y_exp) < 1e-11
+    assert rel_err(s[idx].cpu().numpy(), oracle.md_score(y_exp, md_mean, prec)) < 1e-9
+    # f32 rows (the reference's default feature dtype) and the LaRED contraction
+    y32 = y.float()
+    s32 = hip.md_score(y32, mdm.float(), pp)
+    assert torch.equal(hip.md_score(y32[33_000:33_100].contiguous(), mdm.float(), pp), s32[33_000:33_100])
+    tr = torch.randn(3_000, 64, dtype=torch.float64, device="cuda", generator=g)
+    x = torch.randn(n_rows, 64, dtype=torch.float64, device="cuda", generator=g)
+    st = hip.kde_pack_train(tr)
+    kd = hip.kde_score_packed(st, x, 4.0)
+    assert torch.equal(hip.kde_score_packed(st, x[5_000:5_040].contiguous(), 4.0), kd[5_000:5_040])
+    assert rel_err(kd[:64].cpu().numpy(), oracle.kde_score(tr.cpu().numpy(), x[:64].cpu().numpy(), 4.0)) < 1e-11
+
+
 # ---------------- fused LaREM path (K0 + K1 + K2') at full size and at the launch boundaries -------------------------
 def _larem_state(hip, seed=0, c=512, n=256):
     from runia_core_amd.dimensionality_reduction import DevicePCA
