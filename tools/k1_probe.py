@@ -6,6 +6,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 import bench
 from runia_core_amd import _hip
+if os.environ.get('RUNIA_LIB'):  # an ablation build of the library (tools/ablate)
+    _hip._LIB_PATH = os.environ['RUNIA_LIB']
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--iters", type=int, default=300)
