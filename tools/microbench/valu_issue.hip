@@ -52,6 +52,22 @@ __global__ void bench(float* out, unsigned long long* cyc) {
       if constexpr (KIND == 25) asm volatile("v_mul_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
       if constexpr (KIND == 26) asm volatile("v_cvt_f32_f64 %0, %1" : "=v"(a[i]) : "v"(d[i]));
       if constexpr (KIND == 27) asm volatile("v_min3_u32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+      // mixes in K1's proportions (predicted from the single-kind rows: (4.0 + 4.3 + 4.1 + 2.5) / 4 = 3.7)
+      if constexpr (KIND == 30) {  // kinds alternate instruction by instruction
+        if (i % 4 == 0) asm volatile("v_add_f64 %0, %0, %1" : "+v"(d[i]) : "v"(db));
+        if (i % 4 == 1) asm volatile("v_pk_fma_f32 %0, %0, %1, %2" : "+v"(p[i]) : "v"(pb), "v"(pc));
+        if (i % 4 == 2) asm volatile("v_min_f32 %0, %0, %1" : "+v"(a[i]) : "v"(b));
+        if (i % 4 == 3) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a[i]) : "v"(b), "v"(c));
+      }
+      // three different vector registers per instruction (the rows above reuse two operands throughout)
+      if constexpr (KIND == 32) asm volatile("v_fma_f32 %0, %1, %2, %0" : "+v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]));
+      if constexpr (KIND == 33) asm volatile("v_add_f64 %0, %1, %2" : "=v"(d[i]) : "v"(d[(i + 5) & 15]), "v"(d[(i + 10) & 15]));
+      if constexpr (KIND == 34) asm volatile("v_max_f64 %0, %1, %2" : "=v"(d[i]) : "v"(d[(i + 5) & 15]), "v"(d[(i + 10) & 15]));
+      if constexpr (KIND == 35) asm volatile("v_pk_fma_f32 %0, %1, %2, %0" : "+v"(p[i]) : "v"(p[(i + 5) & 15]), "s"(pb));
+      if constexpr (KIND == 36) asm volatile("v_min_f32 %0, %1, %2" : "=v"(a[i]) : "v"(a[(i + 5) & 15]), "v"(a[(i + 10) & 15]));
+      // dependent chains of 4 (K1's window scan and sort are chains, not 16 independent instructions)
+      if constexpr (KIND == 37) asm volatile("v_max_f64 %0, %0, %1" : "+v"(d[i & 3]) : "v"(d[4 + (i & 3)]));
+      if constexpr (KIND == 38) asm volatile("v_max_f64 %0, %0, %1" : "+v"(d[0]) : "v"(d[4 + (i & 3)]));
     }
   }
   const unsigned long long t1 = __builtin_amdgcn_s_memtime();
@@ -98,5 +114,9 @@ int main() {
   run<16>("v_frexp_mant_f64", buf, cyc); run<18>("v_cmp_lt_f64", buf, cyc); run<19>("v_cndmask_b32", buf, cyc);
   run<20>("v_min_u32", buf, cyc); run<21>("v_max_i32", buf, cyc); run<27>("v_min3_u32", buf, cyc); run<22>("v_or_b32", buf, cyc);
   run<23>("v_xor_b32", buf, cyc); run<24>("v_sub_f32", buf, cyc); run<25>("v_mul_f32", buf, cyc); run<26>("v_cvt_f32_f64", buf, cyc);
+  run<30>("mix alternating", buf, cyc);
+  run<32>("v_fma_f32 3reg", buf, cyc); run<36>("v_min_f32 3reg", buf, cyc); run<33>("v_add_f64 3reg", buf, cyc);
+  run<34>("v_max_f64 3reg", buf, cyc); run<35>("v_pk_fma v,s,v", buf, cyc);
+  run<37>("v_max_f64 4 chains", buf, cyc); run<38>("v_max_f64 1 chain", buf, cyc);
   return 0;
 }
