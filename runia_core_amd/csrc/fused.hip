@@ -626,7 +626,18 @@ __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int li = lane & 15, lg = lane >> 4;
   const int64_t NT = n_pad / 16;
-  const int64_t r0 = (int64_t)blockIdx.x * BM;
+  // Column split (NCT == 2): a 1-D grid whose ids i and i + 8 are the two column halves of one row tile.  Consecutive
+  // workgroup ids go round-robin over the 8 XCDs, so the two halves run on the SAME XCD one dispatch round apart and the
+  // second one finds the row tile in that XCD's L2 (with a (tile, half) 2-D grid they sat 625 ids apart: both read the
+  // tile from HBM, 90.9 MB fetched for 42 MB of rows).
+  int64_t tile = blockIdx.x;
+  int half = 0;
+  if constexpr (NCT == 2) {
+    tile = (int64_t)(blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
+    half = (blockIdx.x >> 3) & 1;
+    if (tile * BM >= g.N) return;  // padding of the last group of 8 tiles (uniform over the workgroup)
+  }
+  const int64_t r0 = tile * BM;
   const int64_t nchunks = k_padded(g.D) / KC;
   constexpr int PER_T = BM * KC / 256;
   double rowsq[NG][RT][4];
@@ -637,7 +648,7 @@ __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) rowsq[q][a][r] = 0.0;
   for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
-    const int64_t ctbase = cb * 16 + (int64_t)blockIdx.y * (4 * NCT) + wave * NCT;
+    const int64_t ctbase = cb * 16 + (int64_t)half * (4 * NCT) + wave * NCT;
     d4 acc[RT][NCT];
 #pragma unroll
     for (int a = 0; a < RT; ++a)
@@ -721,7 +732,7 @@ __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
         // score was zeroed earlier in the stream: two addends per row, and 0 + a + b = 0 + b + a bit for bit
         unsafeAtomicAdd(&g.score[row], -lo);
       } else {
-        g.partial[(int64_t)blockIdx.y * g.N + row] = lo;
+        g.partial[(int64_t)half * g.N + row] = lo;
       }
     }
   }
@@ -974,6 +985,15 @@ extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k) {
   return 0;
 }
 
+// 32 x 256 tiles (fewer re-reads of M, 65 TFLOP/s when they fill the chip evenly) or 16 x 128 half tiles (62 TFLOP/s,
+// whatever the batch)?  The large tile only pays when its last round of workgroups is nearly full: N = 20 000 is 625
+// large tiles = 2.44 rounds on 256 CUs and ran at 51 TFLOP/s; 16 384 / 32 768 / 65 536 rows (whole rounds) at 63-65.
+static bool proj_sq_large_tiles(int64_t N, int64_t cus) {
+  const int64_t tiles32 = (N + 31) / 32;
+  const int64_t rounds = (tiles32 + cus - 1) / cus;
+  return tiles32 >= 2 * cus && 100 * tiles32 >= 93 * rounds * cus;
+}
+
 extern "C" int runia_proj_sq_accumulate_f64(const double* h, const double* packed_m, const double* c, double* score,
                                             int64_t N, int64_t D, int64_t r, runia_stream_t stream) {
   if (N < 0 || D <= 0 || r <= 0) return RUNIA_E_INVALID;
@@ -982,8 +1002,8 @@ extern "C" int runia_proj_sq_accumulate_f64(const double* h, const double* packe
   ProjSqArgs g{h, packed_m, c, score, nullptr, N, D, r};
   hipStream_t s = as_stream(stream);
   const int64_t tiles16 = (N + 15) / 16, cus = runia_cu_count();
-  if (tiles16 >= 4 * cus) proj_sq_kernel<2, 4><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
-  else if (tiles16 > cus / 2) proj_sq_kernel<1, 2, true><<<dim3((unsigned)tiles16, 2), 256, 0, s>>>(g);
+  if (proj_sq_large_tiles(N, cus)) proj_sq_kernel<2, 4><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
+  else if (tiles16 > cus / 2) proj_sq_kernel<1, 2, true><<<(unsigned)((tiles16 + 7) / 8 * 16), 256, 0, s>>>(g);
   else proj_sq_kernel<1, 4><<<(unsigned)tiles16, 256, 0, s>>>(g);
   return runia_check_launch();
 }
@@ -999,11 +1019,11 @@ extern "C" int runia_proj_sq_score_f64(const double* h, const double* packed_m, 
   ProjSqArgs g{h, packed_m, c, score, reinterpret_cast<double*>(workspace), N, D, r};
   hipStream_t s = as_stream(stream);
   const int64_t tiles16 = (N + 15) / 16, cus = runia_cu_count();
-  if (tiles16 >= 4 * cus) {  // many tiles per CU: the tail is short, take the larger tile (fewer re-reads of M)
+  if (proj_sq_large_tiles(N, cus)) {
     proj_sq_kernel<2, 4><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
   } else if (tiles16 > cus / 2 && workspace && workspace_bytes >= runia_proj_sq_workspace_bytes(N)) {
     // (32-, 48- and 64-row tiles with the same column split measured 64, 64 and 78 us against 59 us)
-    proj_sq_kernel<1, 2><<<dim3((unsigned)tiles16, 2), 256, 0, s>>>(g);
+    proj_sq_kernel<1, 2><<<(unsigned)((tiles16 + 7) / 8 * 16), 256, 0, s>>>(g);
     proj_sq_combine_kernel<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(g.partial, score, N);
   } else {
     proj_sq_kernel<1, 4><<<(unsigned)tiles16, 256, 0, s>>>(g);

@@ -7,7 +7,7 @@ if os.environ.get('RUNIA_LIB'):
 torch.manual_seed(0)
 gc.disable()
 lib = _hip.load_library()
-for N in (10000, 4000, 20000):
+for N in ([int(v) for v in sys.argv[1:]] or [10000, 4000, 20000]):
     D, r = 512, 256
     h = torch.randn(N, D, dtype=torch.float64, device="cuda")
     M = torch.randn(D, r, dtype=torch.float64, device="cuda") * 0.05
