@@ -11,7 +11,7 @@
 // ds_read_b64: one 8-byte read feeds two MFMA k-steps, A and B use the same k permutation).  Distances go to a
 // row-chunked workspace [Qc, M]; the k-th order statistic of each row is then found by an 8-bit radix select over
 // the distance bits (distances are clamped >= 0, so unsigned integer order == float order) - no sort, no top-k list.
-// blockIdx.x walks the bank tiles so that the workgroups dealt to one XCD share the same query panel in L2.
+// The tile grid is walked in XCD-aware super-tiles (see knn_dist_kernel).
 #include "common.hpp"
 
 namespace {
@@ -20,6 +20,11 @@ constexpr float kFltMax = 3.4028234663852886e38f;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TQ = 128, TB = 128, KCH = 32, KP = 34;
+#ifndef KNN_SB
+#define KNN_SB 8
+#define KNN_SQ 8
+#endif
+constexpr int kSuperB = KNN_SB, kSuperQ = KNN_SQ;  // super-tile of workgroups that share L2 lines (knn_dist_kernel)
 
 // squared row norms; max_bits (optional): running maximum of the norms as an unsigned bit pattern (norms are >= 0)
 __global__ __launch_bounds__(64 * kRowWaves) void row_sqnorm_kernel(const float* __restrict__ x, float* __restrict__ out,
@@ -84,7 +89,24 @@ __global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wq = wave >> 1, wb = wave & 1;   // 2 x 2 waves
   const int li = lane & 31, lh = lane >> 5;
-  const int64_t q0 = (int64_t)blockIdx.y * TQ, m0 = (int64_t)blockIdx.x * TB;
+  // XCD-aware order of the tile grid.  Consecutive workgroup ids go round-robin over the 8 XCDs; here ids i, i + 8,
+  // i + 16, ... (one XCD's share) walk a super-tile of kSuperB bank tiles x kSuperQ query tiles row by row, and the
+  // super-tiles themselves are dealt round-robin to the XCDs.  The 64 workgroups of a super-tile are resident on one
+  // XCD at the same time and sweep K in step, so every 16 KB slice of a query or bank tile is fetched into that L2
+  // once and read 8 times (with the plain (bank tile, query tile) grid a bank tile was fetched again for every query
+  // tile: 64 x 410 MB per 8 192-query chunk).
+  int64_t q0, m0;
+  {
+    const int64_t nbt = (M + TB - 1) / TB, nqt = (Q + TQ - 1) / TQ;
+    const int64_t nqg = (nqt + kSuperQ - 1) / kSuperQ;
+    const int64_t l = blockIdx.x >> 3;
+    const int64_t st = (l / (kSuperB * kSuperQ)) * 8 + (blockIdx.x & 7);  // super-tile of this workgroup
+    const int r = (int)(l % (kSuperB * kSuperQ));
+    const int64_t bt = (st / nqg) * kSuperB + r % kSuperB, qt = (st % nqg) * kSuperQ + r / kSuperB;
+    if (bt >= nbt || qt >= nqt) return;  // padding of the grid (uniform over the workgroup)
+    q0 = qt * TQ;
+    m0 = bt * TB;
+  }
   const bool vec = ((D & 3) == 0) && ((((uintptr_t)q) & 15) == 0) && ((((uintptr_t)bank) & 15) == 0);
   f32x16 acc[2][2];
 #pragma unroll
@@ -563,6 +585,13 @@ constexpr int64_t kQueryChunk = 8192;  // query rows per distance-workspace pass
 
 }  // namespace
 
+// 1-D grid of knn_dist_kernel for Q x M: whole super-tiles, a multiple of 8 of them
+static inline unsigned knn_dist_grid(int64_t Q, int64_t M) {
+  const int64_t nbt = (M + TB - 1) / TB, nqt = (Q + TQ - 1) / TQ;
+  const int64_t st = ((nbt + kSuperB - 1) / kSuperB) * ((nqt + kSuperQ - 1) / kSuperQ);
+  return (unsigned)(((st + 7) / 8) * 8 * kSuperB * kSuperQ);
+}
+
 extern "C" size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {
   (void)D; (void)k;
   if (N <= 0 || M <= 0) return 0;
@@ -598,8 +627,7 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
   for (int64_t r0 = 0; r0 < N; r0 += qc) {
     const int64_t rows = (N - r0 < qc) ? (N - r0) : qc;
     row_sqnorm_kernel<<<runia_rows_grid(rows), 64 * kRowWaves, 0, s>>>(q + r0 * D, qn, rows, D, nullptr);
-    dim3 grid((unsigned)((M + TB - 1) / TB), (unsigned)((rows + TQ - 1) / TQ));
-    knn_dist_kernel<EPI_DIST><<<grid, 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D, INFINITY);
+    knn_dist_kernel<EPI_DIST><<<knn_dist_grid(rows, M), 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D, INFINITY);
     kth_select_range_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(dist, q + r0 * D, bank, qn, bn_max,
                                                                                  score + r0, rows, M, D, k);
     rc = runia_check_launch();
@@ -619,8 +647,7 @@ extern "C" int runia_linear_f32(const float* x, const float* w, const float* bia
     const int64_t tiles = (qt - t0 < 65535) ? (qt - t0) : 65535;
     const int64_t r0 = t0 * TQ;
     const int64_t rows = (N - r0 < tiles * TQ) ? (N - r0) : tiles * TQ;
-    dim3 grid((unsigned)((C + TB - 1) / TB), (unsigned)tiles);
-    knn_dist_kernel<EPI_LINEAR><<<grid, 256, 0, s>>>(x + r0 * D, w, nullptr, bias, out + r0 * C, rows, C, D, clip_max);
+    knn_dist_kernel<EPI_LINEAR><<<knn_dist_grid(rows, C), 256, 0, s>>>(x + r0 * D, w, nullptr, bias, out + r0 * C, rows, C, D, clip_max);
   }
   return runia_check_launch();
 }

@@ -2,6 +2,8 @@ import sys, os, time, gc
 sys.path.insert(0, os.getcwd())
 import torch
 from runia_core_amd import _hip
+if os.environ.get('RUNIA_LIB'):
+    _hip._LIB_PATH = os.environ['RUNIA_LIB']
 gc.disable()
 torch.manual_seed(0)
 Q, M, D, k = 32768, 50000, 2048, 50
