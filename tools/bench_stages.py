@@ -140,7 +140,7 @@ s = _hip.kde_score(tr, x)
 m = 512
 cpu = cpu_rate(lambda: oracle.kde_score(tr.cpu().numpy(), x[:m].cpu().numpy()), m)
 err = rel(s[:m].cpu().numpy(), oracle.kde_score(tr.cpu().numpy(), x[:m].cpu().numpy()))
-add("KDE / LaRED (a9), direct", f"{N} x train {Mt}x{D} f64", "rows", N, ms, "mfma_f64", 3.0 * Mt * D, cpu, f"numpy brute force, {m} rows", err)
+add("KDE / LaRED (a9), direct (one f64 exp per pair: vector-ALU bound)", f"{N} x train {Mt}x{D} f64", "rows", N, ms, "mfma_f64", 3.0 * Mt * D, cpu, f"numpy brute force, {m} rows", err)
 # LaRED at PCA-256: pair distances on the f64 matrix cores (DetectorKDE takes this path for D >= 24)
 D = 256
 tr = torch.randn(Mt, D, dtype=torch.float64, device=dev, generator=g)
