@@ -1,6 +1,8 @@
 import gc, os, sys, time, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from runia_core_amd import _hip
+if os.environ.get('RUNIA_LIB'):
+    _hip._LIB_PATH = os.environ['RUNIA_LIB']
 gc.disable(); torch.manual_seed(0)
 for (N, M, D) in ((8192, 10000, 16), (8192, 10000, 32), (8192, 10000, 64), (65536, 10000, 16), (65536, 10000, 32)):
     tr = torch.randn(M, D, dtype=torch.float64, device="cuda"); x = torch.randn(N, D, dtype=torch.float64, device="cuda")
