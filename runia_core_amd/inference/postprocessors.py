@@ -87,9 +87,12 @@ class DetectorKDE:
 
     def score_samples_device(self, x: Tensor) -> Tensor:
         train = self._train()
-        if train.shape[1] >= 24:
+        d, n_rows = train.shape[1], x.shape[0]
+        if d >= 24 or (d >= 12 and n_rows <= 16384):
             # pair distances as |x|^2 + |t|^2 - 2 x.t on the f64 matrix cores, online logsumexp (8 192 x 10 000 pairs:
-            # 0.33 / 0.44 / 0.98 ms at D = 32 / 64 / 256 against 0.57 / 1.83 / 21.5 ms for the direct kernels; a tie at 16)
+            # 0.27 / 0.38 / 0.88 ms at D = 32 / 64 / 256 against 0.56 / 1.85 / 21.5 ms for the direct kernels).  At
+            # D = 16 the direct kernel wins on large batches (65 536 rows: 1.47 vs 1.84 ms) and loses on small ones,
+            # where it has too few 64-query workgroups for the chip (8 192 rows: 0.37 vs 0.29 ms)
             if self._packed is None:
                 self._packed = _hip.kde_pack_train(train)
             return _hip.kde_score_packed(self._packed, x.to(torch.float64), float(self.bandwidth))
