@@ -1,0 +1,109 @@
+"""Randomised differential check of the stand-alone stages against the CPU oracle (one MI355X, a few minutes):
+joint / per-dimension entropy, Energy / MSP, normaliser, PCA transform + MD at sizes around the tile switches, kNN
+(k-th distance) and LaRED on both kernel forms.  Shapes are drawn around the places where a kernel changes its launch
+shape or code path (vector widths, register-resident row limits, 16- / 32-row tiles, column halves, chunk limits).
+
+    gpurun -- python tools/fuzz_kernels.py [--seed S] [--rounds R]
+"""
+import argparse, os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np, torch
+import oracle
+from runia_core_amd import _hip
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seed", type=int, default=2024)
+ap.add_argument("--rounds", type=int, default=40)
+a = ap.parse_args()
+rng = np.random.default_rng(a.seed)
+bad = 0
+
+
+def dev(x, dt=None):
+    t = torch.from_numpy(np.ascontiguousarray(x)).cuda()
+    return t if dt is None else t.to(dt)
+
+
+def rel(x, y):
+    x, y = np.asarray(x, np.float64), np.asarray(y, np.float64)
+    both_nan = np.isnan(x) & np.isnan(y)
+    d = np.abs(x - y) / np.maximum(1.0, np.abs(y))
+    d[both_nan] = 0.0
+    d[(x == y)] = 0.0  # equal infinities
+    return float(np.nanmax(d)) if d.size else 0.0
+
+
+def check(name, args, err, tol):
+    global bad
+    if not (err <= tol):
+        bad += 1
+        print("MISMATCH", name, args, err, flush=True)
+
+
+for t in range(a.rounds):
+    # ---- entropy: joint (register form / LDS form) and per dimension ----
+    n_mc = int(rng.choice([2, 3, 5, 6, 8, 9, 12, 16, 17, 24, 32, 33, 40, 64]))
+    d = int(rng.choice([1, 2, 4, 12, 64, 130, 256, 510, 512, 1024, 1028, 2048]))
+    n_img = int(rng.integers(1, 6))
+    z = (rng.standard_normal((n_img * n_mc, d)) * float(rng.choice([1e-3, 1.0, 30.0]))).astype(np.float32)
+    if rng.random() < 0.3:  # constant channels: the min_dist clip
+        z.reshape(n_img, n_mc, d)[:, :, :: max(1, d // 7)] = 0.25
+    k = 5 if n_mc > 5 else n_mc - 1
+    hj = _hip.kl_entropy_joint(dev(z), n_mc, k).cpu().numpy()
+    check("joint entropy", (n_mc, d, n_img), rel(hj, oracle.kl_entropy_joint_vectorized(z, n_mc, k)[:, 0]), 1e-11)
+    hd = _hip.kl_entropy_per_dim(dev(z), n_mc, k).cpu().numpy()
+    check("entropy per dim", (n_mc, d, n_img), rel(hd, oracle.kl_entropy_per_dim_vectorized(z, n_mc, k)), 1e-10)
+
+    # ---- Energy / MSP, normaliser ----
+    c = int(rng.choice([1, 2, 7, 10, 16, 17, 64, 65, 100, 252, 256, 1000, 1001, 2048, 2052, 3000]))
+    n = int(rng.choice([1, 7, 8, 9, 513, 4097]))
+    lg = (rng.standard_normal((n, c)) * float(rng.choice([0.1, 3.0, 40.0]))).astype(np.float32)
+    lse, msp = _hip.row_lse_msp(dev(lg), True, True)
+    check("energy", (n, c), rel(lse.cpu().numpy(), oracle.energy_score(lg)), 2e-6)
+    check("msp", (n, c), rel(msp.cpu().numpy(), oracle.msp_score(lg)), 2e-6)
+    check("normalizer", (n, c), rel(_hip.l2_normalize(dev(lg)).cpu().numpy(), oracle.normalizer(lg)), 1e-6)
+
+    # ---- PCA transform + MD around the tile switches ----
+    dd = int(rng.choice([8, 40, 512, 520]))
+    nn = int(rng.choice([3, 16, 40, 250, 256, 260]))
+    rows = int(rng.choice([1, 15, 17, 33, 1000, 8191, 32768 - 31, 32768 + 1, 40_000]))
+    h = rng.standard_normal((rows, dd))
+    nn = min(nn, dd)
+    comp = np.linalg.qr(rng.standard_normal((dd, nn)))[0].T
+    mean, var = rng.standard_normal(dd), rng.random(nn) + 0.1
+    am = rng.standard_normal((nn, nn))
+    prec = am @ am.T / nn + np.eye(nn)
+    md_mean = rng.standard_normal((1, nn)) * 0.1
+    y = _hip.pca_transform(dev(h), _hip.pack_weights(dev(comp.T)), dev((mean.reshape(1, -1) @ comp.T).ravel()), dev(np.sqrt(var)), nn)
+    sub = np.unique(np.r_[0:min(rows, 40), max(0, rows - 40):rows])
+    y_exp = oracle.pca_transform(h[sub], comp, mean, var)
+    check("pca transform", (rows, dd, nn), rel(y[sub].cpu().numpy(), y_exp), 1e-10)
+    s = _hip.md_score(y, dev(md_mean.ravel()), _hip.pack_weights(dev(prec)))
+    check("md score", (rows, nn), rel(s[sub].cpu().numpy(), oracle.md_score(y_exp, md_mean, prec)), 1e-9)
+    s2 = _hip.pca_md_score(dev(h), _hip.pack_weights(dev(comp.T)), dev((mean.reshape(1, -1) @ comp.T).ravel()), dev(np.sqrt(var)),
+                           dev(md_mean.ravel()), _hip.pack_weights(dev(prec)), nn)
+    check("pca_md (K2)", (rows, dd, nn), rel(s2[sub].cpu().numpy(), oracle.md_score(y_exp, md_mean, prec)), 1e-9)
+
+    # ---- kNN ----
+    m, dk = int(rng.choice([1, 50, 129, 1000, 5000])), int(rng.choice([3, 32, 100, 512]))
+    nq, kk = int(rng.choice([1, 5, 127, 129, 300])), int(rng.choice([1, 5, 50]))
+    bank = rng.standard_normal((m, dk)).astype(np.float32)
+    if rng.random() < 0.3 and m > 10:
+        bank[m // 2:] = bank[: m - m // 2]  # duplicated rows: ties at the k-th distance
+    q = rng.standard_normal((nq, dk)).astype(np.float32)
+    bn = oracle.normalizer(bank)
+    got = _hip.knn_kth(_hip.l2_normalize(dev(q)), dev(bn), kk).cpu().numpy()
+    check("knn", (nq, m, dk, kk), rel(got, oracle.knn_kth_score(bn, q, kk, chunk=64)), 2e-5)
+
+    # ---- LaRED: direct and matrix-core kernels against the exact definition ----
+    dl, mt, nx = int(rng.choice([1, 2, 8, 16, 23, 24, 40, 64, 100])), int(rng.choice([1, 10, 700, 3000])), int(rng.choice([1, 63, 65, 900]))
+    tr, x = rng.standard_normal((mt, dl)), rng.standard_normal((nx, dl)) * float(rng.choice([0.5, 1.0, 3.0]))
+    bw = float(rng.choice([0.5, 1.0, 4.0]))
+    exp = oracle.kde_score(tr, x, bw)
+    check("kde direct", (nx, mt, dl, bw), rel(_hip.kde_score(dev(tr), dev(x), bw).cpu().numpy(), exp), 1e-10)
+    st = _hip.kde_pack_train(dev(tr))
+    check("kde matrix", (nx, mt, dl, bw), rel(_hip.kde_score_packed(st, dev(x), bw).cpu().numpy(), exp), 1e-9)
+    if (t + 1) % 10 == 0:
+        print(f"round {t + 1}/{a.rounds}, mismatches so far: {bad}", flush=True)
+print("fuzz done, mismatches:", bad)
+sys.exit(1 if bad else 0)
