@@ -59,6 +59,13 @@ int runia_mc_drop_flat_f32(const float* x, const float* rand, int64_t rand_image
                            int64_t N, int C, int H, int W, int n_mc, double drop_prob, int block_size,
                            runia_stream_t stream);
 
+/* Reductions of dropped activation maps for the other options of FastMCDSamplesExtractor
+ * (feature_extraction/image_level.py:205-236 through feature_extraction/utils.py:70-92, 113-126):
+ *   x [maps, H, W] f32 (e.g. the output of runia_mc_drop_flat_f32 seen as N*n_mc*C maps)
+ *   mode 0: reduction_method="mean" = torch.mean(dim=3)            -> out [maps, H]
+ *   mode 1: return_stds = torch.std(torch.std(., dim=3), dim=2)    -> out [maps]  (unbiased; NaN when H or W is 1) */
+int runia_map_reduce_f32(const float* x, float* out, int64_t maps, int H, int W, int mode, runia_stream_t stream);
+
 /* ---- a2  Kozachenko-Leonenko kNN entropy --------------------------------- *
  * Replaces the loops of get_dl_h_z / single_image_entropy_calculation
  * (evaluation/entropy.py:20-93) over entropy_estimators.continuous.get_h(col, k,

@@ -30,6 +30,7 @@ _SIGNATURES = {
         c_int,
         [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p],
     ),
+    "runia_map_reduce_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "runia_kl_entropy_per_dim_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_double, c_void_p]),
     "runia_kl_entropy_joint_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_double, c_void_p]),
     "runia_packed_weights_bytes": (c_size_t, [c_int64, c_int64]),
@@ -320,6 +321,21 @@ def mc_drop_flat(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_
             "runia_mc_drop_flat_f32",
         )
         done += m
+    return out
+
+
+def map_reduce(x: torch.Tensor, h: int, w: int, mode: str) -> torch.Tensor:
+    """x [..., h*w] f32 seen as maps of h x w -> ``mode="mean"``: mean over w, [maps, h]; ``mode="std"``: std over the
+    rows of the per-row stds, [maps] (the reductions of ``get_mean_or_fullmean_ls_sample(., "mean")`` and
+    ``get_std_ls_sample`` upstream)."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and x.numel() % (h * w) == 0 and mode in ("mean", "std")
+    x = x.contiguous()
+    maps = x.numel() // (h * w)
+    out = torch.empty((maps, h) if mode == "mean" else (maps,), dtype=torch.float32, device=x.device)
+    _check(lib.runia_map_reduce_f32(x.data_ptr(), out.data_ptr(), maps, h, w, 0 if mode == "mean" else 1, _stream()),
+           "runia_map_reduce_f32")
     return out
 
 

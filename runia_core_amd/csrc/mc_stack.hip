@@ -285,6 +285,55 @@ extern "C" int runia_mc_stack_f32(const float* x, const float* rnd, int64_t rand
   return runia_check_launch();
 }
 
+namespace {
+// Reductions of (already dropped) activation maps the extractor's other options ask for
+// (feature_extraction/utils.py:70-92, 113-126): one thread per map.
+//   mode 0 "mean"   : torch.mean(dim=3)               -> out [maps, H]
+//   mode 1 "std"    : torch.std(torch.std(., 3), 2)   -> out [maps]   (unbiased, as torch's default; a map with one row or
+//                                                         one column gives NaN there too)
+// f64 accumulation (torch's CPU kernels accumulate f32 inputs in f64), one rounding to f32 at the end.
+__global__ __launch_bounds__(256) void map_reduce_kernel(const float* __restrict__ x, float* __restrict__ out,
+                                                          int64_t maps, int H, int W, int mode) {
+  for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < maps; m += (int64_t)gridDim.x * 256) {
+    const float* p = x + m * (int64_t)(H * W);
+    if (mode == 0) {
+      for (int y = 0; y < H; ++y) {
+        double s = 0.0;
+        for (int xw = 0; xw < W; ++xw) s += (double)p[y * W + xw];
+        out[m * H + y] = (float)(s / (double)W);
+      }
+    } else {
+      // std over the row, rounded to f32 as torch materialises it, then std of those over the rows
+      double mean2 = 0.0, m2 = 0.0;
+      for (int y = 0; y < H; ++y) {
+        double s = 0.0;
+        for (int xw = 0; xw < W; ++xw) s += (double)p[y * W + xw];
+        const double mu = s / (double)W;
+        double q = 0.0;
+        for (int xw = 0; xw < W; ++xw) {
+          const double d = (double)p[y * W + xw] - mu;
+          q += d * d;
+        }
+        const double sd = (double)(float)sqrt(q / (double)(W - 1));  // W == 1: 0/0 = NaN
+        const double delta = sd - mean2;  // Welford over the H row values
+        mean2 += delta / (double)(y + 1);
+        m2 += delta * (sd - mean2);
+      }
+      out[m] = (float)sqrt(m2 / (double)(H - 1));
+    }
+  }
+}
+}  // namespace
+
+extern "C" int runia_map_reduce_f32(const float* x, float* out, int64_t maps, int H, int W, int mode,
+                                    runia_stream_t stream) {
+  if (maps < 0 || H <= 0 || W <= 0 || (mode != 0 && mode != 1)) return RUNIA_E_INVALID;
+  if (maps == 0) return RUNIA_OK;
+  if (!x || !out) return RUNIA_E_INVALID;
+  map_reduce_kernel<<<runia_stream_grid(maps, 256), 256, 0, as_stream(stream)>>>(x, out, maps, H, W, mode);
+  return runia_check_launch();
+}
+
 extern "C" int runia_mc_drop_flat_f32(const float* x, const float* rnd, int64_t rand_image_stride, float* out,
                                       int64_t N, int C, int H, int W, int n_mc, double drop_prob, int block_size,
                                       runia_stream_t stream) {

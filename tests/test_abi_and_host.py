@@ -288,6 +288,31 @@ def test_draw_is_the_sequential_cpu_stream():
         assert torch.equal(m.draw(b, h, w, "cpu", generator=torch.Generator().manual_seed(9)), seq)
 
 
+def test_extractor_draws_follow_the_reference_stream():
+    """FastMCDSamplesExtractor with several hooked layers: upstream calls one DropBlock2D per hooked layer inside every MC
+    sample (/root/reference/runia_core/feature_extraction/image_level.py:200-210), each drawing torch.rand(1, H_i, W_i)
+    unless its drop_prob is 0.  ``draw_layers`` makes ONE flat torch.rand per batch and cuts it in that order."""
+    from runia_core_amd.feature_extraction.image_level import FastMCDSamplesExtractor
+
+    shapes = [(7, 7), (4, 4), (1, 5), (3, 2)]
+    probs = [0.5, 0.3, 0.0, 0.2]
+    ex = FastMCDSamplesExtractor(None, [None], "cpu", "Conv", "mean", mcd_nro_samples=5, dropblock_probs=probs,
+                                 dropblock_sizes=[3, 2, 1, 1])
+    batch = 3
+    torch.manual_seed(17)
+    ref = [[] for _ in shapes]
+    for _ in range(batch):
+        for _ in range(5):
+            for i, (h, w) in enumerate(shapes):
+                if probs[i] != 0.0:
+                    ref[i].append(torch.rand(1, h, w))
+    torch.manual_seed(17)
+    got = ex.draw_layers(batch, shapes, "cpu")
+    assert got[2] is None
+    for i in (0, 1, 3):
+        assert torch.equal(got[i], torch.cat(ref[i]).reshape(batch, 5, *shapes[i]))
+
+
 def test_semantic_entropy_reference_goldens():
     """/root/reference/tests/unit_test_llm_uncertainty.py:209-265 (clustering mocked as there): 1.0114042647073516 for
     cluster sizes 3/2/1, 0 for one cluster, log(5) for five singletons; plus the greedy bidirectional-entailment clustering

@@ -871,9 +871,128 @@ def test_fast_mcd_samples_extractor_batched():
             assert np.array_equal(z.cpu().numpy(), exp, equal_nan=True)
         else:  # batches draw per batch: the stream is the same, image after image
             assert np.array_equal(z.cpu().numpy(), exp, equal_nan=True)
+
+
+def _ref_samples_one_image(latents, draws, probs, sizes, reduction, want_std):
+    """/root/reference/runia_core/feature_extraction/image_level.py:162-249 for one image, on the CPU in torch: latents =
+    per-layer (1, C, H, W) arrays, draws[i][s] = the (H, W) uniform draws of layer i in MC sample s."""
+    means, stds = [], []
+    for s in range(len(next(d for d in draws if d is not None))):
+        m_layers, s_layers = [], []
+        for i, x in enumerate(latents):
+            c, h, w = x.shape[1:]
+            if probs[i] != 0.0:
+                y = oracle.mc_stack(x, draws[i][s : s + 1], probs[i], sizes[i], layer_type="FC").reshape(1, c, h, w)
+            else:
+                y = x
+            y = torch.from_numpy(np.ascontiguousarray(y))
+            if reduction == "fullmean":
+                m = torch.squeeze(torch.mean(torch.mean(y, dim=3, keepdim=True), dim=2, keepdim=True))
+            else:
+                m = torch.squeeze(torch.mean(y, dim=3, keepdim=True))
+            m_layers.append(m.reshape(-1))
+            if want_std:
+                s_layers.append(torch.squeeze(torch.std(torch.std(y, dim=3, keepdim=True), dim=2, keepdim=True)).reshape(-1))
+        means.append(torch.cat(m_layers).reshape(1, -1))
+        if want_std:
+            stds.append(torch.cat(s_layers).reshape(1, -1))
+    return torch.cat(means).numpy(), (torch.cat(stds).numpy() if want_std else None)
+
+
+@pytest.mark.parametrize("reduction,want_std,n_layers", [("mean", False, 1), ("fullmean", True, 1), ("mean", True, 2),
+                                                          ("fullmean", False, 3)])
+def test_fast_mcd_samples_extractor_other_options(reduction, want_std, n_layers):
+    """The remaining options of the reference's extractor loop (image_level.py:162-249): reduction_method="mean",
+    return_stds, several hooked layers with their own DropBlock layer (one of them with drop_prob 0: it draws nothing),
+    against a torch CPU restatement of that loop fed with the same generator stream."""
+    from runia_core_amd import Hook
+    from runia_core_amd.feature_extraction import FastMCDSamplesExtractor
+
+    class Branches(torch.nn.Module):  # a layer whose INPUT is a list of feature maps (as an FPN head's)
+        def forward(self, feats):
+            return sum(f.mean() for f in feats)
+
+    class Net(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = torch.nn.Conv2d(3, 10, 3, padding=1)
+            self.c2 = torch.nn.Conv2d(10, 6, 3, padding=1, stride=2)
+            self.c3 = torch.nn.Conv2d(6, 5, 3, padding=1, stride=2)
+            self.head = Branches()
+            self.single = torch.nn.Identity()
+
+        def forward(self, x):
+            a = torch.relu(self.c1(x))
+            b = torch.relu(self.c2(a))
+            c = torch.relu(self.c3(b))
+            self.single(a)
+            return self.head([a, b, c][: self.n_out])
+
+    torch.manual_seed(1)
+    net = Net().cuda().eval()
+    net.n_out = n_layers
+    imgs = torch.randn(5, 3, 8, 8)
+    probs_all, sizes_all = [0.4, 0.0, 0.3], [3, 1, 2]
+    if n_layers == 1:
+        hook, probs, sizes, out_hook = Hook(net.single), 0.4, 3, True
+    else:
+        hook, probs, sizes, out_hook = Hook(net.head), probs_all[:n_layers], sizes_all[:n_layers], False
+    n_mc = 6
+    ex = FastMCDSamplesExtractor(net, [hook], torch.device("cuda"), "Conv", reduction, return_stds=want_std,
+                                 mcd_nro_samples=n_mc, hook_layer_output=out_hook, dropblock_probs=probs, dropblock_sizes=sizes)
+    loader = [(imgs[0:2], torch.zeros(2)), (imgs[2:5], torch.zeros(3))]
+    torch.manual_seed(77)
+    res = ex.get_ls_samples(loader)
+    with torch.no_grad():
+        a = torch.relu(net.c1(imgs.cuda()))
+        b = torch.relu(net.c2(a))
+        c = torch.relu(net.c3(b))
+    lat_all = [t.cpu().numpy() for t in (a, b, c)][:n_layers]
+    pl, sl = ([probs], [sizes]) if n_layers == 1 else (probs, sizes)
+    torch.manual_seed(77)
+    exp_m, exp_s = [], []
+    for i in range(5):
+        draws = [[] if p != 0.0 else None for p in pl]
+        for _ in range(n_mc):
+            for li, p in enumerate(pl):
+                if p != 0.0:
+                    draws[li].append(torch.rand(1, *lat_all[li].shape[2:]).numpy())
+        draws = [np.concatenate(d) if d is not None else None for d in draws]
+        m, sd = _ref_samples_one_image([t[i : i + 1] for t in lat_all], draws, pl, sl, reduction, want_std)
+        exp_m.append(m)
+        exp_s.append(sd)
+    got = res["latent_space_means"].cpu().numpy()
+    exp = np.concatenate(exp_m)
+    assert got.shape == exp.shape
+    assert np.allclose(got, exp, rtol=2e-6, atol=1e-7, equal_nan=True)
+    if want_std:
+        gs, es = res["stds"].cpu().numpy(), np.concatenate(exp_s)
+        assert gs.shape == es.shape and np.allclose(gs, es, rtol=1e-5, atol=1e-7, equal_nan=True)
+
+
+def test_fast_mcd_samples_extractor_fc_layer():
+    """layer_type="FC": torch.nn.Dropout on the hooked vector, mcd_nro_samples rows per image, image-major; a kept entry is
+    x / (1 - p), a dropped one 0 (the device generator makes the masks, as upstream on a GPU)."""
+    from runia_core_amd import Hook
+    from runia_core_amd.feature_extraction import FastMCDSamplesExtractor
+
+    torch.manual_seed(2)
+    net = torch.nn.Sequential(torch.nn.Flatten(), torch.nn.Linear(48, 200)).cuda().eval()
+    hook = Hook(net[1])
+    imgs = torch.randn(4, 3, 4, 4)
+    ex = FastMCDSamplesExtractor(net, [hook], torch.device("cuda"), "FC", "fullmean", mcd_nro_samples=50, dropblock_probs=0.25,
+                                 dropblock_sizes=0)
+    z = ex.get_ls_samples([(imgs[:1], torch.zeros(1)), (imgs[1:], torch.zeros(3))])["latent_space_means"]
+    assert z.shape == (4 * 50, 200)
+    with torch.no_grad():
+        full = net(imgs.cuda())
+    rows = z.reshape(4, 50, 200)
+    kept = rows != 0
+    assert torch.allclose(rows[kept], (full[:, None, :] / 0.75).expand(4, 50, 200)[kept], rtol=1e-6)
+    assert abs(float(kept.float().mean()) - 0.75) < 0.02
     with pytest.raises(NotImplementedError):
-        FastMCDSamplesExtractor(net, [hook], torch.device("cuda"), "Conv", "mean", mcd_nro_samples=4, dropblock_probs=0.5,
-                                dropblock_sizes=2)
+        FastMCDSamplesExtractor(net, [hook], torch.device("cuda"), "FC", "fullmean", mcd_nro_samples=4, dropblock_probs=[0.1, 0.2],
+                                dropblock_sizes=[0, 0])
 
 
 def test_device_fit_randomized_pca_reproduces_sklearn(monkeypatch):
