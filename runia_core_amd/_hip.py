@@ -47,6 +47,7 @@ _SIGNATURES = {
     "runia_md_score_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "runia_md_score_f32x_f64mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "runia_mahalanobis_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "runia_mahalanobis_workspace_bytes_classes": (c_size_t, [c_int64, c_int64, c_int]),
     "runia_mahalanobis_score_f32": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int, c_void_p],
@@ -423,16 +424,19 @@ def md_score(x: torch.Tensor, mean: torch.Tensor, packed_p: torch.Tensor) -> tor
     return s
 
 
-def mahalanobis_score(x: torch.Tensor, class_mean: torch.Tensor, packed_p: torch.Tensor, mu_p: torch.Tensor) -> torch.Tensor:
-    """x [N, D], class_mean [C, D] (both f32 or both f64) -> score [N] f64."""
+def mahalanobis_score(x: torch.Tensor, class_mean: torch.Tensor, packed_p: torch.Tensor, mu_p: torch.Tensor,
+                      class_loop: bool = False) -> torch.Tensor:
+    """x [N, D], class_mean [C, D] (both f32 or both f64) -> score [N] f64.  ``class_loop=True`` hands over the small
+    workspace only (more than 16 classes then take the per-class loop instead of the matrix-core form; tests)."""
     lib = load_library()
     require_gpu()
     assert x.is_cuda and x.dim() == 2 and x.dtype == class_mean.dtype
     x = x.contiguous()
+    class_mean = class_mean.contiguous()
     nrow, d = x.shape
     c = class_mean.shape[0]
     s = torch.empty((nrow,), dtype=torch.float64, device=x.device)
-    ws_bytes = lib.runia_mahalanobis_workspace_bytes(nrow, d)
+    ws_bytes = lib.runia_mahalanobis_workspace_bytes(nrow, d) if class_loop else lib.runia_mahalanobis_workspace_bytes_classes(nrow, d, c)
     ws = torch.empty((max(ws_bytes, 8) // 8,), dtype=torch.float64, device=x.device)
     fn = lib.runia_mahalanobis_score_f32 if x.dtype == torch.float32 else lib.runia_mahalanobis_score_f64
     _check(

@@ -411,6 +411,97 @@ __global__ __launch_bounds__(256) void maha_class_kernel(const TX* __restrict__ 
   }
 }
 
+// ---- many classes (C > 16): the class terms as a second contraction --------------------------------------------------
+// a P a^T = x P x^T - 2 (x P) mu_c^T + mu_c P mu_c^T = qx - 2 S_c + qc with G = x P, S = G M^T (M = class means, D x C
+// on the matrix cores), qc fixed per class.  That is the exact quadratic form of a = x - mu_c; the reference's
+// t = fl32(a) differs from it by ~1e-7 relative, so S only RANKS the classes: every class whose base value comes within
+// 1e-3 of the best one is then re-evaluated with the f32-diff formula of maha_class_kernel (typically one class per row).
+// Work per row: 2 D^2 + 2 D C on MFMA + O(D) per candidate, instead of ~6 D C vector operations + C re-reads of G
+// (C = 1000, D = 2048: 77 ms per 16 384 rows with the class loop).
+template <typename TX>  // packed layout of pack_weights_kernel with B[k][c] = mean[c][k]
+__global__ __launch_bounds__(256) void pack_class_means_kernel(const TX* __restrict__ mean, int64_t D, int C,
+                                                                double* __restrict__ packed, int64_t NT, int64_t total) {
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int h = (int)(i & 1);
+    const int lane = (int)((i >> 1) & 63);
+    const int64_t t = i >> 7;
+    const int64_t ct = t % NT, s2 = t / NT;
+    const int64_t k = 8 * s2 + 4 * h + (lane >> 4);
+    const int64_t c = 16 * ct + (lane & 15);
+    packed[i] = (k < D && c < C) ? (double)mean[c * D + k] : 0.0;
+  }
+}
+
+template <typename TX>  // qc[c] = mu_c P mu_c^T = mu_c . (mu_c P): one wave per class
+__global__ __launch_bounds__(256) void class_quad_kernel(const TX* __restrict__ mean, const double* __restrict__ muP,
+                                                          double* __restrict__ qc, int64_t D, int C) {
+  const int lane = threadIdx.x & 63;
+  const int c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= C) return;
+  double acc = 0.0;
+  for (int64_t j = lane; j < D; j += 64) acc = fma((double)mean[(int64_t)c * D + j], muP[(int64_t)c * D + j], acc);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += shfl_xor_f64(acc, o);
+  if (lane == 0) qc[c] = acc;
+}
+
+template <typename TX>
+__global__ __launch_bounds__(256) void maha_refine_kernel(const TX* __restrict__ x, const TX* __restrict__ mu,
+                                                           const double* __restrict__ G, const double* __restrict__ muP,
+                                                           const double* __restrict__ S, const double* __restrict__ qc,
+                                                           double* __restrict__ score, int64_t rows, int64_t D, int C) {
+  const int lane = threadIdx.x & 63;
+  const int64_t row = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= rows) return;  // wave-uniform
+  const TX* xr = x + row * D;
+  const double* gr = G + row * D;
+  const double* sr = S + row * (int64_t)C;
+  double qx = 0.0;
+  for (int64_t j = lane; j < D; j += 64) qx = fma(gr[j], (double)xr[j], qx);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) qx += shfl_xor_f64(qx, o);
+  // v_c = 2 S_c - qc = qx - (a P a^T): the larger, the closer the class (NaN = class without samples: never a candidate)
+  double m = -kInfD();
+  for (int c = lane; c < C; c += 64) {
+    const double v = 2.0 * sr[c] - qc[c];
+    if (v == v) m = fmax(m, v);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmax(m, shfl_xor_f64(m, o));
+  double best = -kInfD();
+  if (m > -kInfD()) {
+    const double thr = m - (1e-3 * fabs(qx - m) + 1e-12 * (fabs(qx) + fabs(m)));
+    for (int c0 = 0; c0 < C; c0 += 64) {
+      const int c = c0 + lane;
+      bool cand = false;
+      if (c < C) {
+        const double v = 2.0 * sr[c] - qc[c];
+        cand = (v >= thr);
+      }
+      unsigned long long mask = __ballot(cand);
+      while (mask) {  // wave-uniform
+        const int cc = c0 + __builtin_ctzll(mask);
+        mask &= mask - 1;
+        const TX* mm = mu + (int64_t)cc * D;
+        const double* q = muP + (int64_t)cc * D;
+        double acc = 0.0;
+        for (int64_t j = lane; j < D; j += 64) {
+          const TX xv = xr[j], mv = mm[j];
+          const double a = (double)xv - (double)mv;
+          const double t = (double)(TX)(xv - mv);
+          acc += (gr[j] - q[j]) * (2.0 * t - a);
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) acc += shfl_xor_f64(acc, o);
+        double sc = -acc;
+        if (sc != sc) sc = -kInfD();
+        best = fmax(best, sc);
+      }
+    }
+  }
+  if (lane == 0) score[row] = best;
+}
+
 }  // namespace
 
 extern "C" size_t runia_packed_weights_bytes(int64_t K, int64_t n) {
@@ -529,6 +620,18 @@ extern "C" size_t runia_mahalanobis_workspace_bytes(int64_t N, int64_t D) {
   return (size_t)(rows * D) * sizeof(double);
 }
 
+// Workspace that also lets C > 16 classes take the matrix-core form of the class terms (below): the packed class means,
+// qc, and G and S = G M^T for a chunk of rows.  (With only runia_mahalanobis_workspace_bytes the class loop runs.)
+static size_t maha_class_carve_bytes(int64_t D, int C) {
+  return (size_t)packed_elems(D, C) * sizeof(double) + (((size_t)C * sizeof(double) + 255) / 256) * 256;
+}
+extern "C" size_t runia_mahalanobis_workspace_bytes_classes(int64_t N, int64_t D, int C) {
+  if (N <= 0 || D <= 0 || C <= 0) return 0;
+  if (C <= kMahaMaxClasses) return runia_mahalanobis_workspace_bytes(N, D);
+  const int64_t rows = N < 65536 ? N : 65536;
+  return maha_class_carve_bytes(D, C) + (size_t)rows * (size_t)(D + C) * sizeof(double);
+}
+
 template <typename TX>
 static int maha_impl(const TX* x, const TX* class_mean, const double* packed_p, const double* mu_p,
                      double* score, void* workspace, size_t workspace_bytes, int64_t N, int64_t D, int C,
@@ -536,25 +639,58 @@ static int maha_impl(const TX* x, const TX* class_mean, const double* packed_p, 
   if (N < 0 || D <= 0 || C <= 0 || (N > 0 && (!x || !score)) || !class_mean || !packed_p || !mu_p)
     return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
+  hipStream_t s = as_stream(stream);
   if (C <= kMahaMaxClasses) {
     // fused: the class terms are taken from the GEMM accumulators of every 256-column block; G = X P is never written
     // (the two-launch form below spends 20 % of its time re-reading it per class).  The workspace is not touched.
     GemmArgs g{};
     g.x = x; g.ldx = D; g.packed = packed_p; g.N = N; g.K = D; g.n = D;
     g.class_mean = class_mean; g.mu_p = mu_p; g.n_classes = C; g.out = score;
-    return launch_gemm<TX, EPI_MAHA>(g, as_stream(stream));
+    return launch_gemm<TX, EPI_MAHA>(g, s);
+  }
+  if (!workspace) return RUNIA_E_WORKSPACE;
+  const size_t carve = maha_class_carve_bytes(D, C);
+  if ((((uintptr_t)workspace) & 15) == 0 && workspace_bytes >= carve + (size_t)(D + C) * sizeof(double)) {
+    // class terms on the matrix cores: S = G M^T ranks the classes, the f32-diff formula finishes the candidates
+    double* packed_mt = reinterpret_cast<double*>(workspace);
+    double* qc = packed_mt + packed_elems(D, C);
+    double* G = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + carve);
+    const int64_t cap_rows = (int64_t)((workspace_bytes - carve) / ((size_t)(D + C) * sizeof(double)));
+    const int64_t total = packed_elems(D, C);
+    pack_class_means_kernel<TX><<<runia_stream_grid(total, 256), 256, 0, s>>>(class_mean, D, C, packed_mt,
+                                                                               n_padded(C) / 16, total);
+    class_quad_kernel<TX><<<(unsigned)((C + 3) / 4), 256, 0, s>>>(class_mean, mu_p, qc, D, C);
+    int rc = runia_check_launch();
+    if (rc != RUNIA_OK) return rc;
+    for (int64_t r0 = 0; r0 < N; r0 += cap_rows) {
+      const int64_t rows = (N - r0 < cap_rows) ? (N - r0) : cap_rows;
+      double* S = G + rows * D;
+      GemmArgs g{};
+      g.x = x + r0 * D; g.ldx = D; g.packed = packed_p; g.N = rows; g.K = D; g.n = D; g.out = G;
+      rc = launch_gemm<TX, EPI_STORE>(g, s);
+      if (rc != RUNIA_OK) return rc;
+      GemmArgs h{};
+      h.x = G; h.ldx = D; h.packed = packed_mt; h.N = rows; h.K = D; h.n = C; h.out = S;
+      rc = launch_gemm<double, EPI_STORE>(h, s);
+      if (rc != RUNIA_OK) return rc;
+      maha_refine_kernel<TX><<<(unsigned)((rows + 3) / 4), 256, 0, s>>>(x + r0 * D, class_mean, G, mu_p, S, qc,
+                                                                          score + r0, rows, D, C);
+      rc = runia_check_launch();
+      if (rc != RUNIA_OK) return rc;
+    }
+    return RUNIA_OK;
   }
   const int64_t cap_rows = (int64_t)(workspace_bytes / ((size_t)D * sizeof(double)));
-  if (!workspace || cap_rows < 1) return RUNIA_E_WORKSPACE;
+  if (cap_rows < 1) return RUNIA_E_WORKSPACE;
   double* G = reinterpret_cast<double*>(workspace);
   for (int64_t r0 = 0; r0 < N; r0 += cap_rows) {
     const int64_t rows = (N - r0 < cap_rows) ? (N - r0) : cap_rows;
     GemmArgs g{};
     g.x = x + r0 * D; g.ldx = D; g.packed = packed_p; g.N = rows; g.K = D; g.n = D;
     g.sub = nullptr; g.bias = nullptr; g.scale = nullptr; g.out = G;
-    int rc = launch_gemm<TX, EPI_STORE>(g, as_stream(stream));
+    int rc = launch_gemm<TX, EPI_STORE>(g, s);
     if (rc != RUNIA_OK) return rc;
-    maha_class_kernel<TX><<<runia_stream_grid(rows, 4), 256, 0, as_stream(stream)>>>(
+    maha_class_kernel<TX><<<runia_stream_grid(rows, 4), 256, 0, s>>>(
         x + r0 * D, class_mean, G, mu_p, score + r0, rows, D, C);
     rc = runia_check_launch();
     if (rc != RUNIA_OK) return rc;

@@ -241,6 +241,39 @@ def test_mahalanobis_empty_class_and_shapes(hip):
     assert rel_err(s, exp) < 1e-10
 
 
+@pytest.mark.parametrize("d,c,n,dt", [(40, 17, 77, np.float32), (64, 100, 300, np.float32), (300, 40, 50, np.float64),
+                                      (33, 1000, 20, np.float32), (512, 64, 1000, np.float32)])
+def test_mahalanobis_many_classes(hip, d, c, n, dt):
+    """More than 16 classes: the class terms as a second contraction (S = G M^T ranks the classes, the f32-difference
+    formula finishes the candidates) against the oracle and against the per-class loop; an empty class (NaN mean), two
+    identical classes (a tie for the maximum) and rows that sit exactly on a class mean included."""
+    rng = np.random.default_rng(d + c)
+    centres = (rng.standard_normal((c, d)) * 2).astype(dt)
+    centres[3] = np.nan
+    centres[5] = centres[4]
+    lab = rng.integers(0, c, n)
+    lab[lab == 3] = 0
+    x = (np.nan_to_num(centres[lab]) + rng.standard_normal((n, d)) * 0.7 + 10.0).astype(dt)  # far from the origin: cancellation
+    centres = (centres + 10.0).astype(dt)
+    x[1] = centres[7]
+    a = rng.standard_normal((d, d))
+    prec = a @ a.T / d + 0.05 * np.eye(d)
+    with np.errstate(all="ignore"):
+        exp = oracle.mahalanobis_score(x, centres, prec, c)
+        mu_p = centres.astype(np.float64) @ prec
+    tdt = torch.float32 if dt == np.float32 else torch.float64
+    packed = hip.pack_weights(dev(prec, torch.float64))
+    s = hip.mahalanobis_score(dev(x, tdt), dev(centres, tdt), packed, dev(mu_p, torch.float64)).cpu().numpy()
+    loop = hip.mahalanobis_score(dev(x, tdt), dev(centres, tdt), packed, dev(mu_p, torch.float64), class_loop=True).cpu().numpy()
+    assert np.isfinite(s).all()
+    scale = np.maximum(1.0, np.abs(exp))
+    assert (np.abs(s - exp) / scale).max() < 1e-9 and (np.abs(loop - exp) / scale).max() < 1e-9
+    # every class empty -> -inf, as the reference (NaN -> -inf, then the maximum)
+    allnan = np.full((c, d), np.nan, dtype=dt)
+    s2 = hip.mahalanobis_score(dev(x[:5], tdt), dev(allnan, tdt), packed, dev(np.full((c, d), np.nan), torch.float64)).cpu().numpy()
+    assert np.isneginf(s2).all()
+
+
 # ---------------- a8 kNN ----------------------------------------------------------------------------
 @pytest.mark.parametrize("m,d,k,n", [(200, 20, 10, 200), (1000, 64, 50, 33), (300, 2048, 50, 17), (70, 33, 1, 9), (64, 16, 64, 5)])
 def test_knn_vs_oracle(hip, m, d, k, n):

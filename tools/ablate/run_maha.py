@@ -2,8 +2,10 @@ import sys, os, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from runia_core_amd import _hip
+if os.environ.get('RUNIA_LIB'):
+    _hip._LIB_PATH = os.environ['RUNIA_LIB']
 gc.disable()
-N, D, C = 262144, 2048, 10
+N, D, C = [int(v) for v in sys.argv[1:4]] if len(sys.argv) >= 4 else (262144, 2048, 10)
 g = torch.Generator(device="cuda").manual_seed(3)
 centres = torch.randn(C, D, device="cuda", generator=g) * 0.5
 lab = torch.randint(0, C, (N,), device="cuda", generator=g)
@@ -20,4 +22,4 @@ e0.record()
 for _ in range(3): s = _hip.mahalanobis_score(f, cm, packed, mu_p)
 e1.record(); torch.cuda.synchronize()
 ms = e0.elapsed_time(e1) / 3
-print("Mahalanobis %.2f ms  %.1f TFLOP/s (2 D^2 per row)  checksum %.6e" % (ms, 2.0 * N * D * D / ms * 1e-9, float(s.sum())))
+print(f"N {N} D {D} C {C}: " + "Mahalanobis %.2f ms  %.1f TFLOP/s (2 D^2 per row)  checksum %.6e" % (ms, 2.0 * N * D * D / ms * 1e-9, float(s.sum())))
