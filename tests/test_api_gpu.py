@@ -862,8 +862,8 @@ def test_fast_mcd_samples_extractor_batched():
         z = res["latent_space_means"]
         assert z.is_cuda and z.shape == (7 * 16, 12) and res["raw_preds"].shape == (7, 12, 4, 4)
         assert res["gt_labels"].numel() == 7
-        with torch.no_grad():
-            lat = net(imgs.cuda()).cpu().numpy()
+        with torch.no_grad():  # the same batches the extractor ran: a convolution may round differently per batch shape
+            lat = np.concatenate([net(im.cuda()).cpu().numpy() for im, _ in loader])
         torch.manual_seed(123)
         draws = torch.cat([torch.rand(1, 4, 4) for _ in range(7 * 16)]).reshape(7, 16, 4, 4).numpy()
         exp = np.concatenate([oracle.mc_stack(lat[i : i + 1], draws[i], 0.5, 2) for i in range(7)])
@@ -943,11 +943,14 @@ def test_fast_mcd_samples_extractor_other_options(reduction, want_std, n_layers)
     loader = [(imgs[0:2], torch.zeros(2)), (imgs[2:5], torch.zeros(3))]
     torch.manual_seed(77)
     res = ex.get_ls_samples(loader)
-    with torch.no_grad():
-        a = torch.relu(net.c1(imgs.cuda()))
-        b = torch.relu(net.c2(a))
-        c = torch.relu(net.c3(b))
-    lat_all = [t.cpu().numpy() for t in (a, b, c)][:n_layers]
+    parts = []
+    with torch.no_grad():  # per loader batch: a convolution may round differently per batch shape
+        for im, _ in loader:
+            a = torch.relu(net.c1(im.cuda()))
+            b = torch.relu(net.c2(a))
+            c = torch.relu(net.c3(b))
+            parts.append([t.cpu().numpy() for t in (a, b, c)])
+    lat_all = [np.concatenate([p[i] for p in parts]) for i in range(3)][:n_layers]
     pl, sl = ([probs], [sizes]) if n_layers == 1 else (probs, sizes)
     torch.manual_seed(77)
     exp_m, exp_s = [], []

@@ -84,6 +84,24 @@ for t in range(a.rounds):
                            dev(md_mean.ravel()), _hip.pack_weights(dev(prec)), nn)
     check("pca_md (K2)", (rows, dd, nn), rel(s2[sub].cpu().numpy(), oracle.md_score(y_exp, md_mean, prec)), 1e-9)
 
+    # ---- Mahalanobis: fused epilogue (C <= 16), matrix-core class terms (C > 16) and the class loop ----
+    cm_n, dm, nm = int(rng.choice([1, 2, 10, 16, 17, 40, 130, 300])), int(rng.choice([3, 32, 100, 260])), int(rng.choice([1, 31, 33, 500]))
+    ft = np.float32 if rng.random() < 0.7 else np.float64
+    cen = (rng.standard_normal((cm_n, dm)) * 2 + float(rng.choice([0.0, 20.0]))).astype(ft)
+    if cm_n > 2 and rng.random() < 0.3:
+        cen[1] = np.nan
+    xm = (np.nan_to_num(cen[rng.integers(0, cm_n, nm)]) + rng.standard_normal((nm, dm))).astype(ft)
+    am2 = rng.standard_normal((dm, dm))
+    pm = am2 @ am2.T / dm + 0.1 * np.eye(dm)
+    with np.errstate(all="ignore"):
+        em = oracle.mahalanobis_score(xm, cen, pm, cm_n)
+        mup = cen.astype(np.float64) @ pm
+    tdt = torch.float32 if ft == np.float32 else torch.float64
+    pk = _hip.pack_weights(dev(pm))
+    for loop in (False, True):
+        gm = _hip.mahalanobis_score(dev(xm).to(tdt), dev(cen).to(tdt), pk, dev(mup), class_loop=loop).cpu().numpy()
+        check("mahalanobis" + (" (class loop)" if loop else ""), (nm, dm, cm_n, ft.__name__), rel(gm, em), 1e-9)
+
     # ---- kNN ----
     m, dk = int(rng.choice([1, 50, 129, 1000, 5000])), int(rng.choice([3, 32, 100, 512]))
     nq, kk = int(rng.choice([1, 5, 127, 129, 300])), int(rng.choice([1, 5, 50]))
