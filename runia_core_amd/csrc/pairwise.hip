@@ -595,7 +595,11 @@ static inline unsigned knn_dist_grid(int64_t Q, int64_t M) {
 extern "C" size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {
   (void)D; (void)k;
   if (N <= 0 || M <= 0) return 0;
-  const int64_t qc = N < kQueryChunk ? N : kQueryChunk;
+  // query rows per pass: up to 8 192, fewer for very large banks so that the distance tile stays near 2 GiB
+  // (a 1 M-row bank would otherwise ask for 32 GB); the entry point works with whatever it is given (>= 1 row)
+  int64_t qc = N < kQueryChunk ? N : kQueryChunk;
+  const int64_t by_size = ((int64_t)1 << 31) / (4 * M);
+  if (qc > by_size) qc = by_size < 256 ? (N < 256 ? N : 256) : by_size;
   // distance tile rows + |q|^2 for one chunk + |b|^2
   return (size_t)(qc * M + qc + M + 4) * sizeof(float);  // + the maximum bank norm
 }
