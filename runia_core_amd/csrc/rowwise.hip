@@ -2,6 +2,7 @@
 //   a7: scipy.special.logsumexp / softmax-max (reference inference/postprocessors.py:549,606)
 //   a8: normalizer (reference inference/funcs.py:105-115)
 #include "common.hpp"
+#include "entropy_core.hpp"  // sort_asc (register sorting network)
 
 namespace {
 
@@ -255,11 +256,48 @@ __global__ __launch_bounds__(64 * kRowWaves) void ash_s_kernel(const float* __re
   }
 }
 
+constexpr int kGenCompact = 512;  // largest M whose selected probabilities are packed through LDS (2 KB per wave)
+
 // GEN (reference inference/funcs.py:347-375 on softmax(logits)): -sum over the M largest probabilities of
 // p^gamma * (1-p)^gamma, f32.
+// C <= 16 (CIFAR-10-sized heads): one row per lane in registers, as lse_tiny_kernel; the M largest probabilities are
+// the last M entries of the sorted row (16-input network, zero padding sorts to the front and contributes 0).
+// 1 M x 10 rows: 0.61 ms with a wave per row (10 of 64 lanes busy) -> 0.14 ms.
+template <int CT>
+__global__ __launch_bounds__(256) void gen_tiny_kernel(const float* __restrict__ logits, float* __restrict__ score, int64_t N,
+                                                        int M, float gamma) {
+  for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < N; row += (int64_t)gridDim.x * 256) {
+    const float* p = logits + row * CT;
+    float v[16];
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      v[j] = p[j];
+      m = fmaxf(m, v[j]);
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < CT; ++j) {
+      v[j] = expf(v[j] - m);
+      s += v[j];
+    }
+#pragma unroll
+    for (int j = 0; j < 16; ++j) v[j] = (j < CT) ? v[j] / s : 0.f;
+    if (M < CT) runia_entropy::sort_asc<16>(v);  // wave-uniform
+    float acc = 0.f;
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const bool take = (M >= CT) ? (j < CT) : (j >= 16 - M);
+      if (take) acc += powf(v[j], gamma) * powf(1.0f - v[j], gamma);
+    }
+    score[row] = -acc;
+  }
+}
+
 template <int NV>
 __global__ __launch_bounds__(64 * kRowWaves) void gen_kernel(const float* __restrict__ logits, float* __restrict__ score,
                                                    int64_t N, int C, int M, float gamma) {
+  __shared__ float gen_sel[kRowWaves][kGenCompact];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += (int64_t)gridDim.x * kRowWaves) {
     const float* p = logits + row * C;
@@ -293,17 +331,33 @@ __global__ __launch_bounds__(64 * kRowWaves) void gen_kernel(const float* __rest
       acc = wave_sum_f32(acc);
     } else {
       const unsigned thr = kth_largest_key<NV>(key, M);
-      int gt = 0;
+      int gt = 0;  // wave-uniform: elements above the threshold
+      if (M <= kGenCompact) {
+        // The selected probabilities (< M of the row's C) are packed into LDS first, so that the two powf of a term are
+        // evaluated for M/64 elements per lane instead of all NV under a mask (C = 1000, M = 100: 2 instead of 16).
+        float* sel = gen_sel[wave];
 #pragma unroll
-      for (int t = 0; t < NV; ++t) {
-        if (key[t] > thr) {
-          acc += powf(v[t], gamma) * powf(1.0f - v[t], gamma);
-          ++gt;
+        for (int t = 0; t < NV; ++t) {
+          const bool take = key[t] > thr;
+          const unsigned long long mk = __ballot(take);
+          if (take) sel[gt + __popcll(mk & ((1ull << lane) - 1ull))] = v[t];
+          gt += __popcll(mk);
+        }
+        __builtin_amdgcn_wave_barrier();
+        for (int i = lane; i < gt; i += 64) {
+          const float pv = sel[i];
+          acc += powf(pv, gamma) * powf(1.0f - pv, gamma);
+        }
+        __builtin_amdgcn_wave_barrier();  // sel is reused by this wave's next row
+      } else {
+#pragma unroll
+        for (int t = 0; t < NV; ++t) {
+          const bool take = key[t] > thr;
+          if (take) acc += powf(v[t], gamma) * powf(1.0f - v[t], gamma);
+          gt += __popcll(__ballot(take));
         }
       }
       acc = wave_sum_f32(acc);
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) gt += __shfl_xor(gt, o, 64);
       const float pt = __uint_as_float(thr & 0x7fffffffu);
       acc += (float)(M - gt) * (powf(pt, gamma) * powf(1.0f - pt, gamma));
     }
@@ -396,6 +450,17 @@ extern "C" int runia_gen_score_f32(const float* logits, float* score, int64_t N,
   constexpr int kT = 64 * kRowWaves;
   hipStream_t s = as_stream(stream);
   const float g = (float)gamma;
+  if (C <= 16) {
+    const unsigned tg = runia_stream_grid(N, 256);
+#define RUNIA_GEN_TINY(CT) case CT: gen_tiny_kernel<CT><<<tg, 256, 0, s>>>(logits, score, N, M, g); break;
+    switch ((int)C) {
+      RUNIA_GEN_TINY(1) RUNIA_GEN_TINY(2) RUNIA_GEN_TINY(3) RUNIA_GEN_TINY(4) RUNIA_GEN_TINY(5) RUNIA_GEN_TINY(6)
+      RUNIA_GEN_TINY(7) RUNIA_GEN_TINY(8) RUNIA_GEN_TINY(9) RUNIA_GEN_TINY(10) RUNIA_GEN_TINY(11) RUNIA_GEN_TINY(12)
+      RUNIA_GEN_TINY(13) RUNIA_GEN_TINY(14) RUNIA_GEN_TINY(15) RUNIA_GEN_TINY(16)
+    }
+#undef RUNIA_GEN_TINY
+    return runia_check_launch();
+  }
   if (C <= 64) gen_kernel<1><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g);
   else if (C <= 256) gen_kernel<4><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g);
   else if (C <= 1024) gen_kernel<16><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g);

@@ -274,6 +274,18 @@ def test_mahalanobis_many_classes(hip, d, c, n, dt):
     assert np.isneginf(s2).all()
 
 
+@pytest.mark.parametrize("c,m", [(1, 1), (2, 1), (7, 3), (10, 10), (10, 100), (16, 5), (16, 16), (17, 5), (64, 64), (100, 10),
+                                 (1000, 100), (1000, 600), (1000, 1000), (3000, 100)])
+def test_gen_score_widths_and_m(hip, c, m):
+    """GEN over its three kernels (row per lane up to 16 classes, wave per row beyond; selected probabilities packed
+    through LDS for M <= 512) and every relation of M to the number of classes, against the oracle (f32, 1e-5)."""
+    rng = np.random.default_rng(c * 31 + m)
+    lg = (rng.standard_normal((257, c)) * 3).astype(np.float32)
+    lg[5] = 0.0  # ties: every probability equal
+    got = hip.gen_score(dev(lg, torch.float32), 0.1, m).cpu().numpy()
+    assert got.dtype == np.float32 and rel_err(got, oracle.gen_score(lg, 0.1, m)) < 1e-5
+
+
 # ---------------- a8 kNN ----------------------------------------------------------------------------
 @pytest.mark.parametrize("m,d,k,n", [(200, 20, 10, 200), (1000, 64, 50, 33), (300, 2048, 50, 17), (70, 33, 1, 9), (64, 16, 64, 5)])
 def test_knn_vs_oracle(hip, m, d, k, n):
