@@ -585,6 +585,96 @@ constexpr int64_t kQueryChunk = 8192;  // query rows per distance-workspace pass
 
 }  // namespace
 
+namespace {
+// ---- final linear layer with a small head (C <= 16: CIFAR-10-sized ReAct / DICE / ASH / ViM logits) ---------------------
+// The 128 x 128 matrix-core tile spends 118 of its 128 columns on padding there (1 M x 512 -> 10: 4.3 ms, 0.5 TB/s of
+// rows).  Here a wave takes one row at a time: lane = four adjacent features per 256-feature stripe (16-byte loads), the
+// head's weights come from LDS, the C partial dot products of a row are summed over the wave by the halving exchange of
+// the joint-entropy kernel (v_permlane32_swap / v_permlane16_swap / DPP: ~40 instructions for up to 16 sums) and lane
+// quad c writes logit c.  Row-streaming: 1 M x 512 -> 10 in 0.71 ms (2.9 TB/s of rows).
+constexpr int kSkinnyMaxC = 16;
+constexpr int kSkinnyMaxFloats = 24576;  // C * D floats of weights in LDS (96 KB)
+#ifndef SKINNY_RPW
+#define SKINNY_RPW 16
+#endif
+constexpr int kSkinnyRowsPerWave = SKINNY_RPW;   // consecutive rows a wave works through (amortises the weight staging)
+
+template <int CTRL, int BANKS = 0xf>
+__device__ __forceinline__ float dpp_f32(float old, float v) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANKS, false));
+}
+// 16 per-lane partial sums -> their totals over the wave; lane L ends with slot (L >> 2) & 15
+__device__ __forceinline__ float wave_sum16(float (&v)[16], int lane) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 8]), false, false);
+    v[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 4]), false, false);
+    v[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  }
+  const bool u8 = (lane & 8) != 0, u4 = (lane & 4) != 0;
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {  // lanes i, i ^ 8
+    const float send = u8 ? v[j] : v[j + 2], keep = u8 ? v[j + 2] : v[j];
+    v[j] = keep + dpp_f32<0x128>(send, send);  // row_ror:8
+  }
+  {  // lanes i, i ^ 4
+    const float send = u4 ? v[0] : v[1], keep = u4 ? v[1] : v[0];
+    float recv = dpp_f32<0x124, 0xA>(send, send);  // row_ror:4 into banks 1, 3
+    recv = dpp_f32<0x12C, 0x5>(recv, send);        // row_ror:12 into banks 0, 2
+    v[0] = keep + recv;
+  }
+  float r = v[0];
+  r += dpp_f32<0x4E>(r, r);  // quad_perm:[2,3,0,1]
+  r += dpp_f32<0xB1>(r, r);  // quad_perm:[1,0,3,2]
+  return r;
+}
+
+template <int CT>  // CT = classes rounded up to 4, 8, 12 or 16 (accumulator registers)
+__global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                             const float* __restrict__ bias, float* __restrict__ out,
+                                                             int64_t N, int D, int C, float clip_max) {
+  extern __shared__ __attribute__((aligned(16))) float wl[];  // [C][D]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int i = tid; i < C * D / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(w)[i];
+  __syncthreads();
+  const int n4 = D >> 2;                   // float4 per row
+  const int stripes = (n4 + 63) / 64;
+  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * kSkinnyRowsPerWave;
+  for (int rr = 0; rr < kSkinnyRowsPerWave; ++rr) {  // (next row's loads issued ahead of this row's sums: 0.71 -> 0.79 ms)
+    const int64_t row = row0 + rr;
+    if (row >= N) break;  // wave-uniform
+    const float4* xr = reinterpret_cast<const float4*>(x + row * D);
+    float acc[16];
+#pragma unroll
+    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
+    for (int st = 0; st < stripes; ++st) {
+      const int i4 = lane + 64 * st;
+      if (i4 < n4) {
+        float4 v = xr[i4];
+        v.x = fminf(v.x, clip_max); v.y = fminf(v.y, clip_max); v.z = fminf(v.z, clip_max); v.w = fminf(v.w, clip_max);
+#pragma unroll
+        for (int c = 0; c < CT; ++c) {
+          if (c < C) {
+            const float4 ww = reinterpret_cast<const float4*>(wl + c * D)[i4];
+            acc[c] = fmaf(v.x, ww.x, acc[c]);
+            acc[c] = fmaf(v.y, ww.y, acc[c]);
+            acc[c] = fmaf(v.z, ww.z, acc[c]);
+            acc[c] = fmaf(v.w, ww.w, acc[c]);
+          }
+        }
+      }
+    }
+    const float total = wave_sum16(acc, lane);
+    const int c = (lane >> 2) & 15;
+    if ((lane & 3) == 0 && c < C) out[row * C + c] = total + (bias ? bias[c] : 0.f);
+  }
+}
+}  // namespace
+
 // 1-D grid of knn_dist_kernel for Q x M: whole super-tiles, a multiple of 8 of them
 static inline unsigned knn_dist_grid(int64_t Q, int64_t M) {
   const int64_t nbt = (M + TB - 1) / TB, nqt = (Q + TQ - 1) / TQ;
@@ -645,8 +735,30 @@ extern "C" int runia_linear_f32(const float* x, const float* w, const float* bia
   if (N < 0 || D <= 0 || C <= 0) return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
   if (!x || !w || !out) return RUNIA_E_INVALID;
-  const int64_t qt = (N + TQ - 1) / TQ;
   hipStream_t s = as_stream(stream);
+  if (C <= kSkinnyMaxC && C * D <= kSkinnyMaxFloats && (D & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0) {
+    const size_t lds = (size_t)C * D * sizeof(float);
+    const int64_t per_wg = 4 * kSkinnyRowsPerWave;
+    const unsigned grid = (unsigned)((N + per_wg - 1) / per_wg);
+#define RUNIA_SKINNY(CT)                                                                                          \
+  {                                                                                                               \
+    static bool attr = false;                                                                                     \
+    if (!attr) {                                                                                                  \
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_skinny_kernel<CT>),                            \
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)               \
+        return RUNIA_E_LAUNCH;                                                                                    \
+      attr = true;                                                                                                \
+    }                                                                                                             \
+    linear_skinny_kernel<CT><<<grid, 256, lds, s>>>(x, w, bias, out, N, (int)D, (int)C, clip_max);               \
+  }
+    if (C <= 4) RUNIA_SKINNY(4)
+    else if (C <= 8) RUNIA_SKINNY(8)
+    else if (C <= 12) RUNIA_SKINNY(12)
+    else RUNIA_SKINNY(16)
+#undef RUNIA_SKINNY
+    return runia_check_launch();
+  }
+  const int64_t qt = (N + TQ - 1) / TQ;
   for (int64_t t0 = 0; t0 < qt; t0 += 65535) {  // grid.y limit
     const int64_t tiles = (qt - t0 < 65535) ? (qt - t0) : 65535;
     const int64_t r0 = t0 * TQ;

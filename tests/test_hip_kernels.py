@@ -286,6 +286,25 @@ def test_gen_score_widths_and_m(hip, c, m):
     assert got.dtype == np.float32 and rel_err(got, oracle.gen_score(lg, 0.1, m)) < 1e-5
 
 
+@pytest.mark.parametrize("n,d,c", [(1, 4, 1), (65, 512, 10), (1000, 516, 3), (333, 1536, 16), (100, 2048, 12), (70, 512, 17),
+                                   (257, 510, 10), (64, 2048, 16), (129, 100, 16)])
+def test_linear_head_small_and_wide(hip, n, d, c):
+    """Final linear layer (ReAct / DICE / ASH / ViM logits): the row-streaming kernel for heads of up to 16 classes
+    (weights in LDS, wave-level halving sums) and the matrix-core kernel otherwise, with and without clip and bias."""
+    rng = np.random.default_rng(n + d + c)
+    x = np.maximum(rng.standard_normal((n, d)), 0).astype(np.float32) * 2
+    w = (rng.standard_normal((c, d)) / np.sqrt(d)).astype(np.float32)
+    b = rng.standard_normal(c).astype(np.float32)
+    for clip in (float("inf"), 0.9):
+        xc = np.minimum(x, np.float32(clip)).astype(np.float64)
+        exp = xc @ w.astype(np.float64).T
+        got = hip.linear(dev(x, torch.float32), dev(w, torch.float32), dev(b, torch.float32), clip).cpu().numpy()
+        scale = np.abs(xc) @ np.abs(w.astype(np.float64)).T + 1.0  # f32 accumulation error grows with sum |x||w|
+        assert got.shape == (n, c) and (np.abs(got - (exp + b)) / scale).max() < 3e-6
+        nb = hip.linear(dev(x, torch.float32), dev(w, torch.float32), None, clip).cpu().numpy()
+        assert (np.abs(nb - exp) / scale).max() < 3e-6
+
+
 # ---------------- a8 kNN ----------------------------------------------------------------------------
 @pytest.mark.parametrize("m,d,k,n", [(200, 20, 10, 200), (1000, 64, 50, 33), (300, 2048, 50, 17), (70, 33, 1, 9), (64, 16, 64, 5)])
 def test_knn_vs_oracle(hip, m, d, k, n):

@@ -2,6 +2,8 @@
 import gc, os, sys, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from runia_core_amd import _hip
+if os.environ.get('RUNIA_LIB'):
+    _hip._LIB_PATH = os.environ['RUNIA_LIB']
 gc.disable(); torch.manual_seed(0)
 def t(fn, reps=5):
     for _ in range(2): fn()
@@ -23,3 +25,8 @@ ms = t(lambda: _hip.gen_score(lg[:, :10].contiguous(), 0.1, 10)); print(f"gen 1M
 u = torch.randn(D, dtype=torch.float64, device="cuda"); ns = torch.linalg.qr(torch.randn(D, 1024, dtype=torch.float64, device="cuda"))[0]
 pk = _hip.pack_weights(ns.contiguous())
 ms = t(lambda: _hip.proj_norm(x[:65536], u.float(), pk, 1024)); print(f"vim proj_norm 65536x{D}->1024: {ms:.3f} ms  {2.0*65536*D*1024/ms*1e-9:.1f} TFLOP/s")
+# small heads (CIFAR-10-sized)
+w10 = torch.randn(10, 512, device="cuda") * 0.05; b10 = torch.randn(10, device="cuda")
+x512 = torch.relu(torch.randn(1_000_000, 512, device="cuda"))
+ms = t(lambda: _hip.linear(x512, w10, b10)); print(f"linear 1Mx512->10: {ms:.3f} ms  {1e6*512*4/ms*1e-6:.1f} GB/s read")
+ms = t(lambda: _hip.ash_s(x512, 85)); print(f"ash_s 1Mx512: {ms:.3f} ms  {2.0*1e6*512*4/ms*1e-6:.1f} GB/s")
