@@ -615,11 +615,14 @@ struct ProjSqArgs {
 // workgroups share a row tile, each taking one 128-column half of every block (grid.y = 2) and leaving its row
 // sums of squares in `partial`.  The split halves the unit of work: at N = 10 000 the 625 row tiles are 2.44 per
 // CU (3 on some, 2 on most: 19 % of the matrix pipes idle at the end); 1250 half tiles finish within 3 %.
-template <int RT, int NCT, bool ACCUMULATE = false>
+// Few components (the reference's default is nro_components = 16): SPLIT = false with NCT = 1 covers r <= 64 (each wave
+// one 16-column tile), with NCT = 2 r <= 128 - the zero-padded column tiles beyond r are simply not computed (the
+// 256-column forms spend the same 45-50 us on r = 16 as on r = 256).
+template <int RT, int NCT, bool ACCUMULATE = false, bool SPLIT = (NCT == 2)>
 __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
   constexpr int BM = 16 * RT;
   __shared__ double lds_a[2 * BM * APITCH];
-  constexpr int NG = NCT / 2;  // 32-column groups per wave: the unit of the (launch-independent) summation order
+  constexpr int NG = (NCT + 1) / 2;  // 32-column groups per wave: the unit of the (launch-independent) summation order
   __shared__ double part[4 * NG * BM];
   const int64_t n_pad = n_padded(g.r);
   const int tid = threadIdx.x, lane = tid & 63;
@@ -632,7 +635,7 @@ __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
   // tile from HBM, 90.9 MB fetched for 42 MB of rows).
   int64_t tile = blockIdx.x;
   int half = 0;
-  if constexpr (NCT == 2) {
+  if constexpr (SPLIT) {
     tile = (int64_t)(blockIdx.x >> 4) * 8 + (blockIdx.x & 7);
     half = (blockIdx.x >> 3) & 1;
     if (tile * BM >= g.N) return;  // padding of the last group of 8 tiles (uniform over the workgroup)
@@ -728,6 +731,9 @@ __global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
       if constexpr (NCT == 4) {
         const double hi = ((part[4 * BM + tid] + part[5 * BM + tid]) + part[6 * BM + tid]) + part[7 * BM + tid];
         g.score[row] = -(lo + hi);
+      } else if constexpr (!SPLIT) {  // this workgroup holds the whole row (r <= 64 * NCT)
+        if constexpr (ACCUMULATE) unsafeAtomicAdd(&g.score[row], -lo);
+        else g.score[row] = -lo;
       } else if constexpr (ACCUMULATE) {
         // score was zeroed earlier in the stream: two addends per row, and 0 + a + b = 0 + b + a bit for bit
         unsafeAtomicAdd(&g.score[row], -lo);
@@ -1002,7 +1008,9 @@ extern "C" int runia_proj_sq_accumulate_f64(const double* h, const double* packe
   ProjSqArgs g{h, packed_m, c, score, nullptr, N, D, r};
   hipStream_t s = as_stream(stream);
   const int64_t tiles16 = (N + 15) / 16, cus = runia_cu_count();
-  if (proj_sq_large_tiles(N, cus)) proj_sq_kernel<2, 4><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
+  if (r <= 64) proj_sq_kernel<1, 1, true, false><<<(unsigned)tiles16, 256, 0, s>>>(g);
+  else if (r <= 128) proj_sq_kernel<1, 2, true, false><<<(unsigned)tiles16, 256, 0, s>>>(g);
+  else if (proj_sq_large_tiles(N, cus)) proj_sq_kernel<2, 4><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
   else if (tiles16 > cus / 2) proj_sq_kernel<1, 2, true><<<(unsigned)((tiles16 + 7) / 8 * 16), 256, 0, s>>>(g);
   else proj_sq_kernel<1, 4><<<(unsigned)tiles16, 256, 0, s>>>(g);
   return runia_check_launch();
@@ -1019,7 +1027,11 @@ extern "C" int runia_proj_sq_score_f64(const double* h, const double* packed_m, 
   ProjSqArgs g{h, packed_m, c, score, reinterpret_cast<double*>(workspace), N, D, r};
   hipStream_t s = as_stream(stream);
   const int64_t tiles16 = (N + 15) / 16, cus = runia_cu_count();
-  if (proj_sq_large_tiles(N, cus)) {
+  if (r <= 64) {
+    proj_sq_kernel<1, 1, false, false><<<(unsigned)tiles16, 256, 0, s>>>(g);
+  } else if (r <= 128) {
+    proj_sq_kernel<1, 2, false, false><<<(unsigned)tiles16, 256, 0, s>>>(g);
+  } else if (proj_sq_large_tiles(N, cus)) {
     proj_sq_kernel<2, 4><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
   } else if (tiles16 > cus / 2 && workspace && workspace_bytes >= runia_proj_sq_workspace_bytes(N)) {
     // (32-, 48- and 64-row tiles with the same column split measured 64, 64 and 78 us against 59 us)

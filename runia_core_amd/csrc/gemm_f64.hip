@@ -114,7 +114,10 @@ __device__ __forceinline__ void load_a_regs(const GemmArgs& g, int64_t r0, int64
 // One workgroup = 32 rows x all n columns (256 at a time); wave w owns the 64-column slice w of each pass.
 // The rows stream from HBM once per 256-column pass through a double-buffered 32x32 LDS chunk; the packed
 // weights come from L2 one k-step pair ahead (mfma_chunk).
-template <typename TA, typename TS, int EPI, int RT = 2>
+// NCT column tiles per wave (4: the workgroup covers 256 columns per pass; 2 / 1: 128 / 64 columns, for outputs that are
+// no wider - PCA-16 ... PCA-128 and the MD that follows, the reference's default being 16 components: the padded tiles of
+// the 256-column form cost the same 57 us at n = 16 as at n = 256)
+template <typename TA, typename TS, int EPI, int RT = 2, int NCT = 4>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   constexpr int BM = 16 * RT;  // rows per workgroup (shadows the file-level default of 32)
   __shared__ double lds_a[2][BM][APITCH];
@@ -142,16 +145,16 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     for (int r = 0; r < 4; ++r) { rowdot[a][r] = 0.0; rowmax[a][r] = -kInfD(); }
 
   for (int64_t cb = 0; cb < n_pad / BN; ++cb) {
-    const int64_t ctbase = cb * 16 + wave * 4;
-    d4 acc[RT][4];
+    const int64_t ctbase = cb * 16 + wave * NCT;
+    d4 acc[RT][NCT];
 #pragma unroll
     for (int a = 0; a < RT; ++a)
 #pragma unroll
-      for (int c = 0; c < 4; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
+      for (int c = 0; c < NCT; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
     const double2* bp = reinterpret_cast<const double2*>(g.packed) + ctbase * 64 + lane;
-    double2 b0[4];
+    double2 b0[NCT];
 #pragma unroll
-    for (int c = 0; c < 4; ++c) b0[c] = bp[c * 64];
+    for (int c = 0; c < NCT; ++c) b0[c] = bp[c * 64];
 
     double areg[2 * RT];
     load_a_regs<TA, TS, RT>(g, r0, 0, tid, areg);
@@ -165,7 +168,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
       }
       __syncthreads();
       if (ch + 1 < nchunks) load_a_regs<TA, TS, RT>(g, r0, (ch + 1) * KC, tid, areg);
-      mfma_chunk<RT>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
+      mfma_chunk<RT, NCT>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
       buf ^= 1;
     }
 
@@ -176,11 +179,11 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
       // 16 lanes that share a row, added to the (wave, row, class) slot this lane group owns.  ~5 % of the block's MFMA time.
       const TA* xg = reinterpret_cast<const TA*>(g.x);
       const TA* mug = reinterpret_cast<const TA*>(g.class_mean);
-      TA xv[RT][4][4];
+      TA xv[RT][NCT][4];
 #pragma unroll
       for (int a = 0; a < RT; ++a)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NCT; ++c) {
           const int64_t col = (ctbase + c) * 16 + li;
 #pragma unroll
           for (int r = 0; r < 4; ++r) {
@@ -189,10 +192,10 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
           }
         }
       for (int cls = 0; cls < g.n_classes; ++cls) {
-        TA mv[4];
-        double qv[4];
+        TA mv[NCT];
+        double qv[NCT];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
+        for (int c = 0; c < NCT; ++c) {
           const int64_t col = (ctbase + c) * 16 + li;
           mv[c] = (col < g.n) ? mug[(int64_t)cls * g.K + col] : (TA)0;
           qv[c] = (col < g.n) ? g.mu_p[(int64_t)cls * g.K + col] : 0.0;
@@ -203,7 +206,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
           for (int r = 0; r < 4; ++r) {
             double part = 0.0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) {
+            for (int c = 0; c < NCT; ++c) {
               const double ad = (double)xv[a][c][r] - (double)mv[c];
               const double td = (double)(TA)(xv[a][c][r] - mv[c]);
               part = fma(acc[a][c][r] - qv[c], 2.0 * td - ad, part);  // zero beyond n: G = 0, q = 0
@@ -223,10 +226,10 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
         for (int r = 0; r < 4; ++r) {
           const int64_t row = r0 + 16 * a + lg + 4 * r;
           const double rn = (row < g.N) ? g.rown[row] : 0.0;
-          double val[4];
+          double val[NCT];
           double gmax = -kInfD();
 #pragma unroll
-          for (int c = 0; c < 4; ++c) {
+          for (int c = 0; c < NCT; ++c) {
             const int64_t col = (ctbase + c) * 16 + li;
             val[c] = (col < g.n) ? g.alpha * (rn + g.coln[col] - 2.0 * acc[a][c][r]) : -kInfD();
             gmax = fmax(gmax, val[c]);
@@ -235,7 +238,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
             const double mnew = fmax(rowmax[a][r], gmax);
             double part = 0.0;
 #pragma unroll
-            for (int c = 0; c < 4; ++c) part += exp(val[c] - mnew);
+            for (int c = 0; c < NCT; ++c) part += exp(val[c] - mnew);
             rowdot[a][r] = rowdot[a][r] * exp(rowmax[a][r] - mnew) + part;
             rowmax[a][r] = mnew;
           }
@@ -244,7 +247,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
 #pragma unroll
     for (int a = 0; a < RT; ++a) {
 #pragma unroll
-      for (int c = 0; c < 4; ++c) {
+      for (int c = 0; c < NCT; ++c) {
         const int64_t col = (ctbase + c) * 16 + li;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -364,16 +367,27 @@ __global__ __launch_bounds__(256) void row_sqnorm_f64_kernel(const double* __res
 // 16-row instantiation runs (N = 10 000: 313 tiles of 32 rows are 1.2 rounds on 256 CUs - PCA transform 75 us, MD
 // 51 us; 625 tiles of 16 rows: 59 and 33 us; LaRED 8 192 x 10 000 x 256: 0.94 -> 0.88 ms).  A row's bits do not depend on
 // the tile height (tests/test_full_size_gpu.py).
-template <typename TA, int EPI, typename TS = double>
-int launch_gemm(const GemmArgs& g, hipStream_t s) {
+template <typename TA, int EPI, typename TS, int NCT>
+int launch_gemm_nct(const GemmArgs& g, hipStream_t s) {
   const int64_t tiles = (g.N + BM - 1) / BM;
   if (tiles > 0x7fffffff) return RUNIA_E_INVALID;
   if (EPI != EPI_MAHA && tiles < 4 * runia_cu_count()) {
-    gemm_rows_kernel<TA, TS, EPI, 1><<<(unsigned)((g.N + 15) / 16), 256, 0, s>>>(g);
+    gemm_rows_kernel<TA, TS, EPI, 1, NCT><<<(unsigned)((g.N + 15) / 16), 256, 0, s>>>(g);
     return runia_check_launch();
   }
-  gemm_rows_kernel<TA, TS, EPI><<<(unsigned)tiles, 256, 0, s>>>(g);
+  gemm_rows_kernel<TA, TS, EPI, 2, NCT><<<(unsigned)tiles, 256, 0, s>>>(g);
   return runia_check_launch();
+}
+
+template <typename TA, int EPI, typename TS = double>
+int launch_gemm(const GemmArgs& g, hipStream_t s) {
+  // narrow outputs (n <= 64 / 128 columns): one / two column tiles per wave instead of four - the choice depends on n
+  // alone, so a row's bits do not depend on the batch
+  if constexpr (EPI == EPI_PCA || EPI == EPI_ROWDOT || EPI == EPI_STORE || EPI == EPI_ROWNORM) {
+    if (g.n <= 64) return launch_gemm_nct<TA, EPI, TS, 1>(g, s);
+    if (g.n <= 128) return launch_gemm_nct<TA, EPI, TS, 2>(g, s);
+  }
+  return launch_gemm_nct<TA, EPI, TS, 4>(g, s);
 }
 
 // ---- Mahalanobis class terms: one wave per row over G = X P ---------------------------
