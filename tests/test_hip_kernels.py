@@ -441,7 +441,13 @@ def test_kde_goldens(hip):
 # ---------------- a1 mc_stack ------------------------------------------------------------------------------
 @pytest.mark.parametrize("c,h,w,bs,p,n_mc,n", [(512, 4, 4, 2, 0.5, 16, 5), (20, 8, 8, 8, 0.5, 3, 2), (37, 7, 5, 3, 0.3, 6, 3),
                                                (300, 8, 8, 4, 0.4, 16, 2), (64, 4, 4, 2, 0.0, 4, 2), (70, 7, 7, 3, 0.4, 8, 3),
-                                               (33, 2, 2, 1, 0.5, 5, 4), (40, 16, 16, 5, 0.3, 4, 2), (512, 4, 4, 2, 0.9, 16, 40)])
+                                               (33, 2, 2, 1, 0.5, 5, 4), (40, 16, 16, 5, 0.3, 4, 2), (512, 4, 4, 2, 0.9, 16, 40),
+                                               # maps of more than 64 positions: one contraction per image on the matrix cores
+                                               (70, 14, 14, 5, 0.4, 16, 3), (33, 28, 28, 7, 0.3, 16, 2), (130, 32, 32, 4, 0.2, 16, 2),
+                                               (20, 9, 11, 2, 0.3, 33, 2), (17, 14, 14, 14, 0.9, 40, 2), (64, 16, 16, 3, 0.0, 5, 2),
+                                               (100, 13, 5, 3, 0.5, 7, 3),
+                                               # small maps added to the register-resident kernel
+                                               (50, 3, 3, 2, 0.4, 16, 4), (70, 5, 5, 3, 0.3, 16, 3), (40, 6, 6, 2, 0.5, 9, 3)])
 def test_mc_stack_vs_oracle(hip, c, h, w, bs, p, n_mc, n):
     torch.manual_seed(c + h)
     x = torch.relu(torch.randn(n, c, h, w))
@@ -456,7 +462,7 @@ def test_mc_stack_vs_oracle(hip, c, h, w, bs, p, n_mc, n):
     # shared draws for the whole batch (rand_image_stride = 0)
     if p > 0:
         got_s = hip.mc_stack(x.cuda(), rand[0].cuda(), n_mc, p, bs).cpu().numpy().reshape(n, n_mc, c)
-        assert np.array_equal(got_s[0], got[0])
+        assert np.array_equal(got_s[0], got[0], equal_nan=True)
 
 
 SAMPLER_CASES = ["c4x4_bs2", "c4x4_bs2_mc32", "c7x7_bs3", "c8x8_bs8", "c8x8_bs4", "c2x2_bs1", "c2x2_dead",

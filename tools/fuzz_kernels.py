@@ -102,6 +102,24 @@ for t in range(a.rounds):
         gm = _hip.mahalanobis_score(dev(xm).to(tdt), dev(cen).to(tdt), pk, dev(mup), class_loop=loop).cpu().numpy()
         check("mahalanobis" + (" (class loop)" if loop else ""), (nm, dm, cm_n, ft.__name__), rel(gm, em), 1e-9)
 
+    # ---- sampler alone on arbitrary maps: register kernels (<= 64 positions), matrix-core contraction (more), generic ----
+    hh, ww = int(rng.integers(1, 33)), int(rng.integers(1, 33))
+    if hh * ww > 1024:
+        hh = 1024 // ww
+    nm = int(rng.choice([1, 2, 5, 16, 17, 32, 40]))
+    if nm * hh * ww > 16384:  # LDS limit of the mask builders
+        nm = max(1, 16384 // (hh * ww))
+    cc, nn2, bsz = int(rng.choice([1, 15, 64, 65, 130])), int(rng.integers(1, 4)), int(rng.integers(1, min(hh, ww) + 1))
+    pp = float(rng.choice([0.0, 0.1, 0.4, 0.8]))
+    xs = np.maximum(rng.standard_normal((nn2, cc, hh, ww)), 0).astype(np.float32) * float(rng.choice([1e-2, 1.0, 30.0]))
+    rs = rng.random((nn2, nm, hh, ww)).astype(np.float32)
+    gz = _hip.mc_stack(dev(xs), dev(rs) if pp > 0 else None, nm, pp, bsz).cpu().numpy().reshape(nn2, nm, cc)
+    with np.errstate(all="ignore"):
+        ez = np.stack([oracle.mc_stack(xs[i:i + 1], rs[i], pp, bsz) for i in range(nn2)])
+    fin = np.isfinite(ez)
+    okz = np.array_equal(np.isfinite(gz), fin) and np.allclose(gz[fin], ez[fin], rtol=2e-6, atol=1e-30)
+    check("sampler", (nn2, cc, hh, ww, nm, bsz, pp), 0.0 if okz else 1.0, 0.5)
+
     # ---- kNN ----
     m, dk = int(rng.choice([1, 50, 129, 1000, 5000])), int(rng.choice([3, 32, 100, 512]))
     nq, kk = int(rng.choice([1, 5, 127, 129, 300])), int(rng.choice([1, 5, 50]))
