@@ -37,6 +37,7 @@ __global__ __launch_bounds__(256) void jacobi_angles_kernel(const double* __rest
   int p, q;
   tournament_pair(m, t, k, p, q);
   Rot r{1.0, 0.0};
+  bool rotated = false;
   if (q < n) {
     const double app = A[(int64_t)p * n + p], aqq = A[(int64_t)q * n + q], apq = A[(int64_t)p * n + q];
     const double thr = fmax(1e-19 * anorm[0], 1e-17 * sqrt(fabs(app * aqq)));
@@ -45,10 +46,14 @@ __global__ __launch_bounds__(256) void jacobi_angles_kernel(const double* __rest
       const double tt = (theta >= 0.0 ? 1.0 : -1.0) / (fabs(theta) + sqrt(theta * theta + 1.0));
       r.c = 1.0 / sqrt(tt * tt + 1.0);
       r.s = tt * r.c;
-      atomicAdd(rotations, 1u);
+      rotated = true;
     }
   }
   rot[k] = r;
+  // the sweep's rotation count (convergence test of the host loop): one atomic per wave, not per rotation - atomics on
+  // one word retire at ~11 ns each, 1 024 of them per step were half of a step's time at n = 2048
+  const unsigned long long any = __ballot(rotated);
+  if (any && (threadIdx.x & 63) == (unsigned)__builtin_ctzll(__ballot(true))) atomicAdd(rotations, (unsigned)__popcll(any));
 }
 
 __global__ __launch_bounds__(256) void jacobi_apply_kernel(double* __restrict__ A, double* __restrict__ V, int n, int m,

@@ -30,14 +30,41 @@ constexpr int kSuperB = KNN_SB, kSuperQ = KNN_SQ;  // super-tile of workgroups t
 __global__ __launch_bounds__(64 * kRowWaves) void row_sqnorm_kernel(const float* __restrict__ x, float* __restrict__ out,
                                                                     int64_t N, int64_t D, unsigned* __restrict__ max_bits) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const bool vec = ((D & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
   for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += (int64_t)gridDim.x * kRowWaves) {
     const float* p = x + row * D;
     float s = 0.f;
-    for (int64_t i = lane; i < D; i += 64) s = fmaf(p[i], p[i], s);
+    if (vec) {
+      // 16-byte loads, four independent partial sums
+      const float4* p4 = reinterpret_cast<const float4*>(p);
+      const int64_t n4 = D >> 2;
+      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+      int64_t i = lane;
+      for (; i + 192 < n4; i += 256) {
+        const float4 a = p4[i], b = p4[i + 64], c = p4[i + 128], d = p4[i + 192];
+        s0 = fmaf(a.x, a.x, s0); s0 = fmaf(a.y, a.y, s0); s0 = fmaf(a.z, a.z, s0); s0 = fmaf(a.w, a.w, s0);
+        s1 = fmaf(b.x, b.x, s1); s1 = fmaf(b.y, b.y, s1); s1 = fmaf(b.z, b.z, s1); s1 = fmaf(b.w, b.w, s1);
+        s2 = fmaf(c.x, c.x, s2); s2 = fmaf(c.y, c.y, s2); s2 = fmaf(c.z, c.z, s2); s2 = fmaf(c.w, c.w, s2);
+        s3 = fmaf(d.x, d.x, s3); s3 = fmaf(d.y, d.y, s3); s3 = fmaf(d.z, d.z, s3); s3 = fmaf(d.w, d.w, s3);
+      }
+      for (; i < n4; i += 64) {
+        const float4 a = p4[i];
+        s0 = fmaf(a.x, a.x, s0); s0 = fmaf(a.y, a.y, s0); s0 = fmaf(a.z, a.z, s0); s0 = fmaf(a.w, a.w, s0);
+      }
+      s = (s0 + s1) + (s2 + s3);
+    } else {
+      for (int64_t i = lane; i < D; i += 64) s = fmaf(p[i], p[i], s);
+    }
     s = wave_sum_f32(s);
     if (lane == 0) {
       out[row] = s;
-      if (max_bits && s < INFINITY) atomicMax(max_bits, __float_as_uint(s));  // NaN / inf rows do not set the range
+      // Running maximum of the norms (NaN / inf rows do not set the range).  One returning atomic per row on ONE word
+      // serialises at ~88 per microsecond: 50 000 bank rows took 0.58 ms for 0.08 ms of reading.  The atomic is only
+      // issued when the value beats what the word already holds (a stale read only costs a redundant atomic).
+      if (max_bits && s < INFINITY) {
+        const unsigned b = __float_as_uint(s);
+        if (b > __atomic_load_n(max_bits, __ATOMIC_RELAXED)) atomicMax(max_bits, b);
+      }
     }
   }
 }

@@ -1,0 +1,10 @@
+import gc, os, sys, torch
+sys.path.insert(0, os.getcwd())
+from runia_core_amd import _hip
+gc.disable(); torch.manual_seed(0)
+M, D, k = 50000, 2048, 50
+bank = torch.nn.functional.normalize(torch.randn(M, D, device="cuda"), dim=1)
+for Q in (1, 100):
+    q = torch.nn.functional.normalize(torch.randn(Q, D, device="cuda"), dim=1)
+    for _ in range(20): s = _hip.knn_kth(q, bank, k)
+    torch.cuda.synchronize()
