@@ -35,7 +35,10 @@ __global__ __launch_bounds__(256) void range_check_kernel(const T* __restrict__ 
     const T v = (i < n_ind) ? ind[i] : ood[i - n_ind];
     bad = bad || !(v >= (T)0 && v <= (T)1);
   }
-  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(any_outside, 1u);
+  // one word for the whole launch: atomics on it retire at ~88 per microsecond (31 000 waves of out-of-range scores took
+  // 0.36 ms), so: one candidate per workgroup, a bounded grid, and only while the flag is still clear
+  if (__syncthreads_or(bad) && threadIdx.x == 0 && __atomic_load_n(any_outside, __ATOMIC_RELAXED) == 0u)
+    atomicOr(any_outside, 1u);
 }
 
 template <typename T>
@@ -69,16 +72,21 @@ __global__ __launch_bounds__(256) void radix_hist_kernel(const uint64_t* __restr
   table[(size_t)threadIdx.x * nblocks + blockIdx.x] = hist[threadIdx.x];  // digit-major: scan order = (digit, block)
 }
 
-// exclusive scan of `len` unsigned counters in place, one workgroup of 1024 threads
-__global__ __launch_bounds__(1024) void scan_u32_kernel(unsigned* __restrict__ a, int64_t len) {
-  __shared__ unsigned wsum[16];
+// Offsets of a radix pass in two levels, both parallel: workgroup d scans row d of the digit-major table (the counts of
+// digit d in every tile) in place and leaves the row total in dtot[d]; every scatter workgroup then scans the 256 totals
+// itself.  (One workgroup scanning all 256 x tiles counters took 139 us of a 2 M-key pass's 180 - 52 us once staged
+// through LDS; the row scans take a few us.)
+__global__ __launch_bounds__(256) void radix_row_scan_kernel(unsigned* __restrict__ table, unsigned nblocks,
+                                                              unsigned* __restrict__ dtot) {
+  __shared__ unsigned wsum[4];
   __shared__ unsigned carry_s;
+  unsigned* row = table + (size_t)blockIdx.x * nblocks;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   if (tid == 0) carry_s = 0u;
   __syncthreads();
-  for (int64_t base = 0; base < len; base += 1024) {
-    const int64_t i = base + tid;
-    const unsigned v = (i < len) ? a[i] : 0u;
+  for (unsigned base = 0; base < nblocks; base += 256) {
+    const unsigned i = base + tid;
+    const unsigned v = (i < nblocks) ? row[i] : 0u;
     unsigned x = v;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -90,22 +98,39 @@ __global__ __launch_bounds__(1024) void scan_u32_kernel(unsigned* __restrict__ a
     unsigned woff = 0u;
     for (int w = 0; w < wave; ++w) woff += wsum[w];
     const unsigned carry = carry_s;
-    if (i < len) a[i] = carry + woff + x - v;
+    if (i < nblocks) row[i] = carry + woff + x - v;
     __syncthreads();
-    if (tid == 1023) carry_s = carry + woff + x;
+    if (tid == 255) carry_s = carry + woff + x;
     __syncthreads();
   }
+  if (tid == 0) dtot[blockIdx.x] = carry_s;
 }
 
 __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __restrict__ keys_in,
                                                             const uint8_t* __restrict__ lab_in,
                                                             uint64_t* __restrict__ keys_out, uint8_t* __restrict__ lab_out,
                                                             int64_t n, int shift, const unsigned* __restrict__ table,
-                                                            unsigned nblocks) {
+                                                            unsigned nblocks, const unsigned* __restrict__ dtot) {
   __shared__ unsigned base[256];       // next free global slot of every digit for this workgroup
   __shared__ unsigned wcnt[4][256];    // per-wave digit counts of the current chunk
+  __shared__ unsigned dsum[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  base[tid] = table[(size_t)tid * nblocks + blockIdx.x];
+  {
+    // first slot of digit `tid` = number of keys with a smaller digit (exclusive scan of the 256 row totals) ...
+    const unsigned v = dtot[tid];
+    unsigned x = v;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) dsum[wave] = x;
+    __syncthreads();
+    unsigned woff = 0u;
+    for (int w = 0; w < wave; ++w) woff += dsum[w];
+    // ... plus the keys of this digit in earlier tiles
+    base[tid] = woff + x - v + table[(size_t)tid * nblocks + blockIdx.x];
+  }
 #pragma unroll
   for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0u;
   __syncthreads();
@@ -171,18 +196,32 @@ __global__ __launch_bounds__(256) void tile_summary_kernel(const uint64_t* __res
   }
 }
 
-// exclusive scan of the tile summaries (sum: +, end: max), single workgroup, sequential over the tiles
+// exclusive scan of the tile summaries (sum: +, end: max) by one wave, 64 tiles per trip
 __global__ void tile_scan_kernel(unsigned* __restrict__ tile_sum, int* __restrict__ tile_end, int64_t ntiles) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  unsigned s = 0u;
-  int e = -1;
-  for (int64_t t = 0; t < ntiles; ++t) {
-    const unsigned ts = tile_sum[t];
-    const int te = tile_end[t];
-    tile_sum[t] = s;
-    tile_end[t] = e;
-    s += ts;
-    e = max(e, te);
+  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+  const int lane = threadIdx.x;
+  unsigned cs = 0u;
+  int ce = -1;
+  for (int64_t base = 0; base < ntiles; base += 64) {
+    const int64_t i = base + lane;
+    const unsigned ts = (i < ntiles) ? tile_sum[i] : 0u;
+    const int te = (i < ntiles) ? tile_end[i] : -1;
+    unsigned x = ts;
+    int m = te;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned y = __shfl_up(x, o, 64);
+      const int z = __shfl_up(m, o, 64);
+      if (lane >= o) { x += y; m = max(m, z); }
+    }
+    int em = __shfl_up(m, 1, 64);  // exclusive maximum
+    if (lane == 0) em = -1;
+    if (i < ntiles) {
+      tile_sum[i] = cs + x - ts;
+      tile_end[i] = max(ce, em);
+    }
+    cs += __shfl(x, 63, 64);
+    ce = max(ce, __shfl(m, 63, 64));
   }
 }
 
@@ -297,7 +336,7 @@ __global__ void finalize_kernel(const MetricsAccum* __restrict__ acc, const unsi
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, tile_sum, tile_end, accum, flag, total;
+  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, dtot, tile_sum, tile_end, accum, flag, total;
   unsigned nblocks;
 };
 
@@ -312,6 +351,7 @@ Layout make_layout(int64_t n) {
   L.tps = o; o += align256((size_t)n * 4);
   L.prev_end = o; o += align256((size_t)n * 4);
   L.table = o; o += align256((size_t)256 * L.nblocks * 4);
+  L.dtot = o; o += align256(256 * 4);
   L.tile_sum = o; o += align256((size_t)L.nblocks * 4);
   L.tile_end = o; o += align256((size_t)L.nblocks * 4);
   L.accum = o; o += align256(sizeof(MetricsAccum));
@@ -334,6 +374,7 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
   unsigned* tps = reinterpret_cast<unsigned*>(w + L.tps);
   int* prev_end = reinterpret_cast<int*>(w + L.prev_end);
   unsigned* table = reinterpret_cast<unsigned*>(w + L.table);
+  unsigned* dtot = reinterpret_cast<unsigned*>(w + L.dtot);
   unsigned* tile_sum = reinterpret_cast<unsigned*>(w + L.tile_sum);
   int* tile_end = reinterpret_cast<int*>(w + L.tile_end);
   MetricsAccum* acc = reinterpret_cast<MetricsAccum*>(w + L.accum);
@@ -343,21 +384,22 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
   if (hipMemsetAsync(acc, 0, 16, s) != hipSuccess) return RUNIA_E_LAUNCH;
   if (hipMemsetAsync(&acc->fpr95_idx, 0xFF, 8, s) != hipSuccess) return RUNIA_E_LAUNCH;
   const unsigned sgrid = runia_stream_grid(n, 256);
-  range_check_kernel<T><<<sgrid, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag);
+  range_check_kernel<T><<<(sgrid < 1024u ? sgrid : 1024u), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag);
   make_keys_kernel<T><<<sgrid, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, keys[0], labs[0]);
   int cur = 0;
   for (int pass = 0; pass < 8; ++pass) {
     const int shift = 8 * pass;
     radix_hist_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], n, shift, table, L.nblocks);
-    scan_u32_kernel<<<1, 1024, 0, s>>>(table, (int64_t)256 * L.nblocks);
+    radix_row_scan_kernel<<<256, 256, 0, s>>>(table, L.nblocks, dtot);
     radix_scatter_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], labs[cur], keys[cur ^ 1], labs[cur ^ 1], n, shift, table,
-                                                   L.nblocks);
+                                                   L.nblocks, dtot);
     cur ^= 1;
   }
   tile_summary_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], labs[cur], n, tile_sum, tile_end);
   tile_scan_kernel<<<1, 64, 0, s>>>(tile_sum, tile_end, L.nblocks);
   tile_prefix_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], labs[cur], n, tile_sum, tile_end, tps, prev_end);
-  curve_terms_kernel<<<sgrid, 256, 0, s>>>(keys[cur], n, tps, prev_end, acc);
+  // bounded grid: every workgroup ends with three atomics on ONE record
+  curve_terms_kernel<<<(sgrid < 512u ? sgrid : 512u), 256, 0, s>>>(keys[cur], n, tps, prev_end, acc);
   finalize_kernel<<<1, 64, 0, s>>>(acc, tps, n, out3);
   return runia_check_launch();
 }
