@@ -387,7 +387,10 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
   range_check_kernel<T><<<(sgrid < 1024u ? sgrid : 1024u), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag);
   make_keys_kernel<T><<<sgrid, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, keys[0], labs[0]);
   int cur = 0;
-  for (int pass = 0; pass < 8; ++pass) {
+  // f32 scores widened to f64 have 29 zero mantissa bits at the bottom: the three lowest digits are the same for every
+  // key, so those passes would move nothing
+  const int first_pass = (sizeof(T) == 4) ? 3 : 0;
+  for (int pass = first_pass; pass < 8; ++pass) {
     const int shift = 8 * pass;
     radix_hist_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], n, shift, table, L.nblocks);
     radix_row_scan_kernel<<<256, 256, 0, s>>>(table, L.nblocks, dtot);
