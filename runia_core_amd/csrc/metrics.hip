@@ -15,7 +15,10 @@
 
 namespace {
 
-constexpr int kTile = 4096;       // elements per workgroup in every pass
+#ifndef METRICS_TILE
+#define METRICS_TILE 4096
+#endif
+constexpr int kTile = METRICS_TILE;  // elements per workgroup in every pass
 constexpr int kItems = kTile / 256;
 
 __device__ __forceinline__ uint64_t sortable_desc(double v) {

@@ -1,6 +1,8 @@
 import gc, os, sys, torch
 sys.path.insert(0, os.getcwd())
 from runia_core_amd import _hip
+if os.environ.get('RUNIA_LIB'):
+    _hip._LIB_PATH = os.environ['RUNIA_LIB']
 gc.disable(); torch.manual_seed(0)
 a = torch.randn(1_000_000, dtype=torch.float64, device="cuda") + 1.0
 b = torch.randn(1_000_000, dtype=torch.float64, device="cuda")
