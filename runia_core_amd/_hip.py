@@ -230,6 +230,27 @@ def to_device(a, dtype: torch.dtype) -> torch.Tensor:
     return t.to(device=dev, dtype=dtype, non_blocking=False).contiguous()
 
 
+_PINNED_MIN, _PINNED_MAX = 1 << 16, 1 << 30
+
+
+def to_host(t: torch.Tensor) -> np.ndarray:
+    """Device tensor -> host ndarray (the ``.cpu().numpy()`` of every API that returns arrays, as the reference's do).
+    Results between 64 KB and 1 GB land in page-locked memory from torch's caching host allocator and the ndarray is a
+    view of it: a D2H copy into freshly allocated pageable memory runs at ~2 GB/s on this platform (first-touch page
+    faults; the 41 MB of entropies of a 10 000-image batch took 19 ms, 200 x the kernels that made them), into a
+    recycled pinned block at the link rate.  The block returns to the allocator's cache when the array is released."""
+    if not t.is_cuda:
+        return t.detach().numpy()
+    t = t.detach().contiguous()
+    nbytes = t.numel() * t.element_size()
+    if nbytes < _PINNED_MIN or nbytes > _PINNED_MAX:
+        return t.cpu().numpy()
+    out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    out.copy_(t, non_blocking=True)
+    torch.cuda.current_stream().synchronize()
+    return out.numpy()
+
+
 # --------------------------------------------------------------------------------------
 # stage wrappers: device tensors in, device tensors out, stream-ordered, no sync
 # --------------------------------------------------------------------------------------

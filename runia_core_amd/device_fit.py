@@ -40,7 +40,7 @@ def empirical_precision_device(x) -> np.ndarray:
     dtype = torch.float32 if getattr(x, "dtype", None) in (np.float32, torch.float32) else torch.float64
     xd = _hip.to_device(x, dtype)
     _, cov = _hip.covariance(xd)
-    return pinvh_device(cov).cpu().numpy()
+    return _hip.to_host(pinvh_device(cov))
 
 
 class FittedPCA:
@@ -84,7 +84,7 @@ def pca_fit_device(samples, n_components: int, whiten: bool = True) -> FittedPCA
     signs[signs == 0] = 1.0
     vt = vt * signs
     total = float(w.sum().item())
-    return FittedPCA(vt[:n_components].cpu().numpy(), mean.cpu().numpy(), w[:n_components].cpu().numpy(), whiten, n, total)
+    return FittedPCA(_hip.to_host(vt[:n_components]), _hip.to_host(mean), _hip.to_host(w[:n_components]), whiten, n, total)
 
 
 def _inv_sqrt_spd(t: torch.Tensor) -> torch.Tensor:
@@ -146,12 +146,12 @@ def pca_fit_randomized_device(samples, n_components: int, whiten: bool = True, n
     vt = vt * signs
     u = (u * signs.reshape(1, -1)).contiguous()  # svd_flip flips the columns of U with the rows of Vt
     total_var = float(torch.diagonal(s_mat).sum().item()) / (n - 1.0)
-    fitted = FittedPCA(vt[:n_components].cpu().numpy(), mean.cpu().numpy(), (w[:n_components] / (n - 1.0)).cpu().numpy(),
+    fitted = FittedPCA(_hip.to_host(vt[:n_components]), _hip.to_host(mean), _hip.to_host((w[:n_components] / (n - 1.0))),
                        whiten, n, total_var)
     fitted.svd_solver = "randomized"
     # sklearn's fit_transform returns U (scaled), not transform(X): with an approximate SVD the two differ in the trailing
     # components.  U = Q Uhat = M (Z T^(-1/2) Uhat), so the training rows are projected with that matrix instead of V.
     proj = _hip.matmul_f64(_hip.matmul_f64(z, t_ih), u[:, :n_components].contiguous())       # (d, k)
-    scale = np.full(n_components, 1.0 / (n - 1.0)) if whiten else 1.0 / np.maximum(sing[:n_components].cpu().numpy(), 1e-300) ** 2
-    fitted._train_projection = (proj.T.contiguous().cpu().numpy(), scale)
+    scale = np.full(n_components, 1.0 / (n - 1.0)) if whiten else 1.0 / np.maximum(_hip.to_host(sing[:n_components]), 1e-300) ** 2
+    fitted._train_projection = (_hip.to_host(proj.T.contiguous()), scale)
     return fitted

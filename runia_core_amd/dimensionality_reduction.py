@@ -138,4 +138,4 @@ def apply_pca_transform(samples: np.ndarray, pca_transform) -> np.ndarray:
             raise ValueError(f"Expected 2D array, got {x.ndim}D array instead")
     dtype = torch.float32 if (getattr(x, "dtype", None) in (np.float32, torch.float32)) else torch.float64
     xd = _hip.to_device(x, dtype)
-    return dp.transform_device(xd).cpu().numpy()
+    return _hip.to_host(dp.transform_device(xd))

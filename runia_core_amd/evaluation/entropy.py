@@ -30,7 +30,7 @@ def single_image_entropy_calculation(sample: np.ndarray, neighbors: int) -> np.n
     """Per-dimension entropy of one image's ``(n_mc, D)`` MC samples -> ``(D,)`` f64."""
     z = _hip.to_device(np.asarray(sample), torch.float32)
     h = _hip.kl_entropy_per_dim(z, z.shape[0], int(neighbors), MIN_DIST)
-    return h[0].cpu().numpy()
+    return _hip.to_host(h[0])
 
 
 def get_dl_h_z_device(z: Tensor, mcd_samples_nro: int, joint: bool = True):
@@ -66,4 +66,4 @@ def get_dl_h_z(
     n_img = n_rows // mcd_samples_nro
     z = z[: n_img * mcd_samples_nro]
     h_mvn, h_z = get_dl_h_z_device(z, mcd_samples_nro, joint=True)
-    return h_mvn.cpu().numpy().reshape(-1, 1), h_z.cpu().numpy()
+    return _hip.to_host(h_mvn).reshape(-1, 1), _hip.to_host(h_z)

@@ -35,7 +35,7 @@ def auroc_fpr95_aupr_device(ind_scores, ood_scores, to_host: bool = True):
     out = _hip.ood_metrics(a, b)
     if not to_host:
         return out
-    r = out.cpu().numpy()
+    r = _hip.to_host(out)
     return float(r[0]), float(r[1]), float(r[2])
 
 

@@ -76,7 +76,7 @@ def mahalanobis_postprocess(feats: np.ndarray, class_mean: np.ndarray, precision
     """Max over classes of ``-(x - mu_c) P (x - mu_c)^T`` for every row of ``feats`` -> ``(N,)`` f64."""
     state = _state if _state is not None else MahalanobisState(class_mean[:num_classes], precision)
     x = _hip.to_device(feats, _maha_dtype(feats, class_mean))
-    return state.score_device(x).cpu().numpy()
+    return _hip.to_host(state.score_device(x))
 
 
 def normalizer(x):
@@ -86,7 +86,7 @@ def normalizer(x):
         # the reference only feeds the result to faiss (f32); wider inputs keep NumPy semantics
         return arr / (np.linalg.norm(arr, ord=2, axis=-1, keepdims=True) + 1e-10)
     flat = arr.reshape(-1, arr.shape[-1])
-    out = _hip.l2_normalize(_hip.to_device(flat, torch.float32)).cpu().numpy()
+    out = _hip.to_host(_hip.l2_normalize(_hip.to_device(flat, torch.float32)))
     return out.reshape(arr.shape)
 
 

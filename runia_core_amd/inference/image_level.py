@@ -23,8 +23,8 @@ __all__ = ["LaRExInference", "LaRDInference"]
 
 def _score_rows_device(postprocessor, rows: torch.Tensor) -> np.ndarray:
     if hasattr(postprocessor, "postprocess_device"):
-        return postprocessor.postprocess_device(rows).cpu().numpy()
-    return postprocessor.postprocess(rows.cpu().numpy())
+        return _hip.to_host(postprocessor.postprocess_device(rows))
+    return postprocessor.postprocess(_hip.to_host(rows))
 
 
 class LaRExInference(ProbabilisticInferenceModule):
@@ -90,7 +90,7 @@ class LaRExInference(ProbabilisticInferenceModule):
         if pipe._md_state() is not None and self.layer_type == "Conv":
             # LaREM: sampler + entropy and PCA + score as two fused launches (same arithmetic as the stages below)
             s = pipe.score_latents(x, rand if active else None)
-            return s.cpu().numpy() if to_host else s
+            return _hip.to_host(s) if to_host else s
         h = pipe.entropy(self.mc_sampler(x, rand=rand))
         if self.pca_transform:
             h = device_pca_for(self.pca_transform).transform_device(h)
@@ -121,7 +121,7 @@ class LaRExInference(ProbabilisticInferenceModule):
                     pass
                 _ = self.model(input_image)
                 mc_samples.append(layer_hook.output)
-            return torch.cat(mc_samples).cpu().numpy()
+            return _hip.to_host(torch.cat(mc_samples))
 
     @record_time
     def get_score_full_inference(self, input_image, layer_hook):

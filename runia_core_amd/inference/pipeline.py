@@ -36,7 +36,7 @@ class AsyncScores:
 
     def result(self) -> np.ndarray:
         self.done.synchronize()
-        return self.scores.cpu().numpy()
+        return _hip.to_host(self.scores)
 
 
 class LaREMPipeline:
@@ -274,4 +274,4 @@ class LaREMPipeline:
         return self._side_streams[1]
 
     def score_samples_host(self, z: np.ndarray) -> np.ndarray:
-        return self.score_samples(_hip.to_device(z, torch.float32)).cpu().numpy()
+        return _hip.to_host(self.score_samples(_hip.to_device(z, torch.float32)))

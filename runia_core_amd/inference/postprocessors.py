@@ -100,7 +100,7 @@ class DetectorKDE:
 
     def get_density_scores(self, test_embeddings):
         x = _hip.to_device(np.asarray(test_embeddings), torch.float64)
-        return self.score_samples_device(x).cpu().numpy()
+        return _hip.to_host(self.score_samples_device(x))
 
 
 @register_postprocessor("KDE", postprocessor_input=["latent_space_means"])
@@ -180,7 +180,7 @@ class MDLatentSpace(Postprocessor):
     def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
         assert test_data.ndim == 2, "test_feats must be 2 dimensional"
         x = _hip.to_device(test_data, _np_dtype_to_torch(test_data))
-        return self.postprocess_device(x).cpu().numpy()
+        return _hip.to_host(self.postprocess_device(x))
 
 
 @register_postprocessor("cMD", postprocessor_input=["latent_space_means"])
@@ -221,7 +221,7 @@ class cMDLatentSpace(Postprocessor):
                 self.class_mean.append(class_samples.mean(0))
                 centered_data.append(class_samples - self.class_mean[c].view(1, -1))
             self.class_mean = torch.stack(self.class_mean)
-            pooled = torch.cat(centered_data).cpu().numpy().astype(np.float32)
+            pooled = _hip.to_host(torch.cat(centered_data)).astype(np.float32)
             if config.device_fit:
                 precision = empirical_precision_device(pooled)
             else:
@@ -246,7 +246,7 @@ class cMDLatentSpace(Postprocessor):
         if isinstance(test_data, np.ndarray):
             test_data = Tensor(test_data)
         assert test_data.ndim == 2, "test_feats must be 2 dimensional"
-        return self.postprocess_device(_hip.to_device(test_data, torch.float32)).cpu().numpy()
+        return _hip.to_host(self.postprocess_device(_hip.to_device(test_data, torch.float32)))
 
 
 @register_postprocessor("KNN", postprocessor_input=["latent_space_means"])
@@ -313,7 +313,7 @@ class FlatL2Bank:
     def kth_score(self, feats: np.ndarray, k: int) -> np.ndarray:
         """``-D[:, -1]`` of ``search(normalizer(feats), k)`` for every row, f32."""
         q = _hip.l2_normalize(_hip.to_device(np.asarray(feats), torch.float32))
-        return self.kth_score_device(q, k).cpu().numpy()
+        return _hip.to_host(self.kth_score_device(q, k))
 
 
 @register_postprocessor("GMM", postprocessor_input=["latent_space_means"])
@@ -351,7 +351,7 @@ class GMMLatentSpace(Postprocessor):
 
     def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
         assert test_data.ndim == 2, "test_feats must be 2 dimensional"
-        return self.postprocess_device(_hip.to_device(test_data, torch.float32)).cpu().numpy()
+        return _hip.to_host(self.postprocess_device(_hip.to_device(test_data, torch.float32)))
 
 
 # --------------------------------------------------------------------------------------
@@ -362,7 +362,7 @@ def _logits_to_device(test_data) -> Tensor:
 
 
 def _restore_dtype(scores: Tensor, src) -> np.ndarray:
-    out = scores.cpu().numpy()
+    out = _hip.to_host(scores)
     want = np.asarray(src).dtype if not isinstance(src, Tensor) else np.float32
     # scipy keeps the input dtype (f32 logits -> f32 scores; f64 logits -> f64)
     return out.astype(want, copy=False) if want in (np.float32, np.float64) else out
@@ -428,7 +428,7 @@ class KNN(OodPostprocessor):
     def setup(self, ind_train_data: np.ndarray, **kwargs):
         assert "valid_feats" in kwargs, "valid_feats must be provided for KNN setup"
         train = np.asarray(ind_train_data)
-        bank = _hip.l2_normalize(_hip.to_device(train, torch.float32)).cpu().numpy()
+        bank = _hip.to_host(_hip.l2_normalize(_hip.to_device(train, torch.float32)))
         self.index = FlatL2Bank(train.shape[1])
         self.index.add(bank)
         ind_scores = self.postprocess(kwargs["valid_feats"])
@@ -441,7 +441,7 @@ class KNN(OodPostprocessor):
 
     def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
         if isinstance(test_data, Tensor):
-            test_data = test_data.detach().cpu().numpy()
+            test_data = _hip.to_host(test_data)
         scores = self.index.kth_score(np.asarray(test_data), self.k_neighbors)
         return self.flip_sign_fn(scores)
 
@@ -461,7 +461,7 @@ class Mahalanobis(OodPostprocessor):
         if self._state is None:
             self._state = MahalanobisState(self.class_mean[: self.num_classes], self.precision)
         x = _hip.to_device(feats, _maha_dtype(feats, self.class_mean))
-        return self._state.score_device(x).cpu().numpy()
+        return _hip.to_host(self._state.score_device(x))
 
     def setup(self, ind_train_data: np.ndarray, **kwargs):
         assert "train_labels" in kwargs, "train_labels must be provided for Mahalanobis"
@@ -481,7 +481,7 @@ class Mahalanobis(OodPostprocessor):
     def postprocess(self, test_data: Union[np.ndarray, Tensor], **kwargs) -> np.ndarray:
         assert self._setup_flag, "setup() must be called before postprocess()"
         if isinstance(test_data, Tensor):
-            test_data = test_data.cpu().numpy()
+            test_data = _hip.to_host(test_data)
         return self.flip_sign_fn(self._scores(test_data))
 
 
@@ -493,9 +493,9 @@ def _fc_params(kwargs, who: str):
     assert "valid_feats" in kwargs, f"valid_feats must be provided for {who}"
     w, b = kwargs["final_linear_layer_params"]["weight"], kwargs["final_linear_layer_params"]["bias"]
     if isinstance(w, Tensor):
-        w = w.detach().cpu().numpy()
+        w = _hip.to_host(w)
     if isinstance(b, Tensor):
-        b = b.detach().cpu().numpy()
+        b = _hip.to_host(b)
     return w, b
 
 
@@ -539,7 +539,7 @@ class _LinearEnergy(OodPostprocessor):
         w, b = self._device_linear()
         logits = _hip.linear(self._transform(_feats_to_device(feats)), w, b, self._clip())
         lse, _ = _hip.row_lse_msp(logits, True, False)
-        return lse.cpu().numpy()
+        return _hip.to_host(lse)
 
     def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
         assert self._setup_flag, "setup() must be called before postprocess()"
@@ -656,7 +656,7 @@ class GEN(OodPostprocessor):
     def _scores(self, logits) -> np.ndarray:
         if isinstance(logits, Tensor):
             logits = logits.detach()
-        return _hip.gen_score(_hip.to_device(logits, torch.float32), self.gamma, self.num_classes).cpu().numpy()
+        return _hip.to_host(_hip.gen_score(_hip.to_device(logits, torch.float32), self.gamma, self.num_classes))
 
     def postprocess_device(self, logits: Tensor) -> Tensor:
         s = _hip.gen_score(logits, self.gamma, self.num_classes)
@@ -695,12 +695,12 @@ class ViM(OodPostprocessor):
         if dt not in self._dev["u"]:
             self._dev["u"][dt] = _hip.to_device(np.asarray(self.u), dt)
         x = _hip.to_device(feats, dt)
-        return _hip.proj_norm(x, self._dev["u"][dt], self._dev["packed"], np.asarray(self.NS).shape[1]).cpu().numpy()
+        return _hip.to_host(_hip.proj_norm(x, self._dev["u"][dt], self._dev["packed"], np.asarray(self.NS).shape[1]))
 
     @staticmethod
     def _energy(logits) -> np.ndarray:
         if isinstance(logits, Tensor):
-            logits = logits.detach().cpu().numpy()
+            logits = _hip.to_host(logits)
         lse, _ = _hip.row_lse_msp(_hip.to_device(logits, torch.float32), True, False)
         return _restore_dtype(lse, logits)
 
@@ -733,7 +733,7 @@ class ViM(OodPostprocessor):
     def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
         assert self._setup_flag, "setup() must be called before postprocess()"
         if isinstance(test_data, Tensor):
-            test_data = test_data.cpu().numpy()
+            test_data = _hip.to_host(test_data)
         vlogit_test = self._residual_norm(test_data) * self.alpha
         # like the reference, the score is NOT passed through flip_sign_fn here (postprocessors.py:1106-1111)
         return -vlogit_test + self._energy(kwargs["logits"])
@@ -755,7 +755,7 @@ class DDU(OodPostprocessor):
             self._state = GmmState(self.gmm)
         if isinstance(feats, Tensor):
             feats = feats.detach()
-        return self._state.energy_device(_hip.to_device(feats, torch.float32)).cpu().numpy()
+        return _hip.to_host(self._state.energy_device(_hip.to_device(feats, torch.float32)))
 
     def postprocess_device(self, feats: Tensor) -> Tensor:
         if self._state is None:
