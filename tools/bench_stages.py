@@ -62,15 +62,21 @@ def cpu_rate(fn, units):
 
 
 def add(stage, shape, unit, n_units, ms, bound, work_per_unit, cpu, cpu_note, err):
+    """bound: "hbm" (work_per_unit = bytes), "mfma_f32" / "mfma_f64" (FLOP), or - for stages whose time is neither - a
+    free-text limiter ("vector ALU: one f64 exp per pair", "launch latency: 2(n-1) launches per sweep" ...): the achieved
+    rate is then still shown in the unit of work_per_unit, with no fraction of an unrelated peak."""
     rate = n_units / (ms * 1e-3)
     if bound == "hbm":
         ach, peak, u = work_per_unit * rate / 1e9, HBM, "GB/s"
-    else:
+    elif bound in ("mfma_f32", "mfma_f64"):
         ach, peak, u = work_per_unit * rate / 1e12, (F32_MFMA if bound == "mfma_f32" else F64_MFMA), "TFLOP/s"
+    else:
+        ach, peak, u = work_per_unit * rate / 1e9, None, "G work-units/s"
+    frac = None if peak is None else round(ach / peak, 4)
     rows.append(dict(stage=stage, shape=shape, unit=unit, gpu_ms=round(ms, 4), gpu_rate=rate, bound=bound,
                      work_per_unit=work_per_unit, achieved=round(ach, 2), peak=peak, ach_unit=u,
-                     frac=round(ach / peak, 4), cpu_rate=cpu, cpu_note=cpu_note, max_rel_err=err))
-    print(f"{stage:28s} {shape:34s} {ms:9.3f} ms  {rate:12.4g} {unit}/s  {ach:8.1f} {u} ({ach/peak:5.1%})  cpu {cpu:10.4g}/s  err {err:.1e}",
+                     frac=frac, cpu_rate=cpu, cpu_note=cpu_note, max_rel_err=err))
+    print(f"{stage:28s} {shape:34s} {ms:9.3f} ms  {rate:12.4g} {unit}/s  {ach:8.1f} {u} ({'-' if frac is None else format(frac, '5.1%')})  cpu {cpu:10.4g}/s  err {err:.1e}",
           flush=True)
 
 
@@ -140,7 +146,7 @@ s = _hip.kde_score(tr, x)
 m = 512
 cpu = cpu_rate(lambda: oracle.kde_score(tr.cpu().numpy(), x[:m].cpu().numpy()), m)
 err = rel(s[:m].cpu().numpy(), oracle.kde_score(tr.cpu().numpy(), x[:m].cpu().numpy()))
-add("KDE / LaRED (a9), direct (one f64 exp per pair: vector-ALU bound)", f"{N} x train {Mt}x{D} f64", "rows", N, ms, "mfma_f64", 3.0 * Mt * D, cpu, f"numpy brute force, {m} rows", err)
+add("KDE / LaRED (a9), direct", f"{N} x train {Mt}x{D} f64", "rows", N, ms, "vector ALU: one f64 exp per (row, train row) pair; work unit = pair", 1.0 * Mt, cpu, f"numpy brute force, {m} rows", err)
 # LaRED at PCA-256: pair distances on the f64 matrix cores (DetectorKDE takes this path for D >= 24)
 D = 256
 tr = torch.randn(Mt, D, dtype=torch.float64, device=dev, generator=g)
@@ -173,7 +179,7 @@ cpu = cpu_rate(lambda: oracle.get_dl_h_z(zs, NMC), m)
 add("entropy per dim (a2)", f"{N} img x 16 x {C} f32", "images", N, ms, "hbm", NMC * C * 4 + C * 8, cpu, f"k-d tree per (image,dim) [reference form], {m} images", rel(h[:m].cpu().numpy(), oracle.kl_entropy_per_dim_vectorized(zs, NMC)))
 ms = gpu_ms(lambda: _hip.kl_entropy_joint(z, NMC, 5))
 hj = _hip.kl_entropy_joint(z, NMC, 5)
-add("entropy joint (a2)", f"{N} img x 16 x {C} f32", "images", N, ms, "hbm", NMC * C * 4 + 8, float("nan"), "included in the row above", rel(hj[:m].cpu().numpy(), oracle.kl_entropy_joint_vectorized(zs, NMC)[:, 0]))
+add("entropy joint (a2)", f"{N} img x 16 x {C} f32", "images", N, ms, "vector ALU f64: 120 pair maxima x 512 dims per image; work unit = (pair, dim)", 120.0 * C, float("nan"), "included in the row above", rel(hj[:m].cpu().numpy(), oracle.kl_entropy_joint_vectorized(zs, NMC)[:, 0]))
 ms = gpu_ms(lambda: _hip.mc_entropy(x, rand, NMC, 0.5, 2, 5))
 add("K1 mc_entropy (a1+a2)", f"{N}x{C}x{H}x{W} f32", "images", N, ms, "hbm", C * H * W * 4 + NMC * H * W * 4 + C * 8, float("nan"), "-", rel(_hip.mc_entropy(x, rand, NMC, 0.5, 2, 5)[:m].cpu().numpy(), h[:m].cpu().numpy()))
 rng = np.random.default_rng(0)
@@ -233,7 +239,7 @@ for n_e in (256, 512, 2048):
     t0 = time.perf_counter()
     w_ref = np.linalg.eigvalsh(a_.cpu().numpy())
     cpu = 1.0 / (time.perf_counter() - t0)
-    add("Jacobi eigh (f1)", f"{n_e}x{n_e} f64 symmetric", "matrices", 1, ms, "mfma_f64", 10 * 4.0 * n_e**3, cpu,
+    add("Jacobi eigh (f1)", f"{n_e}x{n_e} f64 symmetric", "matrices", 1, ms, "launch latency (n <= 512: 2(n-1) launches per sweep) / L2-MALL bandwidth (n = 2048); work unit = rotation-element update", 10 * 2.0 * n_e**3, cpu,
         "numpy.linalg.eigvalsh (LAPACK, all host cores)", rel(w_.cpu().numpy(), w_ref))
 
 xr = torch.randn(50_000, 512, dtype=torch.float64, device=dev, generator=g) * (0.2 + torch.rand(512, dtype=torch.float64, device=dev, generator=g))
@@ -247,7 +253,7 @@ from sklearn.decomposition import PCA as _PCA  # noqa: E402
 t0 = time.perf_counter()
 ref_fit = _PCA(n_components=256, svd_solver="covariance_eigh", whiten=True).fit(xr.cpu().numpy())
 cpu = 1.0 / (time.perf_counter() - t0)
-add("PCA fit covariance_eigh (f1)", "50000x512 f64 -> 256 (incl. H2D of the rows)", "fits", 1, ms, "mfma_f64", 2.0 * 50_000 * 512 * 512, cpu,
+add("PCA fit covariance_eigh (f1)", "50000x512 f64 -> 256 (incl. H2D of the rows)", "fits", 1, ms, "eigen-solver launch latency + H2D; work unit = covariance FLOP", 2.0 * 50_000 * 512 * 512, cpu,
     "sklearn PCA(svd_solver='covariance_eigh')", float(np.abs(fit.components_ - ref_fit.components_).max()))
 
 fm = torch.relu(torch.randn(1, 256, 50, 80, device=dev, generator=g))
@@ -272,5 +278,5 @@ json.dump({"host_cores": os.cpu_count(), "device": torch.cuda.get_device_name(0)
 with open(os.path.join(ROOT, "gpurun_out", "stages.md"), "w") as f:
     f.write("| stage | shape | GPU ms | GPU units/s | bound | achieved | frac of peak | CPU oracle units/s (1 core) | CPU form | max rel err |\n|---|---|---|---|---|---|---|---|---|---|\n")
     for r in rows:
-        f.write(f"| {r['stage']} | {r['shape']} | {r['gpu_ms']} | {r['gpu_rate']:.4g} {r['unit']}/s | {r['bound']} | {r['achieved']} {r['ach_unit']} | {r['frac']:.1%} | {r['cpu_rate']:.4g} | {r['cpu_note']} | {r['max_rel_err']:.1e} |\n")
+        f.write(f"| {r['stage']} | {r['shape']} | {r['gpu_ms']} | {r['gpu_rate']:.4g} {r['unit']}/s | {r['bound']} | {r['achieved']} {r['ach_unit']} | {'-' if r['frac'] is None else format(r['frac'], '.1%')} | {r['cpu_rate']:.4g} | {r['cpu_note']} | {r['max_rel_err']:.1e} |\n")
 print("written gpurun_out/stages.{json,md}")
