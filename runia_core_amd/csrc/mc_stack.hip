@@ -396,11 +396,11 @@ extern "C" int runia_mc_stack_f32(const float* x, const float* rnd, int64_t rand
   const float gamma = (float)(drop_prob / (double)(block_size * block_size));
   if (H * W > 64) {  // large maps: one contraction per image on the matrix cores
     const int nt = (n_mc + 15) / 16;
-    const int ntp = nt == 3 ? 4 : nt;
-    if (mc_mfma_lds_bytes(H * W, n_mc, ntp) <= 160 * 1024) {
+    if (mc_mfma_lds_bytes(H * W, n_mc, nt) <= 160 * 1024) {
       hipStream_t s = as_stream(stream);
-      if (ntp == 1) return launch_mc_mfma<1>(x, rnd, rand_image_stride, out, N, C, H, W, n_mc, gamma, block_size, identity, s);
-      if (ntp == 2) return launch_mc_mfma<2>(x, rnd, rand_image_stride, out, N, C, H, W, n_mc, gamma, block_size, identity, s);
+      if (nt == 1) return launch_mc_mfma<1>(x, rnd, rand_image_stride, out, N, C, H, W, n_mc, gamma, block_size, identity, s);
+      if (nt == 2) return launch_mc_mfma<2>(x, rnd, rand_image_stride, out, N, C, H, W, n_mc, gamma, block_size, identity, s);
+      if (nt == 3) return launch_mc_mfma<3>(x, rnd, rand_image_stride, out, N, C, H, W, n_mc, gamma, block_size, identity, s);
       return launch_mc_mfma<4>(x, rnd, rand_image_stride, out, N, C, H, W, n_mc, gamma, block_size, identity, s);
     }
   }

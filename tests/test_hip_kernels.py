@@ -445,7 +445,7 @@ def test_kde_goldens(hip):
                                                # maps of more than 64 positions: one contraction per image on the matrix cores
                                                (70, 14, 14, 5, 0.4, 16, 3), (33, 28, 28, 7, 0.3, 16, 2), (130, 32, 32, 4, 0.2, 16, 2),
                                                (20, 9, 11, 2, 0.3, 33, 2), (17, 14, 14, 14, 0.9, 40, 2), (64, 16, 16, 3, 0.0, 5, 2),
-                                               (100, 13, 5, 3, 0.5, 7, 3),
+                                               (100, 13, 5, 3, 0.5, 7, 3), (5, 16, 31, 12, 0.1, 33, 1), (9, 10, 10, 3, 0.3, 48, 2),
                                                # small maps added to the register-resident kernel
                                                (50, 3, 3, 2, 0.4, 16, 4), (70, 5, 5, 3, 0.3, 16, 3), (40, 6, 6, 2, 0.5, 9, 3)])
 def test_mc_stack_vs_oracle(hip, c, h, w, bs, p, n_mc, n):

@@ -107,13 +107,17 @@ for t in range(a.rounds):
     if hh * ww > 1024:
         hh = 1024 // ww
     nm = int(rng.choice([1, 2, 5, 16, 17, 32, 40]))
-    if nm * hh * ww > 16384:  # LDS limit of the mask builders
-        nm = max(1, 16384 // (hh * ww))
+    if nm * hh * ww > 16000:  # LDS limit of the mask builders (n_mc * H * W + n_mc floats in 64 KB for small maps)
+        nm = max(1, 16000 // (hh * ww))
     cc, nn2, bsz = int(rng.choice([1, 15, 64, 65, 130])), int(rng.integers(1, 4)), int(rng.integers(1, min(hh, ww) + 1))
     pp = float(rng.choice([0.0, 0.1, 0.4, 0.8]))
     xs = np.maximum(rng.standard_normal((nn2, cc, hh, ww)), 0).astype(np.float32) * float(rng.choice([1e-2, 1.0, 30.0]))
     rs = rng.random((nn2, nm, hh, ww)).astype(np.float32)
-    gz = _hip.mc_stack(dev(xs), dev(rs) if pp > 0 else None, nm, pp, bsz).cpu().numpy().reshape(nn2, nm, cc)
+    try:
+        gz = _hip.mc_stack(dev(xs), dev(rs) if pp > 0 else None, nm, pp, bsz).cpu().numpy().reshape(nn2, nm, cc)
+    except Exception:
+        print("sampler call failed for", (nn2, cc, hh, ww, nm, bsz, pp), flush=True)
+        raise
     with np.errstate(all="ignore"):
         ez = np.stack([oracle.mc_stack(xs[i:i + 1], rs[i], pp, bsz) for i in range(nn2)])
     fin = np.isfinite(ez)
