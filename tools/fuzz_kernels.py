@@ -143,6 +143,43 @@ for t in range(a.rounds):
     check("kde direct", (nx, mt, dl, bw), rel(_hip.kde_score(dev(tr), dev(x), bw).cpu().numpy(), exp), 1e-10)
     st = _hip.kde_pack_train(dev(tr))
     check("kde matrix", (nx, mt, dl, bw), rel(_hip.kde_score_packed(st, dev(x), bw).cpu().numpy(), exp), 1e-9)
+    # ---- f4: linear head (row-streaming kernel up to 16 classes, matrix cores beyond), GEN, ASH-S ----
+    ch, dh, nh = int(rng.choice([1, 2, 10, 16, 17, 100, 1000])), int(rng.choice([4, 64, 512, 516, 2048])), int(rng.choice([1, 63, 129, 700]))
+    xh = np.maximum(rng.standard_normal((nh, dh)), 0).astype(np.float32) * 2
+    wh = (rng.standard_normal((ch, dh)) / np.sqrt(dh)).astype(np.float32)
+    bh = rng.standard_normal(ch).astype(np.float32)
+    clip = float(rng.choice([np.inf, 1.0]))
+    xc = np.minimum(xh, np.float32(clip)).astype(np.float64)
+    lin = _hip.linear(dev(xh), dev(wh), dev(bh), clip).cpu().numpy()
+    sc = np.abs(xc) @ np.abs(wh.astype(np.float64)).T + 1.0
+    check("linear", (nh, dh, ch, clip), float((np.abs(lin - (xc @ wh.astype(np.float64).T + bh)) / sc).max()), 3e-6)
+    cg, mg = int(rng.choice([1, 2, 7, 10, 16, 17, 100, 1000, 1500])), int(rng.choice([1, 3, 10, 100, 600, 2000]))
+    lgg = (rng.standard_normal((int(rng.choice([1, 65, 300])), cg)) * float(rng.choice([0.5, 3.0]))).astype(np.float32)
+    # GEN in f32 is ill-conditioned for confident rows ((1 - p)^gamma with p -> 1 cancels: the reference's own f32 result
+    # carries an error of gamma * ulp(p) / (1 - p)); a row counts as matching when it is within 1e-5 of the f32 oracle OR
+    # no further from the f64 value than twice the f32 oracle is
+    gg = _hip.gen_score(dev(lgg), 0.1, mg).cpu().numpy().astype(np.float64)
+    o32 = oracle.gen_score(lgg, 0.1, mg).astype(np.float64)
+    o64 = oracle.gen_score(lgg.astype(np.float64), 0.1, mg)
+    okg = (np.abs(gg - o32) <= 1e-5 * np.maximum(1.0, np.abs(o32))) | (np.abs(gg - o64) <= np.maximum(1e-5, 2.0 * np.abs(o32 - o64)))
+    check("gen", (lgg.shape, mg), 0.0 if bool(okg.all()) else float(np.abs(gg - o32).max()), 0.5e-5)
+    da, pa = int(rng.choice([8, 100, 512, 2048, 3000])), int(rng.choice([0, 50, 85, 90, 100]))
+    xa = np.maximum(rng.standard_normal((int(rng.choice([1, 9, 130])), da)), 0).astype(np.float32) + np.float32(0.01)
+    check("ash_s", (xa.shape, pa), rel(_hip.ash_s(dev(xa), pa).cpu().numpy(), oracle.ash_s_defined(xa, pa)), 2e-6)
+
+    # ---- f2: metrics on the device (ties, scores inside and outside [0, 1], both dtypes, uneven set sizes) ----
+    ni, no = int(rng.choice([1, 7, 300, 5000, 70_000])), int(rng.choice([1, 9, 400, 4097, 50_000]))
+    mdt = np.float32 if rng.random() < 0.5 else np.float64
+    si = (rng.standard_normal(ni) + 0.7).astype(mdt)
+    so = rng.standard_normal(no).astype(mdt)
+    if rng.random() < 0.3:
+        si, so = np.round(si, 1), np.round(so, 1)  # heavy ties
+    if rng.random() < 0.3:
+        si, so = (1 / (1 + np.exp(-si))).astype(mdt), (1 / (1 + np.exp(-so))).astype(mdt)  # inside [0, 1]: no sigmoid applied
+    gm3 = _hip.ood_metrics(dev(si), dev(so)).cpu().numpy()
+    em3 = np.array(oracle.auroc_fpr95_aupr(si, so), dtype=np.float64)
+    check("metrics", (ni, no, mdt.__name__), float(np.abs(gm3 - em3).max()), 3e-6)
+
     if (t + 1) % 10 == 0:
         print(f"round {t + 1}/{a.rounds}, mismatches so far: {bad}", flush=True)
 print("fuzz done, mismatches:", bad)
