@@ -84,6 +84,22 @@ for t in range(a.rounds):
                            dev(md_mean.ravel()), _hip.pack_weights(dev(prec)), nn)
     check("pca_md (K2)", (rows, dd, nn), rel(s2[sub].cpu().numpy(), oracle.md_score(y_exp, md_mean, prec)), 1e-9)
 
+    # ---- K2' (folded PCA + LaREM): store and accumulate forms over the component-count and batch-size switches ----
+    rk = int(rng.choice([1, 3, 16, 64, 65, 128, 129, 256, 300]))
+    dk2 = int(rng.choice([8, 100, 512]))
+    nk = int(rng.choice([1, 15, 17, 2000, 4097, 8193, 16384, 20000]))
+    hk = rng.standard_normal((nk, dk2))
+    mk = rng.standard_normal((dk2, rk)) / np.sqrt(dk2)
+    ck = rng.standard_normal(rk)
+    ek = -((hk @ mk + ck) ** 2).sum(1)
+    pmk = _hip.pack_weights(dev(mk))
+    subk = np.unique(np.r_[0:min(nk, 50), max(0, nk - 50):nk])
+    sk = _hip.proj_sq_score(dev(hk), pmk, dev(ck), rk).cpu().numpy()
+    check("K2' store", (nk, dk2, rk), rel(sk[subk], ek[subk]), 1e-11)
+    ak = torch.zeros(nk, dtype=torch.float64, device="cuda")
+    _hip.proj_sq_accumulate(dev(hk), pmk, dev(ck), rk, ak)
+    check("K2' accumulate == store", (nk, dk2, rk), 0.0 if np.array_equal(ak.cpu().numpy(), sk) else 1.0, 0.5)
+
     # ---- Mahalanobis: fused epilogue (C <= 16), matrix-core class terms (C > 16) and the class loop ----
     cm_n, dm, nm = int(rng.choice([1, 2, 10, 16, 17, 40, 130, 300])), int(rng.choice([3, 32, 100, 260])), int(rng.choice([1, 31, 33, 500]))
     ft = np.float32 if rng.random() < 0.7 else np.float64
