@@ -48,8 +48,18 @@ K1_BOUNDARY_BYTES_PER_IMAGE = C * H * W * 4 + N_MC * (H * W + 2) * 4 + C * 8
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
+                    help="cfg2 (default, the headline metric): LaREM-16MC/PCA-256 from latents, weak scaling.  cfg3: "
+                         "BASELINE.json configs[2] - synthetic 1M x 2048 rows through Mahalanobis + Energy + kNN(k=50), "
+                         "the rows sharded over the ranks (strong scaling), one all_gather per postprocessor")
+    ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for cfg2, 3 for cfg3)")
+    ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 10 for cfg2, 1 for cfg3)")
+    ap.add_argument("--rows", type=int, default=1_000_000, help="cfg3: rows of the synthetic test set (all ranks together)")
+    ap.add_argument("--fit-rows", type=int, default=None,
+                    help="cfg3: training rows of the Mahalanobis fit (default: all 50 000 for --workload cfg3, 8 192 in "
+                         "the stages block of the default run; the kNN bank always holds 50 000 rows)")
+    ap.add_argument("--no-stages", action="store_true",
+                    help="cfg2: leave out the `stages` block (cfg3 postprocessors + cfg4 LaRED leg at BASELINE sizes)")
     ap.add_argument("--images", type=int, default=10000, help="test images per GPU (workload: 10 000)")
     ap.add_argument("--train-images", type=int, default=4096)
     ap.add_argument("--input-sets", type=int, default=3,
@@ -76,7 +86,12 @@ def parse_args():
                     help="queue the all_gather on the compute stream, or on a second stream behind an event with "
                          "two output buffers in turn (the next step's kernels then start without waiting for it); "
                          "auto: time both during the warm-up and keep the faster (all ranks agree through a MAX)")
-    return ap.parse_args()
+    args = ap.parse_args()
+    if args.steps is None:
+        args.steps = 200 if args.workload == "cfg2" else 3
+    if args.warmup is None:
+        args.warmup = 10 if args.workload == "cfg2" else 1
+    return args
 
 
 def self_launch(args) -> int:
@@ -164,6 +179,59 @@ def synth_latents(n, seed, shift, device, scale=1.0, corr=0.0):
     return x, rand.contiguous()
 
 
+def main_cfg3(args, device, rank, world, dist, saved_stdout):
+    """--workload cfg3: BASELINE.json configs[2].  A step = this rank's block of the 1M x 2048 synthetic rows (and of
+    their 1M x 1000 / 1M x 10 logits) through Mahalanobis, Energy and kNN(k=50), one all_gather of the score shards per
+    postprocessor.  The rows are sharded (strong scaling): `value` = rows of the WHOLE set scored by all three
+    postprocessors per second."""
+    import gc
+
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_workloads as bw
+
+    gc.collect()
+    gc.disable()
+    log = (lambda m: print(m, file=sys.stderr, flush=True)) if rank == 0 else None
+    rec = bw.run_cfg3(device, rank, world, dist, args.rows, args.fit_rows or bw.BANK_ROWS, args.steps, args.warmup,
+                      cpu_legs=not args.no_cpu_baseline, log=log)
+    gc.enable()
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    st = rec["stages"]
+    knn = st["knn"]
+    out = {
+        "metric": "OOD scores/sec, Mahalanobis + Energy + kNN(k=50) on synthetic 1M x 2048 features",
+        "value": round(rec["value"], 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(rec["ms_per_step"], 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64 (Mahalanobis) / f32 (Energy, kNN)", "data": "synthetic",
+        "config": {"workload": "Synthetic 1M x 2048 features, Mahalanobis + Energy + kNN(k=50) postprocessors, rows sharded "
+                               "over the GPUs (BASELINE.json configs[2])",
+                   "rows": rec["rows_total"], "rows_per_gpu": rec["rows_local"], "features": bw.D_FEAT,
+                   "classes": bw.N_CLASSES, "logits": [bw.N_LOGITS, bw.N_CLASSES], "knn_bank": [bw.BANK_ROWS, bw.D_FEAT],
+                   "k": bw.K_NN, "mahalanobis_fit_rows": rec["fit_rows"], "entry": "postprocess_device (rows resident in HBM)",
+                   "gather": "none (1 GPU)" if dist is None else "one all_gather_into_tensor per postprocessor, compute stream",
+                   "gather_ms_per_call": round(rec["gather_ms_per_call"], 4),
+                   "setup_fit_s": round(rec["fit_s"], 2), "setup_broadcast_s": round(rec["broadcast_s"], 3)},
+        "roofline": {"bound": "mfma", "kernel": "knn_dist_kernel (+ normaliser and k-th select: the whole kNN stage is timed)",
+                     "achieved": knn["achieved"], "peak": knn["peak"], "unit": "TFLOP/s", "frac": knn["frac"], "traffic": None,
+                     "algorithmic_flop_per_row": 2.0 * bw.BANK_ROWS * bw.D_FEAT, "avg_stage_ms": knn["ms"],
+                     "share_of_step": round(knn["ms"] / max(1e-9, sum(v["ms"] for v in st.values())), 4)},
+        "stages": st,
+    }
+    for k in ("cpu_baseline", "parity"):
+        if k in rec:
+            out[k] = rec[k]
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-pool-child":
         return cpu_pool_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), int(sys.argv[6]))
@@ -209,6 +277,8 @@ def main():
     from runia_core_amd.inference import LaREMPipeline, MDLatentSpace
 
     _hip.require_gpu()
+    if args.workload == "cfg3":
+        return main_cfg3(args, device, rank, world, dist if use_dist else None, saved_stdout)
 
     # ---------------- setup (untimed): fit PCA-256 + LaREM on in-distribution entropies ----------
     probe = LaREMPipeline(None, None, N_MC, DROP_PROB, BLOCK)
@@ -515,6 +585,28 @@ def main():
             }
         except Exception as e:  # the pool leg is a reported baseline; its failure must not lose the measurement
             out["cpu_baseline_all_cores"] = {"value": None, "error": repr(e)[:200]}
+    if world == 1 and not args.no_stages and not use_dist:
+        # the other BASELINE.json configs at their own sizes under the driver's clock: cfg3's postprocessors on 1M x 2048
+        # rows (tools/bench_workloads.py, the code of --workload cfg3) and cfg4's LaRED leg
+        try:
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import bench_workloads as bw
+
+            del sets, x, rand
+            torch.cuda.empty_cache()
+            t_s = time.perf_counter()
+            c3 = bw.run_cfg3(device, 0, 1, None, args.rows, args.fit_rows or 8192, 2, 1, cpu_legs=not args.no_cpu_baseline)
+            stages = dict(c3["stages"])
+            stages["cfg3_step"] = {"rows": c3["rows_total"], "ms": round(c3["ms_per_step"], 3), "rows_per_s": round(c3["value"], 1),
+                                   "note": "Mahalanobis + Energy(C=1000) + Energy(C=10) + kNN(k=50) over the same 1M rows = "
+                                           "`python bench.py --workload cfg3`, 2 timed steps",
+                                   "cpu_rows_per_s": c3.get("cpu_baseline", {}).get("value")}
+            torch.cuda.empty_cache()
+            stages["cfg4_lared"] = bw.run_cfg4_lared(device)
+            stages["seconds"] = round(time.perf_counter() - t_s, 1)
+            out["stages"] = stages
+        except Exception as e:  # a reported extra; its failure must not lose the headline measurement
+            out["stages"] = {"error": repr(e)[:300]}
     sys.stdout.flush()
     os.dup2(saved_stdout, 1)
     print(json.dumps(out), flush=True)

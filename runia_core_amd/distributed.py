@@ -7,11 +7,14 @@ each rank scores its block with the HIP kernels, and ONE ``all_gather`` of the p
 shards returns the full ``(N,)`` vector on every rank.  No collective runs
 inside the data path.
 
-Backend ``"nccl"`` is RCCL on ROCm; ``"gloo"`` (CPU tensors) is supported for tests.
+Backend ``"nccl"`` is RCCL on ROCm; ``"gloo"`` is supported for tests and for rehearsing the
+N > 1 control flow with several ranks on one GPU (device tensors are staged through the host).
 """
 from __future__ import annotations
 
-from typing import Callable, Optional, Tuple
+import io
+import pickle
+from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 import torch
@@ -28,16 +31,26 @@ def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
     return start, min(start + per, n_rows)
 
 
+def _active() -> bool:
+    return dist.is_available() and dist.is_initialized()
+
+
 def _world(group) -> Tuple[int, int]:
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _active():
         return 1, 0
     return dist.get_world_size(group), dist.get_rank(group)
 
 
-def gather_scores(local: torch.Tensor, n_rows: int, group=None) -> torch.Tensor:
-    """One all_gather of the per-rank score shards (padded to ``ceil(N/world)``) -> ``(N,)`` on every rank."""
+def _backend(group) -> Optional[str]:
+    return str(dist.get_backend(group)) if _active() else None
+
+
+def gather_scores(local: torch.Tensor, n_rows: int, group=None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """One all_gather of the per-rank score shards (padded to ``ceil(N/world)``) -> ``(N,)`` on every rank, on the
+    device of ``local``.  ``out``: optional preallocated ``(world * ceil(N/world),)`` buffer of the shard's dtype and
+    device (a steady-state caller passes the same buffer every call)."""
     world, _ = _world(group)
-    if not (dist.is_available() and dist.is_initialized()):
+    if not _active():
         return local
     if local.dtype not in (torch.float32, torch.float64):
         raise TypeError(f"gather_scores: score shards must be float32 or float64 on every rank, got {local.dtype}")
@@ -47,14 +60,21 @@ def gather_scores(local: torch.Tensor, n_rows: int, group=None) -> torch.Tensor:
     else:
         buf = torch.zeros(per, dtype=local.dtype, device=local.device)
         buf[: local.numel()] = local
-    out = torch.empty(world * per, dtype=local.dtype, device=local.device)
-    if local.is_cuda:
+    if _backend(group) == "nccl":
+        if not local.is_cuda:
+            raise TypeError("gather_scores: the nccl (RCCL) backend gathers device tensors; got a CPU shard")
+        if out is None:
+            out = torch.empty(world * per, dtype=local.dtype, device=local.device)
+        else:
+            assert out.shape == (world * per,) and out.dtype == local.dtype and out.device == local.device
         dist.all_gather_into_tensor(out, buf, group=group)
-    else:  # gloo
-        parts = [torch.empty_like(buf) for _ in range(world)]
-        dist.all_gather(parts, buf, group=group)
-        out = torch.cat(parts)
-    return out[:n_rows]
+        return out[:n_rows]
+    # gloo: host tensors (device shards are staged through the host; rehearsal / tests only)
+    host = buf.cpu() if buf.is_cuda else buf
+    parts = [torch.empty_like(host) for _ in range(world)]
+    dist.all_gather(parts, host, group=group)
+    full = torch.cat(parts)[:n_rows]
+    return full.to(local.device) if local.is_cuda else full
 
 
 def sharded_scores(score_fn: Callable, rows, group=None) -> torch.Tensor:
@@ -69,21 +89,121 @@ def sharded_scores(score_fn: Callable, rows, group=None) -> torch.Tensor:
     return gather_scores(local.reshape(-1), n, group)
 
 
-def broadcast_fitted(obj, src: int = 0, group=None):
-    """Replicate a fitted (picklable) state object from ``src`` to every rank (setup-time, once)."""
-    world, _ = _world(group)
+# ------------------------------------------------------------------------------------------------------------------
+# fitted state: small parts pickled, arrays sent as tensors
+# ------------------------------------------------------------------------------------------------------------------
+_OOB_MIN_BYTES = 1 << 16
+
+
+def _torch_dtype_of(np_dtype) -> Optional[torch.dtype]:
+    try:
+        return torch.from_numpy(np.empty(0, dtype=np_dtype)).dtype
+    except TypeError:
+        return None
+
+
+class _ArrayLiftingPickler(pickle.Pickler):
+    """Pickles an object graph but leaves every large ndarray / tensor out of the byte stream (``persistent_id``);
+    the arrays travel as tensors through ``dist.broadcast`` instead of through pickle + a byte tensor."""
+
+    def __init__(self, file, min_bytes: int):
+        super().__init__(file, protocol=pickle.HIGHEST_PROTOCOL)
+        self.min_bytes = min_bytes
+        self.arrays: List[torch.Tensor] = []
+        self.meta: List[tuple] = []
+        self._seen = {}
+
+    def persistent_id(self, o):
+        if isinstance(o, np.ndarray):
+            if o.nbytes < self.min_bytes or o.dtype.hasobject or _torch_dtype_of(o.dtype) is None:
+                return None
+            key = id(o)
+            if key not in self._seen:
+                self._seen[key] = len(self.arrays)
+                # the memory layout is part of the state: derived quantities (folded weights, mean @ components.T ...)
+                # come from host BLAS calls whose summation order follows the strides, and every rank must derive
+                # the same bits.  Fortran-ordered arrays (sklearn's components_) travel as their transpose.
+                if o.flags.f_contiguous and not o.flags.c_contiguous:
+                    self.arrays.append(torch.from_numpy(o.T))
+                    self.meta.append(("ndF", tuple(o.T.shape), o.dtype.str))
+                else:
+                    self.arrays.append(torch.from_numpy(np.ascontiguousarray(o)))
+                    self.meta.append(("nd", tuple(o.shape), o.dtype.str))
+            return self._seen[key]
+        if isinstance(o, torch.Tensor) and not isinstance(o, torch.nn.Parameter):
+            if o.numel() * o.element_size() < self.min_bytes or o.is_sparse or o.requires_grad:
+                return None
+            key = id(o)
+            if key not in self._seen:
+                self._seen[key] = len(self.arrays)
+                self.arrays.append(o.detach().contiguous())
+                self.meta.append(("t", tuple(o.shape), str(o.dtype).replace("torch.", "")))
+            return self._seen[key]
+        return None
+
+
+class _ArrayPlacingUnpickler(pickle.Unpickler):
+    def __init__(self, file, arrays):
+        super().__init__(file)
+        self._arrays = arrays
+
+    def persistent_load(self, pid):
+        return self._arrays[pid]
+
+
+def broadcast_fitted(obj, src: int = 0, group=None, min_tensor_bytes: int = _OOB_MIN_BYTES):
+    """Replicate a fitted state object from rank ``src`` to every rank (setup-time, once).
+
+    The object graph (postprocessors, sklearn ``PCA`` objects, dicts / lists of them ...) is pickled WITHOUT its large
+    arrays: every ndarray / tensor of at least ``min_tensor_bytes`` is lifted out and sent with ``dist.broadcast`` as
+    a tensor (on the device for RCCL: host -> HBM -> xGMI -> HBM -> host, no pickle pass over the 410 MB bank or the
+    33.5 MB precision of cfg3); the receivers rebuild the same graph around the arrays they received.  Device-side caches
+    of the postprocessors are not part of the state (their ``__getstate__`` leaves them out) and are rebuilt on first use.
+    Returns ``obj`` itself on ``src`` and the replica elsewhere."""
+    world, rank = _world(group)
     if world == 1:
         return obj
-    box = [obj]
-    dist.broadcast_object_list(box, src=src, group=group)
-    return box[0]
+    nccl = _backend(group) == "nccl"
+    dev = torch.device("cuda", torch.cuda.current_device()) if nccl else torch.device("cpu")
+    head = [None, None]
+    arrays: List[torch.Tensor] = []
+    if rank == src:
+        buf = io.BytesIO()
+        p = _ArrayLiftingPickler(buf, min_tensor_bytes)
+        p.dump(obj)
+        head, arrays = [buf.getvalue(), p.meta], p.arrays
+    dist.broadcast_object_list(head, src=src, group=group)
+    blob, meta = head
+    received = []
+    for i, (kind, shape, dt) in enumerate(meta):
+        tdt = getattr(torch, dt) if kind == "t" else _torch_dtype_of(np.dtype(dt))
+        if rank == src:
+            t = arrays[i].to(dev)
+        else:
+            t = torch.empty(shape, dtype=tdt, device=dev)
+        if t.numel():
+            dist.broadcast(t, src=src, group=group)
+        if rank != src:
+            t = t.cpu() if t.is_cuda else t
+            received.append(t if kind == "t" else (t.numpy().T if kind == "ndF" else t.numpy()))
+        del t
+    if rank == src:
+        return obj
+    return _ArrayPlacingUnpickler(io.BytesIO(blob), received).load()
 
 
 class ShardedPostprocessor:
-    """Wrap a set-up postprocessor: ``postprocess`` scores this rank's block of the rows and gathers.
+    """Wrap a set-up postprocessor: scores this rank's block of the rows and gathers the score vector.
 
-    All ranks must call with the same ``test_data``.  Extra keyword arguments are forwarded
-    (and sliced when they are per-row arrays of the same length, e.g. ``pred_labels``)."""
+    * ``postprocess(test_data, **kw)`` - the reference's host signature: every rank passes the same host rows, gets the
+      full ``(N,)`` ndarray back.
+    * ``postprocess_device(test_data)`` - every rank holds the same device rows; device scores ``(N,)`` out.
+    * ``postprocess_shard(local_rows, n_rows)`` - every rank passes ONLY its own block (a device tensor of the rows
+      ``shard_bounds(n_rows, world, rank)``), e.g. produced on that GPU by the backbone; device scores ``(N,)`` out.
+      Nothing but the score shards crosses the links.
+
+    Extra keyword arguments of ``postprocess`` are forwarded (and sliced when they are per-row arrays of the same
+    length, e.g. ``pred_labels``)."""
 
     def __init__(self, postprocessor, group=None, device: Optional[torch.device] = None):
         self.postprocessor = postprocessor
@@ -93,19 +213,32 @@ class ShardedPostprocessor:
     def __getattr__(self, name):
         return getattr(self.postprocessor, name)
 
+    def postprocess_shard(self, local_rows: torch.Tensor, n_rows: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+        world, rank = _world(self.group)
+        a, b = shard_bounds(n_rows, world, rank)
+        if local_rows.shape[0] != b - a:
+            raise ValueError(f"postprocess_shard: rank {rank} of {world} owns rows [{a}, {b}) of {n_rows}, "
+                             f"got a block of {local_rows.shape[0]} rows")
+        # An empty tail shard still goes through the postprocessor (its kernels return at once for N == 0) so that the
+        # shard carries the dtype the scorer returns: every rank must enter the one all_gather with the same element size.
+        local = self.postprocessor.postprocess_device(local_rows).reshape(-1)
+        return gather_scores(local, n_rows, self.group, out=out)
+
+    def postprocess_device(self, test_data: torch.Tensor) -> torch.Tensor:
+        world, rank = _world(self.group)
+        n = test_data.shape[0]
+        a, b = shard_bounds(n, world, rank)
+        return self.postprocess_shard(test_data[a:b], n)
+
     def postprocess(self, test_data, **kwargs) -> np.ndarray:
         world, rank = _world(self.group)
         n = len(test_data)
         a, b = shard_bounds(n, world, rank)
         kw = {k: (v[a:b] if hasattr(v, "__len__") and not isinstance(v, str) and len(v) == n else v)
               for k, v in kwargs.items()}
-        # An empty tail shard still goes through the postprocessor (its kernels return at once for N == 0) so that
-        # the shard carries the dtype the scorer returns - f32 for energy / msp / knn / cMD / gen / GMM / ddu: every rank
-        # must enter the one all_gather with the same element size.
         local = np.ascontiguousarray(self.postprocessor.postprocess(test_data[a:b], **kw)).reshape(-1)
         local = torch.from_numpy(local)
-        backend = dist.get_backend(self.group) if (dist.is_available() and dist.is_initialized()) else None
-        if backend == "nccl":
+        if _backend(self.group) == "nccl":
             local = local.to(self.device or torch.device("cuda", torch.cuda.current_device()))
         return gather_scores(local, n, self.group).cpu().numpy()
 

@@ -47,8 +47,18 @@ class Postprocessor(ABC):
     ``postprocess`` (= ``__call__``) scores new rows.  ``cfg`` is accepted and ignored
     here, exactly as in the reference (subclasses read their own keys)."""
 
+    # attributes that only cache device copies of the fitted state: left out of pickles / broadcasts (rebuilt on first use)
+    _device_cache_attrs = ("_dev", "_state", "_wd", "_bd")
+
     def __init__(self, cfg=None):
         self._setup_flag = False
+
+    def __getstate__(self):
+        state = dict(self.__dict__)
+        for name in self._device_cache_attrs:
+            if name in state:
+                state[name] = None
+        return state
 
     @abstractmethod
     def setup(self, ind_train_data: ndarray, **kwargs) -> None:

@@ -80,6 +80,9 @@ class DetectorKDE:
         self._packed = None     # matrix-core form of the training set (D >= 24), built on first use
         return self
 
+    def __getstate__(self):
+        return {**self.__dict__, "_train_dev": None, "_packed": None}  # device copies are rebuilt on first use
+
     def _train(self) -> Tensor:
         if self._train_dev is None:
             self._train_dev = _hip.to_device(np.asarray(self.train_embeddings), torch.float64)
@@ -301,6 +304,9 @@ class FlatL2Bank:
         self._host = np.concatenate([self._host, x]) if self.ntotal else x
         self.ntotal = self._host.shape[0]
         self._dev = None
+
+    def __getstate__(self):
+        return {**self.__dict__, "_dev": None}  # the device copy is rebuilt on first use
 
     def _bank(self) -> Tensor:
         if self._dev is None:

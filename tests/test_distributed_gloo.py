@@ -86,3 +86,96 @@ def test_sharded_scoring_world2_gloo(tmp_path, n_rows):
         if n_rows:
             assert np.array_equal(g["mean"], rows.mean(0))
         assert float(g["thr"]) == 1.5
+
+
+class _RowSumDevice(_RowSum32):
+    """`postprocess_device` stand-in (tensor rows in, tensor scores out) for the device-resident sharding entry points."""
+
+    def postprocess_device(self, x):
+        return x.to(torch.float32).sum(dim=1)
+
+
+def _worker_state(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from sklearn.decomposition import PCA
+
+        from runia_core_amd.inference.postprocessors import FlatL2Bank, KNNLatentSpace, MDLatentSpace
+
+        state = None
+        if rank == 0:
+            rng = np.random.default_rng(11)
+            md = MDLatentSpace()
+            md.feats_mean = rng.standard_normal((1, 192))
+            md.precision = rng.standard_normal((192, 192))           # 295 KB: travels as a tensor
+            md._setup_flag = True
+            md._dev = {"not": "picklable on purpose", "fn": lambda: 0}  # device caches must stay behind
+            knn = KNNLatentSpace()
+            knn.activation_log = rng.standard_normal((300, 64)).astype(np.float32)  # 77 KB
+            knn.index = FlatL2Bank(64)
+            knn.index.add(knn.activation_log)
+            knn.index._dev = object()
+            knn._setup_flag = True
+            pca = PCA(n_components=8).fit(rng.standard_normal((400, 128)))
+            assert pca.components_.nbytes < 65536
+            pca.components_ = np.asfortranarray(rng.standard_normal((96, 128)))  # sklearn's layout; 98 KB: out of band
+            shared = rng.standard_normal((128, 128))                   # one array referenced twice stays one array
+            state = {"md": md, "knn": knn, "pca": pca, "twice": [shared, shared], "small": np.arange(5),
+                     "tensor": torch.arange(40000, dtype=torch.float64).reshape(200, 200), "text": "ok"}
+        got = broadcast_fitted(state)
+        assert got["md"]._dev is None and got["knn"].index._dev is None if rank else True
+        assert got["twice"][0] is got["twice"][1]
+        # device-resident sharding entry points on a stand-in scorer
+        rows = torch.from_numpy(np.random.default_rng(5).standard_normal((9, 6)))
+        sp = ShardedPostprocessor(_RowSumDevice())
+        full_dev = sp.postprocess_device(rows)
+        a, b = shard_bounds(9, world, rank)
+        full_shard = sp.postprocess_shard(rows[a:b], 9)
+        try:
+            sp.postprocess_shard(rows[:1], 9)  # neither rank owns exactly one row: refused before any collective
+            wrong = False
+        except ValueError:
+            wrong = True
+        np.savez(os.path.join(out_dir, f"s{rank}.npz"), precision=got["md"].precision, mean=got["md"].feats_mean,
+                 bank=got["knn"].index._host, ntotal=got["knn"].index.ntotal, comp=got["pca"].components_,
+                 pca_mean=got["pca"].mean_, twice=got["twice"][0], small=got["small"], tensor=got["tensor"].numpy(),
+                 full_dev=full_dev.numpy(), full_shard=full_shard.numpy(), wrong=wrong,
+                 comp_f_order=got["pca"].components_.flags.f_contiguous and not got["pca"].components_.flags.c_contiguous,
+                 flag=got["md"]._setup_flag and got["text"] == "ok")
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_fitted_lifts_arrays_and_device_sharding_world2_gloo(tmp_path):
+    """`broadcast_fitted` pickles the object graph without its large arrays (they travel through dist.broadcast as
+    tensors), drops device caches, keeps shared references shared; `postprocess_device` / `postprocess_shard` gather the
+    same vector as the host form."""
+    world = 2
+    mp.spawn(_worker_state, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = np.load(tmp_path / "s0.npz"), np.load(tmp_path / "s1.npz")
+    for key in ("precision", "mean", "bank", "comp", "pca_mean", "twice", "small", "tensor", "full_dev", "full_shard"):
+        assert g0[key].dtype == g1[key].dtype and np.array_equal(g0[key], g1[key]), key
+    assert bool(g0["comp_f_order"]) and bool(g1["comp_f_order"])  # the memory layout travels with the array
+    assert int(g1["ntotal"]) == 300 and bool(g1["flag"]) and bool(g0["wrong"]) and bool(g1["wrong"])
+    rows = np.random.default_rng(5).standard_normal((9, 6))
+    exp = rows.astype(np.float32).sum(axis=1, dtype=np.float32)
+    assert g1["full_dev"].dtype == np.float32 and np.allclose(g1["full_dev"], exp, atol=1e-6)
+    assert np.array_equal(g1["full_dev"], g1["full_shard"])
+
+
+def test_array_lifting_pickler_moves_large_arrays_out_of_band():
+    import io
+
+    from runia_core_amd.distributed import _ArrayLiftingPickler, _ArrayPlacingUnpickler
+
+    big = np.random.default_rng(0).standard_normal((256, 256))
+    obj = {"a": big, "b": [big, np.arange(3)], "s": "x", "c": np.array(["u", "v"], dtype=object)}
+    buf = io.BytesIO()
+    p = _ArrayLiftingPickler(buf, 1 << 16)
+    p.dump(obj)
+    assert len(p.arrays) == 1 and p.meta == [("nd", (256, 256), "<f8")]
+    assert len(buf.getvalue()) < 4096  # the 512 KB array is not in the byte stream
+    back = _ArrayPlacingUnpickler(io.BytesIO(buf.getvalue()), [p.arrays[0].numpy()]).load()
+    assert back["a"] is back["b"][0] and np.array_equal(back["a"], big) and back["c"][1] == "v"

@@ -1,0 +1,100 @@
+"""Two ranks, real kernels: the N > 1 path of SURVEY 8(e) on the one GPU a test box has.
+
+RCCL refuses two ranks on one device, so the two processes share ``cuda:0`` over gloo (score shards are staged through
+the host by ``gather_scores``); everything else - fitting on rank 0, ``broadcast_fitted`` with the arrays sent as
+tensors, ``shard_bounds``, the HIP kernels on each rank's block, the single gather per postprocessor - is the code an
+8-GPU RCCL job runs.  Sharded scores must equal the unsharded bits (rows are independent and every kernel scores a row
+the same wherever it sits in a launch)."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+N_MC, C, HW, N_PCA = 16, 64, 4, 16
+SIZES = (1001, 3, 1)  # uneven blocks (501 + 500), a one-row tail, an empty tail shard
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _inputs(n, seed):
+    g = torch.Generator(device="cuda").manual_seed(seed)
+    x = torch.relu(torch.randn(n, C, HW, HW, device="cuda", generator=g)).contiguous()
+    rand = torch.rand(n, N_MC, HW, HW, device="cuda", generator=g)
+    rand[:, :, 0, 0] = rand[:, :, 0, 0].clamp_min(0.2)  # keep part of every map (no 0/0 upstream)
+    feats = torch.relu(torch.randn(n, 96, device="cuda", generator=g) + 0.3).contiguous()
+    return x, rand.contiguous(), feats
+
+
+def _worker(rank, world, port, out_dir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import runia_core_amd as rc
+        from runia_core_amd.distributed import ShardedPostprocessor, broadcast_fitted, gather_scores, shard_bounds
+        from runia_core_amd.inference import LaREMPipeline, MDLatentSpace
+        from runia_core_amd.inference.postprocessors import KNN, Mahalanobis
+
+        state = None
+        if rank == 0:  # the fit happens on one rank only
+            xtr, rtr, ftr = _inputs(700, 1)
+            probe = LaREMPipeline(None, None, N_MC, 0.5, 2)
+            h_train = probe.entropy(probe.stack(xtr, rtr)).cpu().numpy()
+            np.random.seed(3)
+            red, pca = rc.apply_pca_ds_split(h_train, N_PCA)
+            md = MDLatentSpace()
+            md.setup(red)
+            labels = np.arange(700) % 5
+            ftr_h = ftr.cpu().numpy() + labels[:, None].astype(np.float32) * 0.2
+            maha = Mahalanobis(flip_sign=False, num_classes=5)
+            maha.setup(ftr_h, train_labels=labels, valid_feats=ftr_h[:64])
+            knn = KNN(flip_sign=True, k_neighbors=50)
+            knn.setup(ftr_h, valid_feats=ftr_h[:64])
+            state = {"md": md, "pca": pca, "maha": maha, "knn": knn}
+        state = broadcast_fitted(state, min_tensor_bytes=1024)
+        pipe = LaREMPipeline(state["md"], state["pca"], N_MC, 0.5, 2)
+        out = {}
+        for n in SIZES:
+            x, rand, feats = _inputs(n, 100 + n)  # every rank builds the same rows; only its block is scored
+            a, b = shard_bounds(n, world, rank)
+            larem = gather_scores(pipe.score_latents(x[a:b], rand[a:b]), n)
+            sp_m, sp_k = ShardedPostprocessor(state["maha"]), ShardedPostprocessor(state["knn"])
+            m_dev = sp_m.postprocess_device(feats)
+            k_shard = sp_k.postprocess_shard(feats[a:b], n)
+            k_host = sp_k.postprocess(feats.cpu().numpy())
+            assert larem.is_cuda and m_dev.is_cuda and k_shard.is_cuda and larem.shape == m_dev.shape == k_shard.shape == (n,)
+            out[f"larem_{n}"], out[f"maha_{n}"] = larem.cpu().numpy(), m_dev.cpu().numpy()
+            out[f"knn_{n}"], out[f"knn_host_{n}"] = k_shard.cpu().numpy(), k_host
+            if rank == 0:  # the unsharded scores of the same rows
+                out[f"larem_full_{n}"] = pipe.score_latents(x, rand).cpu().numpy()
+                out[f"maha_full_{n}"] = state["maha"].postprocess_device(feats).cpu().numpy()
+                out[f"knn_full_{n}"] = state["knn"].postprocess_device(feats).cpu().numpy()
+        np.savez(os.path.join(out_dir, f"g{rank}.npz"), **out)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_real_kernels_equal_unsharded_bits(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = np.load(tmp_path / "g0.npz"), np.load(tmp_path / "g1.npz")
+    for n in SIZES:
+        for name, dt in (("larem", np.float64), ("maha", np.float64), ("knn", np.float32)):
+            full = g0[f"{name}_full_{n}"]
+            assert full.shape == (n,) and full.dtype == dt and np.isfinite(full).all()
+            for g in (g0, g1):
+                got = g[f"{name}_{n}"]
+                assert got.dtype == dt and np.array_equal(got, full), (name, n)
+        for g in (g0, g1):
+            assert g[f"knn_host_{n}"].dtype == np.float32 and np.array_equal(g[f"knn_host_{n}"], g0[f"knn_full_{n}"])

@@ -1,0 +1,311 @@
+#!/usr/bin/env python3
+"""Workloads of bench.py beyond the headline cfg2 step (imported by bench.py; nothing here runs on import).
+
+* cfg3 (BASELINE.json configs[2], SURVEY 8d "cfg3-synth"): synthetic F f32[1 000 000, 2048], 10 classes, logits
+  1 M x 1000 and 1 M x 10, kNN bank 50 000 x 2048, scored by ``Mahalanobis`` (reference inference/funcs.py:69-102),
+  ``Energy`` (inference/postprocessors.py:549) and ``KNN(k=50)`` (:873-880) through ``postprocess_device``; the rows
+  are cut with ``shard_bounds``, every rank builds ONLY its own block on its GPU, and each postprocessor ends in one
+  all_gather of the score shards (``gather_scores``).  The synthetic rows are generated in fixed blocks of 15 625 rows
+  keyed by the block index, so the 1 M rows are the same for every world size.
+* cfg4 LaRED leg (configs[3]): 100 000 proposals x 16 MC x 1024-d -> per-dimension entropy -> PCA-256 -> KDE.
+
+The oracle is imported only for the bounded parity / CPU-baseline slices, after the timed regions.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+D_FEAT, N_CLASSES, BANK_ROWS, K_NN, N_LOGITS = 2048, 10, 50_000, 50, 1000
+GEN_BLOCK = 15_625                       # 1 000 000 / 64: the shard boundaries of 1, 2, 4, 8, 16, 32, 64 ranks fall on blocks
+HBM_PEAK_GBS, F32_MFMA_TF, F64_MFMA_TF = 8000.0, 157.3, 78.6  # MI355X_MICROARCH.md; f64 matrix rate: AMD datasheet
+
+
+def _gen(device, seed):
+    return torch.Generator(device=device).manual_seed(seed)
+
+
+def class_centres(device):
+    return torch.randn(N_CLASSES, D_FEAT, device=device, generator=_gen(device, 2024)) * 0.5  # N(0, 0.25 I)
+
+
+def linear_head(device):
+    g = _gen(device, 2025)
+    w = torch.randn(N_LOGITS, D_FEAT, device=device, generator=g) * (D_FEAT ** -0.5)
+    b = torch.randn(N_LOGITS, device=device, generator=g) * 0.1
+    return w.contiguous(), b.contiguous()
+
+
+def feature_block(j: int, split: int, device, centres):
+    """Block j (GEN_BLOCK rows) of split 0 (test) / 1 (train): F = ReLU(mu_label + N(0, I)), labels uniform."""
+    g = _gen(device, 2024 + 7919 * (j + 1) + 1_000_003 * split)
+    lab = torch.randint(0, N_CLASSES, (GEN_BLOCK,), device=device, generator=g)
+    f = torch.relu(centres[lab] + torch.randn(GEN_BLOCK, D_FEAT, device=device, generator=g))
+    return f, lab
+
+
+def feature_rows(a: int, b: int, split: int, device, centres):
+    """Rows [a, b) of the split, identical whatever the sharding."""
+    f = torch.empty((b - a, D_FEAT), dtype=torch.float32, device=device)
+    lab = torch.empty((b - a,), dtype=torch.int64, device=device)
+    j = a // GEN_BLOCK
+    while j * GEN_BLOCK < b:
+        fb, lb = feature_block(j, split, device, centres)
+        lo, hi = max(a, j * GEN_BLOCK), min(b, (j + 1) * GEN_BLOCK)
+        f[lo - a: hi - a] = fb[lo - j * GEN_BLOCK: hi - j * GEN_BLOCK]
+        lab[lo - a: hi - a] = lb[lo - j * GEN_BLOCK: hi - j * GEN_BLOCK]
+        j += 1
+    return f, lab
+
+
+def logits_of(f, w, b):
+    from runia_core_amd import _hip
+
+    out = torch.empty((f.shape[0], w.shape[0]), dtype=torch.float32, device=f.device)
+    for a in range(0, f.shape[0], 131072):  # the head of the synthetic model: setup, untimed
+        out[a: a + 131072] = _hip.linear(f[a: a + 131072], w, b)
+    return out
+
+
+def _rel(a, b):
+    a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
+    return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
+
+
+def fit_cfg3(device, fit_rows: int, centres, w, b):
+    """setup() of the three postprocessors exactly as a user of the reference would call it (host arrays in)."""
+    from runia_core_amd.inference.postprocessors import KNN, Energy, Mahalanobis
+
+    t0 = time.perf_counter()
+    f_tr, lab_tr = feature_rows(0, BANK_ROWS, 1, device, centres)
+    f_val, _ = feature_rows(BANK_ROWS, BANK_ROWS + 2 * GEN_BLOCK, 1, device, centres)
+    f_val = f_val[:2048]
+    tr_host, lab_host, val_host = f_tr.cpu().numpy(), lab_tr.cpu().numpy(), f_val.cpu().numpy()
+    maha = Mahalanobis(flip_sign=False, num_classes=N_CLASSES)
+    maha.setup(tr_host[:fit_rows], train_labels=lab_host[:fit_rows], valid_feats=val_host)
+    knn = KNN(flip_sign=False, k_neighbors=K_NN)
+    knn.setup(tr_host, valid_feats=val_host)
+    energy = Energy(flip_sign=False)
+    energy.setup(logits_of(f_tr[:8192], w, b).cpu().numpy())
+    return {"mahalanobis": maha, "knn": knn, "energy": energy, "fit_s": time.perf_counter() - t0}
+
+
+def run_cfg3(device, rank: int, world: int, dist, rows_total: int, fit_rows: int, steps: int, warmup: int,
+             cpu_legs: bool = True, log=None) -> dict:
+    """One step = the rank's block of the 1 M rows through Mahalanobis, Energy (C = 1000 and C = 10) and kNN, each ending
+    in its all_gather.  Returns the timing record (rank 0: plus parity and the CPU legs)."""
+    from runia_core_amd.distributed import broadcast_fitted, gather_scores, shard_bounds
+
+    say = log or (lambda *_: None)
+    use_dist = dist is not None
+    centres = class_centres(device)
+    w, b = linear_head(device)
+    fitted = fit_cfg3(device, fit_rows, centres, w, b) if rank == 0 else None
+    t_b = time.perf_counter()
+    if use_dist:
+        fitted = broadcast_fitted(fitted, src=0)
+    bcast_s = time.perf_counter() - t_b
+    maha, knn, energy = fitted["mahalanobis"], fitted["knn"], fitted["energy"]
+    say(f"cfg3: fitted in {fitted['fit_s']:.1f} s on rank 0, state broadcast in {bcast_s:.2f} s")
+
+    a, bnd = shard_bounds(rows_total, world, rank)
+    feats, _ = feature_rows(a, bnd, 0, device, centres)
+    logits = logits_of(feats, w, b)
+    logits10 = logits[:, :N_CLASSES].contiguous()
+    n_loc = bnd - a
+    per = -(-rows_total // world)
+    bufs = {name: torch.empty(world * per, dtype=dt, device=device)
+            for name, dt in (("mahalanobis", torch.float64), ("energy_c1000", torch.float32),
+                             ("energy_c10", torch.float32), ("knn", torch.float32))} if use_dist else {}
+    legs = (("mahalanobis", maha, feats), ("energy_c1000", energy, logits), ("energy_c10", energy, logits10),
+            ("knn", knn, feats))
+    events = {name: [] for name, _, _ in legs}
+    gather_events = []
+
+    def one_pass(timed: bool):
+        out = {}
+        for name, pp, x in legs:
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            e0.record()
+            s = pp.postprocess_device(x)
+            e1.record()
+            if use_dist:
+                s = gather_scores(s.reshape(-1), rows_total, out=bufs[name])
+                e2 = torch.cuda.Event(enable_timing=True)
+                e2.record()
+                if timed:
+                    gather_events.append((e1, e2))
+            if timed:
+                events[name].append((e0, e1))
+            out[name] = s
+        return out
+
+    for _ in range(max(1, warmup)):
+        scores = one_pass(False)
+    if use_dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        scores = one_pass(True)
+    torch.cuda.synchronize()
+    if use_dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if use_dist:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    ms = {name: float(np.mean([x.elapsed_time(y) for x, y in ev])) for name, ev in events.items()}
+    gather_ms = float(np.mean([x.elapsed_time(y) for x, y in gather_events])) if gather_events else 0.0
+    rec = {"elapsed": elapsed, "rows_total": rows_total, "rows_local": n_loc, "steps": steps,
+           "ms_per_step": 1e3 * elapsed / steps, "value": rows_total * steps / elapsed, "stage_ms": ms,
+           "gather_ms_per_call": gather_ms, "fit_s": fitted["fit_s"], "broadcast_s": bcast_s, "fit_rows": fit_rows}
+    if rank != 0:
+        return rec
+
+    work = {  # algorithmic work per row
+        "mahalanobis": ("mfma_f64", 2.0 * D_FEAT * D_FEAT + 2.0 * D_FEAT * N_CLASSES + 3.0 * D_FEAT, F64_MFMA_TF, "TFLOP/s"),
+        "energy_c1000": ("hbm", 4.0 * N_LOGITS + 4, HBM_PEAK_GBS, "GB/s"),
+        "energy_c10": ("hbm", 4.0 * N_CLASSES + 4, HBM_PEAK_GBS, "GB/s"),
+        "knn": ("mfma_f32", 2.0 * BANK_ROWS * D_FEAT, F32_MFMA_TF, "TFLOP/s"),
+    }
+    stages = {}
+    for name, (bound, per_row, peak, unit) in work.items():
+        rate = n_loc / (ms[name] * 1e-3)
+        ach = per_row * rate / (1e9 if bound == "hbm" else 1e12)
+        stages[name] = {"rows": n_loc, "ms": round(ms[name], 4), "rows_per_s": round(rate, 1), "bound": bound,
+                        "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4)}
+    stages["knn"]["shape"] = f"{n_loc} queries x bank {BANK_ROWS}x{D_FEAT} f32, k={K_NN} (normaliser + distances + select)"
+    stages["mahalanobis"]["shape"] = f"{n_loc}x{D_FEAT} f32, {N_CLASSES} classes, f64 quadratic forms"
+    stages["energy_c1000"]["shape"] = f"{n_loc}x{N_LOGITS} f32"
+    stages["energy_c10"]["shape"] = f"{n_loc}x{N_CLASSES} f32"
+    rec["stages"] = stages
+    if not cpu_legs:
+        return rec
+
+    import oracle  # checker / CPU baseline only (after the timed region)
+
+    host = {name: scores[name][: min(n_loc, 4096)].cpu().numpy() for name in scores}
+    cm, prec = np.asarray(maha.class_mean), np.asarray(maha.precision)
+    m_m, m_k, m_e = min(n_loc, 96), min(n_loc, 16), min(n_loc, 4096)
+    fs = feats[:m_m].cpu().numpy()
+    t0 = time.perf_counter()
+    ref_m = oracle.mahalanobis_score_reference_form(fs, cm, prec, N_CLASSES)
+    t_m = (time.perf_counter() - t0) / max(1, m_m)
+    stages["mahalanobis"]["max_rel_err"] = _rel(host["mahalanobis"][:m_m], oracle.mahalanobis_score(fs, cm, prec, N_CLASSES))
+    stages["mahalanobis"]["max_rel_err_reference_form"] = _rel(host["mahalanobis"][:m_m], ref_m)
+    stages["mahalanobis"]["cpu_rows_per_s"] = round(1.0 / t_m, 2)
+    stages["mahalanobis"]["cpu_form"] = f"reference double loop over rows and classes, {m_m} rows, 1 core"
+    bank_host = knn.index._host
+    qs = feats[:m_k].cpu().numpy()
+    t0 = time.perf_counter()
+    ref_k = oracle.knn_kth_score(bank_host, qs, K_NN, chunk=1)
+    t_k = (time.perf_counter() - t0) / max(1, m_k)
+    stages["knn"]["max_rel_err"] = _rel(host["knn"][:m_k], ref_k)
+    stages["knn"]["cpu_rows_per_s"] = round(1.0 / t_k, 2)
+    stages["knn"]["cpu_form"] = f"one query at a time, exact f32 differences against the bank, {m_k} queries, 1 core"
+    t_e = {}
+    for name, x in (("energy_c1000", logits), ("energy_c10", logits10)):
+        xs = x[:m_e].cpu().numpy()
+        t0 = time.perf_counter()
+        ref_e = oracle.energy_score(xs)
+        t_e[name] = (time.perf_counter() - t0) / max(1, m_e)
+        stages[name]["max_rel_err"] = _rel(host[name][:m_e], ref_e)
+        stages[name]["cpu_rows_per_s"] = round(1.0 / t_e[name], 1)
+        stages[name]["cpu_form"] = f"scipy logsumexp, {m_e} rows, 1 core"
+    per_row = t_m + t_k + sum(t_e.values())
+    rec["cpu_baseline"] = {
+        "value": round(1.0 / per_row, 3), "unit": "rows/s", "cores": 1, "kind": "port",
+        "sample": f"oracle in the reference's algorithmic form on slices of the same rows: Mahalanobis {m_m} rows "
+                  f"({t_m * 1e3:.1f} ms/row), kNN {m_k} queries ({t_k * 1e3:.1f} ms/query), Energy {m_e} rows twice; "
+                  f"value = 1 / (sum of the per-row times); host has {os.cpu_count()} cores",
+    }
+    rec["parity"] = {name: stages[name]["max_rel_err"] for name in stages}
+    return rec
+
+
+def run_cfg4_lared(device, n_props: int = 100_000, n_train: int = 4000, n_mc: int = 16, d: int = 1024, n_pca: int = 256,
+                   reps: int = 3) -> dict:
+    """BASELINE configs[3], LaRED leg: per-proposal MC samples (n_props*16, 1024) f32 resident in HBM -> per-dimension
+    entropy -> PCA-256 (whitened) -> KDELatentSpace fitted on 4 000 in-distribution proposals."""
+    import runia_core_amd as rc
+    from runia_core_amd import _hip
+    from runia_core_amd.dimensionality_reduction import device_pca_for
+    from runia_core_amd.inference.postprocessors import KDELatentSpace
+
+    g = _gen(device, 44)
+    rel_spread = 0.10 * (0.5 + torch.rand(1, 1, d, device=device, generator=_gen(device, 7)))
+
+    def proposals(n):
+        out = torch.empty((n * n_mc, d), dtype=torch.float32, device=device)
+        for a in range(0, n, 20_000):
+            m = min(20_000, n - a)
+            base = torch.randn(m, 1, d, device=device, generator=g) + 2
+            out[a * n_mc: (a + m) * n_mc] = (base * (1 + rel_spread * torch.randn(m, n_mc, d, device=device, generator=g))).reshape(m * n_mc, d)
+        return out
+
+    h_tr = _hip.to_host(_hip.kl_entropy_per_dim(proposals(n_train), n_mc, 5))
+    np.random.seed(4)
+    red, pca = rc.apply_pca_ds_split(h_tr, n_pca)
+    kde = KDELatentSpace()
+    kde.setup(red)
+    dp = device_pca_for(pca)
+    z = proposals(n_props)
+
+    def chain(ev=None):
+        marks = [torch.cuda.Event(enable_timing=True) for _ in range(4)]
+        marks[0].record()
+        h = _hip.kl_entropy_per_dim(z, n_mc, 5)
+        marks[1].record()
+        y = dp.transform_device(h)
+        marks[2].record()
+        s = kde.postprocess_device(y)
+        marks[3].record()
+        if ev is not None:
+            ev.append(marks)
+        return s
+
+    chain()
+    torch.cuda.synchronize()
+    ev = []
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        s = chain(ev)
+    torch.cuda.synchronize()
+    wall = (time.perf_counter() - t0) / reps
+    ms = [float(np.mean([m[i].elapsed_time(m[i + 1]) for m in ev])) for i in range(3)]
+    ent_gbs = (n_mc * d * 4 + d * 8) * n_props / (ms[0] * 1e-3) / 1e9
+    pca_tf = 2.0 * d * n_pca * n_props / (ms[1] * 1e-3) / 1e12
+    kde_tf = 2.0 * n_train * n_pca * n_props / (ms[2] * 1e-3) / 1e12
+    rec = {"shape": f"{n_props} proposals x {n_mc} MC x {d} f32 -> entropy -> PCA-{n_pca} -> KDE on {n_train} train rows",
+           "rows": n_props, "ms": round(1e3 * wall, 4), "rows_per_s": round(n_props / wall, 1),
+           "entropy": {"ms": round(ms[0], 4), "bound": "hbm", "achieved": round(ent_gbs, 1), "peak": HBM_PEAK_GBS,
+                       "unit": "GB/s", "frac": round(ent_gbs / HBM_PEAK_GBS, 4)},
+           "pca": {"ms": round(ms[1], 4), "bound": "mfma_f64", "achieved": round(pca_tf, 2), "peak": F64_MFMA_TF,
+                   "unit": "TFLOP/s", "frac": round(pca_tf / F64_MFMA_TF, 4)},
+           "kde": {"ms": round(ms[2], 4), "bound": "mfma_f64", "achieved": round(kde_tf, 2), "peak": F64_MFMA_TF,
+                   "unit": "TFLOP/s", "frac": round(kde_tf / F64_MFMA_TF, 4)}}
+    import oracle  # checker / CPU baseline only
+
+    m = 24
+    zs = z[: m * n_mc].cpu().numpy()
+    t0 = time.perf_counter()
+    _, h_o = oracle.get_dl_h_z(zs, n_mc)  # reference form: one k-d tree per (proposal, dim)
+    y_o = oracle.pca_transform(h_o, pca.components_, pca.mean_, pca.explained_variance_)
+    s_o = oracle.kde_score(red, y_o)
+    t_cpu = (time.perf_counter() - t0) / m
+    rec["max_rel_err"] = _rel(s[:m].cpu().numpy(), s_o)
+    rec["cpu_rows_per_s"] = round(1.0 / t_cpu, 2)
+    rec["cpu_form"] = f"k-d tree per (proposal, dim) + numpy PCA + brute-force KDE, {m} proposals, 1 core"
+    del z
+    return rec
