@@ -28,13 +28,17 @@ class DevicePCA:
         components = np.asarray(components, dtype=np.float64)
         self.n_components, self.n_features = components.shape
         self.whiten = bool(whiten)
+        comp_dev = _hip.to_device(np.ascontiguousarray(components), torch.float64)
+        # mean_ @ components_.T through the library's own f64 product, not host BLAS: a host gemv adds in an order that
+        # follows the alignment of its operands, so two ranks holding the same fitted arrays could derive different last
+        # bits (seen on the GPU box: tests/test_distributed_gpu.py); the kernel's order is fixed
         if mean is None:
-            bias = np.zeros(self.n_components)
+            self.bias = torch.zeros(self.n_components, dtype=torch.float64, device=comp_dev.device)
         else:
-            bias = (np.asarray(mean, dtype=np.float64).reshape(1, -1) @ components.T).ravel()
-        self.components_host, self.bias_host, self.scale_host = components, bias, None
-        self.packed_ct = _hip.pack_weights(_hip.to_device(np.ascontiguousarray(components.T), torch.float64))
-        self.bias = _hip.to_device(bias, torch.float64)
+            mean_dev = _hip.to_device(np.asarray(mean, dtype=np.float64).reshape(1, -1), torch.float64)
+            self.bias = _hip.matmul_f64(mean_dev, comp_dev, transpose_b=True).reshape(-1).contiguous()
+        self.components_host, self.bias_host, self.scale_host = components, self.bias.cpu().numpy(), None
+        self.packed_ct = _hip.pack_weights(comp_dev.t().contiguous())
         self.scale = None
         if self.whiten:
             scale = np.sqrt(np.asarray(explained_variance, dtype=np.float64))

@@ -48,11 +48,11 @@ class MahalanobisState:
 
     def __init__(self, class_mean: np.ndarray, precision: np.ndarray):
         self.num_classes, self.dim = class_mean.shape
-        prec = np.asarray(precision, dtype=np.float64)
-        self.packed_p = _hip.pack_weights(_hip.to_device(prec, torch.float64))
-        with np.errstate(all="ignore"):
-            mu_p = np.asarray(class_mean, dtype=np.float64) @ prec
-        self.mu_p = _hip.to_device(mu_p, torch.float64)
+        prec = _hip.to_device(np.asarray(precision, dtype=np.float64), torch.float64)
+        self.packed_p = _hip.pack_weights(prec)
+        # class_mean @ P with the library's f64 product (fixed summation order: every rank of a sharded job derives the
+        # same bits, which a host BLAS call does not promise); an empty class's NaN mean stays a NaN row
+        self.mu_p = _hip.matmul_f64(_hip.to_device(np.asarray(class_mean, dtype=np.float64), torch.float64), prec)
         self._means = {}
         self._class_mean = class_mean
 

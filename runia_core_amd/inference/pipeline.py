@@ -105,27 +105,29 @@ class LaREMPipeline:
               None if self.pca is None else id(self.pca))
         if self._folded is None or self._folded_fp != fp:
             self._folded_fp = fp
-            prec = np.asarray(pp.precision, dtype=np.float64)
-            lam, vec = np.linalg.eigh((prec + prec.T) * 0.5)
-            top = float(np.abs(lam).max()) if lam.size else 0.0
-            if top == 0.0 or lam.min() < -1e-10 * top:
+            # Everything below runs on the device with the library's own kernels (Jacobi eigen-solver, f64 products) and
+            # elementwise torch ops: no host LAPACK / BLAS call, whose last bits follow operand alignment and thread
+            # count - every rank of a sharded job folds the same fitted arrays into the same weights.
+            prec = _hip.to_device(np.asarray(pp.precision, dtype=np.float64), torch.float64)
+            lam, vec = _hip.eigh(prec)                                            # ascending, eigenvectors as columns
+            top = float(lam.abs().max()) if lam.numel() else 0.0
+            if top == 0.0 or float(lam.min()) < -1e-10 * top:
                 self._folded = False
                 return None
             keep = lam > top * max(prec.shape) * np.finfo(np.float64).eps
-            w = np.sqrt(lam[keep])[:, None] * vec[:, keep].T                      # (r, n): precision = w.T @ w
-            mu = np.asarray(pp.feats_mean, dtype=np.float64).ravel()
+            w = (torch.sqrt(lam[keep])[:, None] * vec[:, keep].t()).contiguous()  # (r, n): precision = w.T @ w
+            mu = _hip.to_device(np.asarray(pp.feats_mean, dtype=np.float64).ravel(), torch.float64)
             if self.pca is not None:
-                comp = self.pca.components_host
-                scale = self.pca.scale_host if self.pca.scale_host is not None else np.ones(comp.shape[0])
-                a = comp / scale[:, None]                                        # (n, D)
-                b = -self.pca.bias_host / scale - mu
+                comp = _hip.to_device(self.pca.components_host, torch.float64)
+                scale = self.pca.scale if self.pca.scale is not None else torch.ones_like(self.pca.bias)
+                a = (comp / scale[:, None]).contiguous()                         # (n, D)
+                b = -self.pca.bias / scale - mu
+                m = _hip.matmul_f64(w, a)                                         # (r, D)
             else:
-                a = np.eye(prec.shape[0])
                 b = -mu
-            m = w @ a                                                             # (r, D)
-            c = w @ b
-            self._folded = (_hip.pack_weights(_hip.to_device(np.ascontiguousarray(m.T), torch.float64)),
-                            _hip.to_device(c, torch.float64), int(m.shape[0]))
+                m = w
+            c = _hip.matmul_f64(w, b.reshape(-1, 1).contiguous()).reshape(-1).contiguous()
+            self._folded = (_hip.pack_weights(m.t().contiguous()), c, int(m.shape[0]))
         return self._folded or None
 
     def score_entropies(self, h: Tensor) -> Tensor:
