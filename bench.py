@@ -74,6 +74,11 @@ def parse_args():
     ap.add_argument("--overlap", action="store_true",
                     help="two HIP streams: K1 of batch i+1 beside K2 of batch i (measured: no gain, 0.324 vs 0.329 ms)")
     ap.add_argument("--chunks", type=int, default=None, help="row blocks pipelined over two streams (default: pipeline's)")
+    ap.add_argument("--k0-ahead", action="store_true",
+                    help="build the keep-flag table (K0) of batch i+1 on a side stream while batch i is scored "
+                         "(LaREMPipeline.prepare_draws).  Measured SLOWER than the in-line launch (0.199-0.201 vs 0.179 "
+                         "ms/step: the cross-stream event waits cost more than the 9 us K0 they hide, and K1 slows from "
+                         "0.1245 to 0.136 ms with K0 beside it), so it is off by default; profiles/README.md")
     ap.add_argument("--clock-warmup", type=float, default=1.0,
                     help="seconds of the same step run untimed before the W warm-up steps: the GPU needs ~0.1 s of "
                          "sustained load to reach its working clocks (measured: 0.261 ms/step over the first 10 steps, "
@@ -324,15 +329,26 @@ def main():
         s.record_stream(side_stream)
         return out
 
+    k0_ahead = args.k0_ahead and not args.overlap and args.chunks is None
+    pending = {}  # step number -> keep-flag table prepared for it on the side stream
+
+    def draws_of(no):
+        """Draws of step number `no` (1-based, as counted by step_no after its increment)."""
+        return _hip.CounterDraws(4242 + rank, no * n) if counter else sets[(no - 1) % n_sets][1]
+
     def step(timed=False, index=0, collective=True):
         timed = timed and (index % max(1, args.event_every) == 0)
         j = step_no[0] % n_sets
         step_no[0] += 1
         xs, rs = sets[j]
         if counter:
-            rs = _hip.CounterDraws(4242 + rank, step_no[0] * n)  # fresh image ids every step
+            rs = draws_of(step_no[0])  # fresh image ids every step
         if not args.overlap:
-            s = pipe.score_latents(xs, rs, chunks=args.chunks, k1_events=k1_events if timed else None)
+            prep = pending.pop(step_no[0], None) if k0_ahead else None
+            s = pipe.score_latents(xs, rs, chunks=args.chunks, k1_events=k1_events if timed else None, prepared=prep)
+            if k0_ahead:  # the NEXT step's table: a side stream builds it under this step's kernels
+                pending.clear()
+                pending[step_no[0] + 1] = pipe.prepare_draws(draws_of(step_no[0] + 1), n, H, W, inputs_ready=inputs_ready)
             return gather(s) if (use_dist and collective) else s
         # streaming form: K1 of this batch overlaps K2 of the previous one (two HIP streams); the gather is
         # queued behind this batch's K2 on the same stream, nothing waits on the host until the final sync
@@ -383,6 +399,9 @@ def main():
             print(f"gather placement trial: same {trial[False] / 30 * 1e3:.4f} ms/step, side {trial[True] / 30 * 1e3:.4f} ms/step",
                   file=sys.stderr)
     step_no[0] = 0  # the timed region starts on set 0 and ends on set (K-1) % n_sets on every rank
+    pending.clear()
+    if k0_ahead:
+        pending[1] = pipe.prepare_draws(draws_of(1), n, H, W, inputs_ready=inputs_ready)  # untimed, like the inputs being resident: step 1's table
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
@@ -505,6 +524,8 @@ def main():
                    "input_sets_rotated": n_sets, "input_bytes_per_set": int(x.numel() * 4 + rand.numel() * 4),
                    "pipelining": "batch i+1 K1 overlaps batch i K2 (two HIP streams)" if args.overlap else "none (one stream)",
                    "clock_warmup_s": args.clock_warmup,
+                   "keep_flag_table": ("built for batch i+1 on a side stream while batch i is scored (prepare_draws)" if k0_ahead
+                                       else "built in line on the compute stream"),
                    "gather": ("none (1 GPU)" if not use_dist else
                               ("all_gather on a second stream" if gather_mode["side"] else "all_gather on the compute stream"))},
         "roofline": roofline,

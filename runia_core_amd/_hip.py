@@ -568,18 +568,70 @@ def mc_entropy_supported(h: int, w: int, n_mc: int, k: int) -> bool:
     return bool(load_library().runia_mc_entropy_supported(int(h), int(w), int(n_mc), int(k)))
 
 
+def mc_mask_table(rand: Union[torch.Tensor, CounterDraws, None], n: int, h: int, w: int, n_mc: int, drop_prob: float,
+                  block_size: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """K0 alone: the keep-flag table of a batch of ``n`` <= 65 535 images (``runia_mc_mask_table_f32`` / its counter
+    form) into ``out`` (uint8 workspace of ``runia_mc_entropy_workspace_bytes``) on the current stream.  Pass the result
+    as ``table=`` to :func:`mc_entropy`: a caller that knows the next batch's draws builds its table on a side stream
+    under the previous batch's kernels (``LaREMPipeline.prepare_draws``)."""
+    lib = load_library()
+    dev = require_gpu()
+    assert 0 < n <= 65535
+    ws_bytes = int(lib.runia_mc_entropy_workspace_bytes(n, h, w, n_mc))
+    if out is None:
+        out = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=dev)
+    assert out.is_cuda and out.dtype == torch.uint8 and out.numel() >= ws_bytes
+    if isinstance(rand, CounterDraws):
+        _check(lib.runia_mc_mask_table_counter_f32(int(rand.seed) & (2**64 - 1), int(rand.first_image), out.data_ptr(),
+                                                   ws_bytes, n, h, w, n_mc, float(drop_prob), int(block_size), _stream()),
+               "runia_mc_mask_table_counter_f32")
+        return out
+    stride = 0
+    if rand is not None:
+        assert rand.is_cuda and rand.dtype == torch.float32 and rand.is_contiguous()
+        if rand.dim() == 4:
+            assert rand.shape == (n, n_mc, h, w)
+            stride = n_mc * h * w
+        else:
+            assert rand.shape == (n_mc, h, w)
+    _check(lib.runia_mc_mask_table_f32(_ptr(rand), stride, out.data_ptr(), ws_bytes, n, h, w, n_mc,
+                                       float(drop_prob) if rand is not None else 0.0, int(block_size), _stream()),
+           "runia_mc_mask_table_f32")
+    return out
+
+
 def mc_entropy(x: torch.Tensor, rand: Union[torch.Tensor, CounterDraws, None], n_mc: int, drop_prob: float, block_size: int, k: int,
                min_dist: float = 1e-5, want_samples: bool = False, out: Optional[torch.Tensor] = None,
-               kernel_events: Optional[list] = None, zero_fill: Optional[torch.Tensor] = None):
+               kernel_events: Optional[list] = None, zero_fill: Optional[torch.Tensor] = None,
+               table: Optional[torch.Tensor] = None):
     """Fused sampler + entropy: x [N,C,H,W] f32 (+ draws) -> h [N, C] f64 (and optionally the MC samples).
     ``kernel_events``: if a list, (start, end) HIP event pairs around the sampler + entropy launch alone (the
     keep-flag table launch before it is left out) are appended - bench.py times the dominant kernel with it.
-    ``zero_fill``: optional [N] f64 tensor cleared by the launch (the accumulator of ``proj_sq_accumulate``)."""
+    ``zero_fill``: optional [N] f64 tensor cleared by the launch (the accumulator of ``proj_sq_accumulate``).
+    ``table``: the batch's keep-flag table built earlier by :func:`mc_mask_table` (``rand`` is then ignored)."""
     lib = load_library()
     require_gpu()
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
     x = x.contiguous()
     n, c, hh, ww = x.shape
+    if table is not None:
+        h = torch.empty((n, c), dtype=torch.float64, device=x.device) if out is None else out
+        assert h.is_cuda and h.dtype == torch.float64 and h.shape == (n, c) and h.is_contiguous()
+        z = torch.empty((n * n_mc, c), dtype=torch.float32, device=x.device) if want_samples else None
+        ws_bytes = int(lib.runia_mc_entropy_workspace_bytes(n, hh, ww, n_mc))
+        assert table.is_cuda and table.numel() >= ws_bytes and n <= 65535
+        if zero_fill is not None:
+            assert zero_fill.is_cuda and zero_fill.dtype == torch.float64 and zero_fill.shape == (n,) and zero_fill.is_contiguous()
+        if kernel_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+        _check(lib.runia_mc_entropy_from_table_f32(x.data_ptr(), table.data_ptr(), ws_bytes, h.data_ptr(), _ptr(z),
+                                                   _ptr(zero_fill), n, c, hh, ww, n_mc, int(k), float(min_dist), _stream()),
+               "runia_mc_entropy_from_table_f32")
+        if kernel_events is not None:
+            e1.record()
+            kernel_events.append((e0, e1))
+        return (h, z) if want_samples else h
     stride = 0
     counter = rand if isinstance(rand, CounterDraws) else None
     if counter is not None:

@@ -19,7 +19,14 @@ from .. import _hip
 from ..dimensionality_reduction import DevicePCA, device_pca_for
 from ..evaluation.entropy import MIN_DIST, neighbors_for
 
-__all__ = ["LaREMPipeline", "AsyncScores"]
+__all__ = ["LaREMPipeline", "AsyncScores", "PreparedDraws"]
+
+
+class PreparedDraws:
+    """Keep-flag table of one batch (K0's output), built ahead of its batch on the pipeline's side stream."""
+
+    def __init__(self, table: Tensor, ready: "torch.cuda.Event", slot: int, shape: tuple):
+        self.table, self.ready, self.slot, self.shape = table, ready, slot, shape
 
 
 class AsyncScores:
@@ -68,6 +75,43 @@ class LaREMPipeline:
         self.fold_weights = True
         self._folded = None
         self._folded_fp = None
+        self._k0 = None  # side stream + two table buffers of prepare_draws
+
+    # -- K0 ahead of its batch --------------------------------------------------------
+    def prepare_draws(self, rand, n: int, h: int, w: int,
+                      inputs_ready: Optional["torch.cuda.Event"] = None) -> Optional[PreparedDraws]:
+        """Build the keep-flag table of a COMING batch (its draws ``rand``: an ``(n, n_mc, h, w)`` tensor or
+        ``CounterDraws``) on a side stream, under whatever the main stream is running: K0 is one wave's latency chain
+        per image (~9 us per 10 000 images that leave the chip idle when it runs in line).  Hand the result to
+        ``score_latents(..., prepared=...)``.  Two table buffers alternate; a buffer is rewritten only after the sampler
+        + entropy launch that read it.  ``inputs_ready``: event after which ``rand`` is valid; default: everything queued
+        so far on the caller's stream (safe, but the table launch then starts only after the batch being scored - pass
+        the event to get the overlap).  Returns None when the map shape has no fused kernel or n > 65 535."""
+        if not (0 < n <= 65535 and _hip.mc_entropy_supported(h, w, self.n_mc, self.k)):
+            return None
+        if self._k0 is None:
+            self._k0 = {"stream": torch.cuda.Stream(), "tables": [None, None], "free": [None, None], "turn": 0}
+        k0 = self._k0
+        slot = k0["turn"]
+        k0["turn"] ^= 1
+        nbytes = max(16, int(_hip.load_library().runia_mc_entropy_workspace_bytes(n, h, w, self.n_mc)))
+        if k0["tables"][slot] is None or k0["tables"][slot].numel() < nbytes:
+            k0["tables"][slot] = torch.empty(nbytes, dtype=torch.uint8, device=_hip.require_gpu())
+        s = k0["stream"]
+        if inputs_ready is not None:
+            s.wait_event(inputs_ready)
+        elif not isinstance(rand, _hip.CounterDraws) and rand is not None:
+            s.wait_stream(torch.cuda.current_stream())        # the draws are valid once the caller's stream got here
+        if k0["free"][slot] is not None:
+            s.wait_event(k0["free"][slot])
+        with torch.cuda.stream(s):
+            _hip.mc_mask_table(rand if isinstance(rand, _hip.CounterDraws) else (None if rand is None else rand.contiguous()),
+                               n, h, w, self.n_mc, self.drop_prob if rand is not None else 0.0, self.block_size,
+                               out=k0["tables"][slot])
+            ready = s.record_event()
+        if isinstance(rand, Tensor):
+            rand.record_stream(s)
+        return PreparedDraws(k0["tables"][slot], ready, slot, (n, h, w))
 
     # -- stages ---------------------------------------------------------------------
     def stack(self, latents: Tensor, rand: Optional[Tensor]) -> Tensor:
@@ -78,10 +122,19 @@ class LaREMPipeline:
         return _hip.kl_entropy_per_dim(z, self.n_mc, self.k, MIN_DIST)
 
     def entropy_from_latents(self, latents: Tensor, rand: Optional[Tensor], kernel_events: Optional[list] = None,
-                             zero_fill: Optional[Tensor] = None) -> Tensor:
+                             zero_fill: Optional[Tensor] = None, prepared: Optional[PreparedDraws] = None) -> Tensor:
         """Sampler + per-dimension entropy without materialising the MC samples when the map shape is supported
-        (``runia_mc_entropy_f32``: keep-flag table launch + sampler/entropy launch), else the two unfused kernels."""
-        _, _, h, w = latents.shape
+        (``runia_mc_entropy_f32``: keep-flag table launch + sampler/entropy launch), else the two unfused kernels.
+        ``prepared``: the batch's table from :meth:`prepare_draws` (``rand`` is then not read)."""
+        n, _, h, w = latents.shape
+        if prepared is not None:
+            if prepared.shape != (n, h, w):
+                raise ValueError(f"prepared draws are for a batch of shape {prepared.shape}, got {(n, h, w)}")
+            torch.cuda.current_stream().wait_event(prepared.ready)
+            out = _hip.mc_entropy(latents, None, self.n_mc, self.drop_prob, self.block_size, self.k, MIN_DIST,
+                                  kernel_events=kernel_events, zero_fill=zero_fill, table=prepared.table)
+            self._k0["free"][prepared.slot] = torch.cuda.current_stream().record_event()
+            return out
         if _hip.mc_entropy_supported(h, w, self.n_mc, self.k):
             return _hip.mc_entropy(latents, rand, self.n_mc, self.drop_prob if rand is not None else 0.0,
                                    self.block_size, self.k, MIN_DIST, kernel_events=kernel_events, zero_fill=zero_fill)
@@ -168,7 +221,7 @@ class LaREMPipeline:
         return self.score_entropies(self.entropy(z))
 
     def score_latents(self, latents: Tensor, rand, chunks: Optional[int] = None,
-                      k1_events: Optional[list] = None) -> Tensor:
+                      k1_events: Optional[list] = None, prepared: Optional[PreparedDraws] = None) -> Tensor:
         """Hooked activations ``(N, C, H, W)`` + uniform draws ``(N, n_mc, H, W)`` -> scores ``(N,)``.
         ``rand`` may also be a ``_hip.CounterDraws(seed, first_image)``: the draws are then made inside the keep-flag
         kernel by the counter generator (throughput mode; nothing is read from memory for them).
@@ -177,21 +230,25 @@ class LaREMPipeline:
         entropy kernel (vector ALUs) of block i+1 runs beside the PCA + LaREM kernel (matrix cores) of block i.
         Rows are independent, so the result is identical to the single-launch form.  ``k1_events`` (optional list)
         receives one (start, end) event pair per sampler + entropy launch (the keep-flag table launch before it is
-        left out), recorded on the stream the kernel is launched on."""
+        left out), recorded on the stream the kernel is launched on.  ``prepared``: this batch's keep-flag table from
+        :meth:`prepare_draws` (built ahead on a side stream; same bits as the in-line table launch)."""
         n, _, hh, ww = latents.shape
         chunks = self.overlap_chunks if chunks is None else int(chunks)
         md = self._md_state()
         fused = _hip.mc_entropy_supported(hh, ww, self.n_mc, self.k) and md is not None
         counter = isinstance(rand, _hip.CounterDraws)
-        if not fused or chunks <= 1 or n < 2048 * chunks or (rand is not None and not counter and rand.dim() != 4):
+        if prepared is not None and not fused:
+            prepared = None
+        if prepared is not None or not fused or chunks <= 1 or n < 2048 * chunks or (rand is not None and not counter and rand.dim() != 4):
             folded = self._folded_state() if (fused and self.fold_weights) else None
             if folded is not None and (self.pca is None or latents.shape[1] == self.pca.n_features):
                 # K1 clears the score vector on its way, K2' adds the two column halves of each row into it: no
                 # workspace, no combine launch (bit-identical to the store form)
                 scores = torch.empty((n,), dtype=torch.float64, device=latents.device)
-                h = self.entropy_from_latents(latents, rand, k1_events, zero_fill=scores)
+                h = self.entropy_from_latents(latents, rand, k1_events, zero_fill=scores, prepared=prepared)
                 return _hip.proj_sq_accumulate(h, *folded, out=scores)
-            return self.score_entropies(self.entropy_from_latents(latents, rand, k1_events if fused else None))
+            return self.score_entropies(self.entropy_from_latents(latents, rand, k1_events if fused else None,
+                                                                  prepared=prepared))
         latents = latents.contiguous()
         if rand is not None and not counter:
             rand = rand.contiguous()

@@ -560,6 +560,46 @@ def test_folded_single_contraction_equals_two_stage():
     assert rel_err(s4, oracle.md_score(x8, md3.feats_mean, md3.precision)) < 1e-11
 
 
+def test_prepared_draws_equal_inline_table():
+    """`prepare_draws` (K0 of a coming batch on a side stream, two table buffers in turn) + `score_latents(prepared=)`
+    score the same bits as the in-line table launch - host draws and counter draws, several batches in flight."""
+    from runia_core_amd import _hip
+    from runia_core_amd.dimensionality_reduction import DevicePCA
+
+    rng = np.random.default_rng(21)
+    gp, gm = load_npz("ref_pca.npz"), load_npz("ref_md.npz")
+    md = MDLatentSpace()
+    md.feats_mean, md.precision, md._setup_flag = gm["d256_mean"], gm["d256_precision"], True
+    pipe = LaREMPipeline(md, DevicePCA(gp["d512_components"], gp["d512_mean"], gp["d512_var"], True), 16, 0.5, 2)
+    g = torch.Generator(device="cuda").manual_seed(5)
+    batches = []
+    for n in (3000, 3000, 1777, 3000, 1):
+        x = torch.relu(torch.randn(n, 512, 4, 4, device="cuda", generator=g)).contiguous()
+        r = torch.rand(n, 16, 4, 4, device="cuda", generator=g)
+        batches.append((x, r))
+    inline = [pipe.score_latents(x, r).cpu().numpy() for x, r in batches]
+    inline_c = [pipe.score_latents(x, _hip.CounterDraws(9, 100 * i)).cpu().numpy() for i, (x, _) in enumerate(batches)]
+    # tables prepared one batch ahead, as bench.py does
+    prep = pipe.prepare_draws(batches[0][1], batches[0][0].shape[0], 4, 4)
+    got = []
+    for i, (x, r) in enumerate(batches):
+        s = pipe.score_latents(x, r, prepared=prep)
+        if i + 1 < len(batches):
+            prep = pipe.prepare_draws(batches[i + 1][1], batches[i + 1][0].shape[0], 4, 4)
+        got.append(s)
+    for a, b in zip(inline, got):
+        assert np.array_equal(a, b.cpu().numpy(), equal_nan=True)
+    prep = pipe.prepare_draws(_hip.CounterDraws(9, 0), batches[0][0].shape[0], 4, 4)
+    for i, (x, _) in enumerate(batches):
+        s = pipe.score_latents(x, None, prepared=prep)
+        if i + 1 < len(batches):
+            prep = pipe.prepare_draws(_hip.CounterDraws(9, 100 * (i + 1)), batches[i + 1][0].shape[0], 4, 4)
+        assert np.array_equal(inline_c[i], s.cpu().numpy(), equal_nan=True)
+    with pytest.raises(ValueError):
+        pipe.score_latents(batches[2][0], batches[2][1], prepared=pipe.prepare_draws(batches[0][1], 3000, 4, 4))
+    assert pipe.prepare_draws(torch.rand(4, 16, 5, 6, device="cuda"), 4, 5, 6) is None  # no fused kernel for 5x6 maps
+
+
 # ---------------- LaRED above D ~ 20: reference-run fixtures + cfg4 leg --------------------------------------------
 @pytest.mark.parametrize("d", [16, 64, 256])
 def test_lared_high_dim_reference_run_fixture(d):
