@@ -294,6 +294,16 @@ int runia_ood_metrics_f64(const double* ind_scores, int64_t n_ind, const double*
                           double* out3, void* workspace, size_t workspace_bytes, runia_stream_t stream);
 int runia_ood_metrics_f32(const float* ind_scores, int64_t n_ind, const float* ood_scores, int64_t n_ood,
                           double* out3, void* workspace, size_t workspace_bytes, runia_stream_t stream);
+/* The same launch sequence, additionally leaving torchmetrics' _binary_clf_curve on the device (what get_auroc_results'
+ * roc / precision_recall_curve calls are built from, evaluation/metrics.py:70-81): tps / fps [n_ind + n_ood] u32 =
+ * cumulative true / false positives at the end of every run of equal scores, descending score order; *n_points (device,
+ * int64) = number of runs.  The caller copies n_points entries to the host and forms the float32 curves there. */
+int runia_ood_clf_curve_f64(const double* ind_scores, int64_t n_ind, const double* ood_scores, int64_t n_ood,
+                            double* out3, unsigned* tps, unsigned* fps, int64_t* n_points, void* workspace,
+                            size_t workspace_bytes, runia_stream_t stream);
+int runia_ood_clf_curve_f32(const float* ind_scores, int64_t n_ind, const float* ood_scores, int64_t n_ood,
+                            double* out3, unsigned* tps, unsigned* fps, int64_t* n_points, void* workspace,
+                            size_t workspace_bytes, runia_stream_t stream);
 
 /* ---- f4  remaining logits/features postprocessors (SURVEY 8f "next #4") ------- *
  * runia_linear_f32: out [N, C] = min(x, clip_max) @ w.T + bias on the f32 matrix cores - the final linear layer

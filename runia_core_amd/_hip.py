@@ -103,6 +103,10 @@ _SIGNATURES = {
     "runia_ood_metrics_workspace_bytes": (c_size_t, [c_int64]),
     "runia_ood_metrics_f64": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "runia_ood_metrics_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "runia_ood_clf_curve_f64": (
+        c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
+    "runia_ood_clf_curve_f32": (
+        c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_void_p]),
     "runia_eigh_workspace_bytes": (c_size_t, [c_int64]),
     "runia_eigh_init_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "runia_eigh_sweep_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
@@ -245,7 +249,10 @@ def to_host(t: torch.Tensor) -> np.ndarray:
     nbytes = t.numel() * t.element_size()
     if nbytes < _PINNED_MIN or nbytes > _PINNED_MAX:
         return t.cpu().numpy()
-    out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    try:
+        out = torch.empty(t.shape, dtype=t.dtype, pin_memory=True)
+    except RuntimeError:  # locked-memory limit reached, fragmentation: the pageable copy is slower, never wrong
+        return t.cpu().numpy()
     out.copy_(t, non_blocking=True)
     torch.cuda.current_stream().synchronize()
     return out.numpy()
@@ -838,6 +845,30 @@ def ood_metrics(ind_scores: torch.Tensor, ood_scores: torch.Tensor) -> torch.Ten
     _check(fn(a.data_ptr(), a.numel(), b.data_ptr(), b.numel(), out.data_ptr(), ws.data_ptr() + off, ws_bytes, _stream()),
            "runia_ood_metrics")
     return out
+
+
+def ood_clf_curve(ind_scores: torch.Tensor, ood_scores: torch.Tensor):
+    """Device scores (both f32 or both f64) -> ``(metrics [3] f64 device, tps [runs] int64 host, fps [runs] int64 host)``:
+    torchmetrics' ``_binary_clf_curve`` (cumulative true / false positives at the end of every run of equal scores,
+    descending) from the device sort + scans; only the compacted curve leaves the device (one synchronisation)."""
+    lib = load_library()
+    require_gpu()
+    assert ind_scores.is_cuda and ood_scores.is_cuda and ind_scores.dtype == ood_scores.dtype
+    assert ind_scores.dtype in (torch.float32, torch.float64)
+    a, b = ind_scores.reshape(-1).contiguous(), ood_scores.reshape(-1).contiguous()
+    n = a.numel() + b.numel()
+    ws_bytes = int(lib.runia_ood_metrics_workspace_bytes(n))
+    ws = torch.empty(ws_bytes + 256, dtype=torch.uint8, device=a.device)
+    off = (-ws.data_ptr()) % 256
+    out = torch.empty(3, dtype=torch.float64, device=a.device)
+    curve = torch.empty((2, n), dtype=torch.int32, device=a.device)  # u32 counts < 2^31 (n is limited to 2^31 - 1)
+    n_points = torch.zeros(1, dtype=torch.int64, device=a.device)
+    fn = lib.runia_ood_clf_curve_f64 if a.dtype == torch.float64 else lib.runia_ood_clf_curve_f32
+    _check(fn(a.data_ptr(), a.numel(), b.data_ptr(), b.numel(), out.data_ptr(), curve[0].data_ptr(), curve[1].data_ptr(),
+              n_points.data_ptr(), ws.data_ptr() + off, ws_bytes, _stream()), "runia_ood_clf_curve")
+    m = int(n_points.item())
+    host = to_host(curve[:, :m].contiguous()).astype(np.int64)
+    return out, host[0], host[1]
 
 
 def eigh(a: torch.Tensor, max_sweeps: int = 30):

@@ -3,6 +3,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <atomic>
+
 #include "../../include/runia_hip.h"
 
 #define RUNIA_WAVE 64
@@ -15,6 +17,19 @@ static inline int runia_check_launch() {
 }
 
 static inline hipStream_t as_stream(runia_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// Raise a kernel's dynamic-LDS limit once per DEVICE (the attribute belongs to the device that is current when it is set;
+// a process that moves on to another GPU needs it again).  `done` is one static mask per call site: bit = device id.
+// Two threads racing the first call both set the attribute, which is harmless.
+static inline int runia_allow_dynamic_lds(const void* kernel, int bytes, std::atomic<uint64_t>& done) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return RUNIA_E_LAUNCH;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return RUNIA_OK;
+  if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) != hipSuccess) return RUNIA_E_LAUNCH;
+  done.fetch_or(bit, std::memory_order_release);
+  return RUNIA_OK;
+}
 
 // Grid for thread-per-item streaming kernels: one trip per thread up to 2^20 workgroups (the kernels keep their
 // grid-stride loop for more).  A 4 096-workgroup cap used to sit here; a grid just above it left a second trip to a

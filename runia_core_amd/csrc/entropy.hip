@@ -496,13 +496,9 @@ extern "C" int runia_kl_entropy_joint_f32(const float* z, double* h_mvn, int64_t
     }
   }
   const size_t lds = ((size_t)n_mc * (kJointChunk + 2) + (size_t)n_mc * (n_mc + 1)) * sizeof(double);  // <= 99 KB
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(entropy_joint_kernel),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 100 * 1024) != hipSuccess)
-      return RUNIA_E_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};
+  if (runia_allow_dynamic_lds(reinterpret_cast<const void*>(entropy_joint_kernel), 100 * 1024, lds_ok) != RUNIA_OK)
+    return RUNIA_E_LAUNCH;
   const unsigned grid = (unsigned)(N < 65535 ? N : 65535);
   entropy_joint_kernel<<<grid, 256, lds, s>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n);
   return runia_check_launch();

@@ -761,13 +761,9 @@ int launch_pca_md(const PcaMdArgs& g, hipStream_t s) {
   const int64_t n_pad = n_padded(g.n);
   const size_t shmem = ((size_t)2 * BM * APITCH + (size_t)BM * (n_pad + 2) + 4 * BM) * sizeof(double);
   if (shmem > 160 * 1024) return RUNIA_E_INVALID;
-  static bool attr_set = false;
-  if (!attr_set) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(pca_md_kernel<RT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return RUNIA_E_LAUNCH;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};
+  if (runia_allow_dynamic_lds(reinterpret_cast<const void*>(pca_md_kernel<RT>), 160 * 1024, lds_ok) != RUNIA_OK)
+    return RUNIA_E_LAUNCH;
   const int64_t tiles = (g.N + BM - 1) / BM;
   pca_md_kernel<RT><<<(unsigned)tiles, 256, shmem, s>>>(g);
   return runia_check_launch();

@@ -368,13 +368,9 @@ template <int NT>
 int launch_mc_mfma(const float* x, const float* rnd, int64_t rand_image_stride, float* out, int64_t N, int C, int H, int W,
                    int n_mc, float gamma, int block_size, int identity, hipStream_t s) {
   const size_t lds = mc_mfma_lds_bytes(H * W, n_mc, NT);
-  static bool attr = false;
-  if (!attr) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(mc_stack_mfma_kernel<NT>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024) != hipSuccess)
-      return RUNIA_E_LAUNCH;
-    attr = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};
+  if (runia_allow_dynamic_lds(reinterpret_cast<const void*>(mc_stack_mfma_kernel<NT>), 160 * 1024, lds_ok) != RUNIA_OK)
+    return RUNIA_E_LAUNCH;
   dim3 grid((C + 63) / 64, (unsigned)N);
   mc_stack_mfma_kernel<NT><<<grid, 256, lds, s>>>(x, rnd, rand_image_stride, out, C, H, W, n_mc, gamma, block_size,
                                                    identity);

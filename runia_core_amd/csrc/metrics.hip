@@ -54,7 +54,9 @@ __global__ __launch_bounds__(256) void make_keys_kernel(const T* __restrict__ in
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
     T v = (i < n_ind) ? ind[i] : ood[i - n_ind];
     if (squash) v = (T)1 / ((T)1 + exp(-v));  // torch.sigmoid in the dtype of the scores
-    keys[i] = sortable_desc((double)v);
+    // + 0.0: -0.0 becomes +0.0, so that the two zeros share a key and form ONE curve point, as torchmetrics' run
+    // detection (preds[1:] - preds[:-1] != 0) has it
+    keys[i] = sortable_desc((double)v + 0.0);
     labels[i] = (i < n_ind) ? 1 : 0;
   }
 }
@@ -171,59 +173,66 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
 // tile pass 1: (label sum, index of the last run end) of every tile
 __global__ __launch_bounds__(256) void tile_summary_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
                                                            int64_t n, unsigned* __restrict__ tile_sum,
-                                                           int* __restrict__ tile_end) {
-  __shared__ unsigned ssum[4];
+                                                           int* __restrict__ tile_end, unsigned* __restrict__ tile_cnt) {
+  __shared__ unsigned ssum[4], scnt[4];
   __shared__ int send[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t t0 = (int64_t)blockIdx.x * kTile;
-  unsigned s = 0u;
+  unsigned s = 0u, cnt = 0u;
   int e = -1;
 #pragma unroll
   for (int c = 0; c < kItems; ++c) {
     const int64_t i = t0 + c * 256 + tid;
     if (i < n) {
       s += lab[i];
-      if (i == n - 1 || keys[i] != keys[i + 1]) e = (int)i;  // indices ascend with c
+      if (i == n - 1 || keys[i] != keys[i + 1]) { e = (int)i; ++cnt; }  // indices ascend with c
     }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
     s += __shfl_xor(s, o, 64);
+    cnt += __shfl_xor(cnt, o, 64);
     e = max(e, __shfl_xor(e, o, 64));
   }
-  if (lane == 0) { ssum[wave] = s; send[wave] = e; }
+  if (lane == 0) { ssum[wave] = s; send[wave] = e; scnt[wave] = cnt; }
   __syncthreads();
   if (tid == 0) {
     tile_sum[blockIdx.x] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
     tile_end[blockIdx.x] = max(max(send[0], send[1]), max(send[2], send[3]));
+    tile_cnt[blockIdx.x] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
   }
 }
 
 // exclusive scan of the tile summaries (sum: +, end: max) by one wave, 64 tiles per trip
-__global__ void tile_scan_kernel(unsigned* __restrict__ tile_sum, int* __restrict__ tile_end, int64_t ntiles) {
+__global__ void tile_scan_kernel(unsigned* __restrict__ tile_sum, int* __restrict__ tile_end,
+                                 unsigned* __restrict__ tile_cnt, int64_t ntiles) {
   if (blockIdx.x != 0 || threadIdx.x >= 64) return;
   const int lane = threadIdx.x;
-  unsigned cs = 0u;
+  unsigned cs = 0u, cc = 0u;
   int ce = -1;
   for (int64_t base = 0; base < ntiles; base += 64) {
     const int64_t i = base + lane;
     const unsigned ts = (i < ntiles) ? tile_sum[i] : 0u;
+    const unsigned tc = (i < ntiles) ? tile_cnt[i] : 0u;
     const int te = (i < ntiles) ? tile_end[i] : -1;
-    unsigned x = ts;
+    unsigned x = ts, k = tc;
     int m = te;
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
       const unsigned y = __shfl_up(x, o, 64);
+      const unsigned q = __shfl_up(k, o, 64);
       const int z = __shfl_up(m, o, 64);
-      if (lane >= o) { x += y; m = max(m, z); }
+      if (lane >= o) { x += y; k += q; m = max(m, z); }
     }
     int em = __shfl_up(m, 1, 64);  // exclusive maximum
     if (lane == 0) em = -1;
     if (i < ntiles) {
       tile_sum[i] = cs + x - ts;
+      tile_cnt[i] = cc + k - tc;
       tile_end[i] = max(ce, em);
     }
     cs += __shfl(x, 63, 64);
+    cc += __shfl(k, 63, 64);
     ce = max(ce, __shfl(m, 63, 64));
   }
 }
@@ -231,15 +240,19 @@ __global__ void tile_scan_kernel(unsigned* __restrict__ tile_sum, int* __restric
 // tile pass 2: tps[i] (inclusive) for every element; prev_end[i] for every run end
 __global__ __launch_bounds__(256) void tile_prefix_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
                                                           int64_t n, const unsigned* __restrict__ tile_sum,
-                                                          const int* __restrict__ tile_end, unsigned* __restrict__ tps,
-                                                          int* __restrict__ prev_end) {
-  __shared__ unsigned wsum[4];
+                                                          const int* __restrict__ tile_end,
+                                                          const unsigned* __restrict__ tile_cnt, unsigned* __restrict__ tps,
+                                                          int* __restrict__ prev_end, unsigned* __restrict__ tps_out,
+                                                          unsigned* __restrict__ fps_out, int64_t* __restrict__ n_points) {
+  // tps_out / fps_out (optional): torchmetrics' _binary_clf_curve - cumulative true / false positives at the end of every
+  // run of equal scores, in descending score order (entry r belongs to the run end of rank r)
+  __shared__ unsigned wsum[4], wcnt[4];
   __shared__ int wend[4];
-  __shared__ unsigned carry_sum;
+  __shared__ unsigned carry_sum, carry_cnt;
   __shared__ int carry_end;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t t0 = (int64_t)blockIdx.x * kTile;
-  if (tid == 0) { carry_sum = tile_sum[blockIdx.x]; carry_end = tile_end[blockIdx.x]; }
+  if (tid == 0) { carry_sum = tile_sum[blockIdx.x]; carry_end = tile_end[blockIdx.x]; carry_cnt = tile_cnt[blockIdx.x]; }
   __syncthreads();
   for (int c = 0; c < kItems; ++c) {
     const int64_t i = t0 + c * 256 + tid;
@@ -254,12 +267,14 @@ __global__ __launch_bounds__(256) void tile_prefix_kernel(const uint64_t* __rest
       const int q = __shfl_up(m, o, 64);
       if (lane >= o) { x += y; m = max(m, q); }
     }
-    if (lane == 63) { wsum[wave] = x; wend[wave] = m; }
+    const uint64_t ends = __ballot(is_end);
+    const unsigned ends_before = (unsigned)__popcll(ends & ((lane == 0) ? 0ull : (~0ull >> (64 - lane))));
+    if (lane == 63) { wsum[wave] = x; wend[wave] = m; wcnt[wave] = (unsigned)__popcll(ends); }
     __syncthreads();
-    unsigned woff = 0u;
+    unsigned woff = 0u, coff = 0u;
     int wmax = -1;
-    for (int w = 0; w < wave; ++w) { woff += wsum[w]; wmax = max(wmax, wend[w]); }
-    const unsigned cs = carry_sum;
+    for (int w = 0; w < wave; ++w) { woff += wsum[w]; coff += wcnt[w]; wmax = max(wmax, wend[w]); }
+    const unsigned cs = carry_sum, cc = carry_cnt;
     const int ce = carry_end;
     // exclusive maximum of the run-end indices before i
     int excl = __shfl_up(m, 1, 64);
@@ -267,11 +282,20 @@ __global__ __launch_bounds__(256) void tile_prefix_kernel(const uint64_t* __rest
     excl = max(max(excl, wmax), ce);
     if (valid) {
       tps[i] = cs + woff + x;
-      if (is_end) prev_end[i] = excl;
+      if (is_end) {
+        prev_end[i] = excl;
+        if (tps_out) {
+          const unsigned tp = cs + woff + x, rank = cc + coff + ends_before;
+          tps_out[rank] = tp;
+          fps_out[rank] = (unsigned)(i + 1) - tp;
+          if (i == n - 1) *n_points = (int64_t)rank + 1;
+        }
+      }
     }
     __syncthreads();
     if (tid == 255) {
       carry_sum = cs + woff + x;
+      carry_cnt = cc + coff + ends_before + (is_end ? 1u : 0u);
       carry_end = max(max(m, wmax), ce);
     }
     __syncthreads();
@@ -339,7 +363,7 @@ __global__ void finalize_kernel(const MetricsAccum* __restrict__ acc, const unsi
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, dtot, tile_sum, tile_end, accum, flag, total;
+  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, dtot, tile_sum, tile_end, tile_cnt, accum, flag, total;
   unsigned nblocks;
 };
 
@@ -357,6 +381,7 @@ Layout make_layout(int64_t n) {
   L.dtot = o; o += align256(256 * 4);
   L.tile_sum = o; o += align256((size_t)L.nblocks * 4);
   L.tile_end = o; o += align256((size_t)L.nblocks * 4);
+  L.tile_cnt = o; o += align256((size_t)L.nblocks * 4);
   L.accum = o; o += align256(sizeof(MetricsAccum));
   L.flag = o; o += 256;
   L.total = o;
@@ -364,10 +389,11 @@ Layout make_layout(int64_t n) {
 }
 
 template <typename T>
-int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double* out3, void* workspace,
-                size_t workspace_bytes, runia_stream_t stream) {
+int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double* out3, unsigned* tps_out, unsigned* fps_out,
+                int64_t* n_points, void* workspace, size_t workspace_bytes, runia_stream_t stream) {
   if (n_ind < 1 || n_ood < 1 || n_ind + n_ood >= (1ll << 31)) return RUNIA_E_INVALID;
   if (!ind || !ood || !out3) return RUNIA_E_INVALID;
+  if ((tps_out || fps_out || n_points) && !(tps_out && fps_out && n_points)) return RUNIA_E_INVALID;
   const int64_t n = n_ind + n_ood;
   const Layout L = make_layout(n);
   if (!workspace || workspace_bytes < L.total || (((uintptr_t)workspace) & 255) != 0) return RUNIA_E_WORKSPACE;
@@ -380,6 +406,7 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
   unsigned* dtot = reinterpret_cast<unsigned*>(w + L.dtot);
   unsigned* tile_sum = reinterpret_cast<unsigned*>(w + L.tile_sum);
   int* tile_end = reinterpret_cast<int*>(w + L.tile_end);
+  unsigned* tile_cnt = reinterpret_cast<unsigned*>(w + L.tile_cnt);
   MetricsAccum* acc = reinterpret_cast<MetricsAccum*>(w + L.accum);
   unsigned* flag = reinterpret_cast<unsigned*>(w + L.flag);
   hipStream_t s = as_stream(stream);
@@ -401,9 +428,10 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
                                                    L.nblocks, dtot);
     cur ^= 1;
   }
-  tile_summary_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], labs[cur], n, tile_sum, tile_end);
-  tile_scan_kernel<<<1, 64, 0, s>>>(tile_sum, tile_end, L.nblocks);
-  tile_prefix_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], labs[cur], n, tile_sum, tile_end, tps, prev_end);
+  tile_summary_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], labs[cur], n, tile_sum, tile_end, tile_cnt);
+  tile_scan_kernel<<<1, 64, 0, s>>>(tile_sum, tile_end, tile_cnt, L.nblocks);
+  tile_prefix_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], labs[cur], n, tile_sum, tile_end, tile_cnt, tps, prev_end, tps_out,
+                                               fps_out, n_points);
   // bounded grid: every workgroup ends with three atomics on ONE record
   curve_terms_kernel<<<(sgrid < 512u ? sgrid : 512u), 256, 0, s>>>(keys[cur], n, tps, prev_end, acc);
   finalize_kernel<<<1, 64, 0, s>>>(acc, tps, n, out3);
@@ -419,10 +447,30 @@ extern "C" size_t runia_ood_metrics_workspace_bytes(int64_t n_total) {
 
 extern "C" int runia_ood_metrics_f64(const double* ind_scores, int64_t n_ind, const double* ood_scores, int64_t n_ood,
                                      double* out3, void* workspace, size_t workspace_bytes, runia_stream_t stream) {
-  return ood_metrics<double>(ind_scores, n_ind, ood_scores, n_ood, out3, workspace, workspace_bytes, stream);
+  return ood_metrics<double>(ind_scores, n_ind, ood_scores, n_ood, out3, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                             stream);
 }
 
 extern "C" int runia_ood_metrics_f32(const float* ind_scores, int64_t n_ind, const float* ood_scores, int64_t n_ood,
                                      double* out3, void* workspace, size_t workspace_bytes, runia_stream_t stream) {
-  return ood_metrics<float>(ind_scores, n_ind, ood_scores, n_ood, out3, workspace, workspace_bytes, stream);
+  return ood_metrics<float>(ind_scores, n_ind, ood_scores, n_ood, out3, nullptr, nullptr, nullptr, workspace, workspace_bytes,
+                            stream);
+}
+
+// The same three scalars plus torchmetrics' _binary_clf_curve, from which get_auroc_results builds its ROC / PR curves
+// (reference evaluation/metrics.py:70-81): tps / fps [n_ind + n_ood] u32 device buffers = cumulative true / false positives
+// at the end of every run of equal scores in descending score order, *n_points (device) = number of runs.  Only that many
+// entries need to leave the device; the O(N log N) part (sort, scans, compaction) stays on it.
+extern "C" int runia_ood_clf_curve_f64(const double* ind_scores, int64_t n_ind, const double* ood_scores, int64_t n_ood,
+                                       double* out3, unsigned* tps, unsigned* fps, int64_t* n_points, void* workspace,
+                                       size_t workspace_bytes, runia_stream_t stream) {
+  if (!tps || !fps || !n_points) return RUNIA_E_INVALID;
+  return ood_metrics<double>(ind_scores, n_ind, ood_scores, n_ood, out3, tps, fps, n_points, workspace, workspace_bytes, stream);
+}
+
+extern "C" int runia_ood_clf_curve_f32(const float* ind_scores, int64_t n_ind, const float* ood_scores, int64_t n_ood,
+                                       double* out3, unsigned* tps, unsigned* fps, int64_t* n_points, void* workspace,
+                                       size_t workspace_bytes, runia_stream_t stream) {
+  if (!tps || !fps || !n_points) return RUNIA_E_INVALID;
+  return ood_metrics<float>(ind_scores, n_ind, ood_scores, n_ood, out3, tps, fps, n_points, workspace, workspace_bytes, stream);
 }

@@ -96,7 +96,9 @@ __device__ __forceinline__ void store_chunk(const float (&v)[16], float (*dst)[K
 #pragma unroll
   for (int j = 0; j < 8; ++j) {
     // the clip (ReAct) costs two vector instructions per element: only the instantiation that clips pays for it
-    const float a = CLIP ? fminf(v[2 * j], clip_max) : v[2 * j], b = CLIP ? fminf(v[2 * j + 1], clip_max) : v[2 * j + 1];
+    // np.clip keeps a NaN activation (fminf would return the other operand and hide it)
+    const float a = (CLIP && v[2 * j] > clip_max) ? clip_max : v[2 * j];
+    const float b = (CLIP && v[2 * j + 1] > clip_max) ? clip_max : v[2 * j + 1];
     *reinterpret_cast<float2*>(&dst[row][half * 16 + 2 * j]) = make_float2(a, b);
   }
 }
@@ -682,7 +684,9 @@ __global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restr
       const int i4 = lane + 64 * st;
       if (i4 < n4) {
         float4 v = xr[i4];
-        v.x = fminf(v.x, clip_max); v.y = fminf(v.y, clip_max); v.z = fminf(v.z, clip_max); v.w = fminf(v.w, clip_max);
+        // x > clip ? clip : x keeps a NaN activation, as np.clip and the matmul that follows do upstream
+        v.x = v.x > clip_max ? clip_max : v.x; v.y = v.y > clip_max ? clip_max : v.y;
+        v.z = v.z > clip_max ? clip_max : v.z; v.w = v.w > clip_max ? clip_max : v.w;
 #pragma unroll
         for (int c = 0; c < CT; ++c) {
           if (c < C) {
@@ -769,13 +773,10 @@ extern "C" int runia_linear_f32(const float* x, const float* w, const float* bia
     const unsigned grid = (unsigned)((N + per_wg - 1) / per_wg);
 #define RUNIA_SKINNY(CT)                                                                                          \
   {                                                                                                               \
-    static bool attr = false;                                                                                     \
-    if (!attr) {                                                                                                  \
-      if (hipFuncSetAttribute(reinterpret_cast<const void*>(linear_skinny_kernel<CT>),                            \
-                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024) != hipSuccess)               \
-        return RUNIA_E_LAUNCH;                                                                                    \
-      attr = true;                                                                                                \
-    }                                                                                                             \
+    static std::atomic<uint64_t> lds_ok{0};                                                                       \
+    if (runia_allow_dynamic_lds(reinterpret_cast<const void*>(linear_skinny_kernel<CT>), 96 * 1024, lds_ok) !=    \
+        RUNIA_OK)                                                                                                 \
+      return RUNIA_E_LAUNCH;                                                                                      \
     linear_skinny_kernel<CT><<<grid, 256, lds, s>>>(x, w, bias, out, N, (int)D, (int)C, clip_max);               \
   }
     if (C <= 4) RUNIA_SKINNY(4)

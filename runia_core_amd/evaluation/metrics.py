@@ -3,9 +3,12 @@
 
 ``auroc_fpr95_aupr_device`` keeps the whole step on the GPU (``runia_ood_metrics_*``: radix sort of the scores, scan of
 the labels and run ends, trapezoid sums - ``csrc/metrics.hip``).  ``get_auroc_results`` / ``auroc_fpr95_aupr`` are the
-harness-facing forms: they also return the ROC curve as lists for the results table, which is host data by nature, and
-build it with NumPy (binary AUROC, ROC -> FPR@95, precision-recall -> AUPR; torchmetrics' sigmoid of scores outside
-[0, 1] and its float32 curves reproduced).
+harness-facing forms: they also return the ROC curve as lists for the results table, which is host data by nature.  The
+O(N log N) part - torchmetrics' ``_binary_clf_curve``: sigmoid of scores outside [0, 1], descending sort, cumulative
+true / false positives at the end of every run of equal scores - runs on the GPU (``runia_ood_clf_curve_*``); only the
+compacted curve comes back, and the float32 ROC / precision-recall points and their trapezoid sums are formed from it
+exactly as torchmetrics / sklearn form them (same dtype, same ``torch.trapz`` call).  No CPU fallback: without a GPU the
+functions raise, like every other scoring entry point.
 """
 from __future__ import annotations
 
@@ -39,27 +42,30 @@ def auroc_fpr95_aupr_device(ind_scores, ood_scores, to_host: bool = True):
     return float(r[0]), float(r[1]), float(r[2])
 
 
-def _clf_curve(preds: np.ndarray, target: np.ndarray):
-    order = np.argsort(-preds, kind="stable")
-    preds, target = preds[order], target[order]
-    distinct = np.nonzero(preds[1:] - preds[:-1])[0]
-    idx = np.concatenate([distinct, [target.size - 1]])
-    tps = np.cumsum(target)[idx]
-    fps = 1 + idx - tps
+def _clf_curve_device(ind_scores, ood_scores):
+    """torchmetrics' ``_binary_clf_curve`` on the GPU -> host ``(fps, tps)`` int64 arrays, one entry per run of equal
+    scores in descending order.  Float32 score sets keep torchmetrics' float32 sigmoid, anything else its float64 one."""
+    from .. import _hip
+
+    def dev(a, dt):
+        if isinstance(a, torch.Tensor):
+            return (a if a.is_cuda else a.to(_hip.require_gpu())).reshape(-1).to(dt)
+        return _hip.to_device(np.ravel(np.asarray(a)), dt)
+
+    def is_f32(a):
+        if isinstance(a, torch.Tensor):
+            return a.dtype == torch.float32
+        return np.asarray(a).dtype == np.float32
+
+    dt = torch.float32 if (is_f32(ind_scores) and is_f32(ood_scores)) else torch.float64
+    _, tps, fps = _hip.ood_clf_curve(dev(ind_scores, dt), dev(ood_scores, dt))
     return fps, tps
 
 
-def auroc_fpr95_aupr(ind_scores: np.ndarray, ood_scores: np.ndarray):
-    """InD = positive class.  Returns ``(auroc, fpr@95, aupr, fpr_curve, tpr_curve)``."""
-    # float32 score sets stay float32 through torchmetrics' sigmoid (np.vstack keeps the dtype), anything else is float64
-    dt = np.float32 if (np.asarray(ind_scores).dtype == np.float32 and np.asarray(ood_scores).dtype == np.float32) else np.float64
-    scores = np.concatenate([np.ravel(ind_scores), np.ravel(ood_scores)]).astype(dt)
-    labels = np.concatenate([np.ones(np.size(ind_scores), dtype=np.int64), np.zeros(np.size(ood_scores), dtype=np.int64)])
-    if not np.all((scores >= 0) & (scores <= 1)):
-        with np.errstate(over="ignore"):
-            scores = (dt(1.0) / (dt(1.0) + np.exp(-scores))).astype(dt)
-    scores = scores.astype(np.float64)
-    fps, tps = _clf_curve(scores, labels)
+def auroc_fpr95_aupr(ind_scores, ood_scores):
+    """InD = positive class.  Returns ``(auroc, fpr@95, aupr, fpr_curve, tpr_curve)``; scores may be host arrays or
+    device tensors."""
+    fps, tps = _clf_curve_device(ind_scores, ood_scores)
     tps_r = np.concatenate([[0], tps]).astype(np.float32)
     fps_r = np.concatenate([[0], fps]).astype(np.float32)
     fpr = fps_r / fps_r[-1]

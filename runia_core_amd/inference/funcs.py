@@ -99,10 +99,12 @@ def gmm_fit(embeddings: torch.Tensor, labels: torch.Tensor, num_classes: int):
     ``max(n_c, 2) - 1``, classes without samples left out, and the smallest jitter of ``0, 1e-20, ..., 1e-1`` whose
     ``cov + jitter * I`` has a float32 Cholesky factor.
 
-    Setup-time host fit in float32 torch like the reference, restructured: the class statistics come from one one-hot
-    contraction over all classes at once, and the jitter ladder is walked with ``torch.linalg.cholesky_ex`` (status codes
-    instead of exceptions); the factor found is handed to ``MultivariateNormal(scale_tril=...)`` - the same factor the
-    reference's ``covariance_matrix=`` construction computes internally.
+    Setup-time host fit in float32 torch like the reference, restructured: the class means come from one one-hot
+    contraction over all classes at once, the class covariances from one ``x_c^T x_c`` per class over the rows grouped by
+    label (memory O(N D + C D^2), N D^2 multiply-adds in all - a single ``einsum`` over (rows, classes) would go through an
+    (N, C, D) intermediate: 10 GB at CIFAR-100 size), and the jitter ladder is walked with ``torch.linalg.cholesky_ex``
+    (status codes instead of exceptions); the factor found is handed to ``MultivariateNormal(scale_tril=...)`` - the same
+    factor the reference's ``covariance_matrix=`` construction computes internally.
 
     Returns ``(MultivariateNormal, jitter)``."""
     with torch.no_grad():
@@ -113,9 +115,16 @@ def gmm_fit(embeddings: torch.Tensor, labels: torch.Tensor, num_classes: int):
         counts = member.sum(dim=0)                                                           # (C,)
         present = counts > 0
         means = (member.t() @ x) / counts.clamp_min(1.0).unsqueeze(1)                        # (C, D)
-        centred = x - means[lab.clamp(0, num_classes - 1)]                                   # every row minus its class mean
-        denom = (counts.clamp_min(2.0) - 1.0).reshape(-1, 1, 1)
-        covs = torch.einsum("nc,ni,nj->cij", member, centred, centred) / denom               # (C, D, D)
+        valid = (lab >= 0) & (lab < num_classes)
+        order = torch.argsort(torch.where(valid, lab, torch.full_like(lab, num_classes)), stable=True)  # rows grouped by class
+        starts = torch.cumsum(counts, 0).to(torch.long) - counts.to(torch.long)
+        d = x.shape[1]
+        covs = torch.zeros((num_classes, d, d), dtype=x.dtype)
+        for c in range(num_classes):
+            n_c = int(counts[c])
+            if n_c:
+                rows = x[order[int(starts[c]): int(starts[c]) + n_c]] - means[c]             # the class's rows, centred
+                covs[c] = (rows.t() @ rows) / (max(n_c, 2) - 1)
         means, covs = means[present], covs[present]
         eye = torch.eye(covs.shape[-1], dtype=covs.dtype, device=covs.device)
         chosen, factor = _GMM_JITTERS[-1], None

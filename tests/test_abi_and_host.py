@@ -110,6 +110,8 @@ def test_product_path_fails_loudly_without_gpu():
         rc.get_dl_h_z(np.zeros((6, 4), dtype=np.float32), 3)
     with pytest.raises(_hip.RuniaHipError):
         Energy(flip_sign=False).setup(np.zeros((4, 3), dtype=np.float32))
+    with pytest.raises(_hip.RuniaHipError):  # the metrics step sorts on the device: no host argsort behind the drop-in name
+        rc.evaluation.get_auroc_results("test", np.array([0.9, 0.8]), np.array([0.1, 0.2]))
 
 
 def test_no_product_module_imports_the_oracle():
@@ -256,19 +258,6 @@ def test_sampler_module_contract():
     torch.manual_seed(0)
     ref = torch.cat([torch.rand(1, 4, 4) for _ in range(10)]).reshape(2, 5, 4, 4)
     assert torch.equal(d, ref)  # upstream call sequence: one torch.rand(1,H,W) per drop layer
-
-
-def test_metrics_host_goldens(ref_vectors):
-    np.random.seed(1)
-    ind = 0.5 + np.random.randn(1000)
-    ood = -0.5 + np.random.randn(1000)
-    r = rc.evaluation.get_auroc_results("test", ind, ood, False)
-    fpr95, aupr, auroc = [s["value"] for s in ref_vectors["metrics_hz"]["scalars"]]
-    assert abs(r["auroc"].values[0] - auroc) < 1e-7
-    assert abs(r["fpr@95"].values[0] - fpr95) < 1e-7
-    assert abs(r["aupr"].values[0] - aupr) < 1e-7
-    _, ml = rc.evaluation.get_auroc_results("test", ind, ood, True)
-    assert set(ml) == {"auroc", "aupr", "fpr_95"}
 
 
 def test_draw_is_the_sequential_cpu_stream():

@@ -729,6 +729,64 @@ def test_device_metrics_vs_oracle(case):
     assert out.is_cuda and tuple(out.cpu().numpy()) == pytest.approx(got, abs=1e-12)
 
 
+def test_get_auroc_results_drop_in_on_the_device(ref_vectors):
+    """The harness entry point of the reference (evaluation/metrics.py:37-100) on the device sort: the reference's own
+    metric goldens at its own tolerance (/root/reference/tests/unit_test_metrics.py:21-29, TOL = 1e-7), the table layout,
+    the mlflow dict, and the returned ROC curve against the oracle's restatement of torchmetrics' binary roc."""
+    np.random.seed(1)
+    ind = 0.5 + np.random.randn(1000)
+    ood = -0.5 + np.random.randn(1000)
+    r = rc.evaluation.get_auroc_results("test", ind, ood, False)
+    fpr95, aupr, auroc = _scal(ref_vectors, "metrics_hz")
+    assert list(r.columns) == ["auroc", "fpr@95", "aupr", "fpr", "tpr"] and list(r.index) == ["test"]
+    assert abs(r["auroc"].values[0] - auroc) < 1e-7
+    assert abs(r["fpr@95"].values[0] - fpr95) < 1e-7
+    assert abs(r["aupr"].values[0] - aupr) < 1e-7
+    _, ml = rc.evaluation.get_auroc_results("test", ind, ood, True)
+    assert set(ml) == {"auroc", "aupr", "fpr_95"}
+    # the curve in the table = torchmetrics' roc (leading (0, 0), float32 ratios), from the device's runs
+    from runia_core_amd.evaluation.metrics import auroc_fpr95_aupr
+
+    rng = np.random.default_rng(3)
+    cases = {
+        "f64": (ind, ood),
+        "f32": ((rng.standard_normal(5000) - 2).astype(np.float32), (rng.standard_normal(3000) - 3).astype(np.float32)),
+        "ties": (rng.integers(0, 12, 9000) / 11.0, rng.integers(0, 9, 7000) / 11.0),
+        # -0.0 and +0.0 are ONE run for torchmetrics (preds[1:] - preds[:-1] != 0), on either side of the classes
+        "signed_zero": (np.array([0.0, -0.0, 0.5, 0.25, -0.0]), np.array([-0.0, 0.0, 0.25, 0.0])),
+        "saturated": (-200 - 300 * rng.random(4000), -400 - 900 * rng.random(4000)),
+    }
+    for name, (a, b) in cases.items():
+        got = auroc_fpr95_aupr(a, b)
+        exp = oracle.auroc_fpr95_aupr(a, b)
+        assert got[:3] == pytest.approx(exp, abs=1e-12), (name, got[:3], exp)
+        dt = np.float32 if (a.dtype == np.float32 and b.dtype == np.float32) else np.float64
+        sc = np.concatenate([a, b]).astype(dt)
+        if not np.all((sc >= 0) & (sc <= 1)):
+            with np.errstate(over="ignore"):
+                sc = (dt(1) / (dt(1) + np.exp(-sc))).astype(dt)
+        fps, tps, _ = oracle.binary_clf_curve(sc.astype(np.float64), np.r_[np.ones(a.size, np.int64), np.zeros(b.size, np.int64)])
+        fpr = np.concatenate([[0], fps]).astype(np.float32) / np.float32(fps[-1])
+        tpr = np.concatenate([[0], tps]).astype(np.float32) / np.float32(tps[-1])
+        assert got[3].dtype == np.float32 and got[4].dtype == np.float32
+        if name == "f32":
+            # the float32 sigmoid differs by an ulp between expf on the device and on the host: a pair of scores may tie
+            # on one side only (a point more or less on the curve); the curves are the same function
+            assert abs(len(got[3]) - len(fpr)) <= 2
+            grid = np.linspace(0, 1, 2001)
+            assert np.abs(np.interp(grid, got[3], got[4]) - np.interp(grid, fpr, tpr)).max() < 1e-3
+        else:
+            assert np.array_equal(got[3], fpr) and np.array_equal(got[4], tpr), name
+        # device-resident scores take the same path without an upload
+        got_dev = auroc_fpr95_aupr(torch.from_numpy(np.ascontiguousarray(a)).cuda(), torch.from_numpy(np.ascontiguousarray(b)).cuda())
+        assert got_dev[:3] == got[:3] and np.array_equal(got_dev[3], got[3])
+    # the device-only scalars agree on the signed-zero case too (one tie group, not two)
+    from runia_core_amd.evaluation.metrics import auroc_fpr95_aupr_device
+
+    a, b = cases["signed_zero"]
+    assert auroc_fpr95_aupr_device(a, b) == pytest.approx(oracle.auroc_fpr95_aupr(a, b), abs=3e-7)
+
+
 # ---------------- f1 / f4: Jacobi eigen-solver, pinvh, PCA fit, eigen_score ----------------------------------------------
 @pytest.mark.parametrize("n", [1, 2, 3, 10, 33, 64, 257])
 def test_jacobi_eigh_vs_numpy(n):
