@@ -215,13 +215,17 @@ int runia_mc_entropy_f32(const float* x, const float* rand, int64_t rand_image_s
  * runia_mc_entropy_f32 / runia_mc_stack_f32 gives the same bits as the counter entry points. */
 int runia_mc_draws_f32(float* out, int64_t N, int n_mc, int H, int W, uint64_t seed, int64_t first_image,
                        runia_stream_t stream);
+/* redraw_dead_layers != 0 (opt-in, ABI 3): a drop layer whose block mask removes the WHOLE map - 0 * numel / 0 = NaN in
+ * the reference as well (dropblock==0.3.0 does not guard it) - draws again from the same image's next counter block
+ * (fourth Philox counter word = attempt 1, 2, ... up to 16), so that a batched caller gets no NaN score.  Not the
+ * reference's semantics (it has no redraw); counter mode is not the reference's random stream to begin with. */
 int runia_mc_mask_table_counter_f32(uint64_t seed, int64_t first_image, void* workspace, size_t workspace_bytes,
                                     int64_t N, int H, int W, int n_mc, double drop_prob, int block_size,
-                                    runia_stream_t stream);
+                                    int redraw_dead_layers, runia_stream_t stream);
 int runia_mc_entropy_counter_f32(const float* x, uint64_t seed, int64_t first_image, double* h, float* z_out,
                                  double* zero_fill, void* workspace, size_t workspace_bytes, int64_t N, int C, int H,
                                  int W, int n_mc, double drop_prob, int block_size, int k, double min_dist,
-                                 runia_stream_t stream);
+                                 int redraw_dead_layers, runia_stream_t stream);
 int runia_pca_md_score_f64(const double* h, const double* packed_ct, const double* bias,
                            const double* scale, const double* md_mean, const double* packed_p,
                            double* score, double* y_out, int64_t N, int64_t D, int64_t n,

@@ -31,6 +31,7 @@ __all__ = [
     "rois_mc_entropy",
     "philox4x32_10",
     "counter_draws",
+    "counter_draws_redrawn",
     "pca_transform",
     "empirical_precision",
     "md_setup",
@@ -260,10 +261,11 @@ def philox4x32_10(counter: np.ndarray, key) -> np.ndarray:
     return np.stack([c0, c1, c2, c3], axis=-1).astype(np.uint32)
 
 
-def counter_draws(n: int, n_mc: int, h: int, w: int, seed: int, first_image: int = 0) -> np.ndarray:
+def counter_draws(n: int, n_mc: int, h: int, w: int, seed: int, first_image: int = 0, attempt: int = 0) -> np.ndarray:
     """The draws of ``runia_mc_draws_f32`` / the counter entry points (csrc/philox.hpp): draw i = layer*H*W + position of
-    image g is component ``(i // 64) & 3`` of ``philox((g.lo, g.hi, i % 64 + 64 * (i // 256), 0), seed)``,
-    ``u = (bits >> 8) * 2**-24``.  Returns ``(n, n_mc, h, w)`` float32."""
+    image g is component ``(i // 64) & 3`` of ``philox((g.lo, g.hi, i % 64 + 64 * (i // 256), attempt), seed)``,
+    ``u = (bits >> 8) * 2**-24``; ``attempt`` = 0 for the draws proper, 1, 2, ... for the redraws of
+    ``redraw_dead_layers``.  Returns ``(n, n_mc, h, w)`` float32."""
     per = n_mc * h * w
     i = np.arange(per, dtype=np.uint64)
     g = (np.arange(n, dtype=np.uint64) + np.uint64(first_image))[:, None]
@@ -271,12 +273,28 @@ def counter_draws(n: int, n_mc: int, h: int, w: int, seed: int, first_image: int
     ctr[..., 0] = g & np.uint64(0xFFFFFFFF)
     ctr[..., 1] = g >> np.uint64(32)
     ctr[..., 2] = (i % np.uint64(64) + np.uint64(64) * (i // np.uint64(256)))[None, :]
-    ctr[..., 3] = 0
+    ctr[..., 3] = int(attempt)
     seed = int(seed) & (2**64 - 1)
     blocks = philox4x32_10(ctr, (seed & 0xFFFFFFFF, seed >> 32))
     comp = ((i // np.uint64(64)) & np.uint64(3)).astype(np.int64)
     bits = np.take_along_axis(blocks, np.broadcast_to(comp[None, :, None], (n, per, 1)), axis=2)[..., 0]
     return ((bits >> np.uint32(8)).astype(np.float32) * np.float32(2.0**-24)).reshape(n, n_mc, h, w)
+
+
+def counter_draws_redrawn(n: int, n_mc: int, h: int, w: int, seed: int, first_image: int, drop_prob: float,
+                          block_size: int, max_attempts: int = 16) -> np.ndarray:
+    """Checker of the build's ``CounterDraws(redraw_dead_layers=True)`` (no reference counterpart): the explicit draws
+    that are equivalent to it - every drop layer whose block mask removes the whole map takes the draws of the next
+    attempt (fourth counter word 1, 2, ...) until its mask keeps something or ``max_attempts`` is reached."""
+    rand = counter_draws(n, n_mc, h, w, seed, first_image)
+    for attempt in range(1, max_attempts + 1):
+        bm = dropblock_block_mask(rand.reshape(n * n_mc, h, w), drop_prob, block_size).reshape(n, n_mc, h * w)
+        dead = bm.sum(axis=2) == 0
+        if not dead.any():
+            break
+        again = counter_draws(n, n_mc, h, w, seed, first_image, attempt)
+        rand[dead] = again[dead]
+    return rand
 
 
 def mc_stack(x: np.ndarray, rand: np.ndarray, drop_prob: float, block_size: int, layer_type: str = "Conv") -> np.ndarray:

@@ -93,12 +93,12 @@ _SIGNATURES = {
     "runia_mc_draws_f32": (c_int, [c_void_p, c_int64, c_int, c_int, c_int, c_uint64, c_int64, c_void_p]),
     "runia_mc_mask_table_counter_f32": (
         c_int,
-        [c_uint64, c_int64, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_double, c_int, c_void_p],
+        [c_uint64, c_int64, c_void_p, c_size_t, c_int64, c_int, c_int, c_int, c_double, c_int, c_int, c_void_p],
     ),
     "runia_mc_entropy_counter_f32": (
         c_int,
         [c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int,
-         c_int, c_double, c_int, c_int, c_double, c_void_p],
+         c_int, c_double, c_int, c_int, c_double, c_int, c_void_p],
     ),
     "runia_ood_metrics_workspace_bytes": (c_size_t, [c_int64]),
     "runia_ood_metrics_f64": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -145,10 +145,12 @@ class RuniaHipError(RuntimeError):
 
 class CounterDraws(NamedTuple):
     """DropBlock draws made inside the keep-flag kernel by the counter generator (Philox4x32-10, csrc/philox.hpp):
-    image i of the batch uses image id ``first_image + i`` of the stream keyed by ``seed``."""
+    image i of the batch uses image id ``first_image + i`` of the stream keyed by ``seed``.  ``redraw_dead_layers``:
+    a drop layer that removes the whole map (NaN upstream as well) draws again from the image's next counter block."""
 
     seed: int
     first_image: int = 0
+    redraw_dead_layers: bool = False
 
 
 def library_path() -> str:
@@ -270,7 +272,7 @@ def mc_stack(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob
     n, c, h, w = x.shape
     stride = 0
     if isinstance(rand, CounterDraws):
-        rand = mc_draws(n, n_mc, h, w, rand.seed, rand.first_image)
+        rand = _explicit_counter_draws(rand, n, n_mc, h, w)
     if rand is not None:
         assert rand.is_cuda and rand.dtype == torch.float32
         rand = rand.contiguous()
@@ -309,6 +311,16 @@ def mc_stack(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob
     return out
 
 
+def _explicit_counter_draws(ticket: CounterDraws, n: int, n_mc: int, h: int, w: int) -> torch.Tensor:
+    """Counter draws written out for the kernels that read draws from memory.  The redraw of fully dropped maps lives in
+    the keep-flag kernel (fused table path: 2x2 / 4x4 / 7x7 / 8x8 maps): it cannot be honoured here, so it is refused
+    rather than silently ignored."""
+    if ticket.redraw_dead_layers:
+        raise RuniaHipError("CounterDraws(redraw_dead_layers=True) is implemented by the keep-flag kernel of the fused "
+                            "sampler + entropy path (maps of 2x2, 4x4, 7x7, 8x8); this call takes the explicit-draw kernels")
+    return mc_draws(n, n_mc, h, w, ticket.seed, ticket.first_image)
+
+
 def mc_draws(n: int, n_mc: int, h: int, w: int, seed: int, first_image: int = 0) -> torch.Tensor:
     """The counter generator's draws written out: [n, n_mc, h, w] f32 in [0, 1) (same values the counter entry points
     use inside the keep-flag kernel)."""
@@ -329,7 +341,7 @@ def mc_drop_flat(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_
     n, c, h, w = x.shape
     stride = 0
     if isinstance(rand, CounterDraws):
-        rand = mc_draws(n, n_mc, h, w, rand.seed, rand.first_image)
+        rand = _explicit_counter_draws(rand, n, n_mc, h, w)
     if rand is not None:
         assert rand.is_cuda and rand.dtype == torch.float32
         rand = rand.contiguous()
@@ -590,7 +602,8 @@ def mc_mask_table(rand: Union[torch.Tensor, CounterDraws, None], n: int, h: int,
     assert out.is_cuda and out.dtype == torch.uint8 and out.numel() >= ws_bytes
     if isinstance(rand, CounterDraws):
         _check(lib.runia_mc_mask_table_counter_f32(int(rand.seed) & (2**64 - 1), int(rand.first_image), out.data_ptr(),
-                                                   ws_bytes, n, h, w, n_mc, float(drop_prob), int(block_size), _stream()),
+                                                   ws_bytes, n, h, w, n_mc, float(drop_prob), int(block_size),
+                                                   int(bool(rand.redraw_dead_layers)), _stream()),
                "runia_mc_mask_table_counter_f32")
         return out
     stride = 0
@@ -672,7 +685,8 @@ def mc_entropy(x: torch.Tensor, rand: Union[torch.Tensor, CounterDraws, None], n
                 lib.runia_mc_entropy_counter_f32(x.data_ptr() + done * c * hh * ww * 4, int(counter.seed) & (2**64 - 1),
                                                  int(counter.first_image) + done, h.data_ptr() + done * c * 8, zp, zf,
                                                  ws.data_ptr(), ws_bytes, m, c, hh, ww, n_mc, float(drop_prob),
-                                                 int(block_size), int(k), float(min_dist), _stream()),
+                                                 int(block_size), int(k), float(min_dist),
+                                                 int(bool(counter.redraw_dead_layers)), _stream()),
                 "runia_mc_entropy_counter_f32",
             )
         elif kernel_events is None:
@@ -687,7 +701,7 @@ def mc_entropy(x: torch.Tensor, rand: Union[torch.Tensor, CounterDraws, None], n
                 _check(
                     lib.runia_mc_mask_table_counter_f32(int(counter.seed) & (2**64 - 1), int(counter.first_image) + done,
                                                         ws.data_ptr(), ws_bytes, m, hh, ww, n_mc, float(drop_prob),
-                                                        int(block_size), _stream()),
+                                                        int(block_size), int(bool(counter.redraw_dead_layers)), _stream()),
                     "runia_mc_mask_table_counter_f32",
                 )
             else:

@@ -56,11 +56,7 @@ __device__ __forceinline__ float div_newton(float u, float den, float r) {
   return fmaf(e, r, q);
 }
 
-// ------------------------------------------------------------------------------------------
-// K0, LDS form (maps whose size does not divide 64): DropBlock draws -> per-image mask table.   grid = N, 256 threads
-//   table of one image = n_mc records of HW floats (0.0 / 1.0 keep flags, drop layers sorted by mask sum,
-//   positions in K1's operand order, see mask_slot) followed by n_mc mask sums and n_mc reciprocals.
-// ------------------------------------------------------------------------------------------
+// position p of the map -> slot of its keep flag in a table record (K1's operand order)
 template <int HT, int WT>
 __host__ __device__ constexpr int mask_slot(int p) {
   // even H: rows 2k and 2k+1 are interleaved so that one 64-bit scalar operand feeds a packed FMA
@@ -72,85 +68,7 @@ __host__ __device__ constexpr int mask_slot(int p) {
   }
 }
 
-template <int HT, int WT>
-__global__ __launch_bounds__(256) void mc_mask_kernel(const float* __restrict__ rnd, int64_t rand_stride,
-                                                       float* __restrict__ table, int n_mc, float gamma,
-                                                       int block_size, int identity, int sort_layers,
-                                                       uint64_t seed, int64_t first_image) {
-  constexpr int HW = HT * WT;
-  __shared__ float draws[kMaxMC * HW];
-  __shared__ unsigned keep_lo[kMaxMC], keep_hi[kMaxMC];
-  __shared__ unsigned long long keep_bits[kMaxMC], sbits[kMaxMC];
-  __shared__ float msum[kMaxMC], sflag[kMaxMC];
-  const int tid = threadIdx.x;
-  const int64_t img = blockIdx.x;
-  const int pad = block_size / 2;
-  float* out = table + img * (int64_t)(n_mc * (HW + 2));
-  if (tid < n_mc) { keep_lo[tid] = 0u; keep_hi[tid] = 0u; }
-  if (!identity) {
-    if (rnd) {
-      const float* r = rnd + img * rand_stride;
-      for (int i = tid; i < n_mc * HW; i += 256) draws[i] = r[i];
-    } else {  // counter mode: the draws are a function of (seed, image, index), philox.hpp
-      for (int i = tid; i < n_mc * HW; i += 256) draws[i] = runia_philox::draw(seed, (uint64_t)(first_image + img), i);
-    }
-  }
-  __syncthreads();
-  // one thread per (drop layer, position): max-pool window of the seed mask, keep bit ORed into the layer's mask
-  for (int i = tid; i < n_mc * HW; i += 256) {
-    const int s = i / HW, p = i - s * HW;
-    bool dropped = false;
-    if (!identity) {
-      const int y = p / WT, xw = p - y * WT;
-      for (int dy = 0; dy < block_size; ++dy) {
-        const int yy = y - pad + dy;
-        if (yy < 0 || yy >= HT) continue;
-        for (int dx = 0; dx < block_size; ++dx) {
-          const int xx = xw - pad + dx;
-          if (xx < 0 || xx >= WT) continue;
-          dropped = dropped || (draws[s * HW + yy * WT + xx] < gamma);
-        }
-      }
-    }
-    if (!dropped) {
-      if (p < 32) atomicOr(&keep_lo[s], 1u << p);
-      else atomicOr(&keep_hi[s], 1u << (p - 32));
-    }
-  }
-  __syncthreads();
-  if (tid < n_mc) {
-    const unsigned long long bits = ((unsigned long long)keep_hi[tid] << 32) | keep_lo[tid];
-    keep_bits[tid] = bits;
-    int m;
-    float fl, zh, zl;
-    layer_consts(__popcll(bits), m, fl, zh, zl);
-    msum[tid] = (float)(m ? m : 127);  // sort key: the odd part of the mask sum (fully dropped maps last)
-  }
-  __syncthreads();
-  if (tid < n_mc) {  // counting sort of the drop layers by the odd part of their mask sum (stable)
-    const float mine = msum[tid];
-    int rank = 0;
-    for (int j = 0; j < n_mc; ++j) {
-      const float o = msum[j];
-      rank += (o < mine) || (o == mine && j < tid);
-    }
-    if (!sort_layers) rank = tid;  // table in the order of the draws (runia_mc_stack_table_f32)
-    sbits[rank] = keep_bits[tid];
-    int m;
-    float fl, zh, zl;
-    layer_consts(__popcll(keep_bits[tid]), m, fl, zh, zl);
-    sflag[rank] = fl;
-    out[n_mc * HW + rank] = zh;
-    out[n_mc * (HW + 1) + rank] = zl;
-  }
-  __syncthreads();
-  for (int i = tid; i < n_mc * HW; i += 256) {
-    const int s = i / HW, p = i - s * HW;
-    out[s * HW + mask_slot<HT, WT>(p)] = ((sbits[s] >> p) & 1ull) ? sflag[s] : 0.f;
-  }
-}
-
-// K0 for maps of at most 64 positions whose size divides 64 (2x2, 4x4, 8x8): a drop layer is one 64-bit word and
+// K0 for maps of at most 64 positions (2x2, 4x4, 7x7, 8x8 ...): a drop layer is one 64-bit word and
 // the whole derivation is bit arithmetic in registers - no LDS, no barrier, one HBM round trip.
 //   seeds   : lane = (layer, position); `draw < gamma` -> ballot -> 64/HW layers per word
 //   dilation: lane = layer; separable OR of the seed word shifted over the block window (columns, then rows)
@@ -184,17 +102,25 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
                                                                            float* __restrict__ table, int64_t N,
                                                                            int n_mc, float gamma, int block_size,
                                                                            int identity, int sort_layers,
-                                                                           uint64_t rng_seed, int64_t first_image) {
+                                                                           uint64_t rng_seed, int64_t first_image,
+                                                                           int redraw) {
   constexpr int HW = HT * WT;
-  static_assert(64 % HW == 0 && NP <= 64, "one drop layer per 64-bit word");
-  constexpr int LPW = 64 / HW;                 // layers per ballot word
-  constexpr int WORDS = (NP + LPW - 1) / LPW;
+  static_assert(HW <= 64 && NP <= 64, "one drop layer per 64-bit word");
+  // draw i = layer * HW + position sits in bit i % 64 of ballot word i / 64.  Map sizes that divide 64 (2x2, 4x4, 8x8)
+  // keep whole layers inside a word; any other size (7x7: 49 bits) lets a layer straddle two words, and the lane that
+  // owns the layer stitches its bits together from them.
+  constexpr bool DIV = (64 % HW == 0);
+  constexpr int WORDS = (NP * HW + 63) / 64;
   constexpr unsigned long long FULL = (HW == 64) ? ~0ull : ((1ull << HW) - 1ull);
   const int lane = threadIdx.x & 63;
   const int64_t img = (int64_t)blockIdx.x * kMaskBitsWaves + (threadIdx.x >> 6);
   if (img >= N) return;  // wave-uniform
-  float d[WORDS];
-  if (!identity) {
+  const int bit0 = lane * HW, word0 = bit0 >> 6, off = bit0 & 63;  // where this lane's layer (lane = layer) starts
+  const int pad = block_size / 2;
+
+  // seed word of this lane's layer from attempt `attempt` of the draws (attempt > 0: counter mode only)
+  auto seeds_of = [&](unsigned attempt) -> unsigned long long {
+    float d[WORDS];
     if (rnd) {
       const float* r = rnd + img * rand_stride;
 #pragma unroll
@@ -205,7 +131,7 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
     } else {  // counter mode (philox.hpp): this lane's words 4q .. 4q+3 are the four components of one Philox block
 #pragma unroll
       for (int q = 0; q < (WORDS + 3) / 4; ++q) {
-        const runia_philox::u4 b = runia_philox::lane_block(rng_seed, (uint64_t)(first_image + img), lane, q);
+        const runia_philox::u4 b = runia_philox::lane_block(rng_seed, (uint64_t)(first_image + img), lane, q, attempt);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int t = 4 * q + j;
@@ -213,28 +139,44 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
         }
       }
     }
-  }
-  unsigned long long seed = 0ull;  // this lane's layer (lane = layer index)
+    unsigned long long lo = 0ull, hi = 0ull;
 #pragma unroll
-  for (int t = 0; t < WORDS; ++t) {
-    const unsigned long long w = identity ? 0ull : __ballot(d[t] < gamma);
-    if (lane / LPW == t) seed = (w >> ((lane % LPW) * HW)) & FULL;
+    for (int t = 0; t < WORDS; ++t) {
+      const unsigned long long w = __ballot(d[t] < gamma);
+      if (t == word0) lo = w;
+      if (!DIV && t == word0 + 1) hi = w;
+    }
+    unsigned long long sd = lo >> off;
+    if (!DIV && off + HW > 64) sd |= hi << (64 - off);
+    return sd & FULL;
+  };
+  auto keep_of = [&](unsigned long long seed) -> unsigned long long {
+    unsigned long long hx = 0ull;
+    for (int dx = 0; dx < block_size; ++dx) {  // dropped(y, x) |= seed(y, x + ox)
+      const int ox = dx - pad;
+      if (ox >= WT || -ox >= WT) continue;
+      hx |= (ox >= 0) ? ((seed >> ox) & columns_below<HT, WT>(WT - ox))
+                      : ((seed << -ox) & ~columns_below<HT, WT>(-ox) & FULL);
+    }
+    unsigned long long dropped = 0ull;
+    for (int dy = 0; dy < block_size; ++dy) {  // ... |= hx(y + oy, x)
+      const int oy = dy - pad;
+      if (oy >= HT || -oy >= HT) continue;
+      dropped |= (oy >= 0) ? (hx >> (oy * WT)) : ((hx << (-oy * WT)) & FULL);
+    }
+    return ~dropped & FULL;
+  };
+
+  unsigned long long keep = identity ? FULL : keep_of(seeds_of(0u));
+  if (redraw && !identity && !rnd) {
+    // throughput mode, opt-in: a drop layer that removed the whole map (0 * numel / 0 = NaN upstream) draws again from
+    // the next counter block of the same image - a bounded, wave-uniform loop that only images with such a layer enter
+    for (unsigned attempt = 1; attempt <= 16u; ++attempt) {
+      if (__ballot(lane < n_mc && keep == 0ull) == 0ull) break;
+      const unsigned long long again = keep_of(seeds_of(attempt));
+      if (keep == 0ull) keep = again;
+    }
   }
-  const int pad = block_size / 2;
-  unsigned long long hx = 0ull;
-  for (int dx = 0; dx < block_size; ++dx) {  // dropped(y, x) |= seed(y, x + ox)
-    const int ox = dx - pad;
-    if (ox >= WT || -ox >= WT) continue;
-    hx |= (ox >= 0) ? ((seed >> ox) & columns_below<HT, WT>(WT - ox))
-                    : ((seed << -ox) & ~columns_below<HT, WT>(-ox) & FULL);
-  }
-  unsigned long long dropped = 0ull;
-  for (int dy = 0; dy < block_size; ++dy) {  // ... |= hx(y + oy, x)
-    const int oy = dy - pad;
-    if (oy >= HT || -oy >= HT) continue;
-    dropped |= (oy >= 0) ? (hx >> (oy * WT)) : ((hx << (-oy * WT)) & FULL);
-  }
-  const unsigned long long keep = ~dropped & FULL;
   const int cnt = __popcll(keep);
   int m;
   float flag, zh, zl;
@@ -791,15 +733,12 @@ extern "C" int runia_pca_md_score_f64(const double* h, const double* packed_ct, 
 namespace {
 template <int HH, int WW, int NPP>
 void launch_mask(const float* rnd, int64_t rand_image_stride, float* table, int64_t N, int n_mc, float gamma,
-                 int block_size, int identity, int sort_layers, uint64_t seed, int64_t first_image, hipStream_t s) {
-  if constexpr (64 % (HH * WW) == 0) {
-    mc_mask_bits_kernel<HH, WW, NPP><<<(unsigned)((N + kMaskBitsWaves - 1) / kMaskBitsWaves), 64 * kMaskBitsWaves, 0,
-                                       s>>>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity,
-                                            sort_layers, seed, first_image);
-  } else {
-    mc_mask_kernel<HH, WW><<<(unsigned)N, 256, 0, s>>>(rnd, rand_image_stride, table, n_mc, gamma, block_size,
-                                                       identity, sort_layers, seed, first_image);
-  }
+                 int block_size, int identity, int sort_layers, uint64_t seed, int64_t first_image, int redraw,
+                 hipStream_t s) {
+  static_assert(HH * WW <= 64, "mc_mask_bits_kernel holds a drop layer in one 64-bit word");
+  mc_mask_bits_kernel<HH, WW, NPP><<<(unsigned)((N + kMaskBitsWaves - 1) / kMaskBitsWaves), 64 * kMaskBitsWaves, 0,
+                                     s>>>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity,
+                                          sort_layers, seed, first_image, redraw);
 }
 
 // explicit draws of the counter generator, [N, n_mc, H, W] (tests; callers that want the values themselves)
@@ -827,11 +766,13 @@ static int mc_args_ok(int64_t N, int H, int W, int n_mc, const void* workspace, 
   return RUNIA_OK;
 }
 
-#define RUNIA_MCE_SHAPES(F) F(4, 4, 16, 5) F(4, 4, 32, 5) F(4, 4, 8, 5) F(2, 2, 16, 5) F(7, 7, 16, 5) F(8, 8, 16, 5)
+#define RUNIA_MCE_SHAPES(F) \
+  F(4, 4, 16, 5) F(4, 4, 32, 5) F(4, 4, 8, 5) F(2, 2, 16, 5) F(2, 2, 32, 5) F(7, 7, 16, 5) F(7, 7, 32, 5) F(8, 8, 16, 5) F(8, 8, 32, 5)
 
 static int mc_mask_table(const float* rnd, int64_t rand_image_stride, void* workspace, size_t workspace_bytes,
                          int64_t N, int H, int W, int n_mc, double drop_prob, int block_size, int sort_layers,
-                         runia_stream_t stream, bool counter = false, uint64_t seed = 0, int64_t first_image = 0) {
+                         runia_stream_t stream, bool counter = false, uint64_t seed = 0, int64_t first_image = 0,
+                         int redraw = 0) {
   if (block_size < 1) return RUNIA_E_INVALID;
   if (int rc = mc_args_ok(N, H, W, n_mc, workspace, workspace_bytes)) return rc;
   if (N == 0) return RUNIA_OK;
@@ -844,7 +785,7 @@ static int mc_mask_table(const float* rnd, int64_t rand_image_stride, void* work
 #define RUNIA_MCE(HH, WW, NPP, KK)                                                                          \
   if (H == HH && W == WW && n_mc <= NPP && n_mc > NPP / 2) {                                                \
     launch_mask<HH, WW, NPP>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity,           \
-                             sort_layers, seed, first_image, s);                                            \
+                             sort_layers, seed, first_image, redraw, s);                                    \
     return runia_check_launch();                                                                            \
   }
   RUNIA_MCE_SHAPES(RUNIA_MCE)
@@ -955,16 +896,18 @@ extern "C" int runia_mc_draws_f32(float* out, int64_t N, int n_mc, int H, int W,
 
 extern "C" int runia_mc_mask_table_counter_f32(uint64_t seed, int64_t first_image, void* workspace,
                                                size_t workspace_bytes, int64_t N, int H, int W, int n_mc,
-                                               double drop_prob, int block_size, runia_stream_t stream) {
+                                               double drop_prob, int block_size, int redraw_dead_layers,
+                                               runia_stream_t stream) {
   if (first_image < 0) return RUNIA_E_INVALID;
   return mc_mask_table(nullptr, 0, workspace, workspace_bytes, N, H, W, n_mc, drop_prob, block_size, 1, stream, true,
-                       seed, first_image);
+                       seed, first_image, redraw_dead_layers ? 1 : 0);
 }
 
 extern "C" int runia_mc_entropy_counter_f32(const float* x, uint64_t seed, int64_t first_image, double* h,
                                             float* z_out, double* zero_fill, void* workspace, size_t workspace_bytes,
                                             int64_t N, int C, int H, int W, int n_mc, double drop_prob,
-                                            int block_size, int k, double min_dist, runia_stream_t stream) {
+                                            int block_size, int k, double min_dist, int redraw_dead_layers,
+                                            runia_stream_t stream) {
   if (N < 0 || C <= 0 || H <= 0 || W <= 0 || n_mc < 2 || n_mc > kMaxMC || block_size < 1 || k < 1 || k >= n_mc ||
       first_image < 0)
     return RUNIA_E_INVALID;
@@ -973,7 +916,7 @@ extern "C" int runia_mc_entropy_counter_f32(const float* x, uint64_t seed, int64
   if (!runia_mc_entropy_supported(H, W, n_mc, k)) return RUNIA_E_INVALID;
   if (!(((((uintptr_t)x) & 15) == 0) || (H * W) % 4 != 0)) return RUNIA_E_INVALID;  // before anything is launched
   if (int rc = runia_mc_mask_table_counter_f32(seed, first_image, workspace, workspace_bytes, N, H, W, n_mc,
-                                               drop_prob, block_size, stream))
+                                               drop_prob, block_size, redraw_dead_layers, stream))
     return rc;
   return runia_mc_entropy_from_table_f32(x, workspace, workspace_bytes, h, z_out, zero_fill, N, C, H, W, n_mc, k,
                                          min_dist, stream);
@@ -983,7 +926,9 @@ extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k) {
   if (k != 5 || k >= n_mc) return 0;
   const bool hw = (H == 4 && W == 4);
   if (hw && n_mc > 4 && n_mc <= 32) return 1;
-  if (n_mc > 8 && n_mc <= 16 && ((H == 2 && W == 2) || (H == 7 && W == 7) || (H == 8 && W == 8))) return 1;
+  // 9 ... 32 samples (32 = the reference's default mcd_samples_nro, evaluation/entropy.py:41) on the maps RoI-align
+  // produces (7x7), 8x8 and 2x2
+  if (n_mc > 8 && n_mc <= 32 && ((H == 2 && W == 2) || (H == 7 && W == 7) || (H == 8 && W == 8))) return 1;
   return 0;
 }
 

@@ -29,9 +29,10 @@ __host__ __device__ __forceinline__ u4 philox4x32_10(uint32_t c0, uint32_t c1, u
 
 __host__ __device__ __forceinline__ float to_uniform(uint32_t bits) { return (float)(bits >> 8) * (1.0f / 16777216.0f); }
 
-// the Philox block that holds words 4*q .. 4*q+3 of lane `lane` of image `img`
-__device__ __forceinline__ u4 lane_block(uint64_t seed, uint64_t img, int lane, int q) {
-  return philox4x32_10((uint32_t)img, (uint32_t)(img >> 32), (uint32_t)(lane + 64 * q), 0u, (uint32_t)seed,
+// the Philox block that holds words 4*q .. 4*q+3 of lane `lane` of image `img`; `attempt` (fourth counter word) is 0
+// for the draws proper and 1, 2, ... for the redraws of drop layers that removed a whole map (opt-in, K0)
+__device__ __forceinline__ u4 lane_block(uint64_t seed, uint64_t img, int lane, int q, uint32_t attempt = 0u) {
+  return philox4x32_10((uint32_t)img, (uint32_t)(img >> 32), (uint32_t)(lane + 64 * q), attempt, (uint32_t)seed,
                        (uint32_t)(seed >> 32));
 }
 

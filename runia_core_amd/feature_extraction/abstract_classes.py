@@ -55,10 +55,17 @@ class MCSamplerModule(torch.nn.Module):
         self.draw_source = "cpu"
         self.counter_seed = 0
         self._next_image = 0
+        self.redraw_dead_layers = False
 
-    def use_counter_draws(self, seed: int = 0, first_image: int = 0) -> "MCSamplerModule":
-        """Switch to in-kernel counter-based draws (additive API; the reference has only the CPU stream)."""
+    def use_counter_draws(self, seed: int = 0, first_image: int = 0, redraw_dead_layers: bool = False) -> "MCSamplerModule":
+        """Switch to in-kernel counter-based draws (additive API; the reference has only the CPU stream).
+
+        ``redraw_dead_layers=True``: a drop layer whose block mask removes the whole map - ``0 * numel / 0 = NaN`` in the
+        reference as well, about one image in 200 at 4x4 maps / drop_prob 0.5 / block 2 - draws again from the image's
+        next counter block, so a batch never returns a NaN score.  The reference has no redraw; counter mode is a
+        different random stream anyway (same statistics: bench.py reports the AUROC gap over several seeds)."""
         self.draw_source, self.counter_seed, self._next_image = "counter", int(seed), int(first_image)
+        self.redraw_dead_layers = bool(redraw_dead_layers)
         return self
 
     def use_cpu_draws(self) -> "MCSamplerModule":
@@ -69,7 +76,7 @@ class MCSamplerModule(torch.nn.Module):
         """Draws of the next ``batch`` images from the configured source: a device tensor ``(batch, n_mc, h, w)`` in
         "cpu" mode, a ``_hip.CounterDraws`` ticket in "counter" mode (the kernel makes the draws itself)."""
         if self.draw_source == "counter":
-            ticket = _hip.CounterDraws(self.counter_seed, self._next_image)
+            ticket = _hip.CounterDraws(self.counter_seed, self._next_image, self.redraw_dead_layers)
             self._next_image += int(batch)
             return ticket
         return self.draw(batch, h, w, device)

@@ -112,7 +112,7 @@ class FastMCDSamplesExtractor:
         if self.sampler.draw_source == "counter":
             first = self.sampler._next_image
             self.sampler._next_image += batch
-            rands = [_hip.CounterDraws(self.sampler.counter_seed + 7919 * i, first) if float(p) != 0.0 else None
+            rands = [_hip.CounterDraws(self.sampler.counter_seed + 7919 * i, first, getattr(self.sampler, "redraw_dead_layers", False)) if float(p) != 0.0 else None
                      for i, p in enumerate(self.dropblock_probs)]
         else:
             rands = self.draw_layers(batch, [(t.shape[2], t.shape[3]) for t in xs], xs[0].device)

@@ -267,7 +267,7 @@ class LaREMPipeline:
         for a in range(0, n, per):
             b = min(a + per, n)
             with torch.cuda.stream(s_k1):
-                r_ab = None if rand is None else (_hip.CounterDraws(rand.seed, rand.first_image + a) if counter else rand[a:b])
+                r_ab = None if rand is None else (rand._replace(first_image=rand.first_image + a) if counter else rand[a:b])
                 _hip.mc_entropy(latents[a:b], r_ab, self.n_mc, drop, self.block_size,
                                 self.k, MIN_DIST, out=h[a:b], kernel_events=k1_events)
                 ready = s_k1.record_event()

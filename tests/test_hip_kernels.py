@@ -558,7 +558,8 @@ def test_counter_draws_equal_oracle(hip, n, n_mc, h, w, first):
 
 
 @pytest.mark.parametrize("c,h,w,bs,p,n_mc,n", [(512, 4, 4, 2, 0.5, 16, 33), (64, 4, 4, 2, 0.4, 32, 9), (48, 8, 8, 3, 0.4, 12, 5),
-                                               (40, 7, 7, 3, 0.4, 16, 5), (64, 2, 2, 1, 0.3, 16, 7)])
+                                               (40, 7, 7, 3, 0.4, 16, 5), (64, 2, 2, 1, 0.3, 16, 7), (24, 7, 7, 3, 0.4, 32, 4),
+                                               (16, 8, 8, 3, 0.5, 32, 3), (16, 7, 7, 2, 0.5, 21, 70)])
 def test_counter_mode_equals_explicit_draws(hip, c, h, w, bs, p, n_mc, n):
     """In-kernel draws (runia_mc_entropy_counter_f32) == the parity path fed with the same generator's explicit draws
     (runia_mc_draws_f32 -> runia_mc_entropy_f32), bit for bit; chunks and shards line up through first_image."""
@@ -579,6 +580,41 @@ def test_counter_mode_equals_explicit_draws(hip, c, h, w, bs, p, n_mc, n):
     z_ctr = hip.mc_stack(x, hip.CounterDraws(seed, first), n_mc, p, bs)
     z_par = hip.mc_stack(x, explicit, n_mc, p, bs)
     assert torch.equal(torch.nan_to_num(z_ctr, nan=-7.0), torch.nan_to_num(z_par, nan=-7.0))
+
+
+@pytest.mark.parametrize("c,h,w,bs,p,n_mc,n", [(64, 4, 4, 2, 0.9, 16, 400), (32, 4, 4, 3, 0.6, 32, 120), (24, 7, 7, 5, 0.95, 16, 60),
+                                               (16, 8, 8, 7, 0.9, 12, 40), (40, 2, 2, 1, 0.8, 16, 200), (512, 4, 4, 2, 0.5, 16, 2000)])
+def test_counter_redraw_of_fully_dropped_maps(hip, c, h, w, bs, p, n_mc, n):
+    """CounterDraws(redraw_dead_layers=True): a drop layer that removes the whole map draws again from the image's next
+    counter block (attempt = fourth Philox counter word).  Equal, bit for bit, to the parity path fed with the oracle's
+    equivalent explicit draws; no NaN entropy; images without such a layer are untouched."""
+    torch.manual_seed(c + n)
+    x = torch.relu(torch.randn(n, c, h, w)).cuda()
+    seed, first = 123, 77
+    plain = oracle.counter_draws(n, n_mc, h, w, seed, first)
+    dead0 = (oracle.dropblock_block_mask(plain.reshape(n * n_mc, h, w), p, bs).reshape(n, n_mc, -1).sum(2) == 0)
+    assert dead0.any() or p <= 0.5  # the aggressive cases do contain fully dropped maps (several attempts deep)
+    redrawn = oracle.counter_draws_redrawn(n, n_mc, h, w, seed, first, p, bs)
+    h_exp = hip.mc_entropy(x, torch.from_numpy(redrawn).cuda(), n_mc, p, bs, 5)
+    h_got = hip.mc_entropy(x, hip.CounterDraws(seed, first, True), n_mc, p, bs, 5)
+    assert torch.equal(torch.nan_to_num(h_got, nan=-7.0), torch.nan_to_num(h_exp, nan=-7.0))
+    still_dead = oracle.dropblock_block_mask(redrawn.reshape(n * n_mc, h, w), p, bs).reshape(n, n_mc, -1).sum(2) == 0
+    assert not torch.isnan(h_got[torch.from_numpy(~still_dead.any(axis=1)).cuda()]).any()
+    if p < 0.93:
+        assert not still_dead.any() and not torch.isnan(h_got).any()
+    # images that had no fully dropped map score exactly what the plain counter mode gives them
+    h_plain = hip.mc_entropy(x, hip.CounterDraws(seed, first), n_mc, p, bs, 5)
+    clean = torch.from_numpy(~dead0.any(axis=1)).cuda()
+    assert torch.equal(h_plain[clean], h_got[clean])
+    assert torch.isnan(h_plain[~clean]).all() if (~clean).any() else True
+    # chunks line up through first_image; the table-only entry honours the flag too
+    h_tail = hip.mc_entropy(x[3:].contiguous(), hip.CounterDraws(seed, first + 3, True), n_mc, p, bs, 5)
+    assert torch.equal(torch.nan_to_num(h_tail, nan=-7.0), torch.nan_to_num(h_got[3:], nan=-7.0))
+    tab = hip.mc_mask_table(hip.CounterDraws(seed, first, True), n, h, w, n_mc, p, bs)
+    h_tab = hip.mc_entropy(x, None, n_mc, p, bs, 5, table=tab)
+    assert torch.equal(torch.nan_to_num(h_tab, nan=-7.0), torch.nan_to_num(h_got, nan=-7.0))
+    with pytest.raises(hip.RuniaHipError):  # the explicit-draw kernels cannot redraw: refused, not ignored
+        hip.mc_drop_flat(x, hip.CounterDraws(seed, first, True), n_mc, p, bs)
 
 
 # ---------------- full chain on pre-stacked samples -------------------------------------------------------------
@@ -605,7 +641,12 @@ def test_larem_chain_unfused(hip):
 @pytest.mark.parametrize("c,h,w,bs,p,n_mc,n", [(512, 4, 4, 2, 0.5, 16, 33), (100, 4, 4, 2, 0.7, 32, 5), (64, 4, 4, 3, 0.5, 7, 4),
                                                (70, 7, 7, 3, 0.4, 16, 3), (130, 8, 8, 4, 0.4, 12, 3), (33, 2, 2, 1, 0.5, 16, 6),
                                                (512, 4, 4, 2, 0.0, 16, 3), (40, 4, 4, 4, 0.6, 16, 9), (24, 8, 8, 5, 0.5, 16, 4),
-                                               (24, 8, 8, 8, 0.9, 10, 4), (70, 2, 2, 2, 0.15, 16, 5), (64, 4, 4, 7, 0.05, 16, 12)])
+                                               (24, 8, 8, 8, 0.9, 10, 4), (70, 2, 2, 2, 0.15, 16, 5), (64, 4, 4, 7, 0.05, 16, 12),
+                                               (50, 7, 7, 2, 0.5, 9, 6), (16, 7, 7, 7, 0.3, 16, 5), (30, 7, 7, 4, 0.6, 13, 7),
+                                               (20, 7, 7, 1, 0.5, 16, 300), (12, 7, 7, 5, 0.99, 16, 8),
+                                               # up to 32 MC samples (the reference's default mcd_samples_nro) on 7x7 / 8x8 / 2x2
+                                               (40, 7, 7, 3, 0.4, 32, 5), (24, 8, 8, 3, 0.5, 25, 4), (33, 2, 2, 1, 0.5, 32, 6),
+                                               (20, 7, 7, 3, 0.4, 20, 3), (16, 8, 8, 2, 0.6, 32, 3), (130, 7, 7, 2, 0.3, 17, 2)])
 def test_mc_entropy_fused_equals_unfused(hip, c, h, w, bs, p, n_mc, n):
     torch.manual_seed(c + n_mc)
     x = torch.relu(torch.randn(n, c, h, w)).cuda()
