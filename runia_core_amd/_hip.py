@@ -110,6 +110,10 @@ _SIGNATURES = {
     "runia_eigh_workspace_bytes": (c_size_t, [c_int64]),
     "runia_eigh_init_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "runia_eigh_sweep_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
+    "runia_eigh_block_padded": (c_int64, [c_int64]),
+    "runia_eigh_block_workspace_bytes": (c_size_t, [c_int64]),
+    "runia_eigh_block_init_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
+    "runia_eigh_block_sweep_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "runia_matmul_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
     "runia_centred_gram_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
     "runia_roi_align_f32": (
@@ -885,34 +889,45 @@ def ood_clf_curve(ind_scores: torch.Tensor, ood_scores: torch.Tensor):
     return out, host[0], host[1]
 
 
-def eigh(a: torch.Tensor, max_sweeps: int = 30):
-    """Symmetric eigen-decomposition on the device (Jacobi sweeps of ``runia_eigh_sweep_f64`` until one applies no
-    rotation): a [n, n] f64 -> (eigenvalues [n] ascending, eigenvectors [n, n] as columns), like ``numpy.linalg.eigh``.
+def eigh(a: torch.Tensor, max_sweeps: int = 30, blocked: bool = True):
+    """Symmetric eigen-decomposition on the device: a [n, n] f64 -> (eigenvalues [n] ascending, eigenvectors [n, n] as
+    columns), like ``numpy.linalg.eigh``.  Cyclic Jacobi sweeps until one applies no rotation; ``blocked`` (default):
+    ``runia_eigh_block_sweep_f64`` - 64 x 64 sub-problems in LDS + matrix-core updates, (n/32 - 1) x 2 launches per sweep;
+    ``blocked=False``: the scalar-rotation form ``runia_eigh_sweep_f64`` (2 (n - 1) launches per sweep).
     Setup-time: reads one counter back per sweep."""
     lib = load_library()
     require_gpu()
     assert a.is_cuda and a.dtype == torch.float64 and a.dim() == 2 and a.shape[0] == a.shape[1]
     n = a.shape[0]
-    work = ((a + a.T) * 0.5).contiguous()  # exactly symmetric input
+    sym = (a + a.T) * 0.5  # exactly symmetric input
+    count = torch.zeros(1, dtype=torch.int32, device=a.device)
+    if blocked:
+        big = int(lib.runia_eigh_block_padded(n))
+        work = torch.zeros((big, big), dtype=torch.float64, device=a.device)
+        work[:n, :n] = sym
+        ws_bytes = int(lib.runia_eigh_block_workspace_bytes(n))
+        init, sweep, size = lib.runia_eigh_block_init_f64, lib.runia_eigh_block_sweep_f64, big
+    else:
+        work = sym.contiguous()
+        ws_bytes = int(lib.runia_eigh_workspace_bytes(n))
+        init, sweep, size = lib.runia_eigh_init_f64, lib.runia_eigh_sweep_f64, n
     v = torch.empty_like(work)
-    ws_bytes = int(lib.runia_eigh_workspace_bytes(n))
     ws = torch.empty(ws_bytes + 16, dtype=torch.uint8, device=a.device)
     off = (-ws.data_ptr()) % 16
-    count = torch.zeros(1, dtype=torch.int32, device=a.device)
-    _check(lib.runia_eigh_init_f64(work.data_ptr(), v.data_ptr(), n, ws.data_ptr() + off, ws_bytes, _stream()), "runia_eigh_init_f64")
+    _check(init(work.data_ptr(), v.data_ptr(), size, ws.data_ptr() + off, ws_bytes, _stream()), "runia_eigh_init")
     done = 0
     for _ in range(max_sweeps):
-        _check(lib.runia_eigh_sweep_f64(work.data_ptr(), v.data_ptr(), n, ws.data_ptr() + off, ws_bytes, count.data_ptr(),
-                                        _stream()), "runia_eigh_sweep_f64")
+        _check(sweep(work.data_ptr(), v.data_ptr(), size, ws.data_ptr() + off, ws_bytes, count.data_ptr(), _stream()),
+               "runia_eigh_sweep")
         total = int(count.item())
         if total == done:
             break
         done = total
     else:
-        raise RuniaHipError(f"runia_eigh_sweep_f64 did not converge in {max_sweeps} sweeps (n = {n})")
-    w = torch.diagonal(work).clone()
+        raise RuniaHipError(f"the Jacobi sweeps did not converge in {max_sweeps} sweeps (n = {n})")
+    w = torch.diagonal(work)[:n].clone()
     order = torch.argsort(w)
-    return w[order], v[:, order].contiguous()
+    return w[order], v[:n, :n][:, order].contiguous()
 
 
 def matmul_f64(a: torch.Tensor, b: torch.Tensor, transpose_b: bool = False) -> torch.Tensor:
