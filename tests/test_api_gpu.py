@@ -857,6 +857,23 @@ def test_eigen_score_reference_golden():
     assert abs(eigen_score(hs_dev) - s1) < 1e-12
 
 
+def test_eigen_score_at_llama_width():
+    """BASELINE config 5's shape: 10 samples per prompt, hidden = 4096 (Llama-3.1-8B), against the float64 host
+    definition mean(log(svd(cov + alpha I))) - the O(hidden^3) computation the Gram form replaces - and for n > hidden."""
+    from runia_core_amd.llm_uncertainty import eigen_score
+
+    torch.manual_seed(7)
+    for n, hidden, alpha in ((10, 4096, 1e-3), (10, 4096, 1e-2), (40, 32, 1e-3)):
+        layer = tuple(torch.randn(1, n, hidden) * (0.5 + torch.rand(hidden)) for _ in range(20))
+        hs = (layer,)
+        e = layer[15].squeeze().double().numpy()
+        cov = np.cov(e.T)
+        sv = np.linalg.svd(cov + alpha * np.eye(hidden), compute_uv=False)
+        s = eigen_score(hs, alpha=alpha)
+        # the Gram matrix is formed from float32 embeddings (as the reference's torch.cov is): 1e-6 of the mean log
+        assert abs(s - float(np.mean(np.log(sv)))) < 2e-6, (n, hidden, alpha)
+
+
 def test_refit_invalidates_device_caches():
     """Fitted-state caches follow the live attributes: refitting the same sklearn PCA object, or reassigning
     precision / feats_mean, must change the scores."""

@@ -274,6 +274,33 @@ def test_mahalanobis_many_classes(hip, d, c, n, dt):
     assert np.isneginf(s2).all()
 
 
+@pytest.mark.parametrize("d,c,cond", [(64, 40, 1e5), (128, 100, 1e7), (96, 17, 1e9)])
+def test_mahalanobis_many_classes_ill_conditioned_precision(hip, d, c, cond):
+    """More than 16 classes with a precision matrix of condition 1e5 ... 1e9 and class means far closer to each other than
+    the 1e-3 window in which candidate classes are re-evaluated with the reference's float32-difference form: the exact
+    ranking + re-evaluation must still return the class loop's scores (oracle: reference funcs.py:88-100, vectorised)."""
+    rng = np.random.default_rng(int(np.log10(cond)) + d)
+    q, _ = np.linalg.qr(rng.standard_normal((d, d)))
+    prec = (q * np.logspace(0, np.log10(cond), d)) @ q.T
+    prec = (prec + prec.T) * 0.5
+    base = rng.standard_normal(d).astype(np.float32) * 3 + 5.0
+    # clusters of near-coincident class means: the best classes of a row differ by far less than the score's 1e-3
+    centres = (base[None, :] + rng.standard_normal((c, d)).astype(np.float32) * np.float32(1e-3)).astype(np.float32)
+    centres[::3] += rng.standard_normal((len(centres[::3]), d)).astype(np.float32)
+    n = 400
+    lab = rng.integers(0, c, n)
+    x = (centres[lab] + rng.standard_normal((n, d)).astype(np.float32) * np.float32(0.05)).astype(np.float32)
+    exp = oracle.mahalanobis_score(x, centres, prec, c)
+    mu_p = centres.astype(np.float64) @ prec
+    packed = hip.pack_weights(dev(prec, torch.float64))
+    s = hip.mahalanobis_score(dev(x, torch.float32), dev(centres, torch.float32), packed, dev(mu_p, torch.float64)).cpu().numpy()
+    loop = hip.mahalanobis_score(dev(x, torch.float32), dev(centres, torch.float32), packed, dev(mu_p, torch.float64),
+                                 class_loop=True).cpu().numpy()
+    scale = np.maximum(1.0, np.abs(exp))
+    assert (np.abs(loop - exp) / scale).max() < 1e-9
+    assert (np.abs(s - exp) / scale).max() < 1e-9, float((np.abs(s - exp) / scale).max())
+
+
 @pytest.mark.parametrize("c,m", [(1, 1), (2, 1), (7, 3), (10, 10), (10, 100), (16, 5), (16, 16), (17, 5), (64, 64), (100, 10),
                                  (1000, 100), (1000, 600), (1000, 1000), (3000, 100)])
 def test_gen_score_widths_and_m(hip, c, m):

@@ -6,7 +6,7 @@ tag=${1:-pmc}
 out=$GRAFT_REPO_ROOT/gpurun_out/$tag
 mkdir -p $out
 cd /tmp && export TMPDIR=/tmp PYTHONPATH=$GRAFT_REPO_ROOT
-run() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --clock-warmup 0.2 --no-cpu-baseline --no-api-level > $out/$name.json 2> $out/$name.err || echo "pass $name failed"; }
+run() { name=$1; shift; rocprofv3 --pmc "$@" --kernel-trace --output-format csv -d $out/$name -- python3 $GRAFT_REPO_ROOT/bench.py --steps 16 --warmup 4 --clock-warmup 0.2 --no-cpu-baseline --no-api-level --no-stages > $out/$name.json 2> $out/$name.err || echo "pass $name failed"; }
 run fetch FETCH_SIZE
 run write WRITE_SIZE
 run sq SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_WAVES SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY
