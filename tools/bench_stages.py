@@ -271,6 +271,17 @@ add("roi_align (f3)", f"{kb} boxes x 256 ch x 7x7, sampling 2", "boxes", kb, ms,
     f"numpy restatement, {mb} boxes", rel(rois[:mb].cpu().numpy(), exp))
 ms = gpu_ms(lambda: _hip.mc_entropy(rois, _hip.CounterDraws(3, 0), 16, 0.4, 3, 5))
 add("per-ROI MC entropy 7x7 (f3)", f"{kb} ROIs x 256 ch x 7x7, 16 MC", "boxes", kb, ms, "hbm", 256 * 49 * 4 + 256 * 8, float("nan"), "-", 0.0)
+# the same two launches (K0 + K1) at cfg4's size: 1 000 boxes are one round of workgroups and mostly launch latency
+kb2 = 60_000
+rois2 = torch.relu(torch.randn(kb2, 256, 7, 7, device=dev, generator=g))
+for n_mc_r in (16, 32):
+    ms = gpu_ms(lambda: _hip.mc_entropy(rois2, _hip.CounterDraws(3, 0), n_mc_r, 0.4, 3, 5), reps=3)
+    ref_r = _hip.kl_entropy_per_dim(_hip.mc_stack(rois2[:64], _hip.CounterDraws(3, 0), n_mc_r, 0.4, 3), n_mc_r, 5)
+    got_r = _hip.mc_entropy(rois2[:64].contiguous(), _hip.CounterDraws(3, 0), n_mc_r, 0.4, 3, 5)
+    fin = torch.isfinite(ref_r)
+    add(f"per-ROI MC entropy 7x7, {n_mc_r} MC (f3)", f"{kb2} ROIs x 256 ch x 7x7", "boxes", kb2, ms, "hbm", 256 * 49 * 4 + 256 * 8,
+        float("nan"), "fused vs unfused kernels", float((got_r[fin] - ref_r[fin]).abs().max()))
+del rois2
 
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 json.dump({"host_cores": os.cpu_count(), "device": torch.cuda.get_device_name(0), "rows": rows},

@@ -6,7 +6,7 @@ import numpy as np, torch
 import oracle
 from runia_core_amd import _hip
 rng = np.random.default_rng(123)
-shapes = [(4, 4, range(6, 33)), (2, 2, range(9, 17)), (8, 8, range(9, 17)), (7, 7, range(9, 17))]
+shapes = [(4, 4, range(6, 33)), (2, 2, range(9, 33)), (8, 8, range(9, 33)), (7, 7, range(9, 33))]
 bad = 0
 for t in range(60):
     h, w, nmcs = shapes[rng.integers(len(shapes))]
@@ -31,3 +31,33 @@ for t in range(60):
         bad += 1
         print("MISMATCH", (h, w, n_mc, c, n, bs, p), ok_z, err, nan_ok)
 print("fuzz done, mismatches:", bad)
+
+# ---- round 3: counter draws with the redraw of fully dropped maps (K0) against the oracle's equivalent explicit draws ----
+for t in range(40):
+    h, w, nmcs = shapes[rng.integers(len(shapes))]
+    n_mc = int(rng.choice(list(nmcs)))
+    c = int(rng.integers(1, 80)); n = int(rng.integers(1, 40)); bs = int(rng.integers(1, min(h, w) + 1))
+    p = float(rng.choice([0.3, 0.6, 0.9, 0.99]))
+    seed, first = int(rng.integers(0, 2**40)), int(rng.integers(0, 2**33))
+    x = torch.relu(torch.randn(n, c, h, w)).cuda()
+    red = oracle.counter_draws_redrawn(n, n_mc, h, w, seed, first, p, bs)
+    a = _hip.mc_entropy(x, torch.from_numpy(red).cuda(), n_mc, p, bs, 5)
+    b = _hip.mc_entropy(x, _hip.CounterDraws(seed, first, True), n_mc, p, bs, 5)
+    if not torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(b, nan=-7.0)):
+        bad += 1
+        print("MISMATCH redraw", (h, w, n_mc, c, n, bs, p, seed, first), flush=True)
+# ---- round 3: blocked Jacobi eigen-solver against LAPACK (eigenvalues, residual, orthogonality) ----
+for t in range(25):
+    n = int(rng.integers(1, 300))
+    g = rng.standard_normal((n, max(1, int(rng.integers(1, n + 40)))))
+    a = g @ g.T / g.shape[1] + np.diag(rng.random(n) * float(rng.choice([0.0, 1e-6, 1.0])))
+    w, v = _hip.eigh(torch.from_numpy(a).cuda())
+    w, v = w.cpu().numpy(), v.cpu().numpy()
+    nrm = max(1.0, float(np.abs(a).max()))
+    e1 = float(np.abs(w - np.linalg.eigvalsh(a)).max()) / nrm
+    e2 = float(np.abs(a @ v - v * w).max()) / nrm
+    e3 = float(np.abs(v.T @ v - np.eye(n)).max())
+    if not (e1 < 1e-11 and e2 < 1e-11 and e3 < 1e-11):
+        bad += 1
+        print("MISMATCH eigh", n, e1, e2, e3, flush=True)
+print("fuzz_k1 round-3 families done, mismatches so far:", bad, flush=True)
