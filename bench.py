@@ -87,10 +87,13 @@ def parse_args():
                     help="HIP events bracket the dominant kernel on every n-th timed step (a bracketed step runs the "
                          "table launch and the kernel as two C calls with two event records between them: ~40 us "
                          "slower than an unbracketed step, so bracketing every step would tax the metric by 16 %%)")
-    ap.add_argument("--gather-stream", choices=["auto", "same", "side"], default="auto",
+    ap.add_argument("--gather-stream", choices=["auto", "same", "side", "p2p"], default="auto",
                     help="queue the all_gather on the compute stream, or on a second stream behind an event with "
                          "two output buffers in turn (the next step's kernels then start without waiting for it); "
-                         "auto: time both during the warm-up and keep the faster (all ranks agree through a MAX)")
+                         "auto: time both during the warm-up and keep the faster (all ranks agree through a MAX).  "
+                         "p2p (opt-in, never chosen by auto): the one-shot gather of csrc/p2p.hip instead of RCCL - every "
+                         "rank writes its shard into the peers' IPC-mapped buffers over xGMI, two launches on the compute "
+                         "stream (runia_core_amd.distributed.OneShotGather)")
     args = ap.parse_args()
     if args.steps is None:
         args.steps = 200 if args.workload == "cfg2" else 3
@@ -315,8 +318,21 @@ def main():
     inputs_ready = torch.cuda.current_stream().record_event()  # the input sets are resident from here on
 
     gathered = [torch.empty(world * n, dtype=torch.float64, device=device) for _ in range(2)] if use_dist else None
-    side_stream = torch.cuda.Stream() if (use_dist and args.gather_stream != "same") else None
-    gather_mode = {"side": args.gather_stream == "side"}
+    side_stream = torch.cuda.Stream() if (use_dist and args.gather_stream in ("auto", "side")) else None
+    one_shot = None
+    if use_dist and args.gather_stream in ("auto", "p2p"):
+        from runia_core_amd.distributed import OneShotGather
+
+        try:  # collective; every rank succeeds or every rank raises (distributed.OneShotGather)
+            one_shot = OneShotGather(n, torch.float64)
+        except _hip.RuniaHipError as e:
+            if args.gather_stream == "p2p":
+                raise
+            if rank == 0:
+                print(f"one-shot gather unavailable on this node, RCCL only: {e}", file=sys.stderr)
+    # "kind": how the score shards are gathered - RCCL all_gather on the compute stream ("same"), on a second stream
+    # ("side"), or the one-shot P2P writes of csrc/p2p.hip ("p2p")
+    gather_mode = {"kind": args.gather_stream if args.gather_stream in ("same", "side", "p2p") else "same"}
     gather_turn = [0]
     step_no = [0]
 
@@ -324,9 +340,11 @@ def main():
         """The single RCCL all_gather of the path: equal shards, preallocated output.  Default: queued
         on the compute stream.  --gather-stream side: queued on a second stream behind an event; outputs alternate
         between two buffers (a buffer is rewritten two steps later, in stream order on the same stream)."""
+        if gather_mode["kind"] == "p2p":
+            return one_shot(s, world * n)
         out = gathered[gather_turn[0]]
         gather_turn[0] ^= 1
-        if not gather_mode["side"]:
+        if gather_mode["kind"] != "side":
             dist.all_gather_into_tensor(out, s)
             return out
         side_stream.wait_event(torch.cuda.current_stream().record_event())
@@ -386,9 +404,24 @@ def main():
     if use_dist and args.gather_stream == "auto" and not args.overlap:
         # untimed: which placement of the collective is faster on this node?  (one-GPU rehearsal: same stream
         # +9 us, side stream +23 us per step; with real peers the same-stream form also exposes the ring latency)
-        trial = {False: float("inf"), True: float("inf")}
-        for mode in (False, True, False, True, False, True):  # best of three interleaved trials per placement
-            gather_mode["side"] = mode
+        kinds = ["same", "side"]
+        if one_shot is not None:
+            # the one-shot form is a candidate only if it returns what RCCL returns, on every rank
+            probe = torch.arange(n, dtype=torch.float64, device=device) * 0.25 + float(rank * n)
+            want = torch.empty(world * n, dtype=torch.float64, device=device)
+            dist.all_gather_into_tensor(want, probe)
+            got = one_shot(probe, world * n)
+            agree = torch.tensor([1.0 if bool(torch.equal(got, want)) else 0.0], device=device)
+            try:
+                one_shot.check()
+            except _hip.RuniaHipError:
+                agree.zero_()
+            dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            if float(agree.item()) == 1.0:
+                kinds.append("p2p")
+        trial = {k: float("inf") for k in kinds}
+        for kind in kinds * 3:  # best of three interleaved trials per form
+            gather_mode["kind"] = kind
             for _ in range(3):
                 step()
             dist.barrier()
@@ -399,11 +432,12 @@ def main():
             torch.cuda.synchronize()
             t_m = torch.tensor([time.perf_counter() - t_a], dtype=torch.float64, device=device)
             dist.all_reduce(t_m, op=dist.ReduceOp.MAX)
-            trial[mode] = min(trial[mode], float(t_m.item()))
-        gather_mode["side"] = trial[True] < 0.98 * trial[False]  # the simpler placement unless clearly slower
+            trial[kind] = min(trial[kind], float(t_m.item()))
+        best = min(kinds, key=lambda k: trial[k])
+        gather_mode["kind"] = best if trial[best] < 0.98 * trial["same"] else "same"  # the simplest form unless clearly slower
         if rank == 0:
-            print(f"gather placement trial: same {trial[False] / 30 * 1e3:.4f} ms/step, side {trial[True] / 30 * 1e3:.4f} ms/step",
-                  file=sys.stderr)
+            print("gather trial: " + ", ".join(f"{k} {trial[k] / 30 * 1e3:.4f} ms/step" for k in kinds) +
+                  f" -> {gather_mode['kind']}", file=sys.stderr)
     step_no[0] = 0  # the timed region starts on set 0 and ends on set (K-1) % n_sets on every rank
     pending.clear()
     if k0_ahead:
@@ -424,6 +458,10 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
+    if one_shot is not None:
+        if gather_mode["kind"] == "p2p":
+            one_shot.check()   # a wait that gave up on a peer would have produced garbage: fail loudly
+        one_shot.close()
     kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in k1_events])) if k1_events else float('nan')
     bracketed_steps = len(range(0, args.steps, max(1, args.event_every)))
     k1_launches_per_step = max(1, len(k1_events) // max(1, bracketed_steps))
@@ -538,7 +576,10 @@ def main():
                    "keep_flag_table": ("built for batch i+1 on a side stream while batch i is scored (prepare_draws)" if k0_ahead
                                        else "built in line on the compute stream"),
                    "gather": ("none (1 GPU)" if not use_dist else
-                              ("all_gather on a second stream" if gather_mode["side"] else "all_gather on the compute stream"))},
+                              {"p2p": "one-shot P2P writes into the peers' buffers (csrc/p2p.hip), compute stream",
+                               "side": "RCCL all_gather on a second stream",
+                               "same": "RCCL all_gather on the compute stream"}[gather_mode["kind"]]) +
+                             (" (chosen by the warm-up trial)" if (use_dist and args.gather_stream == "auto") else "")},
         "roofline": roofline,
     }
     if api is not None:

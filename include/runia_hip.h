@@ -321,6 +321,28 @@ int runia_ood_clf_curve_f32(const float* ind_scores, int64_t n_ind, const float*
                             double* out3, unsigned* tps, unsigned* fps, int64_t* n_points, void* workspace,
                             size_t workspace_bytes, runia_stream_t stream);
 
+/* ---- (e) multi-GPU: one-shot all-gather of the score shards (SURVEY section 5's fallback for a latency-bound gather) -- *
+ * The path's only exchange is the (N / world,) score shard of every rank to every rank, one per postprocessor call
+ * (the reference has no distributed code).  Instead of a ring, every rank WRITES its shard into every peer's
+ * receive buffer over xGMI (buffers mapped through HIP IPC) and raises a flag; a second launch waits for the world flags of
+ * the step and copies the gathered vector out.  Stream-ordered, no host synchronisation; a wait that never sees a peer
+ * gives up after timeout_ms and sets a status word (runia_p2p_status) instead of hanging.
+ *   runia_p2p_alloc   : this rank's receive buffer (fine-grained device memory, zeroed), world <= 16
+ *   runia_p2p_export  : its 64-byte HIP IPC handle (send it to the peers over any host channel)
+ *   runia_p2p_open    : map a peer's buffer from its handle;  runia_p2p_close / runia_p2p_free: undo
+ *   runia_p2p_all_gather(local_shard, shard_bytes, out [world * shard_bytes], peer_buffers [world] (HOST array of the
+ *                       mapped device pointers, own buffer at index rank), ..., seq = 1, 2, 3, ... (+1 per call on every
+ *                       rank; slots alternate, a slot is rewritten two calls later), timeout_ms, stream) */
+size_t runia_p2p_buffer_bytes(int world, size_t shard_capacity_bytes);
+int runia_p2p_alloc(int world, size_t shard_capacity_bytes, void** buffer);
+int runia_p2p_free(void* buffer);
+int runia_p2p_export(void* buffer, void* handle64);
+int runia_p2p_open(const void* handle64, void** peer_buffer);
+int runia_p2p_close(void* peer_buffer);
+int runia_p2p_all_gather(const void* local_shard, size_t shard_bytes, void* out, void* const* peer_buffers, int world,
+                         int rank, size_t shard_capacity_bytes, uint64_t seq, int timeout_ms, runia_stream_t stream);
+int runia_p2p_status(void* buffer, int* status);
+
 /* ---- f4  remaining logits/features postprocessors (SURVEY 8f "next #4") ------- *
  * runia_linear_f32: out [N, C] = min(x, clip_max) @ w.T + bias on the f32 matrix cores - the final linear layer
  *   that ReAct / ASH / DICE re-apply to (transformed) features (inference/postprocessors.py:1193, 1441, 1466;

@@ -115,6 +115,15 @@ _SIGNATURES = {
     "runia_eigh_block_init_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p]),
     "runia_eigh_block_sweep_f64": (c_int, [c_void_p, c_void_p, c_int64, c_void_p, c_size_t, c_void_p, c_void_p]),
     "runia_matmul_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_int, c_void_p]),
+    "runia_p2p_buffer_bytes": (c_size_t, [c_int, c_size_t]),
+    "runia_p2p_alloc": (c_int, [c_int, c_size_t, ctypes.POINTER(c_void_p)]),
+    "runia_p2p_free": (c_int, [c_void_p]),
+    "runia_p2p_export": (c_int, [c_void_p, c_void_p]),
+    "runia_p2p_open": (c_int, [c_void_p, ctypes.POINTER(c_void_p)]),
+    "runia_p2p_close": (c_int, [c_void_p]),
+    "runia_p2p_all_gather": (
+        c_int, [c_void_p, c_size_t, c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_size_t, c_uint64, c_int, c_void_p]),
+    "runia_p2p_status": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
     "runia_centred_gram_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
     "runia_roi_align_f32": (
         c_int,
@@ -926,7 +935,8 @@ def eigh(a: torch.Tensor, max_sweeps: int = 30, blocked: bool = True):
     else:
         raise RuniaHipError(f"the Jacobi sweeps did not converge in {max_sweeps} sweeps (n = {n})")
     w = torch.diagonal(work)[:n].clone()
-    order = torch.argsort(w)
+    # ascending order: n scalars, ranked on the host (the convergence loop has synchronised already; no device sort)
+    order = torch.from_numpy(np.argsort(w.cpu().numpy(), kind="stable")).to(a.device)
     return w[order], v[:n, :n][:, order].contiguous()
 
 

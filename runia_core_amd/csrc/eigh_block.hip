@@ -84,8 +84,14 @@ __global__ __launch_bounds__(256) void block_solve_kernel(const double* __restri
         round_robin_pair(SB, ts, lane, p, q);
         const double app = S[p * SP + p], aqq = S[q * SP + q], apq = S[p * SP + q];
         double c = 1.0, s = 0.0;
-        // |apq| > max(1e-19 |A|, 1e-17 sqrt|app aqq|), compared squared (no square root on the serial path of the step)
-        if (apq * apq > fmax(1e-38 * a_norm * a_norm, 1e-34 * fabs(app * aqq))) {
+        // rotate when |apq| > max(1e-19 |A|, 2e-15 sqrt|app aqq|), compared squared (no square root on the serial path).
+        // The relative bound sits ABOVE the rounding noise of the blocked update: a large-angle rotation inside a
+        // cluster of (nearly) equal eigenvalues leaves (R^T S R)_pq = O(eps) sqrt|app aqq| behind - the product does not
+        // return the exact zero a scalar rotation writes - and with the scalar form's 1e-17 that residue was rotated again
+        // sweep after sweep (a PCA-whitened precision matrix, all eigenvalues ~ 1, did not settle in 30 sweeps).
+        // Small-angle rotations leave no such residue (their product terms are O(angle) small), so 2e-15 costs no accuracy
+        // where eigenvalues are separated: measured |w - LAPACK| <= 8e-12 |A| up to n = 2048.
+        if (apq * apq > fmax(1e-38 * a_norm * a_norm, 4e-30 * fabs(app * aqq))) {
           // tan of the rotation angle: t = sign(theta) / (|theta| + sqrt(theta^2 + 1)), theta = (aqq - app) / (2 apq);
           // with x = aqq - app, y = 2 apq:  t = sign(x y) |y| / (|x| + sqrt(x^2 + y^2)) - one division instead of two,
           // reciprocal and reciprocal square root from the hardware seeds + Newton steps (1-2 ulp: a rotation only has to

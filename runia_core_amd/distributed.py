@@ -20,7 +20,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-__all__ = ["shard_bounds", "gather_scores", "sharded_scores", "broadcast_fitted", "ShardedPostprocessor"]
+__all__ = ["shard_bounds", "gather_scores", "sharded_scores", "broadcast_fitted", "ShardedPostprocessor", "OneShotGather"]
 
 
 def shard_bounds(n_rows: int, world: int, rank: int) -> Tuple[int, int]:
@@ -243,3 +243,123 @@ class ShardedPostprocessor:
         return gather_scores(local, n, self.group).cpu().numpy()
 
     __call__ = postprocess
+
+
+class OneShotGather:
+    """One-shot all-gather of equal score shards over xGMI (``csrc/p2p.hip``; SURVEY section 5's fallback for a
+    latency-bound gather): every rank writes its shard straight into every peer's receive buffer (mapped through HIP IPC)
+    and raises a flag; a second small launch waits for the flags of the step and copies the gathered vector out.  Two
+    launches on the caller's stream, no host synchronisation, no ring of ``world - 1`` hops.
+
+    Opt-in alternative to ``gather_scores`` (the RCCL ``all_gather_into_tensor``); same result.  All ranks construct it
+    collectively (the IPC handles travel through ``all_gather_object`` of the default / given group - any backend) and
+    call it the same number of times.  The output buffers alternate between two slots: a gathered vector stays valid until
+    the call after the next one.  ``check()`` reports a wait that timed out (a peer that never arrived)."""
+
+    def __init__(self, max_shard_elems: int, dtype: torch.dtype = torch.float64, group=None, timeout_ms: int = 2000):
+        import ctypes
+
+        from . import _hip
+
+        self._lib = _hip.load_library()
+        _hip.require_gpu()
+        self.world, self.rank = _world(group)
+        if not (1 <= self.world <= 16):
+            raise ValueError("OneShotGather supports up to 16 ranks of one node")
+        self.dtype, self.group, self.timeout_ms = dtype, group, int(timeout_ms)
+        self.elem = torch.empty((), dtype=dtype).element_size()
+        self.capacity = max(1, int(max_shard_elems)) * self.elem
+        # Construction is collective, and a rank that fails (no IPC support, out of memory) must not leave the others
+        # waiting in a collective: every rank always takes part in both exchanges and all ranks raise together.
+        self._own, self._opened, self._peers = None, [], (ctypes.c_void_p * self.world)()
+        raw, err = None, None
+        try:
+            buf = ctypes.c_void_p()
+            _hip._check(self._lib.runia_p2p_alloc(self.world, self.capacity, ctypes.byref(buf)), "runia_p2p_alloc")
+            self._own = buf.value
+            handle = ctypes.create_string_buffer(64)
+            _hip._check(self._lib.runia_p2p_export(self._own, handle), "runia_p2p_export")
+            raw = bytes(handle.raw)
+        except Exception as e:  # noqa: BLE001 - reported to every rank below
+            err = repr(e)
+        handles = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(handles, raw, group=group)
+        else:
+            handles[0] = raw
+        if err is None and all(h is not None for h in handles):
+            try:
+                for r in range(self.world):
+                    if r == self.rank:
+                        self._peers[r] = self._own
+                        continue
+                    p = ctypes.c_void_p()
+                    _hip._check(self._lib.runia_p2p_open(ctypes.create_string_buffer(handles[r], 64), ctypes.byref(p)),
+                                "runia_p2p_open")
+                    self._peers[r] = p.value
+                    self._opened.append(p.value)
+            except Exception as e:  # noqa: BLE001
+                err = repr(e)
+        elif err is None:
+            err = "a peer could not allocate or export its buffer"
+        errs = [None] * self.world
+        if self.world > 1:
+            dist.all_gather_object(errs, err, group=group)  # doubles as the barrier: every mapping exists before a write
+        else:
+            errs[0] = err
+        self._seq = 0
+        self._out = [None, None]
+        if any(e is not None for e in errs):
+            self._release()
+            raise _hip.RuniaHipError(f"OneShotGather could not be set up on every rank: {[e for e in errs if e][:2]}")
+
+    def _release(self) -> None:
+        for p in self._opened:
+            self._lib.runia_p2p_close(p)
+        if self._own is not None:
+            self._lib.runia_p2p_free(self._own)
+        self._own, self._opened = None, []
+
+    def __call__(self, local: torch.Tensor, n_rows: int) -> torch.Tensor:
+        from . import _hip
+
+        per = -(-n_rows // self.world) if n_rows > 0 else 0
+        if local.dtype != self.dtype or not local.is_cuda:
+            raise TypeError(f"OneShotGather({self.dtype}): got a {local.dtype} shard on {local.device}")
+        if per * self.elem > self.capacity:
+            raise ValueError(f"shard of {per} elements exceeds the capacity this gather was built with")
+        if per == 0:
+            return local.new_empty(0)
+        if local.numel() == per and local.is_contiguous():
+            shard = local
+        else:
+            shard = torch.zeros(per, dtype=self.dtype, device=local.device)
+            shard[: local.numel()] = local
+        self._seq += 1
+        slot = self._seq & 1
+        if self._out[slot] is None or self._out[slot].numel() != self.world * per:
+            self._out[slot] = torch.empty(self.world * per, dtype=self.dtype, device=local.device)
+        out = self._out[slot]
+        _hip._check(self._lib.runia_p2p_all_gather(shard.data_ptr(), per * self.elem, out.data_ptr(), self._peers, self.world,
+                                                   self.rank, self.capacity, self._seq, self.timeout_ms, _hip._stream()),
+                    "runia_p2p_all_gather")
+        return out[:n_rows]
+
+    def check(self) -> None:
+        """Synchronises; raises if any wait so far gave up on a peer."""
+        import ctypes
+
+        from . import _hip
+
+        status = ctypes.c_int(0)
+        _hip._check(self._lib.runia_p2p_status(self._own, ctypes.byref(status)), "runia_p2p_status")
+        if status.value != 0:
+            raise _hip.RuniaHipError("OneShotGather: a wait timed out - a peer never delivered its shard")
+
+    def close(self) -> None:
+        if self._own is None:
+            return
+        torch.cuda.synchronize()
+        if self.world > 1:
+            dist.barrier(group=self.group)  # nobody unmaps a buffer a peer may still be writing
+        self._release()

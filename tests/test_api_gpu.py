@@ -807,6 +807,45 @@ def test_jacobi_eigh_vs_numpy(n):
     assert np.abs(a @ v - v * w).max() < 1e-11 * scale
 
 
+@pytest.mark.parametrize("kind", ["whitened", "identity_noise", "two_clusters", "indefinite", "rank_deficient", "zeros"])
+@pytest.mark.parametrize("blocked", [True, False])
+def test_jacobi_eigh_terminates_on_clustered_spectra(kind, blocked):
+    """Spectra on which a Jacobi sweep criterion can fail to settle: the precision matrix of PCA-whitened data (every
+    eigenvalue ~ 1: what LaREMPipeline folds at first use), an identity plus rounding noise, two exact clusters, a
+    zero-diagonal indefinite matrix, a rank-10 Gram matrix, the zero matrix.  Both solver forms must stop within the sweep
+    limit and agree with LAPACK."""
+    from runia_core_amd import _hip
+
+    rng = np.random.default_rng(len(kind))
+    n = 200 if kind != "two_clusters" else 64
+    if kind == "whitened":
+        x = rng.standard_normal((2048, n))
+        x -= x.mean(0)
+        w, v = np.linalg.eigh(x.T @ x / 2048)
+        a = np.linalg.pinv(np.cov((x @ v / np.sqrt(w)).T, bias=True))
+    elif kind == "identity_noise":
+        e = rng.standard_normal((n, n)) * 1e-16
+        a = np.eye(n) + e + e.T
+    elif kind == "two_clusters":
+        q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+        a = (q * np.r_[np.ones(n // 2), 3 * np.ones(n - n // 2)]) @ q.T
+    elif kind == "indefinite":
+        g = rng.standard_normal((n, n))
+        a = g + g.T
+        np.fill_diagonal(a, 0.0)
+    elif kind == "rank_deficient":
+        g = rng.standard_normal((n, 10))
+        a = g @ g.T
+    else:
+        a = np.zeros((n, n))
+    a = (a + a.T) * 0.5
+    w, v = _hip.eigh(torch.from_numpy(a).cuda(), max_sweeps=30, blocked=blocked)
+    w, v = w.cpu().numpy(), v.cpu().numpy()
+    nrm = max(1e-300, float(np.abs(a).max()))
+    assert np.abs(w - np.linalg.eigvalsh(a)).max() / nrm < 1e-11
+    assert np.abs(a @ v - v * w).max() / nrm < 1e-11 and np.abs(v.T @ v - np.eye(n)).max() < 1e-11
+
+
 def test_device_fit_pinvh_and_pca_without_vendor_solver(monkeypatch):
     """config.device_fit: MDLatentSpace.setup (covariance on the matrix cores + Jacobi pinvh, rank-deficient unit case
     included) against the reference-run fixtures, and apply_pca_ds_split(svd_solver="covariance_eigh") against sklearn."""
