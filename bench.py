@@ -184,6 +184,8 @@ def synth_latents(n, seed, shift, device, scale=1.0, corr=0.0, dead="ones"):
         mask = (rand < DROP_PROB / BLOCK**2).float().reshape(n * N_MC, 1, H, W)
         bm = 1 - torch.nn.functional.max_pool2d(mask, BLOCK, 1, BLOCK // 2)[:, :, :-1, :-1]
         gone = bm.sum(dim=(1, 2, 3)) == 0
+        if dead == "keep":
+            break
         if dead == "redraw":  # the policy of CounterDraws(redraw_dead_layers=True): such a layer draws again
             if not bool(gone.any()):
                 break
@@ -624,7 +626,7 @@ def main():
         # means against its standard error.  Both modes redraw fully dropped maps (no NaN score): the counter generator
         # inside K0, the host sets in synth_latents(dead="redraw").
         xo_full, _ = synth_latents(n, 998, 0.0, device, corr=args.ood_corr)
-        n_seeds = 6
+        n_seeds = 12
         au_c, au_p, nan_plain = [], [], 0
         for sd in range(n_seeds):
             ind_c = pipe.score_latents(x, _hip.CounterDraws(99 + sd, 0, True)).cpu().numpy()
