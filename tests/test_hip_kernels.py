@@ -672,7 +672,7 @@ def test_larem_chain_unfused(hip):
                                                (50, 7, 7, 2, 0.5, 9, 6), (16, 7, 7, 7, 0.3, 16, 5), (30, 7, 7, 4, 0.6, 13, 7),
                                                (20, 7, 7, 1, 0.5, 16, 300), (12, 7, 7, 5, 0.99, 16, 8),
                                                # up to 32 MC samples (the reference's default mcd_samples_nro) on 7x7 / 8x8 / 2x2
-                                               (40, 7, 7, 3, 0.4, 32, 5), (24, 8, 8, 3, 0.5, 25, 4), (33, 2, 2, 1, 0.5, 32, 6),
+                                               (40, 7, 7, 3, 0.4, 32, 5), (24, 8, 8, 3, 0.5, 25, 4), (33, 2, 2, 1, 0.15, 32, 6),
                                                (20, 7, 7, 3, 0.4, 20, 3), (16, 8, 8, 2, 0.6, 32, 3), (130, 7, 7, 2, 0.3, 17, 2)])
 def test_mc_entropy_fused_equals_unfused(hip, c, h, w, bs, p, n_mc, n):
     torch.manual_seed(c + n_mc)
@@ -692,7 +692,7 @@ def test_mc_entropy_fused_equals_unfused(hip, c, h, w, bs, p, n_mc, n):
     assert np.array_equal(a[fin], b[fin])
     assert np.isnan(a[~fin]).all()
     exp = oracle.kl_entropy_per_dim_vectorized(np.where(np.isfinite(z.cpu().numpy()), z.cpu().numpy(), 0.0), n_mc, k)
-    assert np.abs(a[fin] - exp[fin]).max() < 1e-11
+    assert fin.any() and np.abs(a[fin] - exp[fin]).max() < 1e-11
 
 
 def test_mc_entropy_two_call_form_equals_one_call(hip):
