@@ -60,6 +60,13 @@ __device__ __forceinline__ void sort_asc(T (&v)[NP]) {
   }
 }
 
+// a * b + c with c held in a scalar register pair (one rounding, as fma)
+__device__ __forceinline__ double fma_scalar_addend(double a, double b, double c) {
+  double r;
+  asm("v_fma_f64 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "s"(c));
+  return r;
+}
+
 // log(f) and the binary exponent e of a positive, finite, normal x = f * 2^e with f in [sqrt(1/2), sqrt(2)):
 // log(f) = 2 atanh(s), s = (f-1)/(f+1), |s| <= 0.1716, odd series to s^21 (next term < 3e-17); plain f64 operations,
 // ~35 instructions against ~75 of the library log (which carries double-double terms this sum does not need: the
@@ -77,16 +84,19 @@ __device__ __forceinline__ double log_mantissa(double x, int& e_out) {
   double q = num * r;
   q = fma(fma(-den, q, num), r, q);             // (f-1)/(f+1) to ~0.5 ulp
   const double t = q * q;
+  // Horner steps with the coefficient as a SCALAR operand of v_fma_f64: as C++ literals the compiler turns every step
+  // into v_fmac_f64 and first materialises its coefficient with two v_mov_b32 (20 vector instructions per thread); the
+  // scalar unit builds the constants for free
   double p = 1.0 / 21.0;
-  p = fma(p, t, 1.0 / 19.0);
-  p = fma(p, t, 1.0 / 17.0);
-  p = fma(p, t, 1.0 / 15.0);
-  p = fma(p, t, 1.0 / 13.0);
-  p = fma(p, t, 1.0 / 11.0);
-  p = fma(p, t, 1.0 / 9.0);
-  p = fma(p, t, 1.0 / 7.0);
-  p = fma(p, t, 1.0 / 5.0);
-  p = fma(p, t, 1.0 / 3.0);
+  p = fma_scalar_addend(p, t, 1.0 / 19.0);
+  p = fma_scalar_addend(p, t, 1.0 / 17.0);
+  p = fma_scalar_addend(p, t, 1.0 / 15.0);
+  p = fma_scalar_addend(p, t, 1.0 / 13.0);
+  p = fma_scalar_addend(p, t, 1.0 / 11.0);
+  p = fma_scalar_addend(p, t, 1.0 / 9.0);
+  p = fma_scalar_addend(p, t, 1.0 / 7.0);
+  p = fma_scalar_addend(p, t, 1.0 / 5.0);
+  p = fma_scalar_addend(p, t, 1.0 / 3.0);
   const double q2 = q + q;
   return fma(q2 * t, p, q2);
 }
@@ -116,6 +126,8 @@ __device__ __forceinline__ double column_log_sum(const float (&vs)[NP], int n, d
 #pragma unroll
     for (int i = i0; i < i0 + 4 && i < NP; ++i) {
       double e = kInf;
+      bool first = true;  // compile-time after unrolling: the first window's candidate is taken as it is (fmin(+inf, x)
+                          // cannot be folded by the compiler - x might be NaN - and cost one v_min_f64 per sample)
 #pragma unroll
       for (int j = 0; j <= K; ++j) {
         const int li = i - j, ri = i + (K - j);
@@ -124,7 +136,8 @@ __device__ __forceinline__ double column_log_sum(const float (&vs)[NP], int n, d
         if (j == 0) cand = gap[i][K - 1];           // gaps of an ascending column are >= 0
         else if (j == K) cand = gap[li][K - 1];
         else cand = fmax(gap[li][j - 1], gap[i][K - j - 1]);
-        e = fmin(e, cand);
+        e = first ? cand : fmin(e, cand);
+        first = false;
       }
       e = fmax(e, min_dist);
       if (FULL || i < n) prod *= e;

@@ -50,6 +50,12 @@ __device__ __forceinline__ void layer_consts(int cnt, int& m, float& flag, float
   zl = cnt ? __uint_as_float(runia_div::kDivLo[(m - 1) >> 1]) : 0.f;
 }
 
+__device__ __forceinline__ float add_f32(float a, float b) {
+  float r;
+  asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+  return r;
+}
+
 __device__ __forceinline__ float div_newton(float u, float den, float r) {
   const float q = u * r;
   const float e = fmaf(-den, q, u);
@@ -277,7 +283,10 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
   float z[NP];
   float q[PAIRS ? 1 : HW];   // quotients (x*numel)/sum ...
   f2 q2[PAIRS ? HW / 2 : 1];  // ... as row pairs in mask_slot order when H is even
-  float cur_zh = 1.0f;  // quotients start out as x / 1 (the m = 1 group comes first in the sorted table)
+  // quotients start out as x / 1 (the m = 1 group comes first in the sorted table).  The divisor in use is tracked by its
+  // BIT PATTERN: both values sit in scalar registers, and gfx950 compares scalar integers on the scalar unit but floats only
+  // on the vector unit (v_mov + v_cmp per drop layer: 32 of the kernel's 772 vector instructions)
+  unsigned cur_zh_bits = __float_as_uint(1.0f);
 #pragma unroll
   for (int p = 0; p < HW; ++p) {
     if constexpr (PAIRS) q2[mask_slot<HT, WT>(p) >> 1][mask_slot<HT, WT>(p) & 1] = u[p];
@@ -293,20 +302,31 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
   // scalar registers to vector lanes - 254 v_readlane / v_writelane; 4 per trip do not)
   constexpr int GCAP = FULL ? K1_GCAP : K1_GCAP / 2;
   constexpr int G = (GCAP / HW < 1) ? 1 : ((GCAP / HW > NP) ? NP : GCAP / HW);
+  // the +inf fill only matters when fewer than NP samples are produced (FULL writes every slot: NP / G whole trips)
+  if constexpr (!(FULL && NP % G == 0)) {
 #pragma unroll
-  for (int s = 0; s < NP; ++s) z[s] = INFINITY;
-#pragma unroll 1
+    for (int s = 0; s < NP; ++s) z[s] = INFINITY;
+  }
+#ifndef K1_TRIP_UNROLL
+#define K1_TRIP_UNROLL 1
+#endif
+#pragma unroll K1_TRIP_UNROLL
   for (int s0 = 0; s0 < NP; s0 += G) {
     float znew[G];
     // all scalar operands of this trip are requested up front (one wait instead of one per drop layer)
     float dg[G], rg[G], mg[G][HW];
+    // FULL: one base pointer per trip and constant offsets from it (the scalar loads then carry the layer's offset as an
+    // immediate; with sc = s0 + g inside the index the compiler kept one 64-bit address per drop layer in scalar registers)
+    const float* mk_t = mk + (FULL ? s0 * HW : 0);
+    const float* zhs_t = zhs + (FULL ? s0 : 0);
+    const float* zls_t = zls + (FULL ? s0 : 0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      const int sc = FULL ? s0 + g : ((s0 + g < n_mc) ? s0 + g : n_mc - 1);
-      dg[g] = zhs[sc];
-      rg[g] = zls[sc];
+      const int sc = FULL ? g : ((s0 + g < n_mc) ? s0 + g : n_mc - 1);
+      dg[g] = zhs_t[sc];
+      rg[g] = zls_t[sc];
 #pragma unroll
-      for (int p = 0; p < HW; ++p) mg[g][p] = mk[sc * HW + p];
+      for (int p = 0; p < HW; ++p) mg[g][p] = mk_t[sc * HW + p];
     }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -314,14 +334,14 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
       znew[g] = INFINITY;
       if (FULL || s < n_mc) {
         const float zh = dg[g], zl = rg[g];
-        if (zh != cur_zh) {  // wave-uniform: every thread of the block works on the same image
+        if (__float_as_uint(zh) != cur_zh_bits) {  // wave-uniform: every thread of the block works on the same image
 #pragma unroll
           for (int p = 0; p < HW; ++p) {
             const float qv = fmaf(u[p], zh, u[p] * zl);  // u / m, correctly rounded (div_consts.hpp)
             if constexpr (PAIRS) q2[mask_slot<HT, WT>(p) >> 1][mask_slot<HT, WT>(p) & 1] = qv;
             else q[p] = qv;
           }
-          cur_zh = zh;
+          cur_zh_bits = __float_as_uint(zh);
         }
         const float* m = mg[g];
         float col;
@@ -347,9 +367,11 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
             rows[2 * k2] = acc.x;
             rows[2 * k2 + 1] = acc.y;
           }
+          // plain v_add_f32: left to itself the compiler adds the halves of the row-pair registers with v_pk_add_f32 and
+          // op_sel, one useful add per packed instruction (4.2 issue cycles instead of 2.5)
           col = rows[0];
 #pragma unroll
-          for (int yi = 1; yi < HT; ++yi) col += rows[torch_chain<HT>(yi)];
+          for (int yi = 1; yi < HT; ++yi) col = add_f32(col, rows[torch_chain<HT>(yi)]);
         } else {
           float rm[HT];
 #pragma unroll
