@@ -795,6 +795,34 @@ def test_proj_sq_accumulate_equals_store_form(hip, n_rows):
     assert float(((a - ref).abs() / ref.abs().clamp_min(1.0)).max()) < 1e-12
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("d,r", [(512, 256), (96, 256), (520, 200), (512, 130)])
+def test_proj_sq_bits_do_not_depend_on_the_launch_shape(hip, d, r):
+    """K2' picks its kernel by the row count - one workgroup per 16-row tile over all columns, 16 x 128 column halves, 32 x 256
+    tiles for whole rounds.  All of them add a row's squares in the same column-group order: a row scores the same bits
+    whatever batch it sits in, stored or accumulated, whatever the alignment of H."""
+    torch.manual_seed(d + r)
+    n = 70000
+    h = torch.randn(n, d, dtype=torch.float64, device="cuda")
+    m = torch.randn(d, r, dtype=torch.float64, device="cuda") * 0.1
+    c = torch.randn(r, dtype=torch.float64, device="cuda")
+    pm = hip.pack_weights(m)
+    whole = hip.proj_sq_score(h, pm, c, r)
+    ref = -((h[:3000] @ m + c) ** 2).sum(1)
+    assert float(((whole[:3000] - ref).abs() / ref.abs().clamp_min(1.0)).max()) < 1e-12
+    for a, b in ((0, 1), (5, 105), (1000, 3100), (20000, 30000), (3, 65536 + 3)):
+        part = hip.proj_sq_score(h[a:b].contiguous(), pm, c, r)
+        assert torch.equal(part, whole[a:b]), (a, b)
+        acc = torch.zeros(b - a, dtype=torch.float64, device="cuda")
+        hip.proj_sq_accumulate(h[a:b].contiguous(), pm, c, r, acc)
+        assert torch.equal(acc, whole[a:b]), (a, b, "accumulate")
+    # rows that start 8 bytes off a 16-byte boundary
+    odd = torch.empty(n * d + 1, dtype=torch.float64, device="cuda")[1:].view(n, d)
+    odd.copy_(h)
+    assert odd.data_ptr() % 16 == 8
+    assert torch.equal(hip.proj_sq_score(odd[:10000], pm, c, r), whole[:10000])
+
+
 @pytest.mark.parametrize("c,h,w,bs,p,n_mc,n", [(512, 4, 4, 2, 0.5, 16, 9), (33, 8, 8, 3, 0.4, 12, 3), (70, 7, 7, 3, 0.4, 16, 3),
                                                (20, 2, 2, 1, 0.3, 16, 5), (64, 4, 4, 2, 0.0, 16, 2)])
 def test_mc_stack_table_path_equals_register_kernel(hip, c, h, w, bs, p, n_mc, n):
