@@ -102,14 +102,13 @@ __device__ __forceinline__ unsigned long long columns_below(int k) {  // positio
 
 constexpr int kMaskBitsWaves = 4;  // images per workgroup (independent waves)
 
-template <int HT, int WT, int NP>
+template <int HT, int WT, int NP, bool REDRAW = false>
 __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const float* __restrict__ rnd,
                                                                            int64_t rand_stride,
                                                                            float* __restrict__ table, int64_t N,
                                                                            int n_mc, float gamma, int block_size,
                                                                            int identity, int sort_layers,
-                                                                           uint64_t rng_seed, int64_t first_image,
-                                                                           int redraw) {
+                                                                           uint64_t rng_seed, int64_t first_image) {
   constexpr int HW = HT * WT;
   static_assert(HW <= 64 && NP <= 64, "one drop layer per 64-bit word");
   // draw i = layer * HW + position sits in bit i % 64 of ballot word i / 64.  Map sizes that divide 64 (2x2, 4x4, 8x8)
@@ -174,7 +173,7 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
   };
 
   unsigned long long keep = identity ? FULL : keep_of(seeds_of(0u));
-  if (redraw && !identity && !rnd) {
+  if (REDRAW && !identity && !rnd) {
     // throughput mode, opt-in: a drop layer that removed the whole map (0 * numel / 0 = NaN upstream) draws again from
     // the next counter block of the same image - a bounded, wave-uniform loop that only images with such a layer enter
     for (unsigned attempt = 1; attempt <= 16u; ++attempt) {
@@ -758,9 +757,13 @@ void launch_mask(const float* rnd, int64_t rand_image_stride, float* table, int6
                  int block_size, int identity, int sort_layers, uint64_t seed, int64_t first_image, int redraw,
                  hipStream_t s) {
   static_assert(HH * WW <= 64, "mc_mask_bits_kernel holds a drop layer in one 64-bit word");
-  mc_mask_bits_kernel<HH, WW, NPP><<<(unsigned)((N + kMaskBitsWaves - 1) / kMaskBitsWaves), 64 * kMaskBitsWaves, 0,
-                                     s>>>(rnd, rand_image_stride, table, N, n_mc, gamma, block_size, identity,
-                                          sort_layers, seed, first_image, redraw);
+  const unsigned grid = (unsigned)((N + kMaskBitsWaves - 1) / kMaskBitsWaves);
+  if (redraw)  // throughput mode, opt-in: its own instantiation, so that the common launch carries neither the check nor the code
+    mc_mask_bits_kernel<HH, WW, NPP, true><<<grid, 64 * kMaskBitsWaves, 0, s>>>(rnd, rand_image_stride, table, N, n_mc, gamma,
+                                                                              block_size, identity, sort_layers, seed, first_image);
+  else
+    mc_mask_bits_kernel<HH, WW, NPP, false><<<grid, 64 * kMaskBitsWaves, 0, s>>>(rnd, rand_image_stride, table, N, n_mc, gamma,
+                                                                               block_size, identity, sort_layers, seed, first_image);
 }
 
 // explicit draws of the counter generator, [N, n_mc, H, W] (tests; callers that want the values themselves)
