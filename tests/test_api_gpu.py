@@ -970,6 +970,29 @@ def test_per_roi_entropy_reference_run_fixture(name):
     assert np.allclose(torch.cat(stds).cpu().numpy(), g[f"{name}_stds"], rtol=1e-4, atol=1e-6)
 
 
+@pytest.mark.parametrize("sr,aligned,osz", [(2, True, 7), (1, True, 7), (2, False, 7), (2, True, (4, 8)), (2, True, 8), (0, True, 7),
+                                            (3, True, 7), (2, True, 9)])
+def test_roi_align_options_and_edge_boxes_vs_oracle(sr, aligned, osz):
+    """runia_roi_align_f32 against the oracle's restatement of torchvision's algorithm over its options - fixed 1x1 / 2x2 /
+    3x3 and adaptive sampling lattices, aligned or not, square and rectangular bins - on boxes inside, across the border,
+    entirely outside the map and degenerate (zero area), two images with batch indices."""
+    from runia_core_amd import _hip
+
+    rng = np.random.default_rng(17)
+    b, c, h, w = 2, 37, 20, 31
+    fm = rng.standard_normal((b, c, h, w)).astype(np.float32)
+    boxes = np.array([[10.0, 12.0, 90.0, 70.0], [-30.0, -20.0, 40.0, 35.0], [200.0, 100.0, 260.0, 170.0],
+                      [300.0, 300.0, 340.0, 350.0], [50.0, 50.0, 50.0, 50.0], [0.0, 0.0, 247.0, 159.0],
+                      [120.5, 33.25, 121.0, 140.75], [5.0, 150.0, 240.0, 158.0]], dtype=np.float32)
+    bidx = np.array([0, 1, 0, 1, 1, 0, 1, 0], dtype=np.int32)
+    scale = w / 248.0
+    got = _hip.roi_align(torch.from_numpy(fm).cuda(), torch.from_numpy(boxes).cuda(), osz, scale, sr, aligned,
+                         batch_idx=torch.from_numpy(bidx).cuda()).cpu().numpy()
+    exp = np.concatenate([oracle.roi_align(fm[bi:bi + 1], boxes[i:i + 1], osz, scale, sr, aligned) for i, bi in enumerate(bidx)])
+    assert got.shape == exp.shape
+    assert np.allclose(got, exp, rtol=2e-6, atol=2e-6), float(np.abs(got - exp).max())
+
+
 def test_cfg4_per_roi_path_at_size():
     """Config 4 shape end to end on the device: 100 proposals per image on a 256-channel 50x80 feature map, 7x7 ROI
     bins, 16 MC DropBlock layers (counter draws) -> (100, 256) entropies per image; rows are independent of the other
