@@ -356,7 +356,16 @@ class OneShotGather:
         if status.value != 0:
             raise _hip.RuniaHipError("OneShotGather: a wait timed out - a peer never delivered its shard")
 
+    def __del__(self):  # best effort for a gather that was never closed: no collective here, just the local resources
+        try:
+            if getattr(self, "_own", None) is not None:
+                torch.cuda.synchronize()
+                self._release()
+        except Exception:  # noqa: BLE001 - interpreter shutdown
+            pass
+
     def close(self) -> None:
+        """Collective: every rank calls it (a barrier makes sure nobody unmaps a buffer a peer may still be writing)."""
         if self._own is None:
             return
         torch.cuda.synchronize()
