@@ -279,7 +279,6 @@ int runia_eigh_init_f64(const double* A, double* V, int64_t n, void* workspace, 
                         runia_stream_t stream);
 int runia_eigh_sweep_f64(double* A, double* V, int64_t n, void* workspace, size_t workspace_bytes,
                          unsigned* rotations, runia_stream_t stream);
-/* C [M, N] = A [M, K] * B  (B [K, N], or B [N, K] read transposed when transpose_b != 0); f64, setup-time sizes. */
 /* Blocked form of the same cyclic Jacobi method (csrc/eigh_block.hip): a sweep is (n/32 - 1) steps of two launches -
  * one 64 x 64 sub-problem per pair of 32-column blocks solved in LDS, then A <- R^T A R, V <- V R as 64^3 products on the
  * f64 matrix cores - instead of 2 (n - 1) launches of scalar rotations.  Works on PADDED matrices: N =
@@ -292,6 +291,7 @@ int runia_eigh_block_init_f64(const double* A, double* V, int64_t N, void* works
                               runia_stream_t stream);
 int runia_eigh_block_sweep_f64(double* A, double* V, int64_t N, void* workspace, size_t workspace_bytes,
                                unsigned* rotations, runia_stream_t stream);
+/* C [M, N] = A [M, K] * B  (B [K, N], or B [N, K] read transposed when transpose_b != 0); f64, setup-time sizes. */
 int runia_matmul_f64(const double* A, const double* B, double* C, int64_t M, int64_t N, int64_t K, int transpose_b,
                      runia_stream_t stream);
 /* f4: Gram form of eigen_score's covariance: G [n, n] = Ec Ec^T / denom with Ec = E - column means, E [n, H] f32

@@ -5,7 +5,8 @@
 * the covariance of ``MDLatentSpace.setup`` and ``mahalanobis_preprocess`` (``np.cov(X.T, bias=1)`` inside sklearn
   ``EmpiricalCovariance``, reference ``inference/postprocessors.py:217-220`` / ``inference/funcs.py:62-66``) to the f64
   matrix cores (``runia_covariance_*``),
-* ``scipy.linalg.pinvh`` to the hand-written Jacobi eigen-solver (``runia_eigh_*``, ``csrc/eigh.hip``) with SciPy's
+* ``scipy.linalg.pinvh`` to the hand-written Jacobi eigen-solver (blocked form ``runia_eigh_block_*``, ``csrc/eigh_block.hip``;
+  scalar-rotation form ``runia_eigh_*``, ``csrc/eigh.hip``) with SciPy's
   cut-off rule and a device matrix product,
 * the PCA fit of ``apply_pca_ds_split`` to the device: ``svd_solver="covariance_eigh" | "full"`` = covariance + the same
   eigen-solver + sklearn's sign convention (``svd_flip(u_based_decision=False)``); the reference's default
