@@ -25,27 +25,61 @@ __device__ __forceinline__ void cswap(double& a, double& b) {
   b = hi;
 }
 
-// Ascending sort of NP (power of two) registers.  NP = 16: the 60-comparator, 10-layer network (the best
-// known size); other sizes: Batcher's odd-even merge sort (19 / 191 / 543 comparators for 8 / 32 / 64).
-// Both were checked with the 0-1 principle (all 2^16 inputs; 2e6 random 0-1 vectors for 32 and 64).
+// One 3-sorter = v_min3_f32 + v_med3_f32 + v_max3_f32: three instructions order three registers, where compare-exchanges
+// need three pairs = six (min / max / med3 all issue at the same ~4.1 cycles on gfx950, tools/microbench/valu_issue.hip).
+// A NaN operand is dropped in favour of another operand (v_med3_f32 returns the minimum then), as with cswap: callers
+// catch NaN samples before sorting.
+__device__ __forceinline__ void sort3(float& a, float& b, float& c) {
+  float lo, md, hi;
+  asm("v_min3_f32 %0, %1, %2, %3" : "=v"(lo) : "v"(a), "v"(b), "v"(c));
+  asm("v_med3_f32 %0, %1, %2, %3" : "=v"(md) : "v"(a), "v"(b), "v"(c));
+  asm("v_max3_f32 %0, %1, %2, %3" : "=v"(hi) : "v"(a), "v"(b), "v"(c));
+  a = lo;
+  b = md;
+  c = hi;
+}
+__device__ __forceinline__ void sort3(double& a, double& b, double& c) {  // no 3-input f64 min / max on gfx950
+  cswap(a, b);
+  cswap(b, c);
+  cswap(a, b);
+}
+
+// Ascending sort of NP (power of two) registers.
+// NP = 16: 28 three-sorters = 84 instructions (the best-known compare-exchange network, 60 comparators in 10 layers, is
+// 120); NP = 8: 8 three-sorters = 24 instructions (19 comparators = 38).  Both networks were found by
+// tools/search/sorter3.cpp (mutate a valid network of 2- and 3-sorters, keep the mutant if it still sorts every 0/1
+// input and costs no more) and are re-checked over all 2^NP 0/1 inputs by tests/test_abi_and_host.py (0-1 principle:
+// min3 / med3 / max3 are monotone, so it carries over).  NP = 32 / 64: 16-blocks by that network + Batcher's odd-even
+// merge stages over them (32: 2 * 84 + 2 * 65 = 298 instructions instead of 2 * 191); smaller sizes: Batcher's sort.
+template <int OFF, int NP, typename T>
+__device__ __forceinline__ void sort16_at(T (&v)[NP]) {
+#define RUNIA_S3(a, b, c) sort3(v[OFF + a], v[OFF + b], v[OFF + c]);
+  RUNIA_S3(6, 7, 15) RUNIA_S3(10, 12, 13) RUNIA_S3(0, 2, 3) RUNIA_S3(1, 4, 5) RUNIA_S3(9, 11, 14)
+  RUNIA_S3(3, 5, 15) RUNIA_S3(8, 13, 14) RUNIA_S3(2, 4, 7) RUNIA_S3(8, 10, 11) RUNIA_S3(9, 10, 12)
+  RUNIA_S3(5, 7, 14) RUNIA_S3(0, 1, 6) RUNIA_S3(11, 12, 13) RUNIA_S3(3, 4, 6) RUNIA_S3(1, 2, 3)
+  RUNIA_S3(5, 6, 13) RUNIA_S3(0, 8, 9) RUNIA_S3(1, 8, 9) RUNIA_S3(3, 7, 11) RUNIA_S3(13, 14, 15)
+  RUNIA_S3(11, 12, 13) RUNIA_S3(4, 8, 11) RUNIA_S3(5, 7, 9) RUNIA_S3(2, 6, 10) RUNIA_S3(6, 7, 8)
+  RUNIA_S3(3, 5, 6) RUNIA_S3(2, 3, 4) RUNIA_S3(9, 10, 11)
+#undef RUNIA_S3
+}
+
 template <int NP, typename T>
 __device__ __forceinline__ void sort_asc(T (&v)[NP]) {
-  if constexpr (NP == 16) {
-#define RUNIA_CX(a, b) cswap(v[a], v[b]);
-    RUNIA_CX(0, 13) RUNIA_CX(1, 12) RUNIA_CX(2, 15) RUNIA_CX(3, 14) RUNIA_CX(4, 8) RUNIA_CX(5, 6) RUNIA_CX(7, 11) RUNIA_CX(9, 10)
-    RUNIA_CX(0, 5) RUNIA_CX(1, 7) RUNIA_CX(2, 9) RUNIA_CX(3, 4) RUNIA_CX(6, 13) RUNIA_CX(8, 14) RUNIA_CX(10, 15) RUNIA_CX(11, 12)
-    RUNIA_CX(0, 1) RUNIA_CX(2, 3) RUNIA_CX(4, 5) RUNIA_CX(6, 8) RUNIA_CX(7, 9) RUNIA_CX(10, 11) RUNIA_CX(12, 13) RUNIA_CX(14, 15)
-    RUNIA_CX(0, 2) RUNIA_CX(1, 3) RUNIA_CX(4, 10) RUNIA_CX(5, 11) RUNIA_CX(6, 7) RUNIA_CX(8, 9) RUNIA_CX(12, 14) RUNIA_CX(13, 15)
-    RUNIA_CX(1, 2) RUNIA_CX(3, 12) RUNIA_CX(4, 6) RUNIA_CX(5, 7) RUNIA_CX(8, 10) RUNIA_CX(9, 11) RUNIA_CX(13, 14)
-    RUNIA_CX(1, 4) RUNIA_CX(2, 6) RUNIA_CX(5, 8) RUNIA_CX(7, 10) RUNIA_CX(9, 13) RUNIA_CX(11, 14)
-    RUNIA_CX(2, 4) RUNIA_CX(3, 6) RUNIA_CX(9, 12) RUNIA_CX(11, 13)
-    RUNIA_CX(3, 5) RUNIA_CX(6, 8) RUNIA_CX(7, 9) RUNIA_CX(10, 12)
-    RUNIA_CX(3, 4) RUNIA_CX(5, 6) RUNIA_CX(7, 8) RUNIA_CX(9, 10) RUNIA_CX(11, 12)
-    RUNIA_CX(6, 7) RUNIA_CX(8, 9)
-#undef RUNIA_CX
+  static_assert((NP & (NP - 1)) == 0, "power of two");
+  if constexpr (NP == 8) {
+#define RUNIA_S3(a, b, c) sort3(v[a], v[b], v[c]);
+    RUNIA_S3(0, 5, 6) RUNIA_S3(1, 2, 3) RUNIA_S3(4, 6, 7) RUNIA_S3(0, 1, 4) RUNIA_S3(2, 5, 6) RUNIA_S3(3, 6, 7) RUNIA_S3(3, 4, 5) RUNIA_S3(1, 2, 3)
+#undef RUNIA_S3
   } else {
+    // 16-blocks by the 3-sorter network, then (and for NP < 16 from the start) Batcher's merge stages
+    if constexpr (NP >= 16) {
+      sort16_at<0>(v);
+      if constexpr (NP >= 32) sort16_at<16>(v);
+      if constexpr (NP >= 64) { sort16_at<32>(v); sort16_at<48>(v); }
+      static_assert(NP <= 64, "add the 16-blocks of a larger sort here");
+    }
 #pragma unroll
-    for (int p = 1; p < NP; p <<= 1) {
+    for (int p = (NP >= 16 ? 16 : 1); p < NP; p <<= 1) {
 #pragma unroll
       for (int k = p; k >= 1; k >>= 1) {
 #pragma unroll

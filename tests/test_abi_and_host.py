@@ -334,3 +334,64 @@ def test_semantic_entropy_reference_goldens():
 
     e, cl = sc.semantic_entropy(_Nli(), _Tok(), ["a1", "b1", "a2", "c1", "b2", "a3"])
     assert cl == {0: [0, 2, 5], 1: [1, 4], 2: [3]} and abs(e - 1.0114042647073516) < 1e-12
+
+
+def _three_sorter_networks():
+    """The 3-sorter networks of csrc/entropy_core.hpp, read from the source: {inputs: [(a, b, c), ...]}."""
+    src = open(os.path.join(ROOT, "runia_core_amd", "csrc", "entropy_core.hpp")).read()
+    body16 = src[src.index("void sort16_at("):src.index("void sort_asc(")]
+    body8 = src[src.index("if constexpr (NP == 8)"):]
+    body8 = body8[:body8.index("#undef RUNIA_S3")]
+    pat = re.compile(r"RUNIA_S3\((\d+), (\d+), (\d+)\)")
+    return {16: [tuple(map(int, m)) for m in pat.findall(body16)], 8: [tuple(map(int, m)) for m in pat.findall(body8)]}
+
+
+def _apply_three_sorters(wires, net, off=0):
+    for a, b, c in net:
+        x, y, z = wires[off + a], wires[off + b], wires[off + c]
+        wires[off + a], wires[off + b], wires[off + c] = x & y & z, (x & y) | (y & z) | (x & z), x | y | z
+
+
+def test_three_sorter_networks_sort_every_zero_one_input():
+    """0-1 principle: a network of monotone elements (min3 / med3 / max3) that sorts every 0/1 vector sorts everything.
+    All 2^16 (2^8) inputs at once, one bit-vector per wire."""
+    nets = _three_sorter_networks()
+    assert len(nets[16]) == 28 and len(nets[8]) == 8  # 84 and 24 instructions
+    for n, net in nets.items():
+        assert all(0 <= a < b < c < n for a, b, c in net)  # min lands on the lowest wire
+        v = np.arange(1 << n, dtype=np.uint32)
+        wires = [((v >> i) & 1).astype(bool) for i in range(n)]
+        _apply_three_sorters(wires, net)
+        for i in range(n - 1):
+            assert not np.any(wires[i] & ~wires[i + 1]), (n, i)
+
+
+def test_sort_of_32_is_two_16_blocks_and_batcher_merge():
+    """sort_asc<32>: the 16-network on each half, then the p = 16 stage of Batcher's odd-even merge sort (same loop
+    as the source).  A merge network is checked by every pair of sorted 0/1 halves (17 x 17); real values on top."""
+    net = _three_sorter_networks()[16]
+
+    def merge_stage(w, n, p):
+        k = p
+        while k >= 1:
+            for j in range(k % p, n - k, 2 * k):
+                for i in range(k):
+                    if i + j + k < n and (i + j) // (2 * p) == (i + j + k) // (2 * p):
+                        lo, hi = np.minimum(w[i + j], w[i + j + k]), np.maximum(w[i + j], w[i + j + k])
+                        w[i + j], w[i + j + k] = lo, hi
+            k //= 2
+
+    cases = np.array([[0] * (16 - a) + [1] * a + [0] * (16 - b) + [1] * b for a in range(17) for b in range(17)])
+    w = [cases[:, i].copy() for i in range(32)]
+    merge_stage(w, 32, 16)
+    assert all(np.all(w[i] <= w[i + 1]) for i in range(31))
+    rng = np.random.default_rng(5)
+    vals = rng.standard_normal((4096, 32)).astype(np.float32)
+    vals[::7, 3] = vals[::7, 9]  # ties
+    w = [vals[:, i].copy() for i in range(32)]
+    for off in (0, 16):
+        for a, b, c in net:
+            t = np.sort(np.stack([w[off + a], w[off + b], w[off + c]]), axis=0)
+            w[off + a], w[off + b], w[off + c] = t[0], t[1], t[2]
+    merge_stage(w, 32, 16)
+    np.testing.assert_array_equal(np.stack(w, axis=1), np.sort(vals, axis=1))
