@@ -581,8 +581,13 @@ struct ProjSqArgs {
 // Few components (the reference's default is nro_components = 16): SPLIT = false with NCT = 1 covers r <= 64 (each wave
 // one 16-column tile), with NCT = 2 r <= 128 - the zero-padded column tiles beyond r are simply not computed (the
 // 256-column forms spend the same 45-50 us on r = 16 as on r = 256).
+// 16-row forms: 96 vector registers = 5 waves per SIMD, so the 1 250 workgroups of 10 000 rows are all resident at once
+// (98 registers = 4 waves left 226 workgroups for a second, thinly occupied round: 45.5 -> 44.5 us)
+#ifndef K2_WAVES
+#define K2_WAVES 5
+#endif
 template <int RT, int NCT, bool ACCUMULATE = false, bool SPLIT = (NCT == 2)>
-__global__ __launch_bounds__(256) void proj_sq_kernel(ProjSqArgs g) {
+__global__ __launch_bounds__(256, (RT == 1 && NCT <= 2) ? K2_WAVES : 1) void proj_sq_kernel(ProjSqArgs g) {
   constexpr int BM = 16 * RT;
   __shared__ double lds_a[2 * BM * APITCH];
   constexpr int NG = (NCT + 1) / 2;  // 32-column groups per wave: the unit of the (launch-independent) summation order
