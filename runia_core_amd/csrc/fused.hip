@@ -586,10 +586,21 @@ struct ProjSqArgs {
 #ifndef K2_WAVES
 #define K2_WAVES 5
 #endif
-template <int RT, int NCT, bool ACCUMULATE = false, bool SPLIT = (NCT == 2)>
-__global__ __launch_bounds__(256, (RT == 1 && NCT <= 2) ? K2_WAVES : 1) void proj_sq_kernel(ProjSqArgs g) {
+#ifndef K2_DMA
+#define K2_DMA 1
+#endif
+#ifndef K2_WAVES_DMA
+#define K2_WAVES_DMA 5  // (the DMA form needs 74 vector registers, but 6 waves per SIMD measured 2 % slower than 5)
+#endif
+template <int RT, int NCT, bool ACCUMULATE, bool SPLIT, bool DMA>
+__global__ __launch_bounds__(256, (RT == 1 && NCT <= 2) ? (DMA ? K2_WAVES_DMA : K2_WAVES) : 1) void proj_sq_kernel(ProjSqArgs g) {
+#if defined(__HIP_DEVICE_COMPILE__)  // (the host pass only needs the launch stub; the body uses device-only buffer builtins)
   constexpr int BM = 16 * RT;
-  __shared__ double lds_a[2 * BM * APITCH];
+  __shared__ double lds_a[DMA ? 1 : 2 * BM * APITCH];
+  // the DMA form's two chunk buffers are separate objects: the compiler orders a ds_read behind every LDS DMA it cannot
+  // prove disjoint (one array: `s_waitcnt vmcnt(0)` in front of each chunk's first read, the DMA of the NEXT chunk included)
+  __shared__ __attribute__((aligned(16))) double lds_d0[DMA ? BM * KC : 2];
+  __shared__ __attribute__((aligned(16))) double lds_d1[DMA ? BM * KC : 2];
   constexpr int NG = (NCT + 1) / 2;  // 32-column groups per wave: the unit of the (launch-independent) summation order
   __shared__ double part[4 * NG * BM];
   const int64_t n_pad = n_padded(g.r);
@@ -609,7 +620,7 @@ __global__ __launch_bounds__(256, (RT == 1 && NCT <= 2) ? K2_WAVES : 1) void pro
     if (tile * BM >= g.N) return;  // padding of the last group of 8 tiles (uniform over the workgroup)
   }
   const int64_t r0 = tile * BM;
-  const int64_t nchunks = k_padded(g.D) / KC;
+  const int nchunks = (int)(k_padded(g.D) / KC);
   constexpr int PER_T = BM * KC / 256;
   double rowsq[NG][RT][4];
 #pragma unroll
@@ -625,41 +636,98 @@ __global__ __launch_bounds__(256, (RT == 1 && NCT <= 2) ? K2_WAVES : 1) void pro
     for (int a = 0; a < RT; ++a)
 #pragma unroll
       for (int c = 0; c < NCT; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
-    const double2* bp = reinterpret_cast<const double2*>(g.packed_m) + ctbase * 64 + lane;
-    double2 bring[4][NCT];  // B fragments three k-step pairs ahead (mfma_chunk_ring)
+    double2 bring[4][NCT];  // B fragments three k-step pairs ahead
+    if constexpr (DMA) {
+      // DMA form (whole chunks of a matrix below 4 GiB, the usual case; proj_sq_dma_ok): per chunk and wave ONE buffer_load ... lds for
+      // the rows (no staging registers, no ds_write), B fragments through a scalar offset, the LDS buffer a compile-time
+      // constant (chunks are taken two at a time): the vector ALU issues the matrix instructions and nothing else.
+      const __amdgpu_buffer_rsrc_t brsrc = buffer_of(g.packed_m, (unsigned)(packed_elems(g.D, g.r) * 8));
+      const int64_t rows_here = (g.N - r0 < BM) ? g.N - r0 : BM;  // rows past N read as zero (range check)
+      const __amdgpu_buffer_rsrc_t arsrc = buffer_of(g.h + r0 * g.D, (unsigned)(rows_here * g.D * 8));
+      const unsigned lane_bytes = (unsigned)lane * 16u;
+      const unsigned pair_stride_bytes = (unsigned)NT * 1024u;
+      const unsigned ct_bytes = (unsigned)ctbase * 1024u;
+      // DMA instruction j of a chunk fills slots 64j .. 64j+63: slot = kpair * BM + row
+      constexpr int NDMA = BM / 4 / 4;  // per wave (BM / 4 instructions per chunk over 4 waves)
+      unsigned a_lane_bytes[NDMA];
 #pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-      for (int c = 0; c < NCT; ++c) bring[j][c] = bp[j * NT * 64 + c * 64];
-    // staging: element q*256 + tid of the BM x KC chunk (a wave covers two 256-byte row segments per pass)
-    double areg[PER_T];
-    const int srow = tid / KC, skk = tid % KC;  // + 256/KC rows per q
-    // interior row tile of a matrix whose width is a whole number of chunks (uniform over the workgroup): plain loads off
-    // one running pointer - predicated loads and 64-bit index arithmetic are vector instructions the matrix pipe waits for
-    const bool interior = (r0 + BM <= g.N) && (g.D % KC == 0);
-    const double* pa = g.h + (r0 + srow) * g.D + skk;
-    auto load_a = [&](int64_t kc) {
-      if (interior) {
-#pragma unroll
-        for (int q = 0; q < PER_T; ++q) areg[q] = pa[(int64_t)q * (256 / KC) * g.D + kc];
-        return;
+      for (int i = 0; i < NDMA; ++i) {
+        const int slot = 64 * (wave + 4 * i) + lane;
+        a_lane_bytes[i] = (unsigned)(((slot % BM) * g.D + 2 * (slot / BM)) * 8);
       }
-      const int64_t gk = kc + skk;
+      auto dma_rows = [&](int bufc, int kc) {
 #pragma unroll
-      for (int q = 0; q < PER_T; ++q) {
-        const int64_t gr = r0 + srow + q * (256 / KC);
-        areg[q] = (gr < g.N && gk < g.D) ? g.h[gr * g.D + gk] : 0.0;
+        for (int i = 0; i < NDMA; ++i)
+          __builtin_amdgcn_raw_ptr_buffer_load_lds(
+              arsrc, (__attribute__((address_space(3))) void*)((bufc ? lds_d1 : lds_d0) + 128 * (wave + 4 * i)), 16,
+              a_lane_bytes[i], (unsigned)kc * 8u, 0, 0);
+        asm volatile("" ::: "memory");  // the B loads of the chunk stay behind the DMA in program order (the wait below counts them)
+      };
+      auto body = [&](auto buf_tag, int ch) {
+        constexpr int bufc = decltype(buf_tag)::value;
+        // this wave's DMA of chunk ch is older than at least 3 * NCT B loads (four pairs in the loop, three in the prologue):
+        // once at most that many loads are outstanding it has landed (loads retire in order); the barrier then publishes
+        // all four waves' parts.  The oldest of those B loads is needed by the first matrix instruction anyway.
+        asm volatile("s_waitcnt vmcnt(%0)" ::"n"(3 * NCT) : "memory");
+        __syncthreads();
+        // (no branch: the last chunk fetches itself again into the idle buffer - with the DMA under a condition the loop
+        // is several basic blocks and the compiler's own wait at their join is vmcnt(0))
+        dma_rows(bufc ^ 1, ((ch + 1 < nchunks) ? ch + 1 : ch) * KC);
+        mfma_chunk_dma<RT, NCT, BM>(acc, bufc ? lds_d1 : lds_d0, li, lg, brsrc, lane_bytes,
+                                    ct_bytes + (unsigned)ch * 4u * pair_stride_bytes, pair_stride_bytes, bring);
+      };
+      // prologue in the loop's own order - DMA first, then the three ring pairs - so the count in body() holds for chunk 0
+      // too (and the compiler's own wait for its DMA -> ds_read dependence merges to the same vmcnt(3 * NCT) at the loop
+      // header instead of vmcnt(0))
+      dma_rows(0, 0);
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c)
+          bring[j][c] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(
+                                                        brsrc, lane_bytes + c * 1024u, ct_bytes + j * pair_stride_bytes, 0));
+      int ch = 0;
+      for (; ch + 1 < nchunks; ch += 2) {
+        body(std::integral_constant<int, 0>{}, ch);
+        body(std::integral_constant<int, 1>{}, ch + 1);
       }
-    };
-    load_a(0);
-    int buf = 0;
-    for (int64_t ch = 0; ch < nchunks; ++ch) {
-#pragma unroll
-      for (int q = 0; q < PER_T; ++q) lds_a[(buf * BM + srow + q * (256 / KC)) * APITCH + skk] = areg[q];
-      __syncthreads();
-      if (ch + 1 < nchunks) load_a((ch + 1) * KC);
-      mfma_chunk_ring<RT, NCT>(acc, lds_a + buf * BM * APITCH, APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, bring);
-      buf ^= 1;
+      if (ch < nchunks) body(std::integral_constant<int, 0>{}, ch);
+    } else {
+      const double2* bp = reinterpret_cast<const double2*>(g.packed_m) + ctbase * 64 + lane;
+    #pragma unroll
+      for (int j = 0; j < 3; ++j)
+  #pragma unroll
+        for (int c = 0; c < NCT; ++c) bring[j][c] = bp[j * NT * 64 + c * 64];
+      // staging: element q*256 + tid of the BM x KC chunk (a wave covers two 256-byte row segments per pass)
+      double areg[PER_T];
+      const int srow = tid / KC, skk = tid % KC;  // + 256/KC rows per q
+      // interior row tile of a matrix whose width is a whole number of chunks (uniform over the workgroup): plain loads off
+      // one running pointer - predicated loads and 64-bit index arithmetic are vector instructions the matrix pipe waits for
+      const bool interior = (r0 + BM <= g.N) && (g.D % KC == 0);
+      const double* pa = g.h + (r0 + srow) * g.D + skk;
+      auto load_a = [&](int64_t kc) {
+        if (interior) {
+  #pragma unroll
+          for (int q = 0; q < PER_T; ++q) areg[q] = pa[(int64_t)q * (256 / KC) * g.D + kc];
+          return;
+        }
+        const int64_t gk = kc + skk;
+  #pragma unroll
+        for (int q = 0; q < PER_T; ++q) {
+          const int64_t gr = r0 + srow + q * (256 / KC);
+          areg[q] = (gr < g.N && gk < g.D) ? g.h[gr * g.D + gk] : 0.0;
+        }
+      };
+      load_a(0);
+      int buf = 0;
+      for (int64_t ch = 0; ch < nchunks; ++ch) {
+  #pragma unroll
+        for (int q = 0; q < PER_T; ++q) lds_a[(buf * BM + srow + q * (256 / KC)) * APITCH + skk] = areg[q];
+        __syncthreads();
+        if (ch + 1 < nchunks) load_a((ch + 1) * KC);
+        mfma_chunk_ring<RT, NCT>(acc, lds_a + buf * BM * APITCH, APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, bring);
+        buf ^= 1;
+      }
     }
 #pragma unroll
     for (int a = 0; a < RT; ++a)
@@ -710,6 +778,7 @@ __global__ __launch_bounds__(256, (RT == 1 && NCT <= 2) ? K2_WAVES : 1) void pro
       }
     }
   }
+#endif
 }
 
 __global__ void proj_sq_combine_kernel(const double* __restrict__ partial, double* __restrict__ score, int64_t N) {
@@ -962,6 +1031,21 @@ extern "C" int runia_mc_entropy_supported(int H, int W, int n_mc, int k) {
   return 0;
 }
 
+// The DMA form addresses the rows and the packed matrix through 32-bit buffer offsets and stages whole 32-deep chunks.
+// Measured against the register-staged form (tools/ablate/run_proj_acc.py, us per launch, D = 512, r = 256):
+//   N = 2 000 / 5 000 / 8 000 / 10 000: 20.9 / 26.1 / 33.9 / 41.4 vs 23.0 / 27.9 / 35.8 / 43.5 (every workgroup resident
+//   at once: 5 per CU); 12 000 / 15 000 / 20 000: 56.8 / 69.7 / 86.2 vs 52.0 / 67.5 / 83.7 (a second, partial round of
+//   16-row workgroups: slower); 32 x 256 tiles at 40 000 / 100 000: 158.8 / 410.3 vs 167.3 / 426.3.
+static bool proj_sq_dma_ok(int64_t D, int64_t r) {
+  return K2_DMA && D % KC == 0 && D < (1 << 23) && packed_elems(D, r) < ((int64_t)1 << 29);
+}
+static bool proj_sq_one_round(unsigned grid) { return (int64_t)grid <= (int64_t)K2_WAVES_DMA * runia_cu_count(); }
+template <int RT, int NCT, bool ACCUMULATE, bool SPLIT>
+static void launch_proj_sq(unsigned grid, hipStream_t s, const ProjSqArgs& g, bool dma) {
+  if (dma && (RT > 1 || proj_sq_one_round(grid))) proj_sq_kernel<RT, NCT, ACCUMULATE, SPLIT, true><<<grid, 256, 0, s>>>(g);
+  else proj_sq_kernel<RT, NCT, ACCUMULATE, SPLIT, false><<<grid, 256, 0, s>>>(g);
+}
+
 // 32 x 256 tiles (fewer re-reads of M, 65 TFLOP/s when they fill the chip evenly) or 16 x 128 half tiles (62 TFLOP/s,
 // whatever the batch)?  The large tile only pays when its last round of workgroups is nearly full: N = 20 000 is 625
 // large tiles = 2.44 rounds on 256 CUs and ran at 51 TFLOP/s; 16 384 / 32 768 / 65 536 rows (whole rounds) at 63-65.
@@ -979,11 +1063,12 @@ extern "C" int runia_proj_sq_accumulate_f64(const double* h, const double* packe
   ProjSqArgs g{h, packed_m, c, score, nullptr, N, D, r};
   hipStream_t s = as_stream(stream);
   const int64_t tiles16 = (N + 15) / 16, cus = runia_cu_count();
-  if (r <= 64) proj_sq_kernel<1, 1, true, false><<<(unsigned)tiles16, 256, 0, s>>>(g);
-  else if (r <= 128) proj_sq_kernel<1, 2, true, false><<<(unsigned)tiles16, 256, 0, s>>>(g);
-  else if (proj_sq_large_tiles(N, cus)) proj_sq_kernel<2, 4><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
-  else if (tiles16 > cus / 2) proj_sq_kernel<1, 2, true><<<(unsigned)((tiles16 + 7) / 8 * 16), 256, 0, s>>>(g);
-  else proj_sq_kernel<1, 4><<<(unsigned)tiles16, 256, 0, s>>>(g);
+  const bool dma = proj_sq_dma_ok(D, r);
+  if (r <= 64) launch_proj_sq<1, 1, true, false>((unsigned)tiles16, s, g, dma);
+  else if (r <= 128) launch_proj_sq<1, 2, true, false>((unsigned)tiles16, s, g, dma);
+  else if (proj_sq_large_tiles(N, cus)) launch_proj_sq<2, 4, false, false>((unsigned)((N + 31) / 32), s, g, dma);
+  else if (tiles16 > cus / 2) launch_proj_sq<1, 2, true, true>((unsigned)((tiles16 + 7) / 8 * 16), s, g, dma);
+  else launch_proj_sq<1, 4, false, false>((unsigned)tiles16, s, g, dma);
   return runia_check_launch();
 }
 
@@ -998,18 +1083,19 @@ extern "C" int runia_proj_sq_score_f64(const double* h, const double* packed_m, 
   ProjSqArgs g{h, packed_m, c, score, reinterpret_cast<double*>(workspace), N, D, r};
   hipStream_t s = as_stream(stream);
   const int64_t tiles16 = (N + 15) / 16, cus = runia_cu_count();
+  const bool dma = proj_sq_dma_ok(D, r);
   if (r <= 64) {
-    proj_sq_kernel<1, 1, false, false><<<(unsigned)tiles16, 256, 0, s>>>(g);
+    launch_proj_sq<1, 1, false, false>((unsigned)tiles16, s, g, dma);
   } else if (r <= 128) {
-    proj_sq_kernel<1, 2, false, false><<<(unsigned)tiles16, 256, 0, s>>>(g);
+    launch_proj_sq<1, 2, false, false>((unsigned)tiles16, s, g, dma);
   } else if (proj_sq_large_tiles(N, cus)) {
-    proj_sq_kernel<2, 4><<<(unsigned)((N + 31) / 32), 256, 0, s>>>(g);
+    launch_proj_sq<2, 4, false, false>((unsigned)((N + 31) / 32), s, g, dma);
   } else if (tiles16 > cus / 2 && workspace && workspace_bytes >= runia_proj_sq_workspace_bytes(N)) {
     // (32-, 48- and 64-row tiles with the same column split measured 64, 64 and 78 us against 59 us)
-    proj_sq_kernel<1, 2><<<(unsigned)((tiles16 + 7) / 8 * 16), 256, 0, s>>>(g);
+    launch_proj_sq<1, 2, false, true>((unsigned)((tiles16 + 7) / 8 * 16), s, g, dma);
     proj_sq_combine_kernel<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(g.partial, score, N);
   } else {
-    proj_sq_kernel<1, 4><<<(unsigned)tiles16, 256, 0, s>>>(g);
+    launch_proj_sq<1, 4, false, false>((unsigned)tiles16, s, g, dma);
   }
   return runia_check_launch();
 }

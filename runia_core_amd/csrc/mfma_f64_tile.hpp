@@ -94,4 +94,49 @@ __device__ __forceinline__ void mfma_chunk_ring(d4 (&acc)[RT][NCT], const double
   }
 }
 
+#if defined(__HIP_DEVICE_COMPILE__)  // buffer resources and their builtins exist in the device pass only
+// ---- buffer-addressed form (K2'): no vector instruction steps an address ----
+// gfx950 buffer loads take a 128-bit resource (scalar registers), a per-lane byte offset (one loop-invariant vector
+// register), a scalar byte offset (stepped on the scalar unit) and an immediate; `buffer_load_dwordx4 ... lds` writes
+// the 64 x 16 bytes of a wave straight into LDS at M0 + 16 * lane.  Out-of-range bytes read as zero.
+using u4 = unsigned __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t buffer_of(const void* base, unsigned bytes) {
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(base), 0, (int)bytes, 0x00020000);
+}
+
+// LDS layout of a staged 32-deep chunk for the DMA form: 16-byte slots (two consecutive k of one row), slot index
+// = kpair * BM + row (kpair = 0..15).  The A fragment of k-step s for lane (li, lg) is the double (lg & 1) of slot
+// (2s + (lg >> 1)) * BM + row: the 64 lanes of a ds_read_b64 cover two contiguous 256-byte runs (no bank conflict), and
+// a wave's DMA instruction j fills slots 64j .. 64j+63 from 16-byte global reads.
+template <int RT, int NCT, int BM>
+__device__ __forceinline__ void mfma_chunk_dma(d4 (&acc)[RT][NCT], const double* a_slots, int li, int lg,
+                                               __amdgpu_buffer_rsrc_t brsrc, unsigned lane_bytes, unsigned pair0_bytes,
+                                               unsigned pair_stride_bytes, double2 (&b)[4][NCT]) {
+  double av[RT][8];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int t = 0; t < 8; ++t) av[a][t] = a_slots[(((2 * t + (lg >> 1)) * BM + 16 * a + li) << 1) + (lg & 1)];
+#pragma unroll
+  for (int s2 = 0; s2 < 4; ++s2) {
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) {
+      const u4 v = __builtin_amdgcn_raw_buffer_load_b128(brsrc, lane_bytes + c * 1024u,
+                                                         pair0_bytes + (unsigned)(s2 + 3) * pair_stride_bytes, 0);
+      b[(s2 + 3) & 3][c] = __builtin_bit_cast(double2, v);
+    }
+#pragma unroll
+    for (int hh = 0; hh < 2; ++hh) {
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        const double bv = hh ? b[s2][c].y : b[s2][c].x;
+#pragma unroll
+        for (int a = 0; a < RT; ++a)
+          acc[a][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[a][2 * s2 + hh], bv, acc[a][c], 0, 0, 0);
+      }
+    }
+  }
+}
+#endif  // __HIP_DEVICE_COMPILE__
+
 }  // namespace runia_mfma

@@ -799,8 +799,9 @@ def test_proj_sq_accumulate_equals_store_form(hip, n_rows):
 @pytest.mark.parametrize("d,r", [(512, 256), (96, 256), (520, 200), (512, 130)])
 def test_proj_sq_bits_do_not_depend_on_the_launch_shape(hip, d, r):
     """K2' picks its kernel by the row count - one workgroup per 16-row tile over all columns, 16 x 128 column halves, 32 x 256
-    tiles for whole rounds.  All of them add a row's squares in the same column-group order: a row scores the same bits
-    whatever batch it sits in, stored or accumulated, whatever the alignment of H."""
+    tiles for whole rounds - and by the widths (rows staged by buffer_load ... lds when D is a whole number of chunks and the
+    grid is resident at once, through registers otherwise).  All of them add a row's squares in the same column-group order:
+    a row scores the same bits whatever batch it sits in, stored or accumulated, whatever the alignment of H."""
     torch.manual_seed(d + r)
     n = 70000
     h = torch.randn(n, d, dtype=torch.float64, device="cuda")
@@ -810,7 +811,7 @@ def test_proj_sq_bits_do_not_depend_on_the_launch_shape(hip, d, r):
     whole = hip.proj_sq_score(h, pm, c, r)
     ref = -((h[:3000] @ m + c) ** 2).sum(1)
     assert float(((whole[:3000] - ref).abs() / ref.abs().clamp_min(1.0)).max()) < 1e-12
-    for a, b in ((0, 1), (5, 105), (1000, 3100), (20000, 30000), (3, 65536 + 3)):
+    for a, b in ((0, 1), (5, 105), (1000, 3100), (20000, 30000), (30000, 45000), (3, 65536 + 3)):  # 15 000 rows: register-staged 16-row form
         part = hip.proj_sq_score(h[a:b].contiguous(), pm, c, r)
         assert torch.equal(part, whole[a:b]), (a, b)
         acc = torch.zeros(b - a, dtype=torch.float64, device="cuda")
