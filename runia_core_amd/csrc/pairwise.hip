@@ -294,7 +294,7 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
                                                                 const float* __restrict__ qn,
                                                                 const unsigned* __restrict__ bn_max_bits,
                                                                 float* __restrict__ score, int64_t Q, int64_t M,
-                                                                int64_t D, int k) {
+                                                                int64_t D, int k, float refine_rel) {
   __shared__ unsigned hist[4096];
   __shared__ unsigned part[256];
   __shared__ unsigned sel[2];
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
     const float sq = sqrtf(qnorm) + sqrtf(bmax);
     const float range = sq * sq * 1.000001f + 1e-30f;
     const float scale = 16777216.0f / range;
-    const float delta = fmaxf(kRefineRel * range, 2.0f / scale);  // refinement half-window, never narrower than two bins
+    const float delta = fmaxf(refine_rel * range, 2.0f / scale);  // refinement half-window, never narrower than two bins
     const float4* drow4 = (((M & 3) == 0) && ((((uintptr_t)drow) & 15) == 0)) ? reinterpret_cast<const float4*>(drow) : nullptr;
     __syncthreads();
     if (tid == 0) { n_below = 0u; n_cand = 0u; n_fast = 0u; }
@@ -713,16 +713,36 @@ static inline unsigned knn_dist_grid(int64_t Q, int64_t M) {
   return (unsigned)(((st + 7) / 8) * 8 * kSuperB * kSuperQ);
 }
 
+// knn_bf16.hip: candidate distances of large problems from bf16 piece products (6/16 of the f32 kernel's matrix-pipe time)
+int64_t runia_knn16_padded_rows(int64_t rows);
+size_t runia_knn16_plane_bytes(int64_t rows, int64_t D);
+bool runia_knn16_fits(int64_t rows, int64_t D);
+int runia_knn16_split(const float* x, uint16_t* planes, int64_t R, int64_t D, hipStream_t s);
+float runia_knn16_refine_rel();
+int runia_knn16_dist(const uint16_t* qp, const uint16_t* bp, const float* qn, const float* bn, float* dist, int64_t Q,
+                     int64_t M, int64_t D, hipStream_t s);
+
+#ifndef KNN_BF16
+#define KNN_BF16 1
+#endif
+// Worth the two split passes and the 256 x 256 tiles: a bank of some thousand rows, wide features, a batch of queries
+static bool knn16_wanted(int64_t N, int64_t M, int64_t D) {
+  return KNN_BF16 && N >= 1024 && M >= 4096 && D >= 256 && runia_knn16_fits(M, D) && runia_knn16_fits(kQueryChunk, D);
+}
+static size_t knn_f32_words(int64_t qc, int64_t M) { return (size_t)(qc * M + qc + M + 4); }  // distances, |q|^2, |b|^2, max |b|^2
+
 extern "C" size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {
-  (void)D; (void)k;
+  (void)k;
   if (N <= 0 || M <= 0) return 0;
   // query rows per pass: up to 8 192, fewer for very large banks so that the distance tile stays near 2 GiB
   // (a 1 M-row bank would otherwise ask for 32 GB); the entry point works with whatever it is given (>= 1 row)
   int64_t qc = N < kQueryChunk ? N : kQueryChunk;
   const int64_t by_size = ((int64_t)1 << 31) / (4 * M);
   if (qc > by_size) qc = by_size < 256 ? (N < 256 ? N : 256) : by_size;
-  // distance tile rows + |q|^2 for one chunk + |b|^2
-  return (size_t)(qc * M + qc + M + 4) * sizeof(float);  // + the maximum bank norm
+  size_t bytes = knn_f32_words(qc, M) * sizeof(float);
+  // + the bf16 planes of the bank and of one chunk of queries when the bf16 kernel will be taken
+  if (knn16_wanted(N, M, D)) bytes = (bytes + 255) / 256 * 256 + runia_knn16_plane_bytes(M, D) + runia_knn16_plane_bytes(qc, D);
+  return bytes;
 }
 
 extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score, void* workspace,
@@ -741,6 +761,24 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
   if (qc < 1) return RUNIA_E_WORKSPACE;
   if (qc > N) qc = N;
   if (qc > kQueryChunk) qc = kQueryChunk;
+  // bf16 candidate distances when the caller's workspace also holds the planes (runia_knn_workspace_bytes asks for them)
+  bool use16 = knn16_wanted(N, M, D);
+  uint16_t *bank_planes = nullptr, *q_planes = nullptr;
+  if (use16) {
+    const size_t need_planes = runia_knn16_plane_bytes(M, D) + runia_knn16_plane_bytes(kQueryChunk < N ? kQueryChunk : N, D);
+    int64_t qc16 = qc;
+    for (;;) {  // the largest chunk whose distances leave room for the planes
+      const size_t head = (knn_f32_words(qc16, M) * sizeof(float) + 255) / 256 * 256;
+      if (head + need_planes <= workspace_bytes) {
+        qc = qc16;
+        bank_planes = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + head);
+        q_planes = bank_planes + runia_knn16_plane_bytes(M, D) / sizeof(uint16_t);
+        break;
+      }
+      if (qc16 <= 1024) { use16 = false; break; }
+      qc16 /= 2;
+    }
+  }
   float* dist = reinterpret_cast<float*>(workspace);
   float* qn = dist + qc * M;
   float* bn = qn + qc;
@@ -749,12 +787,22 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
   row_sqnorm_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(bank, bn, M, D, bn_max);
   int rc = runia_check_launch();
   if (rc != RUNIA_OK) return rc;
+  if (use16) {
+    rc = runia_knn16_split(bank, bank_planes, M, D, s);
+    if (rc != RUNIA_OK) return rc;
+  }
   for (int64_t r0 = 0; r0 < N; r0 += qc) {
     const int64_t rows = (N - r0 < qc) ? (N - r0) : qc;
     row_sqnorm_kernel<<<runia_rows_grid(rows), 64 * kRowWaves, 0, s>>>(q + r0 * D, qn, rows, D, nullptr);
-    knn_dist_kernel<EPI_DIST><<<knn_dist_grid(rows, M), 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D, INFINITY);
-    kth_select_range_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(dist, q + r0 * D, bank, qn, bn_max,
-                                                                                 score + r0, rows, M, D, k);
+    if (use16 && rows >= 256) {
+      rc = runia_knn16_split(q + r0 * D, q_planes, rows, D, s);
+      if (rc == RUNIA_OK) rc = runia_knn16_dist(q_planes, bank_planes, qn, bn, dist, rows, M, D, s);
+      if (rc != RUNIA_OK) return rc;
+    } else {
+      knn_dist_kernel<EPI_DIST><<<knn_dist_grid(rows, M), 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D, INFINITY);
+    }
+    kth_select_range_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(
+        dist, q + r0 * D, bank, qn, bn_max, score + r0, rows, M, D, k, (use16 && rows >= 256) ? runia_knn16_refine_rel() : kRefineRel);
     rc = runia_check_launch();
     if (rc != RUNIA_OK) return rc;
   }

@@ -446,6 +446,56 @@ def test_knn_sampled_threshold_path_and_its_fallbacks(hip, m):
         assert rel_err(got, oracle.knn_kth_score(sorted_bank, q, k, normalize=False)) < 1e-5, (m, k)
 
 
+@pytest.mark.parametrize("n,m,d", [(2048, 8192, 512), (1500, 8200, 300), (1024, 4096, 2048)])
+def test_knn_bf16_candidate_distances_equal_the_f32_path(hip, n, m, d):
+    """Large problems take their candidate distances from bf16 piece products (csrc/knn_bf16.hip) when the caller's
+    workspace holds the planes (runia_knn_workspace_bytes asks for them); with an f32-sized workspace the same entry
+    takes the f32 matrix-core kernel.  Both feed the same selection + exact f32 re-measurement, so the scores agree bit
+    for bit - on unit vectors, on rows spanning six orders of magnitude, with copied bank rows, NaN / infinite rows and
+    ragged sizes (rows not a multiple of 256, width not a multiple of 64) - and both equal the oracle."""
+    lib = hip.load_library()
+    rng = np.random.default_rng(n + m + d)
+    k = 50
+
+    def run(q, bank, big):
+        qd, bd = dev(q, torch.float32), dev(bank, torch.float32)
+        full = lib.runia_knn_workspace_bytes(n, m, d, k)
+        f32_only = (min(n, 8192) * m + min(n, 8192) + m + 4) * 4
+        assert full > f32_only + 6 * m * d  # the planes were asked for: this size takes the bf16 kernel
+        ws_bytes = full if big else f32_only
+        ws = torch.empty(ws_bytes // 4 + 1, dtype=torch.float32, device="cuda")
+        out = torch.full((n,), 123.0, device="cuda")
+        rc = lib.runia_knn_kth_f32(qd.data_ptr(), bd.data_ptr(), out.data_ptr(), ws.data_ptr(), ws_bytes, n, m, d, k,
+                                   torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        return out.cpu().numpy()
+
+    # (1) unit vectors, some queries copies of bank rows
+    bank = rng.standard_normal((m, d)).astype(np.float32)
+    bank /= np.linalg.norm(bank, axis=1, keepdims=True)
+    q = rng.standard_normal((n, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[:100] = bank[500:600]
+    a, b = run(q, bank, True), run(q, bank, False)
+    assert not (a == 123.0).any() and np.array_equal(a, b)
+    rows = [0, 1, 99, 100, n // 2, n - 1]
+    assert rel_err(a[rows], oracle.knn_kth_score(bank, q[rows], k, normalize=False)) < 1e-5
+    # (2) un-normalised rows over six orders of magnitude, a block of copied bank rows, NaN / infinite rows
+    bank2 = (rng.standard_normal((m, d)) * 10.0 ** rng.uniform(-3, 3, size=(m, 1))).astype(np.float32)
+    bank2[1000:1700] = bank2[17]
+    bank2[5, 3] = np.nan
+    bank2[6, 0] = np.inf
+    q2 = (rng.standard_normal((n, d)) * 10.0 ** rng.uniform(-3, 3, size=(n, 1))).astype(np.float32)
+    q2[3] = bank2[17]
+    q2[7, 1] = np.nan
+    q2[8, :] = np.inf
+    a, b = run(q2, bank2, True), run(q2, bank2, False)
+    assert not (a == 123.0).any() and np.array_equal(a, b)
+    assert a[7] == -oracle.FLT_MAX and a[8] == -oracle.FLT_MAX
+    rows = [0, 3, 9, n - 1]
+    assert rel_err(a[rows], oracle.knn_kth_score(bank2, q2[rows], k, normalize=False)) < 1e-5
+
+
 def test_knn_all_baselines_mean(hip, ref_vectors):
     from test_oracle_goldens import _all_baselines_inputs
 
