@@ -232,8 +232,13 @@ def main_cfg3(args, device, rank, world, dist, saved_stdout):
                    "gather": "none (1 GPU)" if dist is None else "one all_gather_into_tensor per postprocessor, compute stream",
                    "gather_ms_per_call": round(rec["gather_ms_per_call"], 4),
                    "setup_fit_s": round(rec["fit_s"], 2), "setup_broadcast_s": round(rec["broadcast_s"], 3)},
-        "roofline": {"bound": "mfma", "kernel": "knn_dist_kernel (+ normaliser and k-th select: the whole kNN stage is timed)",
+        "roofline": {"bound": "mfma",
+                     "kernel": ("knn_dist_bf16_kernel" if knn.get("piece_products") else "knn_dist_kernel")
+                     + " (+ normaliser, piece split and k-th select with exact re-measurement: the whole kNN stage is timed)",
                      "achieved": knn["achieved"], "peak": knn["peak"], "unit": "TFLOP/s", "frac": knn["frac"], "traffic": None,
+                     "dtype_of_peak": "bf16 dense" if knn.get("piece_products") else "f32",
+                     "piece_products": knn.get("piece_products", 0),
+                     "f32_equivalent_tflops": knn.get("f32_equivalent_tflops", knn["achieved"]),
                      "algorithmic_flop_per_row": 2.0 * bw.BANK_ROWS * bw.D_FEAT, "avg_stage_ms": knn["ms"],
                      "share_of_step": round(knn["ms"] / max(1e-9, sum(v["ms"] for v in st.values())), 4)},
         "stages": st,

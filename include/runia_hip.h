@@ -147,8 +147,14 @@ int runia_l2_normalize_f32(const float* x, float* y, int64_t N, int64_t D, runia
  * (inference/postprocessors.py:396-397,419,850-851,878).  q [N, D] and bank [M, D]
  * are already normalised f32; score [N] f32 = -(k-th smallest squared L2), or
  * -FLT_MAX when k > M.  `workspace` holds the distance tiles
- * (runia_knn_workspace_bytes). */
+ * (runia_knn_workspace_bytes) and, for large problems, the bf16 planes of the
+ * candidate-distance kernel: with a workspace of the size asked for, the
+ * candidates of a large problem come from bf16 piece products
+ * (runia_knn_piece_products of them, 0 = the f32 matrix-core kernel); with a
+ * smaller workspace always from the f32 kernel.  The score is the exactly
+ * re-measured f32 distance on either path (identical bits). */
 size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k);
+int runia_knn_piece_products(int64_t N, int64_t M, int64_t D);
 int runia_knn_kth_f32(const float* q, const float* bank, float* score, void* workspace,
                       size_t workspace_bytes, int64_t N, int64_t M, int64_t D, int k,
                       runia_stream_t stream);

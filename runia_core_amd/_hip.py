@@ -59,6 +59,7 @@ _SIGNATURES = {
     "runia_row_lse_msp_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "runia_l2_normalize_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "runia_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    "runia_knn_piece_products": (c_int, [c_int64, c_int64, c_int64]),
     "runia_knn_kth_f32": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int64, c_int, c_void_p],

@@ -312,6 +312,7 @@ int runia_knn16_split(const float* x, uint16_t* planes, int64_t R, int64_t D, hi
 // f32 kernel's own allowance stands.  Three terms: dropped m.m + h.l + l.h <= 3 * 2^-16 sum|q_k||b_k| <= 3 * 2^-16 |q||b|
 // (each piece is below 2^-8 of the one before; Cauchy-Schwarz), |q||b| <= R / 4, and the distance carries twice the
 // product's error: e <= 2.3e-5 R, plus the accumulation allowance -> 5e-5 R.
+int runia_knn16_terms() { return KNN16_TERMS; }
 float runia_knn16_refine_rel() { return KNN16_TERMS == 6 ? 5e-6f : 5e-5f; }
 int runia_knn16_dist(const uint16_t* qp, const uint16_t* bp, const float* qn, const float* bn, float* dist, int64_t Q,
                      int64_t M, int64_t D, hipStream_t s) {

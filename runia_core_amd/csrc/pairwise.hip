@@ -729,6 +729,8 @@ int runia_knn16_dist(const uint16_t* qp, const uint16_t* bp, const float* qn, co
 static bool knn16_wanted(int64_t N, int64_t M, int64_t D) {
   return KNN_BF16 && N >= 1024 && M >= 4096 && D >= 256 && runia_knn16_fits(M, D) && runia_knn16_fits(kQueryChunk, D);
 }
+int runia_knn16_terms();
+extern "C" int runia_knn_piece_products(int64_t N, int64_t M, int64_t D) { return knn16_wanted(N, M, D) ? runia_knn16_terms() : 0; }
 static size_t knn_f32_words(int64_t qc, int64_t M) { return (size_t)(qc * M + qc + M + 4); }  // distances, |q|^2, |b|^2, max |b|^2
 
 extern "C" size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {

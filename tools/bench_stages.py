@@ -68,8 +68,8 @@ def add(stage, shape, unit, n_units, ms, bound, work_per_unit, cpu, cpu_note, er
     rate = n_units / (ms * 1e-3)
     if bound == "hbm":
         ach, peak, u = work_per_unit * rate / 1e9, HBM, "GB/s"
-    elif bound in ("mfma_f32", "mfma_f64"):
-        ach, peak, u = work_per_unit * rate / 1e12, (F32_MFMA if bound == "mfma_f32" else F64_MFMA), "TFLOP/s"
+    elif bound in ("mfma_f32", "mfma_f64", "mfma_bf16"):
+        ach, peak, u = work_per_unit * rate / 1e12, {"mfma_f32": F32_MFMA, "mfma_f64": F64_MFMA, "mfma_bf16": 2500.0}[bound], "TFLOP/s"
     else:
         ach, peak, u = work_per_unit * rate / 1e9, None, "G work-units/s"
     frac = None if peak is None else round(ach / peak, 4)
@@ -115,7 +115,9 @@ bn_host = bank_n.cpu().numpy()
 qs = q[:mq].cpu().numpy()
 cpu = cpu_rate(lambda: oracle.knn_kth_score(bn_host, qs, K, chunk=1), mq)
 err = rel(s[:mq].cpu().numpy(), oracle.knn_kth_score(bn_host, qs, K, chunk=1))
-add("kNN k=50 (a8)", f"{NQ} q x bank {M}x{D}", "queries", NQ, ms, "mfma_f32", 2.0 * M * D, cpu, f"one query at a time, exact f32 differences, {mq} queries", err)
+pieces = int(_hip.load_library().runia_knn_piece_products(NQ, M, D))  # bf16 piece products per distance (0: f32 kernel)
+add("kNN k=50 (a8)" + (f", {pieces} bf16 piece products" if pieces else ""), f"{NQ} q x bank {M}x{D}", "queries", NQ, ms,
+    "mfma_bf16" if pieces else "mfma_f32", max(pieces, 1) * 2.0 * M * D, cpu, f"one query at a time, exact f32 differences, {mq} queries", err)
 del bank, q, bank_n, q_n
 
 # ---- a6 Mahalanobis ---------------------------------------------------------------------------------
