@@ -14,14 +14,14 @@
 // either way; this kernel only decides which bank rows are looked at.
 //
 // Kernel shape.  One workgroup = 256 queries x 256 bank rows, 4 waves of 128 x 128 (4 x 4 MFMA tiles, 256 accumulator
-// registers, one wave per SIMD).  K runs over the six piece pairs x D in chunks of 32: a chunk of a tile is 256 rows x
-// 64 bytes, staged by `buffer_load_dwordx4 ... lds` (8 per wave and chunk, no staging registers, no ds_write) into
-// one of four LDS stages (4 x 32 KB).  LDS slot (16 bytes = 8 consecutive k of one row) of (row, kgroup g) is
-// row * 4 + (g ^ ((row >> 2) & 3)): the four lanes that fetch one row read 64 contiguous bytes, and the ds_read_b128 of
-// an MFMA operand (32 consecutive rows, one kgroup per half-wave) is conflict-free: the LDS serves a b128 read in four
-// groups of 16 lanes - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 - and within a group the rows of one
-// residue mod 4 have row >> 2 in {0, 3, 5, 6} or {1, 2, 4, 7}, four different values mod 4, so the 16 slots fall into the
-// 16 different 16-byte bank groups.  The pipeline is described at the loop.
+// registers, one wave per SIMD).  K runs over the piece pairs x D in stages of 64: a stage of a tile is 256 rows x 128
+// bytes, staged by `buffer_load_dwordx4 ... lds` (16 per wave and stage, no staging registers, no ds_write) into one of
+// two LDS buffers (2 x 64 KB).  LDS slot (16 bytes = 8 consecutive k of one row) of (row, kgroup g) is
+// row * 8 + (g ^ ((row >> 1) & 7)): the eight lanes that fetch one row read its whole 128-byte line, and the
+// ds_read_b128 of an MFMA operand (32 consecutive rows, one kgroup per half-wave) is conflict-free: the LDS serves a b128
+// read in four groups of 16 lanes - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 - and within a group the
+// rows of one parity have row >> 1 in {0, 1, 6, 7, 10, 11, 12, 13} or {2, 3, 4, 5, 8, 9, 14, 15}, eight different values
+// mod 8, so the 16 slots fall into the 16 different 16-byte bank groups.  The pipeline is described at the loop.
 #include "common.hpp"
 
 #include <cstdint>
@@ -30,8 +30,8 @@
 namespace runia_knn16 {
 
 constexpr int TQ = 256, TB = 256;            // tile
-[[maybe_unused]] constexpr int KC = 32;      // k per staged chunk
-[[maybe_unused]] constexpr int kStages = 4, kStageBytes = 2 * 256 * KC * 2;  // one stage = a chunk of both tiles = 32 KB
+[[maybe_unused]] constexpr int KC = 64;      // k per LDS stage
+[[maybe_unused]] constexpr int kStages = 2, kStageBytes = 2 * 256 * KC * 2;  // one stage = 64 k of both tiles = 64 KB
 [[maybe_unused]] constexpr float kFltMax = 3.4028234663852886e38f;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -140,15 +140,19 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
     m0 = bt * TB;
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
-  // DMA: a chunk of a stage = 2048 slots = 32 instructions; wave w issues I = 8 w .. 8 w + 7 (I < 16: query rows
-  // 16 I .. 16 I + 15, else bank rows).  Lane i of an instruction: row i / 4, slot position i % 4.
+  // DMA: a stage (64 k of both tiles) = 4096 slots = 64 instructions of 8 rows x 8 kgroups; wave w issues I = 16 w ..
+  // 16 w + 15 (I < 32: query rows 8 I .. 8 I + 7, else bank rows).  Lane i of an instruction: row i / 8, slot position
+  // i % 8, i.e. kgroup (i % 8) ^ ((row >> 1) & 7) - the eight lanes of a row fetch its whole 128-byte line.
   const bool mine_a = wave < 2;
   const i32x4 rsrc = mine_a ? raw_buffer(qp, (unsigned)(3 * Qpad * Dp * 2)) : raw_buffer(bp, (unsigned)(3 * Mpad * Dp * 2));
   const int64_t rows_pad = mine_a ? Qpad : Mpad;
-  const int64_t tile_row0 = (mine_a ? q0 : m0) + 16 * 8 * (wave & 1);
-  const unsigned voff = (unsigned)((lane >> 2) * Dp * 2 + (((lane & 3) ^ ((lane >> 4) & 3)) * 16));
+  const int64_t tile_row0 = (mine_a ? q0 : m0) + 8 * 16 * (wave & 1);
+  unsigned voff[2];  // by the parity of I: (row >> 1) & 7 = (4 I + (i >> 4)) & 7
+#pragma unroll
+  for (int par = 0; par < 2; ++par)
+    voff[par] = (unsigned)((lane >> 3) * Dp * 2 + (((lane & 7) ^ ((lane >> 4) | (par << 2))) * 16));
   const int nk = (int)(Dp / KC), total = TERMS * nk;
-  int next_t = 0, next_k = 0;  // piece pair and chunk within it of the next DMA (scalar counters: no division per chunk)
+  int next_t = 0, next_k = 0;  // piece pair and stage within it of the next DMA (scalar counters: no division per stage)
   f32x16 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -156,18 +160,18 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // operand reads: lane l reads row (l & 31) of a 32-row tile, kgroup 2 ks + (l >> 5)
+  // operand reads: lane l reads row (l & 31) of a 32-row tile, kgroup 2 ks + (l >> 5), ks = 0 .. 3 within a stage
   const int lrow = lane & 31, lhalf = lane >> 5;
-  const uint4* a_lane = lds + (wq * 128 + lrow) * 4;
-  const uint4* b_lane = lds + 1024 + (wb * 128 + lrow) * 4;
-  int gk[2];
+  const uint4* a_lane = lds + (wq * 128 + lrow) * 8;
+  const uint4* b_lane = lds + 2048 + (wb * 128 + lrow) * 8;
+  int gk[4];
 #pragma unroll
-  for (int ks = 0; ks < 2; ++ks) gk[ks] = (2 * ks + lhalf) ^ ((lane >> 2) & 3);
+  for (int ks = 0; ks < 4; ++ks) gk[ks] = (2 * ks + lhalf) ^ ((lane >> 1) & 7);
   // operand n of a k-step in the order the matrix instructions first need them: a0, b0, b1, b2, b3, a1, a2, a3
   auto load_one = [&](uint4 (&fa)[4], uint4 (&fb)[4], int stage, int ks, int n) {
     const bool is_a = (n == 0 || n >= 5);
     const int t = (n == 0) ? 0 : (n >= 5 ? n - 4 : n - 1);
-    const uint4* base = (is_a ? a_lane : b_lane) + stage * (kStageBytes / 16) + gk[ks] + t * 128;
+    const uint4* base = (is_a ? a_lane : b_lane) + stage * (kStageBytes / 16) + gk[ks] + t * 256;
     if (is_a) fa[t] = *base;
     else fb[t] = *base;
   };
@@ -176,8 +180,7 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
                                                         acc[i][j], 0, 0, 0);
   };
-  // DMA bookkeeping split so that single instructions can be placed between matrix instructions
-  // running source offset of the next chunk: + 64 bytes per chunk, re-based when the piece pair changes
+  // running source offset of the next stage: + 128 bytes per stage, re-based when the piece pair changes
   const unsigned plane_bytes = (unsigned)(rows_pad * Dp * 2), tile_bytes = (unsigned)(tile_row0 * Dp * 2);
   auto term_base = [&](int t) {
     int pa, pb;
@@ -187,83 +190,102 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
   unsigned dma_next = term_base(0), dma_s0 = 0, dma_l0 = 0;
   auto dma_begin = [&](int stage) {
     dma_s0 = dma_next;
-    dma_l0 = lds0 + (unsigned)stage * (unsigned)kStageBytes + (unsigned)wave * 8u * 1024u;
+    dma_l0 = lds0 + (unsigned)stage * (unsigned)kStageBytes + (unsigned)wave * 16u * 1024u;
     dma_next += KC * 2;
     if (++next_k == nk) {
       next_k = 0;
-      if (++next_t == TERMS) { next_t = TERMS - 1; next_k = nk - 1; dma_next = dma_s0; }  // past the end: the last chunk again (never read)
+      if (++next_t == TERMS) { next_t = TERMS - 1; next_k = nk - 1; dma_next = dma_s0; }  // past the end: the last stage again (never read)
       else dma_next = term_base(next_t);
     }
   };
-  auto dma_one = [&](int j) { dma16(dma_l0 + 1024u * j, voff, rsrc, dma_s0 + (unsigned)(16 * j * Dp * 2)); };
+  auto dma_one = [&](int j) { dma16(dma_l0 + 1024u * j, voff[j & 1], rsrc, dma_s0 + (unsigned)(8 * j * Dp * 2)); };
   auto issue = [&](int stage) {
     dma_begin(stage);
 #pragma unroll
-    for (int j = 0; j < 8; ++j) dma_one(j);
+    for (int j = 0; j < 16; ++j) dma_one(j);
   };
-  // Pipeline (NS = 4 stages of 32 k): the DMA runs two chunks ahead of the barrier that publishes it, the operand
-  // registers one k-step ahead of the matrix instructions that consume them, across chunk boundaries too.  A wave issues
-  // matrix instructions back to back (32 cycles each); whatever else it has to do - 16 operand reads, 8 DMA
-  // instructions, one wait and one barrier per chunk - is placed BETWEEN them, two matrix instructions apart, so that it
-  // runs in their shadow (__builtin_amdgcn_sched_barrier pins the order: left alone, the scheduler sinks every read to
-  // just in front of its first use and gathers the rest at the barrier).
-  //   k-step 0 of chunk c:  16 MFMAs on operands (c, 0)  |  the 8 operand reads of (c, 1)
-  //   k-step 1 of chunk c:  16 MFMAs on operands (c, 1)  |  wait "DMA(c+1) landed" + barrier, DMA(c+3) into the stage
-  //                                                         of chunk c-1, the 8 operand reads of (c+1, 0)
-  // Every wave issues its 8 DMA instructions for every chunk index up to total + 2 (past the end: the last chunk again,
-  // into a stage nobody reads), so "at most 8 loads outstanding" always means "everything up to DMA(c+1) has landed".
+  // Pipeline: two LDS stages of 64 k (four k-steps of 16 MFMAs).  The DMA of stage d + 1 flies while stage d is
+  // multiplied; the operand registers run one k-step ahead of the matrix instructions that consume them, across stage
+  // boundaries too.  A wave issues matrix instructions back to back (32 cycles each); whatever else it has to do - 32
+  // operand reads, 16 DMA instructions, one wait and one barrier per stage - is placed BETWEEN them, two matrix
+  // instructions apart, so that it runs in their shadow (__builtin_amdgcn_sched_barrier pins the order: left alone, the
+  // scheduler sinks every read to just in front of its first use and gathers the rest at the barrier).
+  //   k-steps 0..2 of stage d:  16 MFMAs each  |  the 8 operand reads of the next k-step
+  //   k-step 3 of stage d:      16 MFMAs       |  wait "DMA(d+1) landed" + barrier (everyone has read stage d to the
+  //                                               end), DMA(d+2) into the buffer of stage d, the reads of (d+1, 0)
+  // Every request of the DMA is a whole 128-byte line of a row (with 32-k stages - 64 bytes per row - the kernel ran at
+  // the L2's half-line rate: 45 % matrix-pipe utilisation at 7.3 TB/s of L2 reads).  Past the end the last stage is
+  // fetched again into a buffer nobody reads, so the wait is always the plain vmcnt(0).
 #define RUNIA_PIN __builtin_amdgcn_sched_barrier(0)
   issue(0);
   issue(1);
-  issue(2);
   asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
   __syncthreads();
   uint4 fa0[4], fb0[4], fa1[4], fb1[4];
 #pragma unroll
   for (int n = 0; n < 8; ++n) load_one(fa0, fb0, 0, 0, n);
   int stage = 0;
-  for (int c = 0; c < total; ++c) {
-    dma_begin((stage + 3) & 3);  // scalar bookkeeping of the DMA issued in k-step 1, computed here in the shadow of k-step 0
+  for (int d = 0; d < total; ++d) {
     RUNIA_PIN;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {
+    for (int n = 0; n < 8; ++n) {  // k-step 0
       load_one(fa1, fb1, stage, 1, n);
       RUNIA_PIN;
       mfma1(fa0, fb0, 2 * n);
       mfma1(fa0, fb0, 2 * n + 1);
       RUNIA_PIN;
     }
-    mfma1(fa1, fb1, 0);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {  // k-step 1
+      load_one(fa0, fb0, stage, 2, n);
+      RUNIA_PIN;
+      mfma1(fa1, fb1, 2 * n);
+      mfma1(fa1, fb1, 2 * n + 1);
+      RUNIA_PIN;
+    }
+    dma_begin(stage);  // scalar bookkeeping of the DMA issued in k-step 3, in the shadow of k-step 2
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {  // k-step 2
+      load_one(fa1, fb1, stage, 3, n);
+      RUNIA_PIN;
+      mfma1(fa0, fb0, 2 * n);
+      mfma1(fa0, fb0, 2 * n + 1);
+      RUNIA_PIN;
+    }
+    mfma1(fa1, fb1, 0);  // k-step 3
     mfma1(fa1, fb1, 1);
     RUNIA_PIN;
-    asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    stage = (stage + 1) & 3;
-    RUNIA_PIN;
-    mfma1(fa1, fb1, 2);
-    mfma1(fa1, fb1, 3);
+    stage ^= 1;
     RUNIA_PIN;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      dma_one(2 * g);
-      dma_one(2 * g + 1);
+      dma_one(3 * g);
+      dma_one(3 * g + 1);
+      dma_one(3 * g + 2);
       RUNIA_PIN;
-      mfma1(fa1, fb1, 4 + 2 * g);
-      mfma1(fa1, fb1, 5 + 2 * g);
+      mfma1(fa1, fb1, 2 + 2 * g);
+      mfma1(fa1, fb1, 3 + 2 * g);
       RUNIA_PIN;
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
+      dma_one(12 + 2 * g);
+      dma_one(13 + 2 * g);
       load_one(fa0, fb0, stage, 0, 3 * g);
       load_one(fa0, fb0, stage, 0, 3 * g + 1);
       load_one(fa0, fb0, stage, 0, 3 * g + 2);
       RUNIA_PIN;
-      mfma1(fa1, fb1, 12 + 2 * g);
-      mfma1(fa1, fb1, 13 + 2 * g);
+      mfma1(fa1, fb1, 10 + 2 * g);
+      mfma1(fa1, fb1, 11 + 2 * g);
       RUNIA_PIN;
     }
     load_one(fa0, fb0, stage, 0, 6);
     load_one(fa0, fb0, stage, 0, 7);
+    RUNIA_PIN;
+    mfma1(fa1, fb1, 14);
+    mfma1(fa1, fb1, 15);
   }
 #undef RUNIA_PIN
   // epilogue: C[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31] of each 32 x 32 tile

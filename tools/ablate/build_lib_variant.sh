@@ -6,7 +6,8 @@ set -e
 cd "$(dirname "$0")/../../runia_core_amd/csrc"
 src=$1; tag=$2; shift 2
 make -s -j8
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -mllvm -amdgpu-mfma-vgpr-form "$@" -c $src -o /tmp/variant_$tag.o
+form="-mllvm -amdgpu-mfma-vgpr-form"; [ "$src" = knn_bf16.hip ] && form=""   # as the Makefile
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off $form "$@" -c $src -o /tmp/variant_$tag.o
 objs=""
 for f in *.o; do if [ "$f" = "${src%.hip}.o" ]; then objs="$objs /tmp/variant_$tag.o"; else objs="$objs $f"; fi; done
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC $objs -o ../librunia_$tag.so
