@@ -211,7 +211,7 @@ constexpr int kMaxCand = 512;
 // counters (1.03 ms, three reads).  A key bin is range / 2^24 wide; the refinement window (never narrower than two
 // bins) then restores the exact k-th value.
 // Fast path (one read of the row instead of three): the k-th smallest of ANY subset of the row is an upper bound of the
-// row's k-th smallest, so the k-th smallest of a strided sample of 2048 entries (selected in LDS) gives a threshold tau;
+// row's k-th smallest, so the k-th smallest of a spread sample of 2048 entries (selected in LDS) gives a threshold tau;
 // one pass over the row collects the entries <= tau (about k * M / 2048 of them) into LDS and the selection and the
 // refinement window are taken among those.  Whenever that cannot be exact - more candidates than the LDS list holds
 // (ties, a sample that does not represent the row), a window reaching beyond tau - the three-read path runs instead.
@@ -325,9 +325,14 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
     bool windowed = false;
     float approx = 0.f, lo = 0.f, hi = 0.f;
     if (fast_ok) {
-      const int64_t stride = M / kSample;
+      // the sample: 128 runs of 16 consecutive entries spread evenly over the row (any subset gives a valid bound; a
+      // stride-24 sample of single entries touched every cache line of the row, i.e. read it a second time)
+      const int64_t run_stride = M / (kSample / 16);
 #pragma unroll
-      for (int j = 0; j < kSample / 256; ++j) samp[tid + 256 * j] = drow[(int64_t)(tid + 256 * j) * stride];
+      for (int j = 0; j < kSample / 256; ++j) {
+        const int sidx = tid + 256 * j;
+        samp[sidx] = drow[(int64_t)(sidx >> 4) * run_stride + (sidx & 15)];
+      }
       __syncthreads();
       const unsigned key_s = hist_select24([&](int64_t m) { return samp[m]; }, kSample, (unsigned)k, scale, hist, part, sel, tid);
       if (key_s < 16777214u) {

@@ -151,6 +151,45 @@ for t in range(a.rounds):
     got = _hip.knn_kth(_hip.l2_normalize(dev(q)), dev(bn), kk).cpu().numpy()
     check("knn", (nq, m, dk, kk), rel(got, oracle.knn_kth_score(bn, q, kk, chunk=64)), 2e-5)
 
+    # ---- kNN, large problems: candidate distances from bf16 piece products vs the f32 matrix-core kernel ----
+    # (the same entry point takes the bf16 kernel when the workspace holds the planes; both feed the exact f32
+    #  re-measurement, so the scores have to agree bit for bit; a few rows against the oracle)
+    if t % 3 == 0:
+        nq2 = int(rng.choice([1024, 1300, 2048, 3000]))
+        m2 = int(rng.choice([4096, 5000, 8192, 12001]))
+        d2 = int(rng.choice([256, 300, 512, 1000, 2048]))
+        k2 = int(rng.choice([1, 5, 50, 200]))
+        scale_rows = rng.random() < 0.4
+        bank2 = rng.standard_normal((m2, d2)).astype(np.float32)
+        q2 = rng.standard_normal((nq2, d2)).astype(np.float32)
+        if scale_rows:  # un-normalised rows over several orders of magnitude
+            bank2 *= (10.0 ** rng.uniform(-2, 2, size=(m2, 1))).astype(np.float32)
+            q2 *= (10.0 ** rng.uniform(-2, 2, size=(nq2, 1))).astype(np.float32)
+        else:
+            bank2 /= np.linalg.norm(bank2, axis=1, keepdims=True)
+            q2 /= np.linalg.norm(q2, axis=1, keepdims=True)
+        if rng.random() < 0.5:
+            bank2[m2 // 3: m2 // 3 + 300] = bank2[7]  # copied rows: ties around the k-th distance
+            q2[:20] = bank2[100:120]                  # exact hits
+        lib = _hip.load_library()
+        qd, bd = dev(q2), dev(bank2)
+        outs = []
+        full = lib.runia_knn_workspace_bytes(nq2, m2, d2, k2)
+        f32_only = (nq2 * m2 + nq2 + m2 + 4) * 4
+        for ws_bytes in (full, f32_only):
+            ws = torch.empty(ws_bytes // 4 + 1, dtype=torch.float32, device="cuda")
+            o = torch.full((nq2,), 123.0, device="cuda")
+            rc = lib.runia_knn_kth_f32(qd.data_ptr(), bd.data_ptr(), o.data_ptr(), ws.data_ptr(), ws_bytes, nq2, m2, d2, k2,
+                                       torch.cuda.current_stream().cuda_stream)
+            assert rc == 0
+            outs.append(o.cpu().numpy())
+            del ws
+        same = lib.runia_knn_piece_products(nq2, m2, d2) > 0 and full > f32_only and np.array_equal(outs[0], outs[1])
+        check("knn bf16 vs f32 kernel", (nq2, m2, d2, k2, scale_rows), 0.0 if same else 1.0, 0.5)
+        pick = [0, 19, nq2 // 2, nq2 - 1]
+        check("knn bf16 vs oracle", (nq2, m2, d2, k2, scale_rows),
+              rel(outs[0][pick], oracle.knn_kth_score(bank2, q2[pick], k2, normalize=False)), 2e-5)
+
     # ---- LaRED: direct and matrix-core kernels against the exact definition ----
     dl, mt, nx = int(rng.choice([1, 2, 8, 16, 23, 24, 40, 64, 100])), int(rng.choice([1, 10, 700, 3000])), int(rng.choice([1, 63, 65, 900]))
     tr, x = rng.standard_normal((mt, dl)), rng.standard_normal((nx, dl)) * float(rng.choice([0.5, 1.0, 3.0]))
