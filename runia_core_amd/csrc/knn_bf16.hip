@@ -27,6 +27,10 @@
 #include <cstdint>
 #include <type_traits>
 
+#ifndef KNN16_SAMECHUNK
+#define KNN16_SAMECHUNK 0  // timing experiments only
+#endif
+
 namespace runia_knn16 {
 
 constexpr int TQ = 256, TB = 256;            // tile
@@ -172,8 +176,12 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
     const bool is_a = (n == 0 || n >= 5);
     const int t = (n == 0) ? 0 : (n >= 5 ? n - 4 : n - 1);
     const uint4* base = (is_a ? a_lane : b_lane) + stage * (kStageBytes / 16) + gk[ks] + t * 256;
+#if KNN16_NOREAD  // timing experiment (wrong results): operands are not re-read
+    if (ks == 99) { if (is_a) fa[t] = *base; else fb[t] = *base; }
+#else
     if (is_a) fa[t] = *base;
     else fb[t] = *base;
+#endif
   };
   auto mfma1 = [&](const uint4 (&fa)[4], const uint4 (&fb)[4], int n) {  // matrix instruction n = 4 i + j
     const int i = n >> 2, j = n & 3;
@@ -191,14 +199,20 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
   auto dma_begin = [&](int stage) {
     dma_s0 = dma_next;
     dma_l0 = lds0 + (unsigned)stage * (unsigned)kStageBytes + (unsigned)wave * 16u * 1024u;
+#if !KNN16_SAMECHUNK  // (timing experiment, wrong results: every stage re-reads the first one - all L2 hits)
     dma_next += KC * 2;
+#endif
     if (++next_k == nk) {
       next_k = 0;
       if (++next_t == TERMS) { next_t = TERMS - 1; next_k = nk - 1; dma_next = dma_s0; }  // past the end: the last stage again (never read)
-      else dma_next = term_base(next_t);
+      else dma_next = term_base(KNN16_SAMECHUNK ? 0 : next_t);
     }
   };
+#if KNN16_NODMA  // timing experiment (wrong results): no DMA inside the loop
+  auto dma_one = [&](int j) { (void)j; };
+#else
   auto dma_one = [&](int j) { dma16(dma_l0 + 1024u * j, voff[j & 1], rsrc, dma_s0 + (unsigned)(8 * j * Dp * 2)); };
+#endif
   auto issue = [&](int stage) {
     dma_begin(stage);
 #pragma unroll
@@ -212,14 +226,18 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
   // scheduler sinks every read to just in front of its first use and gathers the rest at the barrier).
   //   k-steps 0..2 of stage d:  16 MFMAs each  |  the 8 operand reads of the next k-step
   //   k-step 3 of stage d:      16 MFMAs       |  wait "DMA(d+1) landed" + barrier (everyone has read stage d to the
-  //                                               end), DMA(d+2) into the buffer of stage d, the reads of (d+1, 0)
+  //                                               end), DMA(d+2) into the buffer of stage d begins, the reads of (d+1, 0)
+  //   The 16 DMA instructions of a stage go out ONE per pair of matrix instructions (7 in k-step 3, 8 in the next
+  //   k-step 0, 1 in k-step 1): a vector-memory instruction holds the wave's issue for longer than a pair's shadow.
   // Every request of the DMA is a whole 128-byte line of a row (with 32-k stages - 64 bytes per row - the kernel ran at
   // the L2's half-line rate: 45 % matrix-pipe utilisation at 7.3 TB/s of L2 reads).  Past the end the last stage is
   // fetched again into a buffer nobody reads, so the wait is always the plain vmcnt(0).
 #define RUNIA_PIN __builtin_amdgcn_sched_barrier(0)
   issue(0);
-  issue(1);
-  asm volatile("s_waitcnt vmcnt(16)" ::: "memory");
+  dma_begin(1);  // stage 1 as the loop leaves a stage at its top: instructions 0 .. 6 issued, 7 .. 15 follow in k-steps 0 and 1
+#pragma unroll
+  for (int j = 0; j < 7; ++j) dma_one(j);
+  asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   __syncthreads();
   uint4 fa0[4], fb0[4], fa1[4], fb1[4];
 #pragma unroll
@@ -228,22 +246,24 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
   for (int d = 0; d < total; ++d) {
     RUNIA_PIN;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {  // k-step 0
+    for (int n = 0; n < 8; ++n) {  // k-step 0 (+ DMA instructions 7 .. 14 of the stage whose DMA began in the last k-step 3)
       load_one(fa1, fb1, stage, 1, n);
+      dma_one(7 + n);
       RUNIA_PIN;
       mfma1(fa0, fb0, 2 * n);
       mfma1(fa0, fb0, 2 * n + 1);
       RUNIA_PIN;
     }
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {  // k-step 1
+    for (int n = 0; n < 8; ++n) {  // k-step 1 (+ DMA instruction 15)
       load_one(fa0, fb0, stage, 2, n);
+      if (n == 0) dma_one(15);
       RUNIA_PIN;
       mfma1(fa1, fb1, 2 * n);
       mfma1(fa1, fb1, 2 * n + 1);
       RUNIA_PIN;
     }
-    dma_begin(stage);  // scalar bookkeeping of the DMA issued in k-step 3, in the shadow of k-step 2
+    dma_begin(stage);  // scalar bookkeeping of the DMA that starts in k-step 3, in the shadow of k-step 2
 #pragma unroll
     for (int n = 0; n < 8; ++n) {  // k-step 2
       load_one(fa1, fb1, stage, 3, n);
@@ -260,10 +280,8 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
     stage ^= 1;
     RUNIA_PIN;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      dma_one(3 * g);
-      dma_one(3 * g + 1);
-      dma_one(3 * g + 2);
+    for (int g = 0; g < 4; ++g) {  // one DMA instruction per pair of matrix instructions: a second or third one in the
+      dma_one(g);                  // same gap outlasts the pair's 64 cycles and drains the matrix pipe
       RUNIA_PIN;
       mfma1(fa1, fb1, 2 + 2 * g);
       mfma1(fa1, fb1, 3 + 2 * g);
@@ -271,8 +289,7 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
     }
 #pragma unroll
     for (int g = 0; g < 2; ++g) {
-      dma_one(12 + 2 * g);
-      dma_one(13 + 2 * g);
+      dma_one(4 + g);
       load_one(fa0, fb0, stage, 0, 3 * g);
       load_one(fa0, fb0, stage, 0, 3 * g + 1);
       load_one(fa0, fb0, stage, 0, 3 * g + 2);
@@ -281,6 +298,7 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
       mfma1(fa1, fb1, 11 + 2 * g);
       RUNIA_PIN;
     }
+    dma_one(6);
     load_one(fa0, fb0, stage, 0, 6);
     load_one(fa0, fb0, stage, 0, 7);
     RUNIA_PIN;
@@ -288,6 +306,7 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
     mfma1(fa1, fb1, 15);
   }
 #undef RUNIA_PIN
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail of the last (unused) DMA
   // epilogue: C[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31] of each 32 x 32 tile
 #pragma unroll
   for (int i = 0; i < 4; ++i)
