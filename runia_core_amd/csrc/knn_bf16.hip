@@ -1,41 +1,43 @@
 // a8 kNN, candidate distances of large problems on the bf16 matrix cores (gfx950: v_mfma_f32_32x32x16_bf16, 16x the
 // per-instruction work of v_mfma_f32_32x32x2_f32 at the same issue cost).
 //
-// An f32 value is split into three bf16 pieces, x = h + m + l exactly up to 2^-24 |x| (h = bf16(x), m = bf16(x - h),
-// l = bf16(x - h - m): 8 significand bits each, f32's exponent range, so no scaling and no range restriction).  The dot
-// product q.b is then the sum of the piece products; the six of order <= 2^-16 are kept,
-//     q.b ~= l.h + h.l + m.m + m.h + h.m + h.h        (dropped: m.l + l.m + l.l <= 3 * 2^-24 |q||b|),
-// each an exact bf16 product accumulated in f32 by the matrix cores - the accuracy of the f32 contraction this replaces
-// (whose own accumulation error is ~ sqrt(D) 2^-24), at 6/16 of its matrix-pipe time; or only the three of order
-// <= 2^-8 (m.h + h.m + h.h, error <= 3 * 2^-16 |q||b|, 3/16 of the time) - the default, KNN16_TERMS.  The result feeds
-// the SAME selection + exact f32 re-measurement as the f32 kernel's distances (pairwise.hip, kth_select_range_kernel),
-// whose window is widened to twice this kernel's error bound (runia_knn16_refine_rel): every bank row that could be the
-// k-th neighbour is re-measured with exact f32 differences, so the caller gets the exactly re-measured k-th distance
-// either way; this kernel only decides which bank rows are looked at.
+// An f32 value is split into bf16 pieces, x = h + m + (rest <= 2^-16 |x|): h = bf16(x), m = bf16(x - h), 8 significand
+// bits each, f32's exponent range, so no scaling and no range restriction.  The dot product q.b is taken as the three
+// piece products of order <= 2^-8,
+//     q.b ~= m.h + h.m + h.h        (dropped: m.m + h.l + l.h + ... <= 3 * 2^-16 |q||b|),
+// each an exact bf16 product accumulated in f32 by the matrix cores, 3/16 of the f32 contraction's matrix-pipe time.  The
+// result feeds the SAME selection + exact f32 re-measurement as the f32 kernel's distances (pairwise.hip,
+// kth_select_range_kernel), whose window is widened to twice this kernel's error bound (runia_knn16_refine_rel): every
+// bank row that could be the k-th neighbour is re-measured with exact f32 differences, so the caller gets the exactly
+// re-measured k-th distance either way; this kernel only decides which bank rows are looked at.  (All six products of
+// order <= 2^-16 - f32 accuracy, window unchanged - were built and measured first: 9.3 ms per chunk against 5.3 for
+// three; profiles/README.md.)
+//
+// Memory layout of the pieces ("planes"): per row, per block of 32 k, 64 bytes of h followed by 64 bytes of m - one
+// 128-byte line holds both pieces of a block, so ONE fetched line feeds all three products of that block.
 //
 // Kernel shape.  One workgroup = 256 queries x 256 bank rows, 4 waves of 128 x 128 (4 x 4 MFMA tiles, 256 accumulator
-// registers, one wave per SIMD).  K runs over the piece pairs x D in stages of 64: a stage of a tile is 256 rows x 128
-// bytes, staged by `buffer_load_dwordx4 ... lds` (16 per wave and stage, no staging registers, no ds_write) into one of
-// two LDS buffers (2 x 64 KB).  LDS slot (16 bytes = 8 consecutive k of one row) of (row, kgroup g) is
-// row * 8 + (g ^ ((row >> 1) & 7)): the eight lanes that fetch one row read its whole 128-byte line, and the
-// ds_read_b128 of an MFMA operand (32 consecutive rows, one kgroup per half-wave) is conflict-free: the LDS serves a b128
-// read in four groups of 16 lanes - {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 - and within a group the
-// rows of one parity have row >> 1 in {0, 1, 6, 7, 10, 11, 12, 13} or {2, 3, 4, 5, 8, 9, 14, 15}, eight different values
-// mod 8, so the 16 slots fall into the 16 different 16-byte bank groups.  The pipeline is described at the loop.
+// registers, one wave per SIMD).  K runs over D in stages of 32: a stage of a tile is 256 rows x 128 bytes (h | m),
+// staged by `buffer_load_dwordx4 ... lds` (16 per wave and stage, no staging registers, no ds_write) into one of two LDS
+// buffers (2 x 64 KB), and is multiplied three ways: 96 matrix instructions per 64 KB moved (the form with one product
+// per stage - 64 per 64 KB - was bound by the bytes the DMA moves: profiles/README.md).  LDS slot (16 bytes = 8
+// consecutive k of one piece of one row) g = 0..3 (h) / 4..7 (m) of a row sits at row * 8 + (g ^ ((row >> 1) & 7)):
+// the eight lanes that fetch one row read its whole 128-byte line, and the ds_read_b128 of an MFMA operand (32
+// consecutive rows, one slot per half-wave) is conflict-free: the LDS serves a b128 read in four groups of 16 lanes -
+// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 - and within a group the rows of one parity have row >> 1
+// in {0, 1, 6, 7, 10, 11, 12, 13} or {2, 3, 4, 5, 8, 9, 14, 15}, eight different values mod 8, so the 16 slots fall into
+// the 16 different 16-byte bank groups.  The pipeline is described at the loop.
 #include "common.hpp"
 
 #include <cstdint>
 #include <type_traits>
 
-#ifndef KNN16_SAMECHUNK
-#define KNN16_SAMECHUNK 0  // timing experiments only
-#endif
 
 namespace runia_knn16 {
 
 constexpr int TQ = 256, TB = 256;            // tile
-[[maybe_unused]] constexpr int KC = 64;      // k per LDS stage
-[[maybe_unused]] constexpr int kStages = 2, kStageBytes = 2 * 256 * KC * 2;  // one stage = 64 k of both tiles = 64 KB
+[[maybe_unused]] constexpr int KC = 32;      // k per LDS stage
+[[maybe_unused]] constexpr int kStages = 2, kStageBytes = 2 * 256 * KC * 4;  // one stage = 32 k of both tiles, h | m = 64 KB
 [[maybe_unused]] constexpr float kFltMax = 3.4028234663852886e38f;
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -47,7 +49,7 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {  // bf16 bits of x, roun
   return (b + 0x7fffu + ((b >> 16) & 1u)) >> 16;
 }
 
-// f32 [R, D] -> three bf16 planes [3][Rpad][Dp] (h, m, l), zero in the padding; 8 consecutive k per thread
+// f32 [R, D] -> pieces [Rpad][Dp / 32][h: 32 bf16 | m: 32 bf16], zero in the padding; 8 consecutive k per thread
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes,
                                                          int64_t R, int64_t D, int64_t Rpad, int64_t Dp) {
   const int64_t groups = Dp / 8, total = Rpad * groups;
@@ -67,24 +69,17 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
         for (int j = 0; j < 8; ++j) v[j] = (k0 + j < D) ? p[j] : 0.f;
       }
     }
-    unsigned h[8], m[8], l[8];
+    unsigned h[8], m[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
       h[j] = bf16_rne(v[j]);
       const float hf = __uint_as_float(h[j] << 16);
       const bool fin = (__float_as_uint(hf) & 0x7f800000u) != 0x7f800000u;  // an infinite / NaN head has no tail
-      const float r1 = fin ? v[j] - hf : 0.f;                               // exact: the low 16 bits of the significand
-      m[j] = bf16_rne(r1);
-      const float r2 = r1 - __uint_as_float(m[j] << 16);                    // exact
-      l[j] = bf16_rne(r2);
+      m[j] = bf16_rne(fin ? v[j] - hf : 0.f);                               // v - hf is exact (the low 16 significand bits)
     }
-    const int64_t o = row * Dp + k0, plane = Rpad * Dp;
-    *reinterpret_cast<uint4*>(planes + o) =
-        make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
-    *reinterpret_cast<uint4*>(planes + plane + o) =
-        make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
-    *reinterpret_cast<uint4*>(planes + 2 * plane + o) =
-        make_uint4(l[0] | (l[1] << 16), l[2] | (l[3] << 16), l[4] | (l[5] << 16), l[6] | (l[7] << 16));
+    uint16_t* o = planes + (row * Dp + (k0 / 32) * 32) * 2 + (k0 % 32);  // block of 32 k: 64 bytes h, then 64 bytes m
+    *reinterpret_cast<uint4*>(o) = make_uint4(h[0] | (h[1] << 16), h[2] | (h[3] << 16), h[4] | (h[5] << 16), h[6] | (h[7] << 16));
+    *reinterpret_cast<uint4*>(o + 32) = make_uint4(m[0] | (m[1] << 16), m[2] | (m[3] << 16), m[4] | (m[5] << 16), m[6] | (m[7] << 16));
   }
 }
 
@@ -108,29 +103,18 @@ __device__ __forceinline__ void dma16(unsigned lds_bytes, unsigned voff, i32x4 r
 }
 #endif
 
-// piece pairs, smallest products first (h = 0, m = 1, l = 2): 6 terms  l.h h.l m.m m.h h.m h.h,  3 terms  m.h h.m h.h
-// (error <= 3 * 2^-16 |q||b|: would need a wider refinement window in the caller).  One nibble per term - a table
-// indexed at run time would live in constant memory, and its scalar load waits for every LDS read in flight.
-template <int TERMS>
-__device__ __forceinline__ void piece_pair(int t, int& pa, int& pb) {
-  constexpr unsigned A = TERMS == 6 ? 0x001102u : 0x001u, B = TERMS == 6 ? 0x010120u : 0x010u;
-  pa = (int)((A >> (4 * t)) & 15u);
-  pb = (int)((B >> (4 * t)) & 15u);
-}
-
-template <int TERMS>
 __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ bp,
                                                              const float* __restrict__ qn, const float* __restrict__ bn,
                                                              float* __restrict__ dist, int64_t Q, int64_t M, int64_t Dp,
                                                              int64_t Qpad, int64_t Mpad) {
 #if defined(__HIP_DEVICE_COMPILE__)
-  extern __shared__ __attribute__((aligned(16))) uint4 lds[];  // NS stages x (1024 A slots + 1024 B slots)
+  extern __shared__ __attribute__((aligned(16))) uint4 lds[];  // 2 buffers x (2048 query slots + 2048 bank slots)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wq = wave >> 1, wb = wave & 1;
   // XCD-aware order: ids i, i + 8, ... (one XCD's share) walk a super-tile of 8 query tiles x 4 bank tiles; its 32
-  // workgroups are resident on that XCD together and sweep K in step, so a tile's chunk is fetched into that L2 once
-  // and read 4 (8) times.  Super-tiles are dealt round-robin to the XCDs.
+  // workgroups are resident on that XCD together and sweep K in step, so a tile's stage is fetched into that L2 once
+  // and read 4 (8) times (measured: 79 % L2 hits of the ideal 81 %).  Super-tiles are dealt round-robin to the XCDs.
   int64_t q0, m0;
   {
     const int64_t nqt = (Q + TQ - 1) / TQ, nbt = (M + TB - 1) / TB;
@@ -144,19 +128,18 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
     m0 = bt * TB;
   }
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) void*)lds;
-  // DMA: a stage (64 k of both tiles) = 4096 slots = 64 instructions of 8 rows x 8 kgroups; wave w issues I = 16 w ..
+  // DMA: a stage (32 k of both tiles, h | m) = 4096 slots = 64 instructions of 8 rows x 8 slots; wave w issues I = 16 w ..
   // 16 w + 15 (I < 32: query rows 8 I .. 8 I + 7, else bank rows).  Lane i of an instruction: row i / 8, slot position
-  // i % 8, i.e. kgroup (i % 8) ^ ((row >> 1) & 7) - the eight lanes of a row fetch its whole 128-byte line.
+  // i % 8, i.e. slot (i % 8) ^ ((row >> 1) & 7) of the row - the eight lanes of a row fetch its whole 128-byte line.
   const bool mine_a = wave < 2;
-  const i32x4 rsrc = mine_a ? raw_buffer(qp, (unsigned)(3 * Qpad * Dp * 2)) : raw_buffer(bp, (unsigned)(3 * Mpad * Dp * 2));
-  const int64_t rows_pad = mine_a ? Qpad : Mpad;
+  const unsigned row_bytes = (unsigned)(Dp * 4);  // h and m of one row
+  const i32x4 rsrc = mine_a ? raw_buffer(qp, (unsigned)(Qpad * Dp * 4)) : raw_buffer(bp, (unsigned)(Mpad * Dp * 4));
   const int64_t tile_row0 = (mine_a ? q0 : m0) + 8 * 16 * (wave & 1);
   unsigned voff[2];  // by the parity of I: (row >> 1) & 7 = (4 I + (i >> 4)) & 7
 #pragma unroll
   for (int par = 0; par < 2; ++par)
-    voff[par] = (unsigned)((lane >> 3) * Dp * 2 + (((lane & 7) ^ ((lane >> 4) | (par << 2))) * 16));
-  const int nk = (int)(Dp / KC), total = TERMS * nk;
-  int next_t = 0, next_k = 0;  // piece pair and stage within it of the next DMA (scalar counters: no division per stage)
+    voff[par] = (unsigned)(lane >> 3) * row_bytes + (unsigned)(((lane & 7) ^ ((lane >> 4) | (par << 2))) * 16);
+  const int total = (int)(Dp / KC);
   f32x16 acc[4][4];
 #pragma unroll
   for (int i = 0; i < 4; ++i)
@@ -164,146 +147,119 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-  // operand reads: lane l reads row (l & 31) of a 32-row tile, kgroup 2 ks + (l >> 5), ks = 0 .. 3 within a stage
+  // operand reads: lane l reads row (l & 31) of a 32-row tile; operand set s = 0, 1: the two k-steps of the h piece
+  // (slots 2 s + (l >> 5)), s = 2, 3: of the m piece (slots 4 + 2 (s - 2) + (l >> 5))
   const int lrow = lane & 31, lhalf = lane >> 5;
   const uint4* a_lane = lds + (wq * 128 + lrow) * 8;
   const uint4* b_lane = lds + 2048 + (wb * 128 + lrow) * 8;
   int gk[4];
 #pragma unroll
   for (int ks = 0; ks < 4; ++ks) gk[ks] = (2 * ks + lhalf) ^ ((lane >> 1) & 7);
-  // operand n of a k-step in the order the matrix instructions first need them: a0, b0, b1, b2, b3, a1, a2, a3
-  auto load_one = [&](uint4 (&fa)[4], uint4 (&fb)[4], int stage, int ks, int n) {
-    const bool is_a = (n == 0 || n >= 5);
-    const int t = (n == 0) ? 0 : (n >= 5 ? n - 4 : n - 1);
-    const uint4* base = (is_a ? a_lane : b_lane) + stage * (kStageBytes / 16) + gk[ks] + t * 256;
-#if KNN16_NOREAD  // timing experiment (wrong results): operands are not re-read
-    if (ks == 99) { if (is_a) fa[t] = *base; else fb[t] = *base; }
-#else
-    if (is_a) fa[t] = *base;
-    else fb[t] = *base;
-#endif
-  };
-  auto mfma1 = [&](const uint4 (&fa)[4], const uint4 (&fb)[4], int n) {  // matrix instruction n = 4 i + j
+  typedef uint4 frag4[4];
+  auto load_a = [&](frag4& f, int buf, int ks, int t) { f[t] = a_lane[buf * (kStageBytes / 16) + gk[ks] + t * 256]; };
+  auto load_b = [&](frag4& f, int buf, int ks, int t) { f[t] = b_lane[buf * (kStageBytes / 16) + gk[ks] + t * 256]; };
+  auto mfma1 = [&](const frag4& fa, const frag4& fb, int n) {  // matrix instruction n = 4 i + j
     const int i = n >> 2, j = n & 3;
     acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, fa[i]), __builtin_bit_cast(bf16x8, fb[j]),
                                                         acc[i][j], 0, 0, 0);
   };
-  // running source offset of the next stage: + 128 bytes per stage, re-based when the piece pair changes
-  const unsigned plane_bytes = (unsigned)(rows_pad * Dp * 2), tile_bytes = (unsigned)(tile_row0 * Dp * 2);
-  auto term_base = [&](int t) {
-    int pa, pb;
-    piece_pair<TERMS>(t, pa, pb);
-    return (unsigned)(mine_a ? pa : pb) * plane_bytes + tile_bytes;
-  };
-  unsigned dma_next = term_base(0), dma_s0 = 0, dma_l0 = 0;
-  auto dma_begin = [&](int stage) {
+  // running source offset of the next stage: + 128 bytes (one block of h | m) per stage
+  unsigned dma_next = (unsigned)tile_row0 * row_bytes, dma_s0 = 0, dma_l0 = 0;
+  int next_k = 0;
+  auto dma_begin = [&](int buf) {
     dma_s0 = dma_next;
-    dma_l0 = lds0 + (unsigned)stage * (unsigned)kStageBytes + (unsigned)wave * 16u * 1024u;
-#if !KNN16_SAMECHUNK  // (timing experiment, wrong results: every stage re-reads the first one - all L2 hits)
-    dma_next += KC * 2;
-#endif
-    if (++next_k == nk) {
-      next_k = 0;
-      if (++next_t == TERMS) { next_t = TERMS - 1; next_k = nk - 1; dma_next = dma_s0; }  // past the end: the last stage again (never read)
-      else dma_next = term_base(KNN16_SAMECHUNK ? 0 : next_t);
-    }
+    dma_l0 = lds0 + (unsigned)buf * (unsigned)kStageBytes + (unsigned)wave * 16u * 1024u;
+    if (++next_k < total) dma_next += 128u;  // past the end: the last stage again, into a buffer nobody reads
   };
-#if KNN16_NODMA  // timing experiment (wrong results): no DMA inside the loop
-  auto dma_one = [&](int j) { (void)j; };
-#else
-  auto dma_one = [&](int j) { dma16(dma_l0 + 1024u * j, voff[j & 1], rsrc, dma_s0 + (unsigned)(8 * j * Dp * 2)); };
-#endif
-  auto issue = [&](int stage) {
-    dma_begin(stage);
-#pragma unroll
-    for (int j = 0; j < 16; ++j) dma_one(j);
-  };
-  // Pipeline: two LDS stages of 64 k (four k-steps of 16 MFMAs).  The DMA of stage d + 1 flies while stage d is
-  // multiplied; the operand registers run one k-step ahead of the matrix instructions that consume them, across stage
-  // boundaries too.  A wave issues matrix instructions back to back (32 cycles each); whatever else it has to do - 32
-  // operand reads, 16 DMA instructions, one wait and one barrier per stage - is placed BETWEEN them, two matrix
-  // instructions apart, so that it runs in their shadow (__builtin_amdgcn_sched_barrier pins the order: left alone, the
-  // scheduler sinks every read to just in front of its first use and gathers the rest at the barrier).
-  //   k-steps 0..2 of stage d:  16 MFMAs each  |  the 8 operand reads of the next k-step
-  //   k-step 3 of stage d:      16 MFMAs       |  wait "DMA(d+1) landed" + barrier (everyone has read stage d to the
-  //                                               end), DMA(d+2) into the buffer of stage d begins, the reads of (d+1, 0)
-  //   The 16 DMA instructions of a stage go out ONE per pair of matrix instructions (7 in k-step 3, 8 in the next
-  //   k-step 0, 1 in k-step 1): a vector-memory instruction holds the wave's issue for longer than a pair's shadow.
-  // Every request of the DMA is a whole 128-byte line of a row (with 32-k stages - 64 bytes per row - the kernel ran at
-  // the L2's half-line rate: 45 % matrix-pipe utilisation at 7.3 TB/s of L2 reads).  Past the end the last stage is
-  // fetched again into a buffer nobody reads, so the wait is always the plain vmcnt(0).
+  auto dma_one = [&](int j) { dma16(dma_l0 + 1024u * j, voff[j & 1], rsrc, dma_s0 + (unsigned)(8 * j) * row_bytes); };
+  // Pipeline.  A stage (32 k) is multiplied three ways in six steps of 16 matrix instructions,
+  //     1: Ah0 x Bh0   2: Ah0 x Bm0   3: Am0 x Bh0   4: Ah1 x Bh1   5: Ah1 x Bm1   6: Am1 x Bh1
+  // (Xh0 / Xh1: the two k-steps of the h piece, Xm0 / Xm1: of the m piece), every operand set read from LDS one step
+  // before its first use into five register sets (RA: Ah0 -> Ah1, RB0: Bh0, RB1: Bh1, RX: Bm0 -> Bm1, RY: Am0 -> Am1),
+  // across stage boundaries too.  A wave issues matrix instructions back to back (32 cycles each); whatever else it has
+  // to do - 32 operand reads, 16 DMA instructions, one wait and one barrier per stage - is placed BETWEEN them, at most
+  // one vector-memory instruction per pair (it holds the wave's issue for longer than a pair's shadow), so that it runs
+  // in their shadow (__builtin_amdgcn_sched_barrier pins the order: left alone, the scheduler sinks every read to just in
+  // front of its first use and gathers the rest at the barrier).  In step 6 of stage d: wait "DMA(d+1) landed" +
+  // barrier (everyone has read stage d to the end), DMA(d+2) into the buffer of stage d begins (7 instructions there,
+  // 8 in the next step 1, 1 in step 2), the reads of (d+1: Ah0, Bh0).
 #define RUNIA_PIN __builtin_amdgcn_sched_barrier(0)
-  issue(0);
-  dma_begin(1);  // stage 1 as the loop leaves a stage at its top: instructions 0 .. 6 issued, 7 .. 15 follow in k-steps 0 and 1
+  frag4 RA, RB0, RB1, RX, RY;
+  dma_begin(0);
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dma_one(j);
+  dma_begin(1);  // stage 1 as the loop leaves a stage at its top: instructions 0 .. 6 issued
 #pragma unroll
   for (int j = 0; j < 7; ++j) dma_one(j);
   asm volatile("s_waitcnt vmcnt(7)" ::: "memory");
   __syncthreads();
-  uint4 fa0[4], fb0[4], fa1[4], fb1[4];
 #pragma unroll
-  for (int n = 0; n < 8; ++n) load_one(fa0, fb0, 0, 0, n);
-  int stage = 0;
+  for (int t = 0; t < 4; ++t) { load_a(RA, 0, 0, t); load_b(RB0, 0, 0, t); }
+  int buf = 0;
   for (int d = 0; d < total; ++d) {
     RUNIA_PIN;
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {  // k-step 0 (+ DMA instructions 7 .. 14 of the stage whose DMA began in the last k-step 3)
-      load_one(fa1, fb1, stage, 1, n);
+    for (int n = 0; n < 8; ++n) {  // step 1: Ah0 x Bh0 | read Bm0 -> RX, DMA instructions 7 .. 14
+      if (n < 4) load_b(RX, buf, 2, n);
       dma_one(7 + n);
       RUNIA_PIN;
-      mfma1(fa0, fb0, 2 * n);
-      mfma1(fa0, fb0, 2 * n + 1);
+      mfma1(RA, RB0, 2 * n);
+      mfma1(RA, RB0, 2 * n + 1);
       RUNIA_PIN;
     }
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {  // k-step 1 (+ DMA instruction 15)
-      load_one(fa0, fb0, stage, 2, n);
+    for (int n = 0; n < 8; ++n) {  // step 2: Ah0 x Bm0 | read Am0 -> RY, DMA instruction 15
+      if (n < 4) load_a(RY, buf, 2, n);
       if (n == 0) dma_one(15);
       RUNIA_PIN;
-      mfma1(fa1, fb1, 2 * n);
-      mfma1(fa1, fb1, 2 * n + 1);
+      mfma1(RA, RX, 2 * n);
+      mfma1(RA, RX, 2 * n + 1);
       RUNIA_PIN;
     }
-    dma_begin(stage);  // scalar bookkeeping of the DMA that starts in k-step 3, in the shadow of k-step 2
 #pragma unroll
-    for (int n = 0; n < 8; ++n) {  // k-step 2
-      load_one(fa1, fb1, stage, 3, n);
+    for (int n = 0; n < 8; ++n) {  // step 3: Am0 x Bh0 | read Ah1 -> RA, Bh1 -> RB1
+      if (n < 4) load_a(RA, buf, 1, n);
+      else load_b(RB1, buf, 1, n - 4);
       RUNIA_PIN;
-      mfma1(fa0, fb0, 2 * n);
-      mfma1(fa0, fb0, 2 * n + 1);
+      mfma1(RY, RB0, 2 * n);
+      mfma1(RY, RB0, 2 * n + 1);
       RUNIA_PIN;
     }
-    mfma1(fa1, fb1, 0);  // k-step 3
-    mfma1(fa1, fb1, 1);
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {  // step 4: Ah1 x Bh1 | read Bm1 -> RX
+      if (n < 4) load_b(RX, buf, 3, n);
+      RUNIA_PIN;
+      mfma1(RA, RB1, 2 * n);
+      mfma1(RA, RB1, 2 * n + 1);
+      RUNIA_PIN;
+    }
+    dma_begin(buf);  // scalar bookkeeping of the DMA that starts in step 6, in the shadow of step 5
+#pragma unroll
+    for (int n = 0; n < 8; ++n) {  // step 5: Ah1 x Bm1 | read Am1 -> RY
+      if (n < 4) load_a(RY, buf, 3, n);
+      RUNIA_PIN;
+      mfma1(RA, RX, 2 * n);
+      mfma1(RA, RX, 2 * n + 1);
+      RUNIA_PIN;
+    }
+    mfma1(RY, RB1, 0);  // step 6: Am1 x Bh1
+    mfma1(RY, RB1, 1);
     RUNIA_PIN;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    stage ^= 1;
+    buf ^= 1;
     RUNIA_PIN;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {  // one DMA instruction per pair of matrix instructions: a second or third one in the
-      dma_one(g);                  // same gap outlasts the pair's 64 cycles and drains the matrix pipe
+    for (int g = 0; g < 7; ++g) {  // | DMA instructions 0 .. 6 of stage d + 2, the reads of the next Ah0 -> RA, Bh0 -> RB0
+      dma_one(g);
+      if (g < 4) load_a(RA, buf, 0, g);
+      else load_b(RB0, buf, 0, g - 4);
       RUNIA_PIN;
-      mfma1(fa1, fb1, 2 + 2 * g);
-      mfma1(fa1, fb1, 3 + 2 * g);
-      RUNIA_PIN;
-    }
-#pragma unroll
-    for (int g = 0; g < 2; ++g) {
-      dma_one(4 + g);
-      load_one(fa0, fb0, stage, 0, 3 * g);
-      load_one(fa0, fb0, stage, 0, 3 * g + 1);
-      load_one(fa0, fb0, stage, 0, 3 * g + 2);
-      RUNIA_PIN;
-      mfma1(fa1, fb1, 10 + 2 * g);
-      mfma1(fa1, fb1, 11 + 2 * g);
+      mfma1(RY, RB1, 2 + 2 * g);
+      mfma1(RY, RB1, 3 + 2 * g);
       RUNIA_PIN;
     }
-    dma_one(6);
-    load_one(fa0, fb0, stage, 0, 6);
-    load_one(fa0, fb0, stage, 0, 7);
-    RUNIA_PIN;
-    mfma1(fa1, fb1, 14);
-    mfma1(fa1, fb1, 15);
+    load_b(RB0, buf, 0, 3);
   }
 #undef RUNIA_PIN
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the tail of the last (unused) DMA
@@ -331,11 +287,11 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
 
 // ---- host side (called from pairwise.hip) ----
 int64_t runia_knn16_padded_rows(int64_t rows) { return (rows + 255) / 256 * 256; }
-int64_t runia_knn16_padded_width(int64_t D) { return (D + 63) / 64 * 64; }
+int64_t runia_knn16_padded_width(int64_t D) { return (D + 31) / 32 * 32; }
 size_t runia_knn16_plane_bytes(int64_t rows, int64_t D) {
-  return (size_t)(3 * runia_knn16_padded_rows(rows) * runia_knn16_padded_width(D)) * sizeof(uint16_t);
+  return (size_t)(2 * runia_knn16_padded_rows(rows) * runia_knn16_padded_width(D)) * sizeof(uint16_t);
 }
-// the planes of a matrix must be addressable through one 32-bit buffer
+// the pieces of a matrix must be addressable through one 32-bit buffer
 bool runia_knn16_fits(int64_t rows, int64_t D) { return runia_knn16_plane_bytes(rows, D) < ((size_t)1 << 32) - 4096; }
 
 int runia_knn16_split(const float* x, uint16_t* planes, int64_t R, int64_t D, hipStream_t s) {
@@ -344,28 +300,25 @@ int runia_knn16_split(const float* x, uint16_t* planes, int64_t R, int64_t D, hi
   return runia_check_launch();
 }
 
-#ifndef KNN16_TERMS
-#define KNN16_TERMS 3
-#endif
 // Half-width of the caller's refinement window, relative to the row's range bound R = (|q| + max|b|)^2: it has to be at
 // least TWICE the largest error e of a candidate distance (then every bank row outside the window lies on the same side
-// of the true k-th distance as of the approximate one).  Six terms: the dropped products are <= 3 * 2^-24 |q||b| - the
-// f32 kernel's own allowance stands.  Three terms: dropped m.m + h.l + l.h <= 3 * 2^-16 sum|q_k||b_k| <= 3 * 2^-16 |q||b|
-// (each piece is below 2^-8 of the one before; Cauchy-Schwarz), |q||b| <= R / 4, and the distance carries twice the
-// product's error: e <= 2.3e-5 R, plus the accumulation allowance -> 5e-5 R.
-int runia_knn16_terms() { return KNN16_TERMS; }
-float runia_knn16_refine_rel() { return KNN16_TERMS == 6 ? 5e-6f : 5e-5f; }
+// of the true k-th distance as of the approximate one).  Dropped products: m.m + h.l + l.h + ... <= 3 * 2^-16 sum|q_k||b_k|
+// <= 3 * 2^-16 |q||b| (each piece is below 2^-8 of the one before; Cauchy-Schwarz), |q||b| <= R / 4, and the distance
+// carries twice the product's error: e <= 2.3e-5 R, plus the f32 kernel's accumulation allowance -> 5e-5 R.
+int runia_knn16_terms() { return 3; }
+float runia_knn16_refine_rel() { return 5e-5f; }
+
 int runia_knn16_dist(const uint16_t* qp, const uint16_t* bp, const float* qn, const float* bn, float* dist, int64_t Q,
                      int64_t M, int64_t D, hipStream_t s) {
   using namespace runia_knn16;
   constexpr size_t lds_bytes = (size_t)kStages * kStageBytes;
   static std::atomic<uint64_t> lds_ok{0};
-  const int rc = runia_allow_dynamic_lds(reinterpret_cast<const void*>(knn_dist_bf16_kernel<KNN16_TERMS>), lds_bytes, lds_ok);
+  const int rc = runia_allow_dynamic_lds(reinterpret_cast<const void*>(knn_dist_bf16_kernel), lds_bytes, lds_ok);
   if (rc != RUNIA_OK) return rc;
   const int64_t nqt = (Q + TQ - 1) / TQ, nbt = (M + TB - 1) / TB;
   const int64_t st = ((nqt + 7) / 8) * ((nbt + 3) / 4);
   const unsigned grid = (unsigned)(((st + 7) / 8) * 8 * 32);
-  knn_dist_bf16_kernel<KNN16_TERMS><<<grid, 256, lds_bytes, s>>>(qp, bp, qn, bn, dist, Q, M, runia_knn16_padded_width(D),
-                                                                  runia_knn16_padded_rows(Q), runia_knn16_padded_rows(M));
+  knn_dist_bf16_kernel<<<grid, 256, lds_bytes, s>>>(qp, bp, qn, bn, dist, Q, M, runia_knn16_padded_width(D),
+                                                     runia_knn16_padded_rows(Q), runia_knn16_padded_rows(M));
   return runia_check_launch();
 }

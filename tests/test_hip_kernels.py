@@ -461,7 +461,7 @@ def test_knn_bf16_candidate_distances_equal_the_f32_path(hip, n, m, d):
         qd, bd = dev(q, torch.float32), dev(bank, torch.float32)
         full = lib.runia_knn_workspace_bytes(n, m, d, k)
         f32_only = (min(n, 8192) * m + min(n, 8192) + m + 4) * 4
-        assert full > f32_only + 6 * m * d  # the planes were asked for: this size takes the bf16 kernel
+        assert full > f32_only + 4 * m * d  # the pieces (h | m, 4 bytes per element) were asked for: this size takes the bf16 kernel
         ws_bytes = full if big else f32_only
         ws = torch.empty(ws_bytes // 4 + 1, dtype=torch.float32, device="cuda")
         out = torch.full((n,), 123.0, device="cuda")
