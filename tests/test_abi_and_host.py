@@ -395,3 +395,29 @@ def test_sort_of_32_is_two_16_blocks_and_batcher_merge():
             w[off + a], w[off + b], w[off + c] = t[0], t[1], t[2]
     merge_stage(w, 32, 16)
     np.testing.assert_array_equal(np.stack(w, axis=1), np.sort(vals, axis=1))
+
+
+def test_bf16_piece_products_error_bound_behind_the_knn_window():
+    """csrc/knn_bf16.hip ranks bank rows by q.b ~ m.h + h.m + h.h with x = h + m + rest (h = bf16(x), m = bf16(x - h),
+    round to nearest even) and widens the refinement window of the exact re-measurement to twice its error bound
+    3 * 2^-16 * sum|q_k||b_k| <= 3 * 2^-16 |q||b|.  The bound, restated in NumPy (f64 sums of exact piece products) on
+    vectors over many orders of magnitude: the split is exact to 2^-16 per element and the dropped products stay below it."""
+    rng = np.random.default_rng(3)
+
+    def bf16(x):  # round-to-nearest-even truncation of f32 to 8 significand bits, as bf16_rne in the kernel
+        u = np.ascontiguousarray(x, dtype=np.float32).view(np.uint32)
+        r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) >> np.uint32(16)) << np.uint32(16)
+        return r.astype(np.uint32).view(np.float32)
+
+    for scale in (1.0, 1e-6, 1e6):
+        q = (rng.standard_normal((64, 2048)) * scale * 10.0 ** rng.uniform(-2, 2, size=(64, 1))).astype(np.float32)
+        b = (rng.standard_normal((64, 2048)) * 10.0 ** rng.uniform(-2, 2, size=(64, 1))).astype(np.float32)
+        qh, bh = bf16(q), bf16(b)
+        qm, bm = bf16(q - qh), bf16(b - bh)  # q - qh is exact in f32 (the low 16 significand bits)
+        assert np.all(np.abs((q - qh).astype(np.float64) - (q.astype(np.float64) - qh.astype(np.float64))) == 0)
+        assert np.all(np.abs(q - qh - qm) <= 2.0 ** -16 * np.abs(q) * (1 + 2.0 ** -7))
+        exact = (q.astype(np.float64) * b.astype(np.float64)).sum(1)
+        three = (qm.astype(np.float64) * bh + qh.astype(np.float64) * bm + qh.astype(np.float64) * bh).sum(1)
+        bound = 3 * 2.0 ** -16 * (np.abs(q).astype(np.float64) * np.abs(b)).sum(1)
+        assert np.all(np.abs(exact - three) <= bound * 1.01)
+        assert np.all(bound <= 3 * 2.0 ** -16 * np.linalg.norm(q.astype(np.float64), axis=1) * np.linalg.norm(b.astype(np.float64), axis=1) * (1 + 1e-12))

@@ -3,6 +3,8 @@
 // Evolutionary search in the style of the published sorting-network hunters: mutate a valid network, keep the
 // mutant when it still sorts all 2^N 0/1 inputs (0-1 principle) and does not cost more.
 //   g++ -O3 -march=native -o /tmp/sorter3 tools/search/sorter3.cpp && /tmp/sorter3 <seed> <seconds> [N] ["start network"]
+// N < 0: search for a MERGING network of two sorted halves of |N| / 2 inputs instead (checked on every pair of sorted
+// 0/1 halves, (|N|/2 + 1)^2 vectors; start: the last stage of Batcher's odd-even merge sort).
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -45,17 +47,32 @@ int main(int argc, char** argv) {
   const unsigned seed = argc > 1 ? atoi(argv[1]) : 1;
   const double seconds = argc > 2 ? atof(argv[2]) : 60;
   if (argc > 3) N = atoi(argv[3]);
-  const size_t V = (size_t)1 << N;
+  const bool merge_mode = N < 0;
+  if (merge_mode) N = -N;
+  std::vector<uint64_t> vecs;  // the 0/1 test vectors (bit i = wire i)
+  if (merge_mode) {
+    const int H = N / 2;
+    for (int a = 0; a <= H; ++a)
+      for (int b = 0; b <= H; ++b) {  // halves sorted ascending: a (b) ones at the top of the lower (upper) half
+        uint64_t v = 0;
+        for (int i = H - a; i < H; ++i) v |= 1ull << i;
+        for (int i = N - b; i < N; ++i) v |= 1ull << i;
+        vecs.push_back(v);
+      }
+  } else {
+    for (uint64_t v = 0; v < ((uint64_t)1 << N); ++v) vecs.push_back(v);
+  }
+  const size_t V = vecs.size();
   W = (int)((V + 63) / 64);
   init_words.assign((size_t)N * W, 0);
   for (size_t v = 0; v < V; ++v)
-    for (int i = 0; i < N; ++i) if ((v >> i) & 1) init_words[(size_t)i * W + (v >> 6)] |= 1ull << (v & 63);
+    for (int i = 0; i < N; ++i) if ((vecs[v] >> i) & 1) init_words[(size_t)i * W + (v >> 6)] |= 1ull << (v & 63);
   std::mt19937_64 rng(seed * 7919u + 13u);
   auto rnd = [&](int n) { return (int)(rng() % (uint64_t)n); };
   // start: odd-even transposition sort is always valid; bubble-ish start keeps the search unbiased but slow, so use
   // Batcher's odd-even merge sort as the seed network
   std::vector<El> cur;
-  for (int p = 1; p < N; p <<= 1)
+  for (int p = merge_mode ? N / 2 : 1; p < N; p <<= 1)
     for (int k = p; k >= 1; k >>= 1)
       for (int j = k % p; j + k < N; j += 2 * k)
         for (int i = 0; i < k; ++i)
