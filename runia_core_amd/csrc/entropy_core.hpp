@@ -49,8 +49,9 @@ __device__ __forceinline__ void sort3(double& a, double& b, double& c) {  // no 
 // 120); NP = 8: 8 three-sorters = 24 instructions (19 comparators = 38).  Both networks were found by
 // tools/search/sorter3.cpp (mutate a valid network of 2- and 3-sorters, keep the mutant if it still sorts every 0/1
 // input and costs no more) and are re-checked over all 2^NP 0/1 inputs by tests/test_abi_and_host.py (0-1 principle:
-// min3 / med3 / max3 are monotone, so it carries over).  NP = 32 / 64: 16-blocks by that network + Batcher's odd-even
-// merge stages over them (32: 2 * 84 + 2 * 65 = 298 instructions instead of 2 * 191); smaller sizes: Batcher's sort.
+// min3 / med3 / max3 are monotone, so it carries over).  NP = 32: two 16-blocks by that network + a searched merging
+// network (2 * 84 + 100 = 268 instructions; Batcher's 32-sorter: 191 comparators = 382); NP = 64: the same on both halves
+// + Batcher's last merge stage; smaller sizes: Batcher's sort.
 template <int OFF, int NP, typename T>
 __device__ __forceinline__ void sort16_at(T (&v)[NP]) {
 #define RUNIA_S3(a, b, c) sort3(v[OFF + a], v[OFF + b], v[OFF + c]);
@@ -60,6 +61,24 @@ __device__ __forceinline__ void sort16_at(T (&v)[NP]) {
   RUNIA_S3(5, 6, 13) RUNIA_S3(0, 8, 9) RUNIA_S3(1, 8, 9) RUNIA_S3(3, 7, 11) RUNIA_S3(13, 14, 15)
   RUNIA_S3(11, 12, 13) RUNIA_S3(4, 8, 11) RUNIA_S3(5, 7, 9) RUNIA_S3(2, 6, 10) RUNIA_S3(6, 7, 8)
   RUNIA_S3(3, 5, 6) RUNIA_S3(2, 3, 4) RUNIA_S3(9, 10, 11)
+#undef RUNIA_S3
+}
+
+// Merge of two ascending 16-blocks at OFF .. OFF+15 and OFF+16 .. OFF+31: 30 three-sorters + 5 compare-exchanges = 100
+// instructions (Batcher's odd-even merge: 65 comparators = 130), found by tools/search/sorter3.cpp in merge mode (valid
+// iff it orders every pair of sorted 0/1 halves - 17 x 17 inputs - re-checked by tests/test_abi_and_host.py).
+template <int OFF, int NP, typename T>
+__device__ __forceinline__ void merge16x2_at(T (&v)[NP]) {
+#define RUNIA_S3(a, b, c) sort3(v[OFF + a], v[OFF + b], v[OFF + c]);
+#define RUNIA_S2(a, b) cswap(v[OFF + a], v[OFF + b]);
+  RUNIA_S2(10, 26) RUNIA_S3(14, 26, 30) RUNIA_S3(12, 26, 28) RUNIA_S3(4, 12, 20) RUNIA_S3(0, 4, 16)
+  RUNIA_S3(1, 4, 17) RUNIA_S3(3, 17, 19) RUNIA_S3(2, 10, 18) RUNIA_S3(15, 30, 31) RUNIA_S3(6, 10, 22)
+  RUNIA_S3(5, 17, 21) RUNIA_S3(2, 3, 4) RUNIA_S3(13, 21, 29) RUNIA_S3(7, 19, 23) RUNIA_S3(11, 19, 27)
+  RUNIA_S3(9, 21, 25) RUNIA_S3(7, 9, 17) RUNIA_S3(8, 20, 24) RUNIA_S3(15, 23, 27) RUNIA_S3(6, 7, 16)
+  RUNIA_S3(11, 13, 17) RUNIA_S3(14, 18, 22) RUNIA_S3(8, 12, 16) RUNIA_S3(15, 19, 21) RUNIA_S3(9, 10, 12)
+  RUNIA_S2(5, 6) RUNIA_S3(21, 22, 24) RUNIA_S3(18, 19, 20) RUNIA_S3(23, 25, 26) RUNIA_S3(15, 17, 18)
+  RUNIA_S3(27, 28, 29) RUNIA_S3(14, 15, 16) RUNIA_S2(23, 24) RUNIA_S2(13, 14) RUNIA_S2(11, 12)
+#undef RUNIA_S2
 #undef RUNIA_S3
 }
 
@@ -78,8 +97,12 @@ __device__ __forceinline__ void sort_asc(T (&v)[NP]) {
       if constexpr (NP >= 64) { sort16_at<32>(v); sort16_at<48>(v); }
       static_assert(NP <= 64, "add the 16-blocks of a larger sort here");
     }
+    if constexpr (NP >= 32) {
+      merge16x2_at<0>(v);
+      if constexpr (NP >= 64) merge16x2_at<32>(v);
+    }
 #pragma unroll
-    for (int p = (NP >= 16 ? 16 : 1); p < NP; p <<= 1) {
+    for (int p = (NP >= 32 ? 32 : (NP >= 16 ? 16 : 1)); p < NP; p <<= 1) {
 #pragma unroll
       for (int k = p; k >= 1; k >>= 1) {
 #pragma unroll

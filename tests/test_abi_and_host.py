@@ -339,7 +339,7 @@ def test_semantic_entropy_reference_goldens():
 def _three_sorter_networks():
     """The 3-sorter networks of csrc/entropy_core.hpp, read from the source: {inputs: [(a, b, c), ...]}."""
     src = open(os.path.join(ROOT, "runia_core_amd", "csrc", "entropy_core.hpp")).read()
-    body16 = src[src.index("void sort16_at("):src.index("void sort_asc(")]
+    body16 = src[src.index("void sort16_at("):src.index("void merge16x2_at(")]
     body8 = src[src.index("if constexpr (NP == 8)"):]
     body8 = body8[:body8.index("#undef RUNIA_S3")]
     pat = re.compile(r"RUNIA_S3\((\d+), (\d+), (\d+)\)")
@@ -366,34 +366,34 @@ def test_three_sorter_networks_sort_every_zero_one_input():
             assert not np.any(wires[i] & ~wires[i + 1]), (n, i)
 
 
-def test_sort_of_32_is_two_16_blocks_and_batcher_merge():
-    """sort_asc<32>: the 16-network on each half, then the p = 16 stage of Batcher's odd-even merge sort (same loop
-    as the source).  A merge network is checked by every pair of sorted 0/1 halves (17 x 17); real values on top."""
-    net = _three_sorter_networks()[16]
+def test_sort_of_32_is_two_16_blocks_and_a_merging_network():
+    """sort_asc<32>: the 16-network on each half, then the searched merging network of csrc/entropy_core.hpp (30
+    three-sorters + 5 compare-exchanges).  A merging network is valid iff it orders every pair of sorted 0/1 halves
+    (17 x 17 inputs; min3 / med3 / max3 are monotone); real values with ties on top."""
+    net16 = _three_sorter_networks()[16]
+    src = open(os.path.join(ROOT, "runia_core_amd", "csrc", "entropy_core.hpp")).read()
+    body = src[src.index("void merge16x2_at("):src.index("void sort_asc(")]
+    merge = [tuple(int(x) for x in m.groups() if x is not None)
+             for m in re.finditer(r"RUNIA_S[23]\((\d+), (\d+)(?:, (\d+))?\)", body)]
+    assert sum(len(e) for e in merge) == 100 and all(list(e) == sorted(set(e)) and e[-1] < 32 for e in merge)
 
-    def merge_stage(w, n, p):
-        k = p
-        while k >= 1:
-            for j in range(k % p, n - k, 2 * k):
-                for i in range(k):
-                    if i + j + k < n and (i + j) // (2 * p) == (i + j + k) // (2 * p):
-                        lo, hi = np.minimum(w[i + j], w[i + j + k]), np.maximum(w[i + j], w[i + j + k])
-                        w[i + j], w[i + j + k] = lo, hi
-            k //= 2
+    def run(w, net, off=0):
+        for e in net:
+            t = np.sort(np.stack([w[off + i] for i in e]), axis=0)
+            for j, i in enumerate(e):
+                w[off + i] = t[j]
 
     cases = np.array([[0] * (16 - a) + [1] * a + [0] * (16 - b) + [1] * b for a in range(17) for b in range(17)])
     w = [cases[:, i].copy() for i in range(32)]
-    merge_stage(w, 32, 16)
+    run(w, merge)
     assert all(np.all(w[i] <= w[i + 1]) for i in range(31))
     rng = np.random.default_rng(5)
     vals = rng.standard_normal((4096, 32)).astype(np.float32)
     vals[::7, 3] = vals[::7, 9]  # ties
     w = [vals[:, i].copy() for i in range(32)]
-    for off in (0, 16):
-        for a, b, c in net:
-            t = np.sort(np.stack([w[off + a], w[off + b], w[off + c]]), axis=0)
-            w[off + a], w[off + b], w[off + c] = t[0], t[1], t[2]
-    merge_stage(w, 32, 16)
+    run(w, net16, 0)
+    run(w, net16, 16)
+    run(w, merge)
     np.testing.assert_array_equal(np.stack(w, axis=1), np.sort(vals, axis=1))
 
 
