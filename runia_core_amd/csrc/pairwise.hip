@@ -238,7 +238,7 @@ __device__ __forceinline__ unsigned hist_select24(Load load, int64_t count, unsi
   unsigned bin1 = 0;
   for (int pass = 0; pass < 2; ++pass) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) hist[tid * 16 + j] = 0u;
+    for (int j = 0; j < 16; ++j) hist[j * 256 + tid] = 0u;  // (consecutive lanes, consecutive words)
     __syncthreads();
     auto tally = [&](float d) {
       const unsigned key = dist_key(d, scale);
@@ -261,24 +261,38 @@ __device__ __forceinline__ unsigned hist_select24(Load load, int64_t count, unsi
       for (int64_t m = tid; m < count; m += 256) tally(load(m));
     }
     __syncthreads();
+    // Thread t owns bins 16 t .. 16 t + 15.  The group that holds the wanted rank is found by a parallel prefix sum over
+    // the 256 group totals (wave scan + four wave totals) and its bin by that one thread from registers.  (One thread
+    // walking the 256 totals and then 16 bins - every step a dependent LDS read - took ~25 000 cycles per pass, four
+    // passes per row: half of the select kernel's time.)
+    unsigned hb[16];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint4 v = reinterpret_cast<const uint4*>(hist + tid * 16)[j];
+      hb[4 * j] = v.x; hb[4 * j + 1] = v.y; hb[4 * j + 2] = v.z; hb[4 * j + 3] = v.w;
+    }
     unsigned ssum = 0;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) ssum += hist[tid * 16 + j];
-    part[tid] = ssum;
+    for (int j = 0; j < 16; ++j) ssum += hb[j];
+    unsigned incl = ssum;  // inclusive prefix within the wave
+    const int lane = tid & 63;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned up = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += up;
+    }
+    if (lane == 63) part[tid >> 6] = incl;
     __syncthreads();
-    if (tid == 0) {
-      unsigned r = rank, t = 0;
-      for (; t < 255; ++t) {
-        if (r <= part[t]) break;
-        r -= part[t];
+    unsigned before = incl - ssum;  // entries in the groups below this one
+    for (int w = 0; w < (tid >> 6); ++w) before += part[w];
+    // exactly one owner: before < rank <= before + ssum; the last group takes whatever is left (as the serial walk did)
+    if ((before < rank && rank <= before + ssum && tid < 255) || (tid == 255 && before < rank)) {
+      unsigned r = rank - before, b = 0;
+#pragma unroll
+      for (int j = 0; j < 15; ++j) {
+        if (b == (unsigned)j && r > hb[j]) { r -= hb[j]; b = j + 1; }
       }
-      unsigned b = t * 16;
-      for (; b < t * 16 + 15; ++b) {
-        const unsigned c = hist[b];
-        if (r <= c) break;
-        r -= c;
-      }
-      sel[0] = b;
+      sel[0] = tid * 16 + b;
       sel[1] = r;
     }
     __syncthreads();
