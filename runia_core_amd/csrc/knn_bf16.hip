@@ -1,5 +1,5 @@
-// a8 kNN, candidate distances of large problems on the bf16 matrix cores (gfx950: v_mfma_f32_32x32x16_bf16, 16x the
-// per-instruction work of v_mfma_f32_32x32x2_f32 at the same issue cost).
+// a8 kNN, candidate distances of large problems on the bf16 matrix cores (gfx950: v_mfma_f32_16x16x32_bf16, 16x the
+// work per matrix-pipe cycle of the f32 forms).
 //
 // An f32 value is split into bf16 pieces, x = h + m + (rest <= 2^-16 |x|): h = bf16(x), m = bf16(x - h), 8 significand
 // bits each, f32's exponent range, so no scaling and no range restriction.  The dot product q.b is taken as the three
@@ -16,22 +16,21 @@
 // Memory layout of the pieces ("planes"): per row, per block of 32 k, 64 bytes of h followed by 64 bytes of m - one
 // 128-byte line holds both pieces of a block, so ONE fetched line feeds all three products of that block.
 //
-// Kernel shape.  One workgroup = 256 queries x 256 bank rows, 4 waves of 128 x 128 (4 x 4 MFMA tiles, 256 accumulator
-// registers, one wave per SIMD).  K runs over D in stages of 32: a stage of a tile is 256 rows x 128 bytes (h | m),
-// staged by `buffer_load_dwordx4 ... lds` (16 per wave and stage, no staging registers, no ds_write) into one of two LDS
-// buffers (2 x 64 KB), and is multiplied three ways: 96 matrix instructions per 64 KB moved (the form with one product
-// per stage - 64 per 64 KB - was bound by the bytes the DMA moves: profiles/README.md).  LDS slot (16 bytes = 8
-// consecutive k of one piece of one row) g = 0..3 (h) / 4..7 (m) of a row sits at row * 8 + (g ^ ((row >> 1) & 7)):
-// the eight lanes that fetch one row read its whole 128-byte line, and the ds_read_b128 of an MFMA operand (32
-// consecutive rows, one slot per half-wave) is conflict-free: the LDS serves a b128 read in four groups of 16 lanes -
-// {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31} and the same + 32 - and within a group the rows of one parity have row >> 1
-// in {0, 1, 6, 7, 10, 11, 12, 13} or {2, 3, 4, 5, 8, 9, 14, 15}, eight different values mod 8, so the 16 slots fall into
-// the 16 different 16-byte bank groups.  The pipeline is described at the loop.
+// Kernel shape.  One workgroup = 256 queries x 256 bank rows, 4 waves of 128 x 128 (8 x 8 MFMA tiles of 16 x 16, 256
+// accumulator registers, one wave per SIMD).  K runs over D in stages of 32: a stage of a tile is 256 rows x 128 bytes
+// (h | m), staged by `buffer_load_dwordx4 ... lds` (16 per wave and stage, no staging registers, no ds_write) into one of
+// two LDS buffers (2 x 64 KB), and is multiplied three ways: 192 matrix instructions (16 cycles each) per 64 KB moved (the
+// form with one product per staged chunk was bound by the bytes the DMA moves: profiles/README.md).  LDS slot (16 bytes =
+// 8 consecutive k of one piece of one row) g = 0..3 (h) / 4..7 (m) of a row sits at row * 8 + (g ^ ((row >> 1) & 7)): the
+// eight lanes that fetch one row read its whole 128-byte line, and the ds_read_b128 of an MFMA operand (lane l: row l & 15
+// of a 16-row tile, slot l >> 4) is conflict-free: the LDS serves a b128 read in four groups of 16 lanes - {0-3, 12-15,
+// 20-27}, {4-11, 16-19, 28-31} and the same + 32 - i.e. rows {0-3, 12-15} of one slot with rows {4-11} of the next, and
+// under the swizzle those 16 (row, slot) pairs fall into the 16 different 16-byte bank groups (SQ_LDS_BANK_CONFLICT = 0).
+// The pipeline is described at the loop.
 #include "common.hpp"
 
 #include <cstdint>
 #include <type_traits>
-
 
 namespace runia_knn16 {
 
@@ -39,7 +38,6 @@ constexpr int TQ = 256, TB = 256;            // tile
 [[maybe_unused]] constexpr int KC = 32;      // k per LDS stage
 [[maybe_unused]] constexpr int kStages = 2, kStageBytes = 2 * 256 * KC * 4;  // one stage = 32 k of both tiles, h | m = 64 KB
 [[maybe_unused]] constexpr float kFltMax = 3.4028234663852886e38f;
-typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
 

@@ -421,3 +421,21 @@ def test_bf16_piece_products_error_bound_behind_the_knn_window():
         bound = 3 * 2.0 ** -16 * (np.abs(q).astype(np.float64) * np.abs(b)).sum(1)
         assert np.all(np.abs(exact - three) <= bound * 1.01)
         assert np.all(bound <= 3 * 2.0 ** -16 * np.linalg.norm(q.astype(np.float64), axis=1) * np.linalg.norm(b.astype(np.float64), axis=1) * (1 + 1e-12))
+
+
+def test_knn_kernel_choice_and_workspace_are_host_decisions():
+    """runia_knn_piece_products / runia_knn_workspace_bytes need no GPU: small problems keep the f32 matrix-core kernel
+    (0 piece products, the f32-sized workspace), large ones ask for the bf16 pieces on top (4 bytes per element of the
+    bank and of one chunk of queries, rows padded to 256, width to 32)."""
+    lib = _hip.load_library()
+    f32_words = lambda n, m: (min(n, 8192) * m + min(n, 8192) + m + 4)
+    for n, m, d in ((10, 50000, 2048), (4096, 1000, 2048), (4096, 50000, 64)):
+        assert lib.runia_knn_piece_products(n, m, d) == 0
+        assert lib.runia_knn_workspace_bytes(n, m, d, 50) == f32_words(n, m) * 4
+    for n, m, d in ((1024, 4096, 256), (100000, 50000, 2048), (3000, 5000, 300)):
+        assert lib.runia_knn_piece_products(n, m, d) == 3
+        pad = lambda r: (r + 255) // 256 * 256
+        dp = (d + 31) // 32 * 32
+        want = (f32_words(n, m) * 4 + 255) // 256 * 256 + 4 * dp * (pad(m) + pad(min(n, 8192)))
+        assert lib.runia_knn_workspace_bytes(n, m, d, 50) == want
+    assert lib.runia_knn_piece_products(4096, 2_000_000, 2048) == 0  # pieces beyond one 32-bit buffer: f32 kernel
