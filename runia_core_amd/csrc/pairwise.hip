@@ -744,26 +744,35 @@ int runia_knn16_dist(const uint16_t* qp, const uint16_t* bp, const float* qn, co
 #ifndef KNN_BF16
 #define KNN_BF16 1
 #endif
-// Worth the two split passes and the 256 x 256 tiles: a bank of some thousand rows, wide features, a batch of queries
+// Worth the two split passes and the 256 x 256 tiles: a bank of some thousand rows, wide features, a batch of queries, 2^31
+// multiply-adds (tools/ablate/run_knn_paths.py: 1 024 x 4 096 x 256 is 8 % slower on the bf16 kernel, 1 024 x 4 096 x 2048
+// 1.46 x faster, 8 192 x 50 000 x 2048 2.67 x)
 static bool knn16_wanted(int64_t N, int64_t M, int64_t D) {
-  return KNN_BF16 && N >= 1024 && M >= 4096 && D >= 256 && runia_knn16_fits(M, D) && runia_knn16_fits(kQueryChunk, D);
+  return KNN_BF16 && N >= 1024 && M >= 4096 && D >= 256 && N * M >= ((int64_t)1 << 31) / D && runia_knn16_fits(M, D) &&
+         runia_knn16_fits(kQueryChunk, D);
 }
 int runia_knn16_terms();
 extern "C" int runia_knn_piece_products(int64_t N, int64_t M, int64_t D) { return knn16_wanted(N, M, D) ? runia_knn16_terms() : 0; }
 static size_t knn_f32_words(int64_t qc, int64_t M) { return (size_t)(qc * M + qc + M + 4); }  // distances, |q|^2, |b|^2, max |b|^2
 
-extern "C" size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {
-  (void)k;
-  if (N <= 0 || M <= 0) return 0;
-  // query rows per pass: up to 8 192, fewer for very large banks so that the distance tile stays near 2 GiB
-  // (a 1 M-row bank would otherwise ask for 32 GB); the entry point works with whatever it is given (>= 1 row)
+// query rows per pass: up to 8 192, fewer for very large banks so that the distance tile stays near 2 GiB (a 1 M-row bank
+// would otherwise ask for 32 GB)
+static int64_t knn_chunk_rows(int64_t N, int64_t M) {
   int64_t qc = N < kQueryChunk ? N : kQueryChunk;
   const int64_t by_size = ((int64_t)1 << 31) / (4 * M);
   if (qc > by_size) qc = by_size < 256 ? (N < 256 ? N : 256) : by_size;
-  size_t bytes = knn_f32_words(qc, M) * sizeof(float);
-  // + the bf16 planes of the bank and of one chunk of queries when the bf16 kernel will be taken
-  if (knn16_wanted(N, M, D)) bytes = (bytes + 255) / 256 * 256 + runia_knn16_plane_bytes(M, D) + runia_knn16_plane_bytes(qc, D);
-  return bytes;
+  return qc;
+}
+static size_t knn16_head_bytes(int64_t qc, int64_t M) { return (knn_f32_words(qc, M) * sizeof(float) + 255) / 256 * 256; }
+
+extern "C" size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {
+  (void)k;
+  if (N <= 0 || M <= 0) return 0;
+  const int64_t qc = knn_chunk_rows(N, M);
+  // + the bf16 pieces of the bank and of one chunk of queries when the bf16 kernel will be taken; the entry point works
+  // with whatever it is given (>= 1 row of distances), but takes the bf16 kernel only with at least this much
+  if (knn16_wanted(N, M, D)) return knn16_head_bytes(qc, M) + runia_knn16_plane_bytes(M, D) + runia_knn16_plane_bytes(qc, D);
+  return knn_f32_words(qc, M) * sizeof(float);
 }
 
 extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score, void* workspace,
@@ -782,23 +791,14 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
   if (qc < 1) return RUNIA_E_WORKSPACE;
   if (qc > N) qc = N;
   if (qc > kQueryChunk) qc = kQueryChunk;
-  // bf16 candidate distances when the caller's workspace also holds the planes (runia_knn_workspace_bytes asks for them)
-  bool use16 = knn16_wanted(N, M, D);
+  // bf16 candidate distances exactly when the caller hands over the workspace runia_knn_workspace_bytes asks for (a
+  // smaller one - e.g. the f32 kernel's (chunk * M + chunk + M + 4) floats - keeps the f32 kernel: the caller's switch)
+  const bool use16 = knn16_wanted(N, M, D) && workspace_bytes >= runia_knn_workspace_bytes(N, M, D, k);
   uint16_t *bank_planes = nullptr, *q_planes = nullptr;
   if (use16) {
-    const size_t need_planes = runia_knn16_plane_bytes(M, D) + runia_knn16_plane_bytes(kQueryChunk < N ? kQueryChunk : N, D);
-    int64_t qc16 = qc;
-    for (;;) {  // the largest chunk whose distances leave room for the planes
-      const size_t head = (knn_f32_words(qc16, M) * sizeof(float) + 255) / 256 * 256;
-      if (head + need_planes <= workspace_bytes) {
-        qc = qc16;
-        bank_planes = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + head);
-        q_planes = bank_planes + runia_knn16_plane_bytes(M, D) / sizeof(uint16_t);
-        break;
-      }
-      if (qc16 <= 1024) { use16 = false; break; }
-      qc16 /= 2;
-    }
+    qc = knn_chunk_rows(N, M);
+    bank_planes = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + knn16_head_bytes(qc, M));
+    q_planes = bank_planes + runia_knn16_plane_bytes(M, D) / sizeof(uint16_t);
   }
   float* dist = reinterpret_cast<float*>(workspace);
   float* qn = dist + qc * M;
