@@ -14,6 +14,8 @@ from typing import NamedTuple, Optional, Union
 import numpy as np
 import torch  # imported before the library so that both share one HIP runtime
 
+from . import config as _config
+
 _LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "librunia_hip.so")
 _lib: Optional[ctypes.CDLL] = None
 
@@ -535,6 +537,10 @@ def knn_kth(q: torch.Tensor, bank: torch.Tensor, k: int) -> torch.Tensor:
     m = bank.shape[0]
     s = torch.empty((n,), dtype=torch.float32, device=q.device)
     ws_bytes = lib.runia_knn_workspace_bytes(n, m, d, k)
+    if not _config.knn_bf16_candidates and lib.runia_knn_piece_products(n, m, d) > 0:
+        # the f32 kernel's workspace (one chunk of distances, |q|^2, |b|^2, max |b|^2): the entry point then keeps that kernel
+        qc = min(n, 8192, max(256, (1 << 31) // (4 * m)))
+        ws_bytes = (qc * m + qc + m + 4) * 4
     ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=q.device)
     _check(
         lib.runia_knn_kth_f32(q.data_ptr(), bank.data_ptr(), s.data_ptr(), ws.data_ptr(), ws_bytes, n, m, d, int(k), _stream()),

@@ -908,3 +908,21 @@ def test_kde_matrix_core_path_equals_exact_differences(hip, m, n, d, bw):
     # embeddings far from the origin: the training mean is removed at setup, so the norm expansion stays exact
     far = hip.kde_score_packed(hip.kde_pack_train(td + 1.0e4), xd + 1.0e4, bw).cpu().numpy()
     assert np.abs(far - exp).max() / max(1.0, np.abs(exp).max()) < 1e-9
+
+
+def test_knn_config_switch_keeps_the_f32_kernel(hip):
+    """runia_core_amd.config.knn_bf16_candidates = False: hip.knn_kth hands the entry point the f32-sized workspace, which keeps
+    the f32 matrix-core kernel; the scores are the same bits as with the bf16 candidate kernel."""
+    from runia_core_amd import config
+
+    torch.manual_seed(5)
+    bank = torch.nn.functional.normalize(torch.randn(6000, 512, device="cuda"), dim=1)
+    q = torch.nn.functional.normalize(torch.randn(1500, 512, device="cuda"), dim=1)
+    assert hip.load_library().runia_knn_piece_products(1500, 6000, 512) == 3
+    a = hip.knn_kth(q, bank, 50)
+    try:
+        config.knn_bf16_candidates = False
+        b = hip.knn_kth(q, bank, 50)
+    finally:
+        config.knn_bf16_candidates = True
+    assert torch.equal(a, b)
