@@ -749,7 +749,7 @@ int runia_knn16_dist(const uint16_t* qp, const uint16_t* bp, const float* qn, co
 // 1.46 x faster, 8 192 x 50 000 x 2048 2.67 x)
 static bool knn16_wanted(int64_t N, int64_t M, int64_t D) {
   return KNN_BF16 && N >= 1024 && M >= 4096 && D >= 256 && N * M >= ((int64_t)1 << 31) / D && runia_knn16_fits(M, D) &&
-         runia_knn16_fits(kQueryChunk, D);
+         runia_knn16_fits(kQueryChunk, D) && 4 * M * 256 <= ((int64_t)1 << 31);  // (chunks of >= 256 queries: whole tiles)
 }
 int runia_knn16_terms();
 extern "C" int runia_knn_piece_products(int64_t N, int64_t M, int64_t D) { return knn16_wanted(N, M, D) ? runia_knn16_terms() : 0; }
