@@ -223,7 +223,10 @@ def main_cfg3(args, device, rank, world, dist, saved_stdout):
         "metric": "OOD scores/sec, Mahalanobis + Energy + kNN(k=50) on synthetic 1M x 2048 features",
         "value": round(rec["value"], 1), "unit": "rows/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(rec["ms_per_step"], 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
-        "dtype": "f64 (Mahalanobis) / f32 (Energy, kNN)", "data": "synthetic",
+        "dtype": "f64 (Mahalanobis) / f32 (Energy, kNN)" + (
+            "; kNN scores are exactly re-measured f32 distances, the bank rows to re-measure are ranked by bf16 piece products "
+            "(same bits as with the f32 matrix-core kernel: tests/test_hip_kernels.py::test_knn_bf16_candidate_distances_equal_the_f32_path)"
+            if st["knn"].get("piece_products") else ""), "data": "synthetic",
         "config": {"workload": "Synthetic 1M x 2048 features, Mahalanobis + Energy + kNN(k=50) postprocessors, rows sharded "
                                "over the GPUs (BASELINE.json configs[2])",
                    "rows": rec["rows_total"], "rows_per_gpu": rec["rows_local"], "features": bw.D_FEAT,
