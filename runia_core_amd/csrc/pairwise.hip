@@ -303,6 +303,30 @@ __device__ __forceinline__ unsigned hist_select24(Load load, int64_t count, unsi
   return (bin1 << 12) | sel[0];
 }
 
+// Exact squared L2 distance of two rows by one wave: lane l accumulates the elements l, l + 64, ... in that order (one
+// fma chain per lane, as ever - the bits of the re-measured distances do not change), eight loads of each row in flight
+// per lane instead of one dependent pair per trip (the refinement of a chunk of 8 192 rows: 0.21 -> 0.07 ms).
+__device__ __forceinline__ float exact_sqdist_wave(const float* __restrict__ qr, const float* __restrict__ br, int64_t D,
+                                                   int lane) {
+  float acc = 0.f;
+  int64_t i = lane;
+  for (; i + 448 < D; i += 512) {
+    float qa[8], ba[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) { qa[u] = qr[i + 64 * u]; ba[u] = br[i + 64 * u]; }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const float df = qa[u] - ba[u];
+      acc = fmaf(df, df, acc);
+    }
+  }
+  for (; i < D; i += 64) {
+    const float df = qr[i] - br[i];
+    acc = fmaf(df, df, acc);
+  }
+  return wave_sum_f32(acc);
+}
+
 __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict__ dist, const float* __restrict__ q,
                                                                 const float* __restrict__ bank,
                                                                 const float* __restrict__ qn,
@@ -434,13 +458,7 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
       for (int64_t m = wave; m < M; m += 4) {
         const float d = drow[m];  // wave-uniform
         if (d >= lo && d <= hi) {
-          const float* br = bank + m * D;
-          float acc = 0.f;
-          for (int64_t i = lane; i < D; i += 64) {
-            const float df = qr[i] - br[i];
-            acc = fmaf(df, df, acc);
-          }
-          acc = wave_sum_f32(acc);
+          const float acc = exact_sqdist_wave(qr, bank + m * D, D, lane);
           if (lane == 0) drow[m] = __uint_as_float(__float_as_uint(acc) | 0x80000000u);
         }
       }
@@ -475,13 +493,7 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
       continue;
     }
     for (unsigned c = wave; c < nc; c += 4) {
-      const float* br = bank + (int64_t)cand_idx[c] * D;
-      float acc = 0.f;
-      for (int64_t i = lane; i < D; i += 64) {
-        const float df = qr[i] - br[i];
-        acc = fmaf(df, df, acc);
-      }
-      acc = wave_sum_f32(acc);
+      const float acc = exact_sqdist_wave(qr, bank + (int64_t)cand_idx[c] * D, D, lane);
       if (lane == 0) cand_d[c] = acc;
     }
     __syncthreads();
