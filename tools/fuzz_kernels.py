@@ -158,7 +158,7 @@ for t in range(a.rounds):
         nq2 = int(rng.choice([1024, 1300, 2048, 3000]))
         m2 = int(rng.choice([4096, 5000, 8192, 12001]))
         d2 = int(rng.choice([256, 300, 512, 1000, 2048]))
-        k2 = int(rng.choice([1, 5, 50, 200]))
+        k2 = int(rng.choice([1, 5, 50, 200, 513, 1500]))  # > 512: the three-read selection; 1500 < every bank size here
         scale_rows = rng.random() < 0.4
         bank2 = rng.standard_normal((m2, d2)).astype(np.float32)
         q2 = rng.standard_normal((nq2, d2)).astype(np.float32)
