@@ -327,6 +327,69 @@ __device__ __forceinline__ float exact_sqdist_wave(const float* __restrict__ qr,
   return wave_sum_f32(acc);
 }
 
+// A handful of queries (serving: one image at a time): the 128-row tiles of the matrix-core kernels would compute 120+
+// rows of padding per bank tile (one query against 50 000 x 2048: 0.6 ms).  Here one wave takes one bank row, reads it
+// ONCE and measures it against every query with exact f32 differences - the same per-lane fma chain as
+// exact_sqdist_wave, so the distances are the values the large paths arrive at by re-measurement and a row scores the
+// same bits alone as inside a batch - and adds up the row's squared norm on the way (the selection's range bound).
+constexpr int kSmallQ = 8;
+__global__ __launch_bounds__(64 * kRowWaves) void knn_small_dist_kernel(const float* __restrict__ q,
+                                                                        const float* __restrict__ bank,
+                                                                        float* __restrict__ dist,
+                                                                        unsigned* __restrict__ bn_max_bits, int Q, int64_t M,
+                                                                        int64_t D) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int64_t m = (int64_t)blockIdx.x * kRowWaves + wave; m < M; m += (int64_t)gridDim.x * kRowWaves) {
+    const float* br = bank + m * D;
+    float acc[kSmallQ], bsq = 0.f;
+#pragma unroll
+    for (int j = 0; j < kSmallQ; ++j) acc[j] = 0.f;
+    int64_t i = lane;
+    for (; i + 448 < D; i += 512) {
+      float ba[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) ba[u] = br[i + 64 * u];
+#pragma unroll
+      for (int j = 0; j < kSmallQ; ++j) {
+        if (j < Q) {  // (uniform)
+          const float* qr = q + (int64_t)j * D;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float df = qr[i + 64 * u] - ba[u];
+            acc[j] = fmaf(df, df, acc[j]);
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) bsq = fmaf(ba[u], ba[u], bsq);
+    }
+    for (; i < D; i += 64) {
+      const float b = br[i];
+#pragma unroll
+      for (int j = 0; j < kSmallQ; ++j) {
+        if (j < Q) {
+          const float df = q[(int64_t)j * D + i] - b;
+          acc[j] = fmaf(df, df, acc[j]);
+        }
+      }
+      bsq = fmaf(b, b, bsq);
+    }
+#pragma unroll
+    for (int j = 0; j < kSmallQ; ++j) {
+      if (j < Q) {
+        const float d = wave_sum_f32(acc[j]);
+        // as the matrix-core kernels' epilogues: a NaN or infinite distance counts as faiss's FLT_MAX fill
+        if (lane == 0) dist[(int64_t)j * M + m] = (d == d) ? fminf(d, kFltMax) : kFltMax;
+      }
+    }
+    bsq = wave_sum_f32(bsq);
+    if (lane == 0 && bsq < INFINITY) {  // NaN / inf rows do not set the range (as row_sqnorm_kernel)
+      const unsigned b = __float_as_uint(bsq);
+      if (b > __atomic_load_n(bn_max_bits, __ATOMIC_RELAXED)) atomicMax(bn_max_bits, b);
+    }
+  }
+}
+
 __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict__ dist, const float* __restrict__ q,
                                                                 const float* __restrict__ bank,
                                                                 const float* __restrict__ qn,
@@ -817,6 +880,12 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
   float* bn = qn + qc;
   unsigned* bn_max = reinterpret_cast<unsigned*>(bn + M);
   if (hipMemsetAsync(bn_max, 0, sizeof(unsigned), s) != hipSuccess) return RUNIA_E_LAUNCH;
+  if (N <= kSmallQ && M >= 1024 && qc >= N) {  // a handful of queries: one pass over the bank, exact distances
+    row_sqnorm_kernel<<<runia_rows_grid(N), 64 * kRowWaves, 0, s>>>(q, qn, N, D, nullptr);
+    knn_small_dist_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(q, bank, dist, bn_max, (int)N, M, D);
+    kth_select_range_kernel<<<(unsigned)N, 256, 0, s>>>(dist, q, bank, qn, bn_max, score, N, M, D, k, kRefineRel);
+    return runia_check_launch();
+  }
   row_sqnorm_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(bank, bn, M, D, bn_max);
   int rc = runia_check_launch();
   if (rc != RUNIA_OK) return rc;

@@ -926,3 +926,44 @@ def test_knn_config_switch_keeps_the_f32_kernel(hip):
     finally:
         config.knn_bf16_candidates = True
     assert torch.equal(a, b)
+
+
+def test_knn_handful_of_queries_scores_the_bits_of_a_batch(hip):
+    """Up to 8 queries against a bank of >= 1 024 rows take one pass over the bank with exact f32 distances
+    (knn_small_dist_kernel) instead of the matrix-core tiles.  A row scores the same bits alone, among a handful and
+    inside a large batch (f32 kernel and bf16 candidate kernel), on unit vectors, un-normalised rows, copied bank rows and
+    NaN / infinite rows; the oracle on top."""
+    rng = np.random.default_rng(21)
+    m, d = 6000, 512
+    bank = rng.standard_normal((m, d)).astype(np.float32)
+    bank /= np.linalg.norm(bank, axis=1, keepdims=True)
+    bank[1000:1600] = bank[3]      # 600 copies: ties, the crowded-window path
+    q = rng.standard_normal((1500, d)).astype(np.float32)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0] = bank[3]
+    q[5] = bank[77]
+    bd, qd = dev(bank, torch.float32), dev(q, torch.float32)
+    for k in (1, 50, 599, 601, 2000):
+        whole = hip.knn_kth(qd, bd, k)                       # bf16 candidate kernel (1 500 x 6 000 x 512)
+        mid = hip.knn_kth(qd[:100].contiguous(), bd, k)      # f32 matrix-core kernel
+        assert torch.equal(mid, whole[:100]), k
+        for a, b in ((0, 1), (5, 6), (0, 8), (3, 7), (92, 100)):
+            few = hip.knn_kth(qd[a:b].contiguous(), bd, k)   # the handful path
+            assert torch.equal(few, whole[a:b]), (k, a, b)
+        exp = oracle.knn_kth_score(bank, q[:8], k, normalize=False)
+        assert rel_err(hip.knn_kth(qd[:8].contiguous(), bd, k).cpu().numpy(), exp) < 1e-5, k
+    # un-normalised rows over six orders of magnitude, NaN / infinite rows, a width that is not a multiple of 64
+    m2, d2 = 3000, 100
+    bank2 = (rng.standard_normal((m2, d2)) * 10.0 ** rng.uniform(-3, 3, size=(m2, 1))).astype(np.float32)
+    bank2[4, 1] = np.nan
+    bank2[9, 0] = np.inf
+    q2 = (rng.standard_normal((8, d2)) * 10.0 ** rng.uniform(-3, 3, size=(8, 1))).astype(np.float32)
+    q2[2, 0] = np.nan
+    q2[6, :] = np.inf
+    for k in (1, 50, 2998, 2999, 3000):
+        got = hip.knn_kth(dev(q2, torch.float32), dev(bank2, torch.float32), k).cpu().numpy()
+        exp = oracle.knn_kth_score(bank2, q2, k, normalize=False)
+        assert got[2] == -oracle.FLT_MAX and got[6] == -oracle.FLT_MAX
+        assert np.isfinite(got).all() and rel_err(got, exp) < 1e-5, k
+        many = hip.knn_kth(dev(np.concatenate([q2, q2, q2]), torch.float32), dev(bank2, torch.float32), k).cpu().numpy()
+        assert np.array_equal(many[:8], got) and np.array_equal(many[8:16], got), k
