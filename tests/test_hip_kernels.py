@@ -967,3 +967,27 @@ def test_knn_handful_of_queries_scores_the_bits_of_a_batch(hip):
         assert np.isfinite(got).all() and rel_err(got, exp) < 1e-5, k
         many = hip.knn_kth(dev(np.concatenate([q2, q2, q2]), torch.float32), dev(bank2, torch.float32), k).cpu().numpy()
         assert np.array_equal(many[:8], got) and np.array_equal(many[8:16], got), k
+
+
+@pytest.mark.parametrize("d,c", [(2048, 10), (300, 16), (512, 3)])
+def test_mahalanobis_small_batches_split_columns_and_keep_the_bits(hip, d, c):
+    """Few row tiles (< one per compute unit): the 256-column blocks of a tile go to separate workgroups and a finishing
+    launch adds their partial sums in the unsplit kernel's order (one row against a 2048 x 2048 precision: 1.6 -> 0.25 ms).
+    A row scores the same bits alone, in a small batch and in a batch large enough for the one-workgroup-per-tile launch;
+    the oracle's class loop on top."""
+    torch.manual_seed(d + c)
+    n = 9000  # 282 tiles of 32 rows >= 256 compute units: unsplit
+    a = torch.randn(d, d, dtype=torch.float64)
+    prec = (a @ a.T / d + torch.eye(d, dtype=torch.float64)).numpy()
+    cm = torch.randn(c, d).numpy().astype(np.float32)
+    f = torch.relu(torch.randn(n, d) + 0.3).cuda()
+    packed = hip.pack_weights(torch.from_numpy(prec).cuda())
+    mu_p = torch.from_numpy(cm.astype(np.float64) @ prec).cuda()
+    cmd = torch.from_numpy(cm).cuda()
+    whole = hip.mahalanobis_score(f, cmd, packed, mu_p)
+    for a0, b0 in ((0, 1), (5, 12), (100, 133), (1000, 1512), (2000, 7000)):
+        part = hip.mahalanobis_score(f[a0:b0].contiguous(), cmd, packed, mu_p)
+        assert torch.equal(part, whole[a0:b0]), (a0, b0)
+    rows = [0, 5, 100, 8999]
+    exp = oracle.mahalanobis_score(f[rows].cpu().numpy(), cm, prec, c)
+    assert rel_err(whole[rows].cpu().numpy(), exp) < 1e-9

@@ -1,0 +1,38 @@
+"""Latency of ONE call on few rows (serving one image or one request at a time), kernels through the Python wrappers:
+host wall time per call with a synchronize after every call.    gpurun -- python tools/ablate/run_serving_latency.py"""
+import gc, os, sys, time, numpy as np, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+from runia_core_amd import _hip
+gc.disable(); torch.manual_seed(0)
+
+def t(fn, reps=200):
+    for _ in range(20): fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(reps):
+        fn(); torch.cuda.synchronize()
+    return (time.perf_counter() - t0) / reps * 1e6
+
+dev = "cuda"
+# kNN bank 50 000 x 2048
+bank = torch.nn.functional.normalize(torch.randn(50000, 2048, device=dev), dim=1)
+# Mahalanobis 2048-d, 10 classes
+D, C = 2048, 10
+a = torch.randn(D, D, dtype=torch.float64, device=dev); prec = (a @ a.T / D + torch.eye(D, dtype=torch.float64, device=dev)).contiguous()
+pp = _hip.pack_weights(prec); cm = torch.randn(C, D, device=dev); mu_p = (cm.double() @ prec).contiguous()
+# LaREM from latents (cfg2 shapes): folded weights 512 -> 256
+m = torch.randn(512, 256, dtype=torch.float64, device=dev).contiguous() * 0.05; cvec = torch.randn(256, dtype=torch.float64, device=dev)
+pm = _hip.pack_weights(m)
+for n in (1, 8, 64, 512):
+    q = torch.nn.functional.normalize(torch.randn(n, 2048, device=dev), dim=1)
+    f = torch.randn(n, D, device=dev)
+    lg = torch.randn(n, 1000, device=dev)
+    x = torch.relu(torch.randn(n, 512, 4, 4, device=dev)); rand = torch.rand(n, 16, 4, 4, device=dev)
+    out = torch.zeros(n, dtype=torch.float64, device=dev)
+    def larem():
+        h = _hip.mc_entropy(x, rand, 16, 0.5, 2, 5)
+        out.zero_()
+        _hip.proj_sq_accumulate(h, pm, cvec, 256, out)
+    print(f"rows {n:4d}:  kNN(k=50, bank 50000x2048) {t(lambda: _hip.knn_kth(q, bank, 50)):8.1f} us   Mahalanobis(2048, 10 classes) "
+          f"{t(lambda: _hip.mahalanobis_score(f, cm, pp, mu_p)):8.1f} us   Energy+MSP(1000) {t(lambda: _hip.row_lse_msp(lg, True, True)):7.1f} us   "
+          f"LaREM from latents (K0+K1+K2') {t(larem):7.1f} us", flush=True)
