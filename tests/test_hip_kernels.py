@@ -991,3 +991,21 @@ def test_mahalanobis_small_batches_split_columns_and_keep_the_bits(hip, d, c):
     rows = [0, 5, 100, 8999]
     exp = oracle.mahalanobis_score(f[rows].cpu().numpy(), cm, prec, c)
     assert rel_err(whole[rows].cpu().numpy(), exp) < 1e-9
+
+
+@pytest.mark.parametrize("d,c,clip", [(2048, 1000, float("inf")), (512, 100, 0.8), (300, 37, float("inf")), (33, 17, 1.0)])
+def test_linear_few_rows_score_the_bits_of_a_batch(hip, d, c, clip):
+    """Up to 8 rows take one thread per (row, class) with the matrix-core kernel's fma chain (k order 0, 2, 1, 3 within
+    every four: v_mfma_f32_32x32x2_f32 is an exact fma chain) instead of its 128 x 128 tiles: same bits as inside a batch,
+    with and without bias and ReAct clip, widths that are not multiples of 4 or 32, NaN activations kept."""
+    torch.manual_seed(d + c)
+    x = torch.randn(300, d, device="cuda")
+    x[3, 5] = float("nan")
+    w = torch.randn(c, d, device="cuda") * 0.1
+    b = torch.randn(c, device="cuda")
+    for bias in (b, None):
+        whole = hip.linear(x, w, bias, clip)
+        for a0, b0 in ((0, 1), (3, 4), (10, 18), (292, 300)):
+            few = hip.linear(x[a0:b0].contiguous(), w, bias, clip)
+            same = (few == whole[a0:b0]) | (torch.isnan(few) & torch.isnan(whole[a0:b0]))
+            assert bool(same.all()), (a0, b0, bias is None)
