@@ -68,6 +68,7 @@ _SIGNATURES = {
     ),
     "runia_kde_score_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_void_p]),
     "runia_row_sqnorm_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "runia_kde_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "runia_kde_score_packed_f64": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int64, c_double, c_void_p],
@@ -579,9 +580,10 @@ def kde_score_packed(state, x: torch.Tensor, bandwidth: float = 1.0) -> torch.Te
     x = (x - mean).contiguous()
     n = x.shape[0]
     out = torch.empty((n,), dtype=torch.float64, device=x.device)
-    ws = torch.empty((max(n, 1),), dtype=torch.float64, device=x.device)
+    ws_bytes = int(lib.runia_kde_workspace_bytes(n, m))  # query norms (+ the values of the column-split launch on few rows)
+    ws = torch.empty((max(ws_bytes // 8, 1),), dtype=torch.float64, device=x.device)
     _check(lib.runia_kde_score_packed_f64(packed.data_ptr(), tn.data_ptr(), x.data_ptr(), out.data_ptr(), ws.data_ptr(),
-                                          n * 8, m, n, d, float(bandwidth), _stream()),
+                                          ws_bytes, m, n, d, float(bandwidth), _stream()),
            "runia_kde_score_packed_f64")
     return out
 

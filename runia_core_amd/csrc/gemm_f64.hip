@@ -47,6 +47,9 @@ struct GemmArgs {
   const void* class_mean;  // [C, K] (TA)
   const double* mu_p;      // [C, K] f64 = class_mean @ P
   int n_classes;
+  // EPI_KDE, few row tiles: one workgroup per (row tile, 256-column block) stores its alpha * (...) values to kde_vals
+  // [tile][block][thread][RT * 4][NCT]; kde_replay_kernel then runs the online logsumexp over the blocks in order
+  double* kde_vals;
   // EPI_MAHA, few row tiles: one workgroup per (row tile, 256-column block); the (block, wave, row, class) partial sums go
   // to maha_part [n_blocks][4][N][C] and maha_split_finish_kernel adds them up in the unsplit kernel's order
   double* maha_part;
@@ -120,6 +123,60 @@ __device__ __forceinline__ void load_a_regs(const GemmArgs& g, int64_t r0, int64
 // NCT column tiles per wave (4: the workgroup covers 256 columns per pass; 2 / 1: 128 / 64 columns, for outputs that are
 // no wider - PCA-16 ... PCA-128 and the MD that follows, the reference's default being 16 components: the padded tiles of
 // the 256-column form cost the same 57 us at n = 16 as at n = 256)
+// EPI_KDE, shared by the fused kernel and by the replay of the column-split launch (the same arithmetic in the same
+// order: a row scores the same bits on both):
+// one block's NCT values of a lane's accumulator row into the lane's running (max, sum of exp(. - max))
+template <int NCT>
+__device__ __forceinline__ void kde_online_update(const double (&val)[NCT], double& rowmax, double& rowdot) {
+  double gmax = -kInfD();
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) gmax = fmax(gmax, val[c]);
+  if (gmax > -kInfD()) {
+    const double mnew = fmax(rowmax, gmax);
+    double part = 0.0;
+#pragma unroll
+    for (int c = 0; c < NCT; ++c) part += exp(val[c] - mnew);
+    rowdot = rowdot * exp(rowmax - mnew) + part;
+    rowmax = mnew;
+  }
+}
+// the (max, sum) pairs of the 16 lanes that share a row, then of the four waves -> out[row]
+template <int RT>
+__device__ __forceinline__ void kde_merge_store(double (&rowdot)[RT][4], double (&rowmax)[RT][4], double (*lds_m)[16 * RT],
+                                                double (*lds_s)[16 * RT], int wave, int li, int lg, int tid, int64_t r0,
+                                                int64_t N, double addc, double* __restrict__ out) {
+  constexpr int BM = 16 * RT;
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      double m = rowmax[a][r], sm = rowdot[a][r];
+#pragma unroll
+      for (int o = 1; o < 16; o <<= 1) {
+        const double m2 = shfl_xor_f64(m, o), s2 = shfl_xor_f64(sm, o);
+        const double mn = fmax(m, m2);
+        sm = (mn > -kInfD()) ? sm * exp(m - mn) + s2 * exp(m2 - mn) : 0.0;
+        m = mn;
+      }
+      if (li == 0) {
+        lds_m[wave][16 * a + lg + 4 * r] = m;
+        lds_s[wave][16 * a + lg + 4 * r] = sm;
+      }
+    }
+  __syncthreads();
+  if (tid < BM) {
+    const int64_t row = r0 + tid;
+    if (row < N) {
+      const double gm = fmax(fmax(lds_m[0][tid], lds_m[1][tid]), fmax(lds_m[2][tid], lds_m[3][tid]));
+      double gs = 0.0;
+#pragma unroll
+      for (int w = 0; w < 4; ++w)
+        if (lds_s[w][tid] > 0.0) gs += lds_s[w][tid] * exp(lds_m[w][tid] - gm);
+      out[row] = log(gs) + gm + addc;
+    }
+  }
+}
+
 template <typename TA, typename TS, int EPI, int RT = 2, int NCT = 4>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   constexpr int BM = 16 * RT;  // rows per workgroup (shadows the file-level default of 32)
@@ -139,8 +196,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   const int64_t NT = n_pad / 16;
   const int64_t nchunks = k_padded(g.K) / KC;
   int64_t tile_id = blockIdx.x, cb_begin = 0, cb_end = n_pad / BN;
-  if constexpr (EPI == EPI_MAHA) {
-    if (g.maha_part) {  // column-split launch (uniform)
+  if constexpr (EPI == EPI_MAHA || EPI == EPI_KDE) {
+    if ((EPI == EPI_MAHA) ? (g.maha_part != nullptr) : (g.kde_vals != nullptr)) {  // column-split launch (uniform)
       const int64_t nb = n_pad / BN;
       tile_id = blockIdx.x / nb;
       cb_begin = blockIdx.x % nb;
@@ -239,20 +296,17 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
           const int64_t row = r0 + 16 * a + lg + 4 * r;
           const double rn = (row < g.N) ? g.rown[row] : 0.0;
           double val[NCT];
-          double gmax = -kInfD();
 #pragma unroll
           for (int c = 0; c < NCT; ++c) {
             const int64_t col = (ctbase + c) * 16 + li;
             val[c] = (col < g.n) ? g.alpha * (rn + g.coln[col] - 2.0 * acc[a][c][r]) : -kInfD();
-            gmax = fmax(gmax, val[c]);
           }
-          if (gmax > -kInfD()) {
-            const double mnew = fmax(rowmax[a][r], gmax);
-            double part = 0.0;
+          if (g.kde_vals) {  // column-split launch: the values go to memory, kde_replay_kernel does the rest
+            double* dst = g.kde_vals + ((((tile_id * (n_pad / BN) + cb) * 256 + tid) * (RT * 4) + (a * 4 + r)) * NCT);
 #pragma unroll
-            for (int c = 0; c < NCT; ++c) part += exp(val[c] - mnew);
-            rowdot[a][r] = rowdot[a][r] * exp(rowmax[a][r] - mnew) + part;
-            rowmax[a][r] = mnew;
+            for (int c = 0; c < NCT; ++c) dst[c] = val[c];
+          } else {
+            kde_online_update<NCT>(val, rowmax[a][r], rowdot[a][r]);
           }
         }
     } else
@@ -315,36 +369,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     }
   }
   if constexpr (EPI == EPI_KDE) {
-    // merge the (max, sum) pairs of the 16 lanes that share a row, then of the four waves
-#pragma unroll
-    for (int a = 0; a < RT; ++a)
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        double m = rowmax[a][r], sm = rowdot[a][r];
-#pragma unroll
-        for (int o = 1; o < 16; o <<= 1) {
-          const double m2 = shfl_xor_f64(m, o), s2 = shfl_xor_f64(sm, o);
-          const double mn = fmax(m, m2);
-          sm = (mn > -kInfD()) ? sm * exp(m - mn) + s2 * exp(m2 - mn) : 0.0;
-          m = mn;
-        }
-        if (li == 0) {
-          lds_part[wave][16 * a + lg + 4 * r] = m;
-          lds_part2[wave][16 * a + lg + 4 * r] = sm;
-        }
-      }
-    __syncthreads();
-    if (tid < BM) {
-      const int64_t row = r0 + tid;
-      if (row < g.N) {
-        const double gm = fmax(fmax(lds_part[0][tid], lds_part[1][tid]), fmax(lds_part[2][tid], lds_part[3][tid]));
-        double gs = 0.0;
-#pragma unroll
-        for (int w = 0; w < 4; ++w)
-          if (lds_part2[w][tid] > 0.0) gs += lds_part2[w][tid] * exp(lds_part[w][tid] - gm);
-        g.out[row] = log(gs) + gm + g.addc;
-      }
-    }
+    if (g.kde_vals) return;
+    kde_merge_store<RT>(rowdot, rowmax, lds_part, lds_part2, wave, li, lg, tid, r0, g.N, g.addc, g.out);
   }
   if constexpr (EPI == EPI_ROWDOT || EPI == EPI_ROWNORM) {
 #pragma unroll
@@ -631,6 +657,45 @@ extern "C" int runia_row_sqnorm_f64(const double* x, double* out, int64_t N, int
   return runia_check_launch();
 }
 
+// Second half of the column-split KDE launch: per 16-row tile, the blocks' values in block order through the same
+// update and the same merges as the fused kernel (thread t of the tile's workgroup is thread t of the fused kernel).
+__global__ __launch_bounds__(256) void kde_replay_kernel(const double* __restrict__ vals, double* __restrict__ out,
+                                                          int64_t N, int64_t nb, double addc) {
+  constexpr int RT = 1, NCT = 4;
+  __shared__ double lds_m[4][16 * RT], lds_s[4][16 * RT];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * 16 * RT;
+  double rowdot[RT][4], rowmax[RT][4];
+#pragma unroll
+  for (int a = 0; a < RT; ++a)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { rowdot[a][r] = 0.0; rowmax[a][r] = -kInfD(); }
+  for (int64_t cb = 0; cb < nb; ++cb) {
+    const double* src = vals + (((int64_t)blockIdx.x * nb + cb) * 256 + tid) * (RT * 4 * NCT);
+#pragma unroll
+    for (int a = 0; a < RT; ++a)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        double val[NCT];
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) val[c] = src[(a * 4 + r) * NCT + c];
+        kde_online_update<NCT>(val, rowmax[a][r], rowdot[a][r]);
+      }
+  }
+  kde_merge_store<RT>(rowdot, rowmax, lds_m, lds_s, wave, li, lg, tid, r0, N, addc, out);
+}
+
+// query norms, + the values of the column-split launch when the batch has fewer 16-row tiles than the chip has compute units
+static bool kde_split_wanted(int64_t N, int64_t M) { return (N + 15) / 16 < runia_cu_count() && n_padded(M) / BN > 1; }
+extern "C" size_t runia_kde_workspace_bytes(int64_t N, int64_t M) {
+  if (N <= 0 || M <= 0) return 0;
+  size_t bytes = (((size_t)N * sizeof(double)) + 255) / 256 * 256;
+  if (kde_split_wanted(N, M)) bytes += (size_t)(((N + 15) / 16) * (n_padded(M) / BN) * 256 * 16) * sizeof(double);
+  return bytes;
+}
+
 extern "C" int runia_kde_score_packed_f64(const double* packed_train_t, const double* train_sqnorm, const double* x,
                                           double* score, void* workspace, size_t workspace_bytes, int64_t M,
                                           int64_t N, int64_t D, double bandwidth, runia_stream_t stream) {
@@ -646,6 +711,18 @@ extern "C" int runia_kde_score_packed_f64(const double* packed_train_t, const do
   g.alpha = -0.5 / (bandwidth * bandwidth);
   g.addc = -log((double)M) - (double)D * log(bandwidth) - 0.5 * (double)D * log(2.0 * M_PI);
   g.out = score;
+  // Few rows (LaRED on the ~100 proposals of one image): one workgroup per 16-row tile walks the whole training set on ONE
+  // compute unit (8 rows against 10 000 x 256: 0.6 ms).  With the workspace runia_kde_workspace_bytes asks for, the
+  // 256-column blocks of a tile go to separate workgroups, which store their values, and a second launch replays the
+  // online logsumexp over them in block order with the fused kernel's own update and merges: the same bits.
+  if (kde_split_wanted(N, M) && workspace_bytes >= runia_kde_workspace_bytes(N, M)) {
+    hipStream_t s = as_stream(stream);
+    const int64_t tiles = (N + 15) / 16, nb = n_padded(M) / BN;
+    g.kde_vals = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((size_t)N * sizeof(double)) + 255) / 256 * 256);
+    gemm_rows_kernel<double, double, EPI_KDE, 1, 4><<<(unsigned)(tiles * nb), 256, 0, s>>>(g);
+    kde_replay_kernel<<<(unsigned)tiles, 256, 0, s>>>(g.kde_vals, score, N, nb, g.addc);
+    return runia_check_launch();
+  }
   return launch_gemm<double, EPI_KDE>(g, as_stream(stream));
 }
 

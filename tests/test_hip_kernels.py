@@ -1009,3 +1009,23 @@ def test_linear_few_rows_score_the_bits_of_a_batch(hip, d, c, clip):
             few = hip.linear(x[a0:b0].contiguous(), w, bias, clip)
             same = (few == whole[a0:b0]) | (torch.isnan(few) & torch.isnan(whole[a0:b0]))
             assert bool(same.all()), (a0, b0, bias is None)
+
+
+@pytest.mark.parametrize("m,d", [(10000, 256), (3000, 100), (700, 130)])
+def test_kde_few_rows_split_columns_and_keep_the_bits(hip, m, d):
+    """LaRED on few rows (fewer 16-row tiles than compute units): the 256-column blocks of a tile go to separate
+    workgroups, which store their values, and a second launch replays the online logsumexp over them in block order with
+    the fused kernel's own update and merges - a row scores the same bits alone, in a small batch and in a batch large
+    enough for the fused launch (8 rows against 10 000 x 256: 0.6 -> 0.2 ms); the exact definition on top."""
+    torch.manual_seed(m + d)
+    tr = torch.randn(m, d, dtype=torch.float64, device="cuda")
+    x = torch.randn(6000, d, dtype=torch.float64, device="cuda") * 1.2  # 375 tiles of 16 rows >= 256: fused launch
+    st = hip.kde_pack_train(tr)
+    for bw in (1.0, 4.0):
+        whole = hip.kde_score_packed(st, x, bw)
+        for a0, b0 in ((0, 1), (7, 20), (100, 228), (1000, 1999)):
+            part = hip.kde_score_packed(st, x[a0:b0].contiguous(), bw)
+            assert torch.equal(part, whole[a0:b0]), (bw, a0, b0)
+        rows = [0, 7, 5999]
+        exp = oracle.kde_score(tr.cpu().numpy(), x[rows].cpu().numpy(), bw)
+        assert rel_err(whole[rows].cpu().numpy(), exp) < 1e-10
