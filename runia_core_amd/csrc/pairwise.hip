@@ -890,11 +890,14 @@ int runia_knn16_dist(const uint16_t* qp, const uint16_t* bp, const float* qn, co
 #ifndef KNN_BF16
 #define KNN_BF16 1
 #endif
+#ifndef KNN16_MIN_ROWS
+#define KNN16_MIN_ROWS 512  // (256 queries x 50 000 x 2048: 0.99 ms against 0.75 on the f32 kernel; 512: 0.97 against 1.12; 1 000 x 20 000: 0.51 against 0.95)
+#endif
 // Worth the two split passes and the 256 x 256 tiles: a bank of some thousand rows, wide features, a batch of queries, 2^31
-// multiply-adds (tools/ablate/run_knn_paths.py: 1 024 x 4 096 x 256 is 8 % slower on the bf16 kernel, 1 024 x 4 096 x 2048
+// multiply-adds, 512 queries (tools/ablate/run_knn_paths.py: 1 024 x 4 096 x 256 is 8 % slower on the bf16 kernel, 1 024 x 4 096 x 2048
 // 1.46 x faster, 8 192 x 50 000 x 2048 2.67 x)
 static bool knn16_wanted(int64_t N, int64_t M, int64_t D) {
-  return KNN_BF16 && N >= 1024 && M >= 4096 && D >= 256 && N * M >= ((int64_t)1 << 31) / D && runia_knn16_fits(M, D) &&
+  return KNN_BF16 && N >= KNN16_MIN_ROWS && M >= 4096 && D >= 256 && N * M >= ((int64_t)1 << 31) / D && runia_knn16_fits(M, D) &&
          runia_knn16_fits(kQueryChunk, D) && 4 * M * 256 <= ((int64_t)1 << 31);  // (chunks of >= 256 queries: whole tiles)
 }
 int runia_knn16_terms();

@@ -6,7 +6,7 @@ from runia_core_amd import _hip
 lib = _hip.load_library()
 torch.manual_seed(0)
 k = 50
-for (n, m, d) in ((1024, 4096, 256), (1024, 4096, 2048), (1024, 50000, 256), (2048, 8192, 512), (4096, 16384, 1024),
+for (n, m, d) in ((256, 20000, 2048), (256, 50000, 2048), (512, 50000, 2048), (1000, 20000, 2048), (600, 8192, 512), (1024, 4096, 256), (1024, 4096, 2048), (1024, 50000, 256), (2048, 8192, 512), (4096, 16384, 1024),
                   (8192, 50000, 256), (1024, 50000, 2048), (8192, 50000, 2048), (32768, 200000, 512)):
     q = torch.nn.functional.normalize(torch.randn(n, d, device="cuda"), dim=1)
     b = torch.nn.functional.normalize(torch.randn(m, d, device="cuda"), dim=1)
