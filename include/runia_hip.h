@@ -155,6 +155,18 @@ int runia_l2_normalize_f32(const float* x, float* y, int64_t N, int64_t D, runia
  * re-measured f32 distance on either path (identical bits). */
 size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k);
 int runia_knn_piece_products(int64_t N, int64_t M, int64_t D);
+/* The same search against a bank prepared once (the index of a deployed postprocessor; faiss does its `add` once, too):
+ * `state` (runia_knn_bank_state_bytes, 16-byte aligned) receives |b|^2, their maximum and - for banks the bf16 kernel can
+ * take - the bf16 pieces; a call then needs runia_knn_prepared_workspace_bytes of workspace (one chunk of distances,
+ * |q|^2, the chunk's pieces) and skips the bank passes.  Same scores, bit for bit, as runia_knn_kth_f32; a state of only
+ * (M + 1) floats (rounded up to 256 bytes) or a smaller workspace keeps the f32 kernel. */
+size_t runia_knn_bank_state_bytes(int64_t M, int64_t D);
+int runia_knn_prepare_bank_f32(const float* bank, void* state, size_t state_bytes, int64_t M, int64_t D,
+                               runia_stream_t stream);
+size_t runia_knn_prepared_workspace_bytes(int64_t N, int64_t M, int64_t D, int k);
+int runia_knn_kth_prepared_f32(const float* q, const float* bank, const void* state, size_t state_bytes, float* score,
+                               void* workspace, size_t workspace_bytes, int64_t N, int64_t M, int64_t D, int k,
+                               runia_stream_t stream);
 int runia_knn_kth_f32(const float* q, const float* bank, float* score, void* workspace,
                       size_t workspace_bytes, int64_t N, int64_t M, int64_t D, int k,
                       runia_stream_t stream);

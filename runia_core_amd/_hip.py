@@ -62,6 +62,11 @@ _SIGNATURES = {
     "runia_l2_normalize_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "runia_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "runia_knn_piece_products": (c_int, [c_int64, c_int64, c_int64]),
+    "runia_knn_bank_state_bytes": (c_size_t, [c_int64, c_int64]),
+    "runia_knn_prepare_bank_f32": (c_int, [c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
+    "runia_knn_prepared_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
+    "runia_knn_kth_prepared_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_size_t, c_void_p, c_void_p, c_size_t, c_int64, c_int64,
+                                           c_int64, c_int, c_void_p]),
     "runia_knn_kth_f32": (
         c_int,
         [c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int64, c_int, c_void_p],
@@ -527,8 +532,23 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
-def knn_kth(q: torch.Tensor, bank: torch.Tensor, k: int) -> torch.Tensor:
-    """q [N, D], bank [M, D] (both L2-normalised f32) -> -(k-th smallest squared L2) [N] f32."""
+def knn_prepare_bank(bank: torch.Tensor) -> torch.Tensor:
+    """Once per bank: squared row norms, their maximum and (banks the bf16 kernel can take) the bf16 pieces, as one
+    device buffer for ``knn_kth(..., state=)``.  A deployed index scores many batches against the same bank; each call
+    then skips the bank passes (50 000 x 2048: 0.4 ms)."""
+    lib = load_library()
+    require_gpu()
+    assert bank.is_cuda and bank.dtype == torch.float32 and bank.dim() == 2 and bank.is_contiguous()
+    m, d = bank.shape
+    nbytes = int(lib.runia_knn_bank_state_bytes(m, d))
+    state = torch.empty((max(nbytes, 16) + 15) // 16 * 4, dtype=torch.float32, device=bank.device)  # (16-byte granules)
+    _check(lib.runia_knn_prepare_bank_f32(bank.data_ptr(), state.data_ptr(), nbytes, m, d, _stream()), "runia_knn_prepare_bank_f32")
+    return state
+
+
+def knn_kth(q: torch.Tensor, bank: torch.Tensor, k: int, state: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """q [N, D], bank [M, D] (both L2-normalised f32) -> -(k-th smallest squared L2) [N] f32.
+    ``state``: ``knn_prepare_bank(bank)`` of the same bank (same scores, without the per-call bank passes)."""
     lib = load_library()
     require_gpu()
     assert q.is_cuda and bank.is_cuda and q.dtype == torch.float32 and bank.dtype == torch.float32
@@ -537,10 +557,20 @@ def knn_kth(q: torch.Tensor, bank: torch.Tensor, k: int) -> torch.Tensor:
     n, d = q.shape
     m = bank.shape[0]
     s = torch.empty((n,), dtype=torch.float32, device=q.device)
+    f32_only = not _config.knn_bf16_candidates and lib.runia_knn_piece_products(n, m, d) > 0
+    qc = min(n, 8192, max(256, (1 << 31) // (4 * m)))  # the f32 kernel's chunk of distances (+ |q|^2 ...)
+    if state is not None and m > 0 and n > 0:
+        ws_bytes = (qc * m + qc) * 4 if f32_only else int(lib.runia_knn_prepared_workspace_bytes(n, m, d, k))
+        ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=q.device)
+        _check(
+            lib.runia_knn_kth_prepared_f32(q.data_ptr(), bank.data_ptr(), state.data_ptr(), state.numel() * 4, s.data_ptr(),
+                                           ws.data_ptr(), ws_bytes, n, m, d, int(k), _stream()),
+            "runia_knn_kth_prepared_f32",
+        )
+        return s
     ws_bytes = lib.runia_knn_workspace_bytes(n, m, d, k)
-    if not _config.knn_bf16_candidates and lib.runia_knn_piece_products(n, m, d) > 0:
+    if f32_only:
         # the f32 kernel's workspace (one chunk of distances, |q|^2, |b|^2, max |b|^2): the entry point then keeps that kernel
-        qc = min(n, 8192, max(256, (1 << 31) // (4 * m)))
         ws_bytes = (qc * m + qc + m + 4) * 4
     ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=q.device)
     _check(

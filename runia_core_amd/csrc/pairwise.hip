@@ -924,6 +924,30 @@ extern "C" size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int
   return knn_f32_words(qc, M) * sizeof(float);
 }
 
+// The passes of a kNN call once the bank's |b|^2, their maximum and (use16) its bf16 pieces exist - computed by the call
+// itself into its workspace, or once per bank by runia_knn_prepare_bank_f32.
+static int knn_scan(const float* q, const float* bank, float* score, float* dist, float* qn, const float* bn,
+                    unsigned* bn_max, const uint16_t* bank_planes, uint16_t* q_planes, int64_t qc, bool use16, int64_t N,
+                    int64_t M, int64_t D, int k, hipStream_t s) {
+  for (int64_t r0 = 0; r0 < N; r0 += qc) {
+    const int64_t rows = (N - r0 < qc) ? (N - r0) : qc;
+    row_sqnorm_kernel<<<runia_rows_grid(rows), 64 * kRowWaves, 0, s>>>(q + r0 * D, qn, rows, D, nullptr);
+    int rc = RUNIA_OK;
+    if (use16 && rows >= 256) {
+      rc = runia_knn16_split(q + r0 * D, q_planes, rows, D, s);
+      if (rc == RUNIA_OK) rc = runia_knn16_dist(q_planes, bank_planes, qn, bn, dist, rows, M, D, s);
+      if (rc != RUNIA_OK) return rc;
+    } else {
+      knn_dist_kernel<EPI_DIST><<<knn_dist_grid(rows, M), 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D, INFINITY);
+    }
+    kth_select_range_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(
+        dist, q + r0 * D, bank, qn, bn_max, score + r0, rows, M, D, k, (use16 && rows >= 256) ? runia_knn16_refine_rel() : kRefineRel);
+    rc = runia_check_launch();
+    if (rc != RUNIA_OK) return rc;
+  }
+  return RUNIA_OK;
+}
+
 extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score, void* workspace,
                                  size_t workspace_bytes, int64_t N, int64_t M, int64_t D, int k,
                                  runia_stream_t stream) {
@@ -967,22 +991,80 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
     rc = runia_knn16_split(bank, bank_planes, M, D, s);
     if (rc != RUNIA_OK) return rc;
   }
-  for (int64_t r0 = 0; r0 < N; r0 += qc) {
-    const int64_t rows = (N - r0 < qc) ? (N - r0) : qc;
-    row_sqnorm_kernel<<<runia_rows_grid(rows), 64 * kRowWaves, 0, s>>>(q + r0 * D, qn, rows, D, nullptr);
-    if (use16 && rows >= 256) {
-      rc = runia_knn16_split(q + r0 * D, q_planes, rows, D, s);
-      if (rc == RUNIA_OK) rc = runia_knn16_dist(q_planes, bank_planes, qn, bn, dist, rows, M, D, s);
-      if (rc != RUNIA_OK) return rc;
-    } else {
-      knn_dist_kernel<EPI_DIST><<<knn_dist_grid(rows, M), 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D, INFINITY);
-    }
-    kth_select_range_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(
-        dist, q + r0 * D, bank, qn, bn_max, score + r0, rows, M, D, k, (use16 && rows >= 256) ? runia_knn16_refine_rel() : kRefineRel);
-    rc = runia_check_launch();
-    if (rc != RUNIA_OK) return rc;
+  return knn_scan(q, bank, score, dist, qn, bn, bn_max, bank_planes, q_planes, qc, use16, N, M, D, k, s);
+}
+
+// ---- a bank prepared once (the index of a deployed postprocessor): |b|^2, their maximum and - for banks the bf16 kernel
+// can take - the bf16 pieces.  A call against a prepared bank skips those passes (50 000 x 2048: 0.13 ms of norms + 0.25 ms
+// of splitting, more than the scan itself for some hundred queries); the scores are the same bits.
+static bool knn16_bank_ok(int64_t M, int64_t D) {
+  return KNN_BF16 && M >= 4096 && D >= 256 && runia_knn16_fits(M, D) && runia_knn16_fits(kQueryChunk, D) &&
+         4 * M * 256 <= ((int64_t)1 << 31);
+}
+static size_t knn_state_head_bytes(int64_t M) { return (((size_t)M + 1) * sizeof(float) + 255) / 256 * 256; }
+extern "C" size_t runia_knn_bank_state_bytes(int64_t M, int64_t D) {
+  if (M <= 0 || D <= 0) return 0;
+  return knn_state_head_bytes(M) + (knn16_bank_ok(M, D) ? runia_knn16_plane_bytes(M, D) : 0);
+}
+extern "C" int runia_knn_prepare_bank_f32(const float* bank, void* state, size_t state_bytes, int64_t M, int64_t D,
+                                          runia_stream_t stream) {
+  if (M <= 0 || D <= 0 || !bank || !state) return RUNIA_E_INVALID;
+  if ((((uintptr_t)state) & 15) != 0 || state_bytes < knn_state_head_bytes(M)) return RUNIA_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  float* bn = reinterpret_cast<float*>(state);
+  unsigned* bn_max = reinterpret_cast<unsigned*>(bn + M);
+  if (hipMemsetAsync(bn_max, 0, sizeof(unsigned), s) != hipSuccess) return RUNIA_E_LAUNCH;
+  row_sqnorm_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(bank, bn, M, D, bn_max);
+  int rc = runia_check_launch();
+  if (rc != RUNIA_OK) return rc;
+  if (knn16_bank_ok(M, D) && state_bytes >= runia_knn_bank_state_bytes(M, D))
+    rc = runia_knn16_split(bank, reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(state) + knn_state_head_bytes(M)), M, D, s);
+  return rc;
+}
+// workspace of a call against a prepared bank: one chunk of distances, |q|^2 and (bf16 kernel) the chunk's pieces
+extern "C" size_t runia_knn_prepared_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {
+  (void)k;
+  if (N <= 0 || M <= 0) return 0;
+  const int64_t qc = knn_chunk_rows(N, M);
+  const size_t head = ((size_t)(qc * M + qc) * sizeof(float) + 255) / 256 * 256;
+  return head + (knn16_wanted(N, M, D) ? runia_knn16_plane_bytes(qc, D) : 0);
+}
+extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, const void* state, size_t state_bytes,
+                                          float* score, void* workspace, size_t workspace_bytes, int64_t N, int64_t M,
+                                          int64_t D, int k, runia_stream_t stream) {
+  if (N < 0 || M <= 0 || D <= 0 || k < 1) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!q || !score || !bank || !state) return RUNIA_E_INVALID;
+  if (state_bytes < knn_state_head_bytes(M)) return RUNIA_E_WORKSPACE;
+  hipStream_t s = as_stream(stream);
+  if (k > M) {
+    fill_kernel<<<runia_stream_grid(N, 256), 256, 0, s>>>(score, N, -kFltMax);
+    return runia_check_launch();
   }
-  return RUNIA_OK;
+  if (!workspace || workspace_bytes < (size_t)(M + 1) * sizeof(float)) return RUNIA_E_WORKSPACE;
+  const float* bn = reinterpret_cast<const float*>(state);
+  unsigned* bn_max = const_cast<unsigned*>(reinterpret_cast<const unsigned*>(bn + M));  // (only ever re-written with its own value)
+  // the bf16 kernel when the state holds the pieces and the workspace is the one asked for; else the f32 kernel with as
+  // many query rows per pass as the workspace holds
+  const bool use16 = knn16_wanted(N, M, D) && state_bytes >= runia_knn_bank_state_bytes(M, D) &&
+                     workspace_bytes >= runia_knn_prepared_workspace_bytes(N, M, D, k);
+  int64_t qc = use16 ? knn_chunk_rows(N, M) : (int64_t)(workspace_bytes / sizeof(float) / (size_t)(M + 1));
+  if (qc < 1) return RUNIA_E_WORKSPACE;
+  if (qc > N) qc = N;
+  if (qc > kQueryChunk) qc = kQueryChunk;
+  float* dist = reinterpret_cast<float*>(workspace);
+  float* qn = dist + qc * M;
+  if (N <= kSmallQ && M >= 1024 && qc >= N) {  // a handful of queries: one pass over the bank, exact distances
+    row_sqnorm_kernel<<<runia_rows_grid(N), 64 * kRowWaves, 0, s>>>(q, qn, N, D, nullptr);
+    knn_small_dist_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(q, bank, dist, bn_max, (int)N, M, D);
+    kth_select_range_kernel<<<(unsigned)N, 256, 0, s>>>(dist, q, bank, qn, bn_max, score, N, M, D, k, kRefineRel);
+    return runia_check_launch();
+  }
+  const uint16_t* bank_planes = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(state) + knn_state_head_bytes(M));
+  uint16_t* q_planes = use16 ? reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) +
+                                                           ((size_t)(qc * M + qc) * sizeof(float) + 255) / 256 * 256)
+                             : nullptr;
+  return knn_scan(q, bank, score, dist, qn, bn, bn_max, bank_planes, q_planes, qc, use16, N, M, D, k, s);
 }
 
 extern "C" int runia_linear_f32(const float* x, const float* w, const float* bias, float* out, int64_t N, int64_t D,

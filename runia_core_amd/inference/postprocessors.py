@@ -297,6 +297,7 @@ class FlatL2Bank:
         self.ntotal = 0
         self._host = np.zeros((0, d), dtype=np.float32)
         self._dev = None
+        self._state = None
 
     def add(self, x: np.ndarray) -> None:
         x = np.ascontiguousarray(np.asarray(x).astype(np.float32))
@@ -304,17 +305,28 @@ class FlatL2Bank:
         self._host = np.concatenate([self._host, x]) if self.ntotal else x
         self.ntotal = self._host.shape[0]
         self._dev = None
+        self._state = None
 
     def __getstate__(self):
-        return {**self.__dict__, "_dev": None}  # the device copy is rebuilt on first use
+        return {**self.__dict__, "_dev": None, "_state": None}  # the device copies are rebuilt on first use
 
     def _bank(self) -> Tensor:
         if self._dev is None:
             self._dev = _hip.to_device(self._host, torch.float32)
+            self._state = None
         return self._dev
 
+    def _bank_state(self) -> Tensor:
+        """Row norms (+ bf16 pieces) of the bank, made once: like faiss's ``add``, not part of a ``search``."""
+        bank = self._bank()
+        if getattr(self, "_state", None) is None:
+            self._state = _hip.knn_prepare_bank(bank)
+        return self._state
+
     def kth_score_device(self, q_normed: Tensor, k: int) -> Tensor:
-        return _hip.knn_kth(q_normed, self._bank(), k)
+        if self.ntotal == 0 or k > self.ntotal:
+            return _hip.knn_kth(q_normed, self._bank(), k)
+        return _hip.knn_kth(q_normed, self._bank(), k, state=self._bank_state())
 
     def kth_score(self, feats: np.ndarray, k: int) -> np.ndarray:
         """``-D[:, -1]`` of ``search(normalizer(feats), k)`` for every row, f32."""

@@ -1029,3 +1029,27 @@ def test_kde_few_rows_split_columns_and_keep_the_bits(hip, m, d):
         rows = [0, 7, 5999]
         exp = oracle.kde_score(tr.cpu().numpy(), x[rows].cpu().numpy(), bw)
         assert rel_err(whole[rows].cpu().numpy(), exp) < 1e-10
+
+
+@pytest.mark.parametrize("n,m,d", [(3, 5000, 512), (300, 5000, 512), (1500, 6000, 512), (600, 9000, 300)])
+def test_knn_prepared_bank_scores_the_same_bits(hip, n, m, d):
+    """runia_knn_prepare_bank_f32 + runia_knn_kth_prepared_f32 (the bank's norms and bf16 pieces made once, as FlatL2Bank
+    does at its first search) = runia_knn_kth_f32 bit for bit, on the handful path, the f32 kernel and the bf16 candidate
+    kernel; with the bf16 candidates switched off too."""
+    from runia_core_amd import config
+
+    torch.manual_seed(n + m)
+    bank = torch.randn(m, d, device="cuda")
+    bank[100:400] = bank[7]
+    q = torch.randn(n, d, device="cuda")
+    q[0] = bank[7]
+    state = hip.knn_prepare_bank(bank)
+    for k in (1, 50, 299, 301):
+        a = hip.knn_kth(q, bank, k)
+        assert torch.equal(hip.knn_kth(q, bank, k, state=state), a), k
+    try:
+        config.knn_bf16_candidates = False
+        assert torch.equal(hip.knn_kth(q, bank, 50, state=state), hip.knn_kth(q, bank, 50))
+    finally:
+        config.knn_bf16_candidates = True
+    assert torch.equal(hip.knn_kth(q, bank, 50, state=state), hip.knn_kth(q, bank, 50))
