@@ -557,7 +557,7 @@ def knn_kth(q: torch.Tensor, bank: torch.Tensor, k: int, state: Optional[torch.T
     n, d = q.shape
     m = bank.shape[0]
     s = torch.empty((n,), dtype=torch.float32, device=q.device)
-    f32_only = not _config.knn_bf16_candidates and lib.runia_knn_piece_products(n, m, d) > 0
+    f32_only = not _config.knn_bf16_candidates  # (hand the entry point the f32 kernel's workspace: it keeps that kernel)
     qc = min(n, 8192, max(256, (1 << 31) // (4 * m)))  # the f32 kernel's chunk of distances (+ |q|^2 ...)
     if state is not None and m > 0 and n > 0:
         ws_bytes = (qc * m + qc) * 4 if f32_only else int(lib.runia_knn_prepared_workspace_bytes(n, m, d, k))
@@ -569,7 +569,7 @@ def knn_kth(q: torch.Tensor, bank: torch.Tensor, k: int, state: Optional[torch.T
         )
         return s
     ws_bytes = lib.runia_knn_workspace_bytes(n, m, d, k)
-    if f32_only:
+    if f32_only and lib.runia_knn_piece_products(n, m, d) > 0:
         # the f32 kernel's workspace (one chunk of distances, |q|^2, |b|^2, max |b|^2): the entry point then keeps that kernel
         ws_bytes = (qc * m + qc + m + 4) * 4
     ws = torch.empty((max(ws_bytes, 4) // 4,), dtype=torch.float32, device=q.device)

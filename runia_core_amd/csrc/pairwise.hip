@@ -25,6 +25,11 @@ constexpr int TQ = 128, TB = 128, KCH = 32, KP = 34;
 #define KNN_SQ 8
 #endif
 constexpr int kSuperB = KNN_SB, kSuperQ = KNN_SQ;  // super-tile of workgroups that share L2 lines (knn_dist_kernel)
+// Query tiles of a super-tile: kSuperQ, or all of them when the batch has fewer (the super-tile is then kSuperB x nqt
+// workgroups, every one of them with a tile).  Workgroups go to compute units in a fixed rotation: with a batch of one
+// query tile in 8 x 8 super-tiles only every eighth workgroup had a tile, and those landed on one eighth of the compute
+// units (100 queries against 50 000 x 2048: 0.45 ms, as much as 1 000).
+__host__ __device__ inline int knn_super_q(int64_t nqt) { return nqt < kSuperQ ? (int)nqt : kSuperQ; }
 
 // squared row norms; max_bits (optional): running maximum of the norms as an unsigned bit pattern (norms are >= 0)
 __global__ __launch_bounds__(64 * kRowWaves) void row_sqnorm_kernel(const float* __restrict__ x, float* __restrict__ out,
@@ -127,11 +132,12 @@ __global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__
   int64_t q0, m0;
   {
     const int64_t nbt = (M + TB - 1) / TB, nqt = (Q + TQ - 1) / TQ;
-    const int64_t nqg = (nqt + kSuperQ - 1) / kSuperQ;
+    const int sq = knn_super_q(nqt), wps = kSuperB * sq;  // workgroups per super-tile (see knn_super_q)
+    const int64_t nqg = (nqt + sq - 1) / sq;
     const int64_t l = blockIdx.x >> 3;
-    const int64_t st = (l / (kSuperB * kSuperQ)) * 8 + (blockIdx.x & 7);  // super-tile of this workgroup
-    const int r = (int)(l % (kSuperB * kSuperQ));
-    const int64_t bt = (st / nqg) * kSuperB + r % kSuperB, qt = (st % nqg) * kSuperQ + r / kSuperB;
+    const int64_t st = (l / wps) * 8 + (blockIdx.x & 7);  // super-tile of this workgroup
+    const int r = (int)(l % wps);
+    const int64_t bt = (st / nqg) * kSuperB + r % kSuperB, qt = (st % nqg) * sq + r / kSuperB;
     if (bt >= nbt || qt >= nqt) return;  // padding of the grid (uniform over the workgroup)
     q0 = qt * TQ;
     m0 = bt * TB;
@@ -874,8 +880,9 @@ __global__ __launch_bounds__(256) void linear_few_rows_kernel(const float* __res
 // 1-D grid of knn_dist_kernel for Q x M: whole super-tiles, a multiple of 8 of them
 static inline unsigned knn_dist_grid(int64_t Q, int64_t M) {
   const int64_t nbt = (M + TB - 1) / TB, nqt = (Q + TQ - 1) / TQ;
-  const int64_t st = ((nbt + kSuperB - 1) / kSuperB) * ((nqt + kSuperQ - 1) / kSuperQ);
-  return (unsigned)(((st + 7) / 8) * 8 * kSuperB * kSuperQ);
+  const int sq = knn_super_q(nqt);
+  const int64_t st = ((nbt + kSuperB - 1) / kSuperB) * ((nqt + sq - 1) / sq);
+  return (unsigned)(((st + 7) / 8) * 8 * kSuperB * sq);
 }
 
 // knn_bf16.hip: candidate distances of large problems from bf16 piece products (6/16 of the f32 kernel's matrix-pipe time)
@@ -928,12 +935,13 @@ extern "C" size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int
 // itself into its workspace, or once per bank by runia_knn_prepare_bank_f32.
 static int knn_scan(const float* q, const float* bank, float* score, float* dist, float* qn, const float* bn,
                     unsigned* bn_max, const uint16_t* bank_planes, uint16_t* q_planes, int64_t qc, bool use16, int64_t N,
-                    int64_t M, int64_t D, int k, hipStream_t s) {
+                    int64_t M, int64_t D, int k, hipStream_t s, int64_t min_rows16 = 256) {
   for (int64_t r0 = 0; r0 < N; r0 += qc) {
     const int64_t rows = (N - r0 < qc) ? (N - r0) : qc;
     row_sqnorm_kernel<<<runia_rows_grid(rows), 64 * kRowWaves, 0, s>>>(q + r0 * D, qn, rows, D, nullptr);
     int rc = RUNIA_OK;
-    if (use16 && rows >= 256) {
+    const bool now16 = use16 && rows >= min_rows16;
+    if (now16) {
       rc = runia_knn16_split(q + r0 * D, q_planes, rows, D, s);
       if (rc == RUNIA_OK) rc = runia_knn16_dist(q_planes, bank_planes, qn, bn, dist, rows, M, D, s);
       if (rc != RUNIA_OK) return rc;
@@ -941,7 +949,7 @@ static int knn_scan(const float* q, const float* bank, float* score, float* dist
       knn_dist_kernel<EPI_DIST><<<knn_dist_grid(rows, M), 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D, INFINITY);
     }
     kth_select_range_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(
-        dist, q + r0 * D, bank, qn, bn_max, score + r0, rows, M, D, k, (use16 && rows >= 256) ? runia_knn16_refine_rel() : kRefineRel);
+        dist, q + r0 * D, bank, qn, bn_max, score + r0, rows, M, D, k, now16 ? runia_knn16_refine_rel() : kRefineRel);
     rc = runia_check_launch();
     if (rc != RUNIA_OK) return rc;
   }
@@ -1001,6 +1009,14 @@ static bool knn16_bank_ok(int64_t M, int64_t D) {
   return KNN_BF16 && M >= 4096 && D >= 256 && runia_knn16_fits(M, D) && runia_knn16_fits(kQueryChunk, D) &&
          4 * M * 256 <= ((int64_t)1 << 31);
 }
+#ifndef KNN16_MIN_ROWS_PREPARED
+#define KNN16_MIN_ROWS_PREPARED 64
+#endif
+// with the bank's pieces already there, the bf16 kernel pays from far fewer queries (its 256-row query tile is padded)
+static bool knn16_prepared_wanted(int64_t N, int64_t M, int64_t D) {
+  return knn16_bank_ok(M, D) && N >= KNN16_MIN_ROWS_PREPARED && N * M >= ((int64_t)1 << 29) / D &&
+         (M * D >= ((int64_t)1 << 23) || N >= 1000);  // (tools/ablate/run_knn_prepared.py: small banks stay on the f32 kernel)
+}
 static size_t knn_state_head_bytes(int64_t M) { return (((size_t)M + 1) * sizeof(float) + 255) / 256 * 256; }
 extern "C" size_t runia_knn_bank_state_bytes(int64_t M, int64_t D) {
   if (M <= 0 || D <= 0) return 0;
@@ -1027,7 +1043,7 @@ extern "C" size_t runia_knn_prepared_workspace_bytes(int64_t N, int64_t M, int64
   if (N <= 0 || M <= 0) return 0;
   const int64_t qc = knn_chunk_rows(N, M);
   const size_t head = ((size_t)(qc * M + qc) * sizeof(float) + 255) / 256 * 256;
-  return head + (knn16_wanted(N, M, D) ? runia_knn16_plane_bytes(qc, D) : 0);
+  return head + (knn16_prepared_wanted(N, M, D) ? runia_knn16_plane_bytes(qc, D) : 0);
 }
 extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, const void* state, size_t state_bytes,
                                           float* score, void* workspace, size_t workspace_bytes, int64_t N, int64_t M,
@@ -1046,7 +1062,7 @@ extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, con
   unsigned* bn_max = const_cast<unsigned*>(reinterpret_cast<const unsigned*>(bn + M));  // (only ever re-written with its own value)
   // the bf16 kernel when the state holds the pieces and the workspace is the one asked for; else the f32 kernel with as
   // many query rows per pass as the workspace holds
-  const bool use16 = knn16_wanted(N, M, D) && state_bytes >= runia_knn_bank_state_bytes(M, D) &&
+  const bool use16 = knn16_prepared_wanted(N, M, D) && state_bytes >= runia_knn_bank_state_bytes(M, D) &&
                      workspace_bytes >= runia_knn_prepared_workspace_bytes(N, M, D, k);
   int64_t qc = use16 ? knn_chunk_rows(N, M) : (int64_t)(workspace_bytes / sizeof(float) / (size_t)(M + 1));
   if (qc < 1) return RUNIA_E_WORKSPACE;
@@ -1064,7 +1080,7 @@ extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, con
   uint16_t* q_planes = use16 ? reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) +
                                                            ((size_t)(qc * M + qc) * sizeof(float) + 255) / 256 * 256)
                              : nullptr;
-  return knn_scan(q, bank, score, dist, qn, bn, bn_max, bank_planes, q_planes, qc, use16, N, M, D, k, s);
+  return knn_scan(q, bank, score, dist, qn, bn, bn_max, bank_planes, q_planes, qc, use16, N, M, D, k, s, 1);
 }
 
 extern "C" int runia_linear_f32(const float* x, const float* w, const float* bias, float* out, int64_t N, int64_t D,
