@@ -28,6 +28,7 @@
 // under the swizzle those 16 (row, slot) pairs fall into the 16 different 16-byte bank groups (SQ_LDS_BANK_CONFLICT = 0).
 // The pipeline is described at the loop.
 #include "common.hpp"
+#include "knn_perm.hpp"
 
 #include <cstdint>
 #include <type_traits>
@@ -48,8 +49,11 @@ __device__ __forceinline__ unsigned bf16_rne(float x) {  // bf16 bits of x, roun
 }
 
 // f32 [R, D] -> pieces [Rpad][Dp / 32][h: 32 bf16 | m: 32 bf16], zero in the padding; 8 consecutive k per thread
+// `pm`: piece row p holds matrix row knn_perm_row(p) (the bank; identity for queries); `norms` / `norms_p` (optional): the
+// rows' squared norms in matrix order -> in piece order, NaN in the padding (a padding column never passes a threshold)
 __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ x, uint16_t* __restrict__ planes,
-                                                         int64_t R, int64_t D, int64_t Rpad, int64_t Dp) {
+                                                         int64_t R, int64_t D, int64_t Rpad, int64_t Dp, KnnPerm pm,
+                                                         const float* __restrict__ norms, float* __restrict__ norms_p) {
   const int64_t groups = Dp / 8, total = Rpad * groups;
   const bool vec = ((D & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
@@ -57,8 +61,10 @@ __global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict
     float v[8];
 #pragma unroll
     for (int j = 0; j < 8; ++j) v[j] = 0.f;
+    const int64_t src = row < R ? knn_perm_row(row, pm) : row;
+    if (norms_p && k0 == 0) norms_p[row] = row < R ? norms[src] : __builtin_nanf("");
     if (row < R) {
-      const float* p = x + row * D + k0;
+      const float* p = x + src * D + k0;
       if (vec && k0 + 8 <= D) {
         const float4 a = reinterpret_cast<const float4*>(p)[0], b = reinterpret_cast<const float4*>(p)[1];
         v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
@@ -101,13 +107,42 @@ __device__ __forceinline__ void dma16(unsigned lds_bytes, unsigned voff, i32x4 r
 }
 #endif
 
+// What leaves the kernel (FILTER):
+//   false  the distances, dense: dist [Q, M].  `q_count` (optional, device): only the first *q_count - q_first query rows
+//          exist (the dense fallback of the filter path works on however many rows overflowed; the grid is sized for Q)
+//   true   per query row only the bank rows whose distance is <= thr[row], appended as (distance bits, col0 + column) to
+//          lists[row * cap ..] with the running count in counts[row] (counted past cap, so an overflow shows): the
+//          candidate filter of the k-th-neighbour search.  The Q x M matrix - 1.6 GB per 8 192 x 50 000 chunk, written
+//          here and read again by the selection - is never formed; about k * M / (sample rows) entries per row are.
+//          Per tile: every lane tests its 256 distances, the hits of a row are counted over the 16 lanes that hold it
+//          (four rows' 8-bit counters per DPP scan), the two waves that share a row meet in LDS, ONE global atomic per
+//          row and tile reserves the row's slots, and the hits are stored behind it.
+struct KnnFilterOut {
+  const float* thr;
+  unsigned* counts;
+  uint2* lists;
+  int cap;
+  int col0;
+};
+template <int CTRL>
+__device__ __forceinline__ unsigned dpp_row_u32(unsigned v) {  // lanes shifted in from outside the row of 16 read 0
+  return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xf, 0xf, true);
+}
+
+template <bool FILTER>
 __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __restrict__ qp, const uint16_t* __restrict__ bp,
                                                              const float* __restrict__ qn, const float* __restrict__ bn,
                                                              float* __restrict__ dist, int64_t Q, int64_t M, int64_t Dp,
-                                                             int64_t Qpad, int64_t Mpad) {
+                                                             int64_t Qpad, int64_t Mpad, const int* __restrict__ q_count,
+                                                             int q_first, KnnFilterOut fo) {
 #if defined(__HIP_DEVICE_COMPILE__)
   extern __shared__ __attribute__((aligned(16))) uint4 lds[];  // 2 buffers x (2048 query slots + 2048 bank slots)
   const int tid = threadIdx.x, lane = tid & 63;
+  if (!FILTER && q_count) {  // (uniform)
+    const int64_t have = (int64_t)*q_count - q_first;
+    if (have < Q) Q = have;
+    if (Q <= 0) return;
+  }
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wq = wave >> 1, wb = wave & 1;
   // XCD-aware order: ids i, i + 8, ... (one XCD's share) walk a super-tile of 8 query tiles x 4 bank tiles; its 32
@@ -237,6 +272,83 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
 #undef RUNIA_PIN
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) DMA
   // epilogue: C[row = 4 * (lane >> 4) + reg][col = lane & 15] of each 16 x 16 tile
+  if constexpr (FILTER) {
+    __syncthreads();  // the stage buffers are free: every wave has read its last operands
+    float* qn_l = reinterpret_cast<float*>(lds);                 // [256] |q|^2 of the tile's rows
+    float* th_l = qn_l + 256;                                    // [256] their thresholds (-inf: no such row)
+    unsigned* c_l = reinterpret_cast<unsigned*>(th_l + 256);     // [256][2] hits of (row, column half)
+    unsigned* b_l = c_l + 512;                                   // [256] first slot of the row's hits in its list
+    {
+      const int64_t row = q0 + tid;
+      qn_l[tid] = row < Q ? qn[row] : 0.f;
+      th_l[tid] = row < Q ? fo.thr[row] : -INFINITY;
+    }
+    float bnv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int64_t col = m0 + wb * 128 + j * 16 + lrow;
+      bnv[j] = (col < M) ? bn[col] : __builtin_nanf("");  // NaN: the comparison below is false
+    }
+    __syncthreads();
+    unsigned maskp[8], exclp[8];  // per i: the hit masks of r = 0..3 (8 bits each) and the hits of the lanes before this one
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      unsigned cnt4 = 0u;
+      maskp[i] = 0u;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int rowl = wq * 128 + i * 16 + 4 * lq + r;
+        const float qnr = qn_l[rowl], tr = th_l[rowl];
+        unsigned m = 0u;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float dd = (qnr + bnv[j]) - 2.0f * acc[i][j][r];
+          m |= (dd <= tr) ? (1u << j) : 0u;
+        }
+        maskp[i] |= m << (8 * r);
+        cnt4 |= (unsigned)__builtin_popcount(m) << (8 * r);
+      }
+      unsigned incl = cnt4;  // inclusive scan over the 16 lanes of a row (a row's total <= 128: no carry between the bytes)
+      incl += dpp_row_u32<0x111>(incl);
+      incl += dpp_row_u32<0x112>(incl);
+      incl += dpp_row_u32<0x114>(incl);
+      incl += dpp_row_u32<0x118>(incl);
+      exclp[i] = incl - cnt4;
+      if (lrow == 15) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) c_l[(wq * 128 + i * 16 + 4 * lq + r) * 2 + wb] = (incl >> (8 * r)) & 255u;
+      }
+    }
+    __syncthreads();
+    {
+      const unsigned n = c_l[2 * tid] + c_l[2 * tid + 1];
+      b_l[tid] = (n != 0u) ? atomicAdd(&fo.counts[q0 + tid], n) : 0u;  // (rows beyond Q have no hits)
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      if (maskp[i] == 0u) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const unsigned m = (maskp[i] >> (8 * r)) & 255u;
+        if (m == 0u) continue;
+        const int rowl = wq * 128 + i * 16 + 4 * lq + r;
+        const float qnr = qn_l[rowl];
+        unsigned off = b_l[rowl] + (wb ? c_l[2 * rowl] : 0u) + ((exclp[i] >> (8 * r)) & 255u);
+        uint2* lrow_out = fo.lists + (q0 + rowl) * (int64_t)fo.cap;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          if ((m >> j) & 1u) {
+            const float dd = fmaxf((qnr + bnv[j]) - 2.0f * acc[i][j][r], 0.f);
+            if (off < (unsigned)fo.cap)
+              lrow_out[off] = make_uint2(__float_as_uint(dd), (unsigned)(fo.col0 + (int)(m0 + wb * 128 + j * 16 + lrow)));
+            ++off;
+          }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int i = 0; i < 8; ++i)
 #pragma unroll
@@ -269,7 +381,16 @@ bool runia_knn16_fits(int64_t rows, int64_t D) { return runia_knn16_plane_bytes(
 
 int runia_knn16_split(const float* x, uint16_t* planes, int64_t R, int64_t D, hipStream_t s) {
   const int64_t Rpad = runia_knn16_padded_rows(R), Dp = runia_knn16_padded_width(D);
-  runia_knn16::split_bf16_kernel<<<runia_stream_grid(Rpad * (Dp / 8), 256), 256, 0, s>>>(x, planes, R, D, Rpad, Dp);
+  runia_knn16::split_bf16_kernel<<<runia_stream_grid(Rpad * (Dp / 8), 256), 256, 0, s>>>(x, planes, R, D, Rpad, Dp,
+                                                                                        knn_perm_identity(), nullptr, nullptr);
+  return runia_check_launch();
+}
+// the bank: rows in the sample order of knn_perm.hpp, with the squared norms `bn` (matrix order) copied into that order
+// (`bn_p`, one per padded row, NaN in the padding)
+int runia_knn16_split_bank(const float* x, uint16_t* planes, const float* bn, float* bn_p, int64_t R, int64_t D, hipStream_t s) {
+  const int64_t Rpad = runia_knn16_padded_rows(R), Dp = runia_knn16_padded_width(D);
+  runia_knn16::split_bf16_kernel<<<runia_stream_grid(Rpad * (Dp / 8), 256), 256, 0, s>>>(x, planes, R, D, Rpad, Dp,
+                                                                                        knn_perm_for(R), bn, bn_p);
   return runia_check_launch();
 }
 
@@ -277,22 +398,56 @@ int runia_knn16_split(const float* x, uint16_t* planes, int64_t R, int64_t D, hi
 // least TWICE the largest error e of a candidate distance (then every bank row outside the window lies on the same side
 // of the true k-th distance as of the approximate one).  Dropped products: m.m + h.l + l.h + ... <= 3 * 2^-16 sum|q_k||b_k|
 // <= 3 * 2^-16 |q||b| (each piece is below 2^-8 of the one before; Cauchy-Schwarz), |q||b| <= R / 4, and the distance
-// carries twice the product's error: e <= 2.3e-5 R, plus the f32 kernel's accumulation allowance -> 5e-5 R.
+// carries twice the product's error: e <= 2.3e-5 R.  Accumulation: the matrix cores add the 3 * D / 32 staged partial
+// sums of a dot product in f32, each addition within 2^-24 of the running sum's magnitude <= 2 sum|q_k||b_k| <= R / 2, and
+// the 32 products inside an instruction are summed at no less than that accuracy: <= (3 D / 32 + 32) * 2^-24 * R / 2 per
+// dot product, twice that in the distance - 1.3e-5 R at D = 2048 as a worst case (the observed error is ~sqrt of the
+// count: 1e-7 R).  Window = 2 e = 4.6e-5 R + D * 1.2e-8 R, rounded up to 5e-5 + 1.5e-8 D; D is capped where the window
+// would no longer separate neighbours usefully (runia_knn16_max_width: the f32 kernel takes wider rows).
 int runia_knn16_terms() { return 3; }
-float runia_knn16_refine_rel() { return 5e-5f; }
+int64_t runia_knn16_max_width() { return 16384; }
+float runia_knn16_refine_rel(int64_t D) { return 5e-5f + 1.5e-8f * (float)D; }
 
-int runia_knn16_dist(const uint16_t* qp, const uint16_t* bp, const float* qn, const float* bn, float* dist, int64_t Q,
-                     int64_t M, int64_t D, hipStream_t s) {
+static int knn16_launch_dims(int64_t Q, int64_t M, unsigned* grid) {
   using namespace runia_knn16;
-  constexpr size_t lds_bytes = (size_t)kStages * kStageBytes;
-  static std::atomic<uint64_t> lds_ok{0};
-  const int rc = runia_allow_dynamic_lds(reinterpret_cast<const void*>(knn_dist_bf16_kernel), lds_bytes, lds_ok);
-  if (rc != RUNIA_OK) return rc;
   const int64_t nqt = (Q + TQ - 1) / TQ, nbt = (M + TB - 1) / TB;
   const int sq = nqt < 8 ? (int)nqt : 8;  // query tiles of a super-tile (see the kernel)
   const int64_t st = ((nqt + sq - 1) / sq) * ((nbt + 3) / 4);
-  const unsigned grid = (unsigned)(((st + 7) / 8) * 8 * 4 * sq);
-  knn_dist_bf16_kernel<<<grid, 256, lds_bytes, s>>>(qp, bp, qn, bn, dist, Q, M, runia_knn16_padded_width(D),
-                                                     runia_knn16_padded_rows(Q), runia_knn16_padded_rows(M));
+  *grid = (unsigned)(((st + 7) / 8) * 8 * 4 * sq);
+  return RUNIA_OK;
+}
+
+// dense distances [Q, M] of queries against piece rows 0 .. M - 1 of `bp` (`planes_rows`: padded rows behind bp);
+// `q_count` / `q_first`: see the kernel
+int runia_knn16_dist(const uint16_t* qp, const uint16_t* bp, const float* qn, const float* bn, float* dist, int64_t Q,
+                     int64_t M, int64_t D, int64_t q_planes_rows, int64_t b_planes_rows, const int* q_count, int q_first,
+                     hipStream_t s) {
+  using namespace runia_knn16;
+  constexpr size_t lds_bytes = (size_t)kStages * kStageBytes;
+  static std::atomic<uint64_t> lds_ok{0};
+  const int rc = runia_allow_dynamic_lds(reinterpret_cast<const void*>(knn_dist_bf16_kernel<false>), lds_bytes, lds_ok);
+  if (rc != RUNIA_OK) return rc;
+  unsigned grid;
+  knn16_launch_dims(Q, M, &grid);
+  knn_dist_bf16_kernel<false><<<grid, 256, lds_bytes, s>>>(qp, bp, qn, bn, dist, Q, M, runia_knn16_padded_width(D),
+                                                            q_planes_rows, b_planes_rows, q_count, q_first,
+                                                            KnnFilterOut{nullptr, nullptr, nullptr, 0, 0});
+  return runia_check_launch();
+}
+
+// candidate lists (see the kernel): piece rows 0 .. M - 1 of `bp` are columns col0 .. col0 + M - 1
+int runia_knn16_filter(const uint16_t* qp, const uint16_t* bp, const float* qn, const float* bn, const float* thr,
+                       unsigned* counts, void* lists, int cap, int col0, int64_t Q, int64_t M, int64_t D,
+                       int64_t q_planes_rows, int64_t b_planes_rows, hipStream_t s) {
+  using namespace runia_knn16;
+  constexpr size_t lds_bytes = (size_t)kStages * kStageBytes;
+  static std::atomic<uint64_t> lds_ok{0};
+  const int rc = runia_allow_dynamic_lds(reinterpret_cast<const void*>(knn_dist_bf16_kernel<true>), lds_bytes, lds_ok);
+  if (rc != RUNIA_OK) return rc;
+  unsigned grid;
+  knn16_launch_dims(Q, M, &grid);
+  knn_dist_bf16_kernel<true><<<grid, 256, lds_bytes, s>>>(qp, bp, qn, bn, nullptr, Q, M, runia_knn16_padded_width(D),
+                                                           q_planes_rows, b_planes_rows, nullptr, 0,
+                                                           KnnFilterOut{thr, counts, reinterpret_cast<uint2*>(lists), cap, col0});
   return runia_check_launch();
 }

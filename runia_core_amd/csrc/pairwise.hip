@@ -13,6 +13,7 @@
 // the distance bits (distances are clamped >= 0, so unsigned integer order == float order) - no sort, no top-k list.
 // The tile grid is walked in XCD-aware super-tiles (see knn_dist_kernel).
 #include "common.hpp"
+#include "knn_perm.hpp"
 
 namespace {
 
@@ -396,12 +397,17 @@ __global__ __launch_bounds__(64 * kRowWaves) void knn_small_dist_kernel(const fl
   }
 }
 
+// `pm`: column m of a distance row is bank row knn_perm_row(m) (the bf16 kernel's piece order; identity otherwise).
+// `row_map` / `n_rows` / `row_first` (the dense fallback of the candidate filter): distance row r belongs to query
+// row_map[row_first + r], and only min(Q, *n_rows - row_first) rows exist.
 __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict__ dist, const float* __restrict__ q,
                                                                 const float* __restrict__ bank,
                                                                 const float* __restrict__ qn,
                                                                 const unsigned* __restrict__ bn_max_bits,
                                                                 float* __restrict__ score, int64_t Q, int64_t M,
-                                                                int64_t D, int k, float refine_rel) {
+                                                                int64_t D, int k, float refine_rel, KnnPerm pm,
+                                                                const int* __restrict__ row_map,
+                                                                const int* __restrict__ n_rows, int row_first) {
   __shared__ unsigned hist[4096];
   __shared__ unsigned part[256];
   __shared__ unsigned sel[2];
@@ -415,8 +421,13 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const float bmax = __uint_as_float(*bn_max_bits);
   const bool fast_ok = (M >= 4 * (int64_t)kSample) && (k <= kSample / 4);
-  for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
-    float* drow = dist + row * M;
+  if (n_rows) {
+    const int64_t have = (int64_t)*n_rows - row_first;
+    if (have < Q) Q = have;
+  }
+  for (int64_t drow_i = blockIdx.x; drow_i < Q; drow_i += gridDim.x) {
+    float* drow = dist + drow_i * M;
+    const int64_t row = row_map ? (int64_t)row_map[row_first + drow_i] : drow_i;
     const float qnorm = qn[row];
     if (!(qnorm < INFINITY)) {  // NaN or infinite query: every distance is FLT_MAX (wave-uniform branch)
       if (tid == 0) score[row] = -kFltMax;
@@ -483,7 +494,7 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
                 ++below;
               } else if (d <= hi) {
                 const unsigned slot = atomicAdd(&n_cand, 1u);
-                if (slot < (unsigned)kMaxCand) cand_idx[slot] = fast_i[c];
+                if (slot < (unsigned)kMaxCand) cand_idx[slot] = (int)knn_perm_row(fast_i[c], pm);
               }
             }
             atomicAdd(&n_below, below);
@@ -512,7 +523,7 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
           ++below;
         } else if (d <= hi) {
           const unsigned slot = atomicAdd(&n_cand, 1u);
-          if (slot < (unsigned)kMaxCand) cand_idx[slot] = (int)m;
+          if (slot < (unsigned)kMaxCand) cand_idx[slot] = (int)knn_perm_row(m, pm);
         }
       }
       atomicAdd(&n_below, below);
@@ -527,7 +538,7 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
       for (int64_t m = wave; m < M; m += 4) {
         const float d = drow[m];  // wave-uniform
         if (d >= lo && d <= hi) {
-          const float acc = exact_sqdist_wave(qr, bank + m * D, D, lane);
+          const float acc = exact_sqdist_wave(qr, bank + knn_perm_row(m, pm) * D, D, lane);
           if (lane == 0) drow[m] = __uint_as_float(__float_as_uint(acc) | 0x80000000u);
         }
       }
@@ -575,6 +586,170 @@ __global__ __launch_bounds__(256) void kth_select_range_kernel(float* __restrict
       }
       if (less < want && want <= leq) score[row] = -dc;  // all writers hold the same value
     }
+  }
+}
+
+// ---- candidate filter (bf16 kernel, FILTER epilogue): the selection without the Q x M matrix -------------------------
+// (1) knn_tau_kernel: the k-th smallest of a row's distances to the SAMPLE (the first S piece rows of the bank, dense
+//     [Q, S]) is an upper bound tau of the row's k-th smallest distance; thr = tau + 2 windows is what the main pass lets
+//     through.  (2) knn_dist_bf16_kernel<true> over the other piece rows.  (3) kth_select_lists_kernel: the row's list +
+//     its sample entries <= thr hold EVERY bank row at or below thr, so the k-th smallest key among them is the row's
+//     k-th smallest, the window around it is complete, and the rows below the window are counted - the same selection,
+//     window and exact re-measurement as kth_select_range_kernel's fast path, i.e. the same bits.  A row where that
+//     cannot be done (more hits than a list holds, fewer than k comparable sample entries, a crowded window) is put on
+//     the overflow list and takes the dense kernels afterwards (knn_gather_rows_kernel + the dense epilogue +
+//     kth_select_range_kernel over however many rows overflowed).
+constexpr int kListCap = 2048;  // entries a row's list holds (expected: k * M / S ~ 1 250 +- 180 at the S chosen below)
+static_assert(kListCap <= kFastCap, "a full list fits the selection's LDS buffer");
+
+__global__ __launch_bounds__(256) void knn_tau_kernel(const float* __restrict__ samp, const float* __restrict__ qn,
+                                                       const unsigned* __restrict__ bn_max_bits, float* __restrict__ thr,
+                                                       unsigned* __restrict__ counts, int* __restrict__ n_ov, int64_t Q,
+                                                       int S, int k, float refine_rel) {
+  __shared__ unsigned hist[4096];
+  __shared__ unsigned part[256];
+  __shared__ unsigned sel[2];
+  const int tid = threadIdx.x;
+  const float bmax = __uint_as_float(*bn_max_bits);
+  if (blockIdx.x == 0 && tid == 0) *n_ov = 0;
+  for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+    const float qnorm = qn[row];
+    if (tid == 0) counts[row] = 0u;
+    if (!(qnorm < INFINITY)) {  // (uniform) nothing passes; the selection writes -FLT_MAX
+      if (tid == 0) thr[row] = -INFINITY;
+      continue;
+    }
+    const float sq = sqrtf(qnorm) + sqrtf(bmax);
+    const float range = sq * sq * 1.000001f + 1e-30f;
+    const float scale = 16777216.0f / range;
+    const float delta = fmaxf(refine_rel * range, 2.0f / scale);
+    const float* srow = samp + row * (int64_t)S;
+    const unsigned key_s = hist_select24([&](int64_t m) { return srow[m]; }, S, (unsigned)k, scale, hist, part, sel, tid,
+                                         reinterpret_cast<const float4*>(srow));
+    // fewer than k comparable sample rows: everything passes, the row overflows and takes the dense kernels
+    if (tid == 0) thr[row] = (key_s < 16777214u) ? ((float)key_s + 1.0f) / scale * 1.000001f + 2.0f * delta : kFltMax;
+    __syncthreads();
+  }
+}
+
+__global__ __launch_bounds__(256) void kth_select_lists_kernel(const float* __restrict__ samp, int S,
+                                                                const uint2* __restrict__ lists,
+                                                                const unsigned* __restrict__ counts,
+                                                                const float* __restrict__ thr, const float* __restrict__ q,
+                                                                const float* __restrict__ bank, const float* __restrict__ qn,
+                                                                const unsigned* __restrict__ bn_max_bits,
+                                                                float* __restrict__ score, int* __restrict__ ov_list,
+                                                                int* __restrict__ n_ov, int64_t Q, int64_t D, int k,
+                                                                float refine_rel, KnnPerm pm) {
+  __shared__ unsigned hist[4096];
+  __shared__ unsigned part[256];
+  __shared__ unsigned sel[2];
+  __shared__ unsigned n_below, n_cand, n_fast;
+  __shared__ int cand_idx[kMaxCand];
+  __shared__ float cand_d[kMaxCand];
+  __shared__ float fast_d[kFastCap];
+  __shared__ int fast_i[kFastCap];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float bmax = __uint_as_float(*bn_max_bits);
+  for (int64_t row = blockIdx.x; row < Q; row += gridDim.x) {
+    const float qnorm = qn[row];
+    if (!(qnorm < INFINITY)) {
+      if (tid == 0) score[row] = -kFltMax;
+      continue;
+    }
+    const float sq = sqrtf(qnorm) + sqrtf(bmax);
+    const float range = sq * sq * 1.000001f + 1e-30f;
+    const float scale = 16777216.0f / range;
+    const float delta = fmaxf(refine_rel * range, 2.0f / scale);
+    __syncthreads();
+    if (tid == 0) { n_below = 0u; n_cand = 0u; n_fast = 0u; }
+    __syncthreads();
+    const float t = thr[row];
+    const unsigned cnt = counts[row];
+    bool dense = cnt > (unsigned)kListCap || !(t < kFltMax);  // (uniform)
+    unsigned nf = 0;
+    if (!dense) {
+      const uint2* lrow = lists + row * (int64_t)kListCap;
+      for (unsigned c = tid; c < cnt; c += 256) {
+        const uint2 e = lrow[c];
+        fast_d[c] = __uint_as_float(e.x);
+        fast_i[c] = (int)e.y;
+      }
+      const float4* srow4 = reinterpret_cast<const float4*>(samp + row * (int64_t)S);
+      auto keep = [&](float d, int m) {
+        if (d <= t) {
+          const unsigned slot = cnt + atomicAdd(&n_fast, 1u);
+          if (slot < (unsigned)kFastCap) { fast_d[slot] = d; fast_i[slot] = m; }
+        }
+      };
+      for (int m = tid; m < S / 4; m += 256) {
+        const float4 a = srow4[m];
+        keep(a.x, 4 * m); keep(a.y, 4 * m + 1); keep(a.z, 4 * m + 2); keep(a.w, 4 * m + 3);
+      }
+      __syncthreads();
+      nf = cnt + n_fast;
+      dense = nf > (unsigned)kFastCap || nf < (unsigned)k;
+    }
+    float lo = 0.f, hi = 0.f;
+    if (!dense) {
+      const unsigned key_f = hist_select24([&](int64_t m) { return fast_d[m]; }, nf, (unsigned)k, scale, hist, part, sel, tid);
+      const float approx = ((float)key_f + 0.5f) / scale;
+      lo = approx - delta;
+      hi = approx + delta;
+      if (key_f < 16777215u && hi <= t) {  // (hi <= t by construction: the k-th key is at most the sample's)
+        unsigned below = 0;
+        for (unsigned c = tid; c < nf; c += 256) {
+          const float d = fast_d[c];
+          if (d < lo) {
+            ++below;
+          } else if (d <= hi) {
+            const unsigned slot = atomicAdd(&n_cand, 1u);
+            if (slot < (unsigned)kMaxCand) cand_idx[slot] = (int)knn_perm_row(fast_i[c], pm);
+          }
+        }
+        atomicAdd(&n_below, below);
+        __syncthreads();
+        const int want = k - (int)n_below;
+        dense = n_cand > (unsigned)kMaxCand || want < 1 || (unsigned)want > n_cand;
+      } else {
+        dense = true;
+      }
+    }
+    if (dense) {
+      if (tid == 0) ov_list[atomicAdd(n_ov, 1)] = (int)row;
+      continue;
+    }
+    const unsigned nc = n_cand;
+    const int want = k - (int)n_below;
+    const float* qr = q + row * D;
+    for (unsigned c = wave; c < nc; c += 4) {
+      const float acc = exact_sqdist_wave(qr, bank + (int64_t)cand_idx[c] * D, D, lane);
+      if (lane == 0) cand_d[c] = acc;
+    }
+    __syncthreads();
+    for (unsigned c = tid; c < nc; c += 256) {
+      const float dc = cand_d[c];
+      int less = 0, leq = 0;
+      for (unsigned o = 0; o < nc; ++o) {
+        less += (cand_d[o] < dc);
+        leq += (cand_d[o] <= dc);
+      }
+      if (less < want && want <= leq) score[row] = -dc;  // all writers hold the same value
+    }
+  }
+}
+
+// the overflowed rows' pieces and norms, packed for the dense kernel: row r of the output = query ov_list[first + r]
+__global__ __launch_bounds__(256) void knn_gather_rows_kernel(const uint4* __restrict__ planes, const float* __restrict__ qn,
+                                                               const int* __restrict__ ov_list, const int* __restrict__ n_ov,
+                                                               int first, int max_rows, uint4* __restrict__ planes_out,
+                                                               float* __restrict__ qn_out, int64_t row_u4) {
+  int have = *n_ov - first;
+  if (have > max_rows) have = max_rows;  // (this round's share)
+  for (int r = blockIdx.x; r < have; r += gridDim.x) {
+    const int64_t src = ov_list[first + r];
+    for (int64_t i = threadIdx.x; i < row_u4; i += 256) planes_out[(int64_t)r * row_u4 + i] = planes[src * row_u4 + i];
+    if (threadIdx.x == 0) qn_out[r] = qn[src];
   }
 }
 
@@ -887,12 +1062,19 @@ static inline unsigned knn_dist_grid(int64_t Q, int64_t M) {
 
 // knn_bf16.hip: candidate distances of large problems from bf16 piece products (6/16 of the f32 kernel's matrix-pipe time)
 int64_t runia_knn16_padded_rows(int64_t rows);
+int64_t runia_knn16_padded_width(int64_t D);
 size_t runia_knn16_plane_bytes(int64_t rows, int64_t D);
 bool runia_knn16_fits(int64_t rows, int64_t D);
 int runia_knn16_split(const float* x, uint16_t* planes, int64_t R, int64_t D, hipStream_t s);
-float runia_knn16_refine_rel();
+int runia_knn16_split_bank(const float* x, uint16_t* planes, const float* bn, float* bn_p, int64_t R, int64_t D, hipStream_t s);
+float runia_knn16_refine_rel(int64_t D);
+int64_t runia_knn16_max_width();
 int runia_knn16_dist(const uint16_t* qp, const uint16_t* bp, const float* qn, const float* bn, float* dist, int64_t Q,
-                     int64_t M, int64_t D, hipStream_t s);
+                     int64_t M, int64_t D, int64_t q_planes_rows, int64_t b_planes_rows, const int* q_count, int q_first,
+                     hipStream_t s);
+int runia_knn16_filter(const uint16_t* qp, const uint16_t* bp, const float* qn, const float* bn, const float* thr,
+                       unsigned* counts, void* lists, int cap, int col0, int64_t Q, int64_t M, int64_t D,
+                       int64_t q_planes_rows, int64_t b_planes_rows, hipStream_t s);
 
 #ifndef KNN_BF16
 #define KNN_BF16 1
@@ -900,12 +1082,25 @@ int runia_knn16_dist(const uint16_t* qp, const uint16_t* bp, const float* qn, co
 #ifndef KNN16_MIN_ROWS
 #define KNN16_MIN_ROWS 512  // (256 queries x 50 000 x 2048: 0.99 ms against 0.75 on the f32 kernel; 512: 0.97 against 1.12; 1 000 x 20 000: 0.51 against 0.95)
 #endif
+#ifndef KNN16_FILTER
+#define KNN16_FILTER 1
+#endif
+#ifndef KNN16_FILTER_MIN_ROWS
+#define KNN16_FILTER_MIN_ROWS 1024  // queries of a call from which the candidate filter is taken (fewer: the dense form)
+#endif
+#ifndef KNN16_DENSE_ROWS
+#define KNN16_DENSE_ROWS 2048  // rows of the dense fallback matrix of the candidate filter (one round of three launches per that many overflowed rows)
+#endif
+// the bank side of the bf16 kernel: some thousand rows, wide (but not wider than its window allows) features
+static bool knn16_bank_ok(int64_t M, int64_t D) {
+  return KNN_BF16 && M >= 4096 && D >= 256 && D <= runia_knn16_max_width() && runia_knn16_fits(M, D) &&
+         runia_knn16_fits(kQueryChunk, D) && 4 * M * 256 <= ((int64_t)1 << 31);  // (chunks of >= 256 queries: whole tiles)
+}
 // Worth the two split passes and the 256 x 256 tiles: a bank of some thousand rows, wide features, a batch of queries, 2^31
 // multiply-adds, 512 queries (tools/ablate/run_knn_paths.py: 1 024 x 4 096 x 256 is 8 % slower on the bf16 kernel, 1 024 x 4 096 x 2048
 // 1.46 x faster, 8 192 x 50 000 x 2048 2.67 x)
 static bool knn16_wanted(int64_t N, int64_t M, int64_t D) {
-  return KNN_BF16 && N >= KNN16_MIN_ROWS && M >= 4096 && D >= 256 && N * M >= ((int64_t)1 << 31) / D && runia_knn16_fits(M, D) &&
-         runia_knn16_fits(kQueryChunk, D) && 4 * M * 256 <= ((int64_t)1 << 31);  // (chunks of >= 256 queries: whole tiles)
+  return knn16_bank_ok(M, D) && N >= KNN16_MIN_ROWS && N * M >= ((int64_t)1 << 31) / D;
 }
 int runia_knn16_terms();
 extern "C" int runia_knn_piece_products(int64_t N, int64_t M, int64_t D) { return knn16_wanted(N, M, D) ? runia_knn16_terms() : 0; }
@@ -921,39 +1116,141 @@ static int64_t knn_chunk_rows(int64_t N, int64_t M) {
 }
 static size_t knn16_head_bytes(int64_t qc, int64_t M) { return (knn_f32_words(qc, M) * sizeof(float) + 255) / 256 * 256; }
 
+// Sample rows of the candidate filter (0 = the dense form): the expected number of bank rows at or below a row's
+// threshold is k * M / S, with a spread of ~ sqrt(k) * M / S; S is the multiple of 256 that puts the mean at 0.6 of a
+// list (k = 50, M = 50 000: S = 2 048, 1 220 +- 170 entries of 2 048).  Not worth it when the sample would be a
+// quarter of the bank or more (large k), or for a call of a few hundred queries.
+static int64_t knn16_sample_rows(int64_t N, int64_t M, int k) {
+  if (!KNN16_FILTER || N < KNN16_FILTER_MIN_ROWS) return 0;
+  int64_t S = ((int64_t)k * M * 10 / (6 * kListCap) + 255) / 256 * 256;
+  if (S < 1024) S = 1024;
+  if (S < 4 * (int64_t)k) S = (4 * (int64_t)k + 255) / 256 * 256;
+  return (4 * S <= M) ? S : 0;
+}
+
+static size_t align256(size_t b) { return (b + 255) / 256 * 256; }
+// Workspace of one call of the bf16 kernel after the head (dense rows, |q|^2, |b|^2, max |b|^2) and outside the pieces:
+//   bn_p [Mpad] (not for a prepared bank: the state holds it) | samp [qc, S] | thr [qc] | counts [qc] | ov_list [qc] |
+//   n_ov [64] | lists [qc, kListCap] x 8 B | pieces of the overflowed rows [dense rows, padded] | their |q|^2 | |q|^2 [qc]
+struct Knn16Filter {
+  size_t bn_p, samp, thr, counts, ov_list, n_ov, lists, ov_planes, ov_qn, qn, end;
+};
+static Knn16Filter knn16_filter_layout(size_t at, int64_t qc, int64_t dense_rows, int64_t M, int64_t D, int64_t S, bool own_bn_p) {
+  Knn16Filter f;
+  const size_t on = S > 0 ? 1 : 0;  // (the dense form keeps only bn_p and |q|^2)
+  f.bn_p = at;       at += own_bn_p ? align256((size_t)runia_knn16_padded_rows(M) * 4) : 0;
+  f.samp = at;       at += align256((size_t)(qc * S) * 4) * on;
+  f.thr = at;        at += align256((size_t)qc * 4) * on;
+  f.counts = at;     at += align256((size_t)qc * 4) * on;
+  f.ov_list = at;    at += align256((size_t)qc * 4) * on;
+  f.n_ov = at;       at += 256 * on;
+  f.lists = at;      at += align256((size_t)qc * kListCap * 8) * on;
+  f.ov_planes = at;  at += S ? runia_knn16_plane_bytes(dense_rows, D) : 0;
+  f.ov_qn = at;      at += align256((size_t)runia_knn16_padded_rows(dense_rows) * 4) * on;
+  f.qn = at;         at += align256((size_t)qc * 4);  // |q|^2 of the chunk
+  f.end = at;
+  return f;
+}
+// rows of the dense matrix a bf16 call keeps: the whole chunk in the dense form, the overflow rounds' share with the filter
+static int64_t knn16_dense_rows(int64_t qc, int64_t S) {
+  return (S > 0 && qc > KNN16_DENSE_ROWS) ? (int64_t)KNN16_DENSE_ROWS : qc;
+}
+
 extern "C" size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {
-  (void)k;
   if (N <= 0 || M <= 0) return 0;
   const int64_t qc = knn_chunk_rows(N, M);
   // + the bf16 pieces of the bank and of one chunk of queries when the bf16 kernel will be taken; the entry point works
   // with whatever it is given (>= 1 row of distances), but takes the bf16 kernel only with at least this much
-  if (knn16_wanted(N, M, D)) return knn16_head_bytes(qc, M) + runia_knn16_plane_bytes(M, D) + runia_knn16_plane_bytes(qc, D);
+  if (knn16_wanted(N, M, D)) {
+    const int64_t S = knn16_sample_rows(N, M, k), dr = knn16_dense_rows(qc, S);
+    const Knn16Filter f = knn16_filter_layout(knn16_head_bytes(dr, M), qc, dr, M, D, S, true);
+    return f.end + runia_knn16_plane_bytes(M, D) + runia_knn16_plane_bytes(qc, D);
+  }
   return knn_f32_words(qc, M) * sizeof(float);
 }
 
 // The passes of a kNN call once the bank's |b|^2, their maximum and (use16) its bf16 pieces exist - computed by the call
 // itself into its workspace, or once per bank by runia_knn_prepare_bank_f32.
+struct Knn16Run {            // (use16 only)
+  const uint16_t* bank_planes;
+  uint16_t* q_planes;
+  const float* bn_p;         // |b|^2 in piece order
+  int64_t S, dense_rows;
+  char* ws;                  // base of the workspace `f` is laid out in
+  Knn16Filter f;
+};
 static int knn_scan(const float* q, const float* bank, float* score, float* dist, float* qn, const float* bn,
-                    unsigned* bn_max, const uint16_t* bank_planes, uint16_t* q_planes, int64_t qc, bool use16, int64_t N,
-                    int64_t M, int64_t D, int k, hipStream_t s, int64_t min_rows16 = 256) {
+                    unsigned* bn_max, const Knn16Run* r16, int64_t qc, int64_t N, int64_t M, int64_t D, int k,
+                    hipStream_t s, int64_t min_rows16 = 256) {
+  const KnnPerm pm = r16 ? knn_perm_for(M) : knn_perm_identity();
+  const int64_t Mpad = runia_knn16_padded_rows(M), qpad = runia_knn16_padded_rows(qc);
   for (int64_t r0 = 0; r0 < N; r0 += qc) {
     const int64_t rows = (N - r0 < qc) ? (N - r0) : qc;
     row_sqnorm_kernel<<<runia_rows_grid(rows), 64 * kRowWaves, 0, s>>>(q + r0 * D, qn, rows, D, nullptr);
     int rc = RUNIA_OK;
-    const bool now16 = use16 && rows >= min_rows16;
+    const bool now16 = r16 && rows >= min_rows16;
+    const unsigned sel_grid = (unsigned)(rows < 4096 ? rows : 4096);
+    if (now16 && r16->S > 0) {  // candidate filter: no Q x M matrix
+      const int64_t S = r16->S;
+      const float rel = runia_knn16_refine_rel(D);
+      float* samp = reinterpret_cast<float*>(r16->ws + r16->f.samp);
+      float* thr = reinterpret_cast<float*>(r16->ws + r16->f.thr);
+      unsigned* counts = reinterpret_cast<unsigned*>(r16->ws + r16->f.counts);
+      int* ov_list = reinterpret_cast<int*>(r16->ws + r16->f.ov_list);
+      int* n_ov = reinterpret_cast<int*>(r16->ws + r16->f.n_ov);
+      void* lists = r16->ws + r16->f.lists;
+      uint16_t* ov_planes = reinterpret_cast<uint16_t*>(r16->ws + r16->f.ov_planes);
+      float* ov_qn = reinterpret_cast<float*>(r16->ws + r16->f.ov_qn);
+      rc = runia_knn16_split(q + r0 * D, r16->q_planes, rows, D, s);
+      if (rc == RUNIA_OK) rc = runia_knn16_dist(r16->q_planes, r16->bank_planes, qn, r16->bn_p, samp, rows, S, D, qpad, Mpad, nullptr, 0, s);
+      if (rc != RUNIA_OK) return rc;
+      knn_tau_kernel<<<sel_grid, 256, 0, s>>>(samp, qn, bn_max, thr, counts, n_ov, rows, (int)S, k, rel);
+      const int64_t Dp2 = 2 * runia_knn16_padded_width(D);  // uint16 per piece row
+      rc = runia_knn16_filter(r16->q_planes, r16->bank_planes + S * Dp2, qn, r16->bn_p + S, thr, counts, lists, kListCap,
+                              (int)S, rows, M - S, D, qpad, Mpad - S, s);
+      if (rc != RUNIA_OK) return rc;
+      kth_select_lists_kernel<<<sel_grid, 256, 0, s>>>(samp, (int)S, reinterpret_cast<const uint2*>(lists), counts, thr,
+                                                       q + r0 * D, bank, qn, bn_max, score + r0, ov_list, n_ov, rows, D, k, rel, pm);
+      // the rows that overflowed (none, as a rule: the launches below then end at their first instruction)
+      const int64_t dr = r16->dense_rows;
+      for (int64_t first = 0; first < rows; first += dr) {
+        const int64_t cap_rows = (rows - first < dr) ? (rows - first) : dr;
+        knn_gather_rows_kernel<<<(unsigned)(cap_rows < 1024 ? cap_rows : 1024), 256, 0, s>>>(
+            reinterpret_cast<const uint4*>(r16->q_planes), qn, ov_list, n_ov, (int)first, (int)cap_rows, reinterpret_cast<uint4*>(ov_planes),
+            ov_qn, Dp2 / 8);
+        rc = runia_knn16_dist(ov_planes, r16->bank_planes, ov_qn, r16->bn_p, dist, cap_rows, M, D,
+                              runia_knn16_padded_rows(dr), Mpad, n_ov, (int)first, s);
+        if (rc != RUNIA_OK) return rc;
+        kth_select_range_kernel<<<(unsigned)(cap_rows < 4096 ? cap_rows : 4096), 256, 0, s>>>(
+            dist, q + r0 * D, bank, qn, bn_max, score + r0, cap_rows, M, D, k, rel, pm, ov_list, n_ov, (int)first);
+      }
+      rc = runia_check_launch();
+      if (rc != RUNIA_OK) return rc;
+      continue;
+    }
     if (now16) {
-      rc = runia_knn16_split(q + r0 * D, q_planes, rows, D, s);
-      if (rc == RUNIA_OK) rc = runia_knn16_dist(q_planes, bank_planes, qn, bn, dist, rows, M, D, s);
+      rc = runia_knn16_split(q + r0 * D, r16->q_planes, rows, D, s);
+      if (rc == RUNIA_OK) rc = runia_knn16_dist(r16->q_planes, r16->bank_planes, qn, r16->bn_p, dist, rows, M, D, qpad, Mpad, nullptr, 0, s);
       if (rc != RUNIA_OK) return rc;
     } else {
       knn_dist_kernel<EPI_DIST><<<knn_dist_grid(rows, M), 256, 0, s>>>(q + r0 * D, bank, qn, bn, dist, rows, M, D, INFINITY);
     }
-    kth_select_range_kernel<<<(unsigned)(rows < 4096 ? rows : 4096), 256, 0, s>>>(
-        dist, q + r0 * D, bank, qn, bn_max, score + r0, rows, M, D, k, now16 ? runia_knn16_refine_rel() : kRefineRel);
+    kth_select_range_kernel<<<sel_grid, 256, 0, s>>>(dist, q + r0 * D, bank, qn, bn_max, score + r0, rows, M, D, k,
+                                                     now16 ? runia_knn16_refine_rel(D) : kRefineRel,
+                                                     now16 ? pm : knn_perm_identity(), nullptr, nullptr, 0);
     rc = runia_check_launch();
     if (rc != RUNIA_OK) return rc;
   }
   return RUNIA_OK;
+}
+
+static int knn_small_path(const float* q, const float* bank, float* score, float* dist, float* qn, unsigned* bn_max,
+                          int64_t N, int64_t M, int64_t D, int k, hipStream_t s) {
+  row_sqnorm_kernel<<<runia_rows_grid(N), 64 * kRowWaves, 0, s>>>(q, qn, N, D, nullptr);
+  knn_small_dist_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(q, bank, dist, bn_max, (int)N, M, D);
+  kth_select_range_kernel<<<(unsigned)N, 256, 0, s>>>(dist, q, bank, qn, bn_max, score, N, M, D, k, kRefineRel,
+                                                      knn_perm_identity(), nullptr, nullptr, 0);
+  return runia_check_launch();
 }
 
 extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score, void* workspace,
@@ -975,40 +1272,40 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
   // bf16 candidate distances exactly when the caller hands over the workspace runia_knn_workspace_bytes asks for (a
   // smaller one - e.g. the f32 kernel's (chunk * M + chunk + M + 4) floats - keeps the f32 kernel: the caller's switch)
   const bool use16 = knn16_wanted(N, M, D) && workspace_bytes >= runia_knn_workspace_bytes(N, M, D, k);
-  uint16_t *bank_planes = nullptr, *q_planes = nullptr;
+  Knn16Run r16{};
+  int64_t dense_rows = qc;
   if (use16) {
     qc = knn_chunk_rows(N, M);
-    bank_planes = reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) + knn16_head_bytes(qc, M));
-    q_planes = bank_planes + runia_knn16_plane_bytes(M, D) / sizeof(uint16_t);
+    r16.S = knn16_sample_rows(N, M, k);
+    r16.dense_rows = dense_rows = knn16_dense_rows(qc, r16.S);
+    r16.ws = reinterpret_cast<char*>(workspace);
+    r16.f = knn16_filter_layout(knn16_head_bytes(dense_rows, M), qc, dense_rows, M, D, r16.S, true);
+    uint16_t* planes = reinterpret_cast<uint16_t*>(r16.ws + r16.f.end);
+    r16.bank_planes = planes;
+    r16.q_planes = planes + runia_knn16_plane_bytes(M, D) / sizeof(uint16_t);
+    r16.bn_p = reinterpret_cast<const float*>(r16.ws + r16.f.bn_p);
   }
   float* dist = reinterpret_cast<float*>(workspace);
-  float* qn = dist + qc * M;
-  float* bn = qn + qc;
+  float* qn = dist + dense_rows * M;  // (bf16 kernel: the head keeps `dense_rows` slots; the chunk's |q|^2 have their own block)
+  float* bn = qn + dense_rows;
   unsigned* bn_max = reinterpret_cast<unsigned*>(bn + M);
+  if (use16) qn = reinterpret_cast<float*>(r16.ws + r16.f.qn);
   if (hipMemsetAsync(bn_max, 0, sizeof(unsigned), s) != hipSuccess) return RUNIA_E_LAUNCH;
-  if (N <= kSmallQ && M >= 1024 && qc >= N) {  // a handful of queries: one pass over the bank, exact distances
-    row_sqnorm_kernel<<<runia_rows_grid(N), 64 * kRowWaves, 0, s>>>(q, qn, N, D, nullptr);
-    knn_small_dist_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(q, bank, dist, bn_max, (int)N, M, D);
-    kth_select_range_kernel<<<(unsigned)N, 256, 0, s>>>(dist, q, bank, qn, bn_max, score, N, M, D, k, kRefineRel);
-    return runia_check_launch();
-  }
+  if (N <= kSmallQ && M >= 1024 && qc >= N)  // a handful of queries: one pass over the bank, exact distances
+    return knn_small_path(q, bank, score, dist, qn, bn_max, N, M, D, k, s);
   row_sqnorm_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(bank, bn, M, D, bn_max);
   int rc = runia_check_launch();
   if (rc != RUNIA_OK) return rc;
   if (use16) {
-    rc = runia_knn16_split(bank, bank_planes, M, D, s);
+    rc = runia_knn16_split_bank(bank, const_cast<uint16_t*>(r16.bank_planes), bn, const_cast<float*>(r16.bn_p), M, D, s);
     if (rc != RUNIA_OK) return rc;
   }
-  return knn_scan(q, bank, score, dist, qn, bn, bn_max, bank_planes, q_planes, qc, use16, N, M, D, k, s);
+  return knn_scan(q, bank, score, dist, qn, bn, bn_max, use16 ? &r16 : nullptr, qc, N, M, D, k, s);
 }
 
 // ---- a bank prepared once (the index of a deployed postprocessor): |b|^2, their maximum and - for banks the bf16 kernel
-// can take - the bf16 pieces.  A call against a prepared bank skips those passes (50 000 x 2048: 0.13 ms of norms + 0.25 ms
-// of splitting, more than the scan itself for some hundred queries); the scores are the same bits.
-static bool knn16_bank_ok(int64_t M, int64_t D) {
-  return KNN_BF16 && M >= 4096 && D >= 256 && runia_knn16_fits(M, D) && runia_knn16_fits(kQueryChunk, D) &&
-         4 * M * 256 <= ((int64_t)1 << 31);
-}
+// can take - |b|^2 in piece order and the bf16 pieces.  A call against a prepared bank skips those passes (50 000 x 2048:
+// 0.13 ms of norms + 0.25 ms of splitting, more than the scan itself for some hundred queries); the scores are the same bits.
 #ifndef KNN16_MIN_ROWS_PREPARED
 #define KNN16_MIN_ROWS_PREPARED 64
 #endif
@@ -1018,9 +1315,10 @@ static bool knn16_prepared_wanted(int64_t N, int64_t M, int64_t D) {
          (M * D >= ((int64_t)1 << 23) || N >= 1000);  // (tools/ablate/run_knn_prepared.py: small banks stay on the f32 kernel)
 }
 static size_t knn_state_head_bytes(int64_t M) { return (((size_t)M + 1) * sizeof(float) + 255) / 256 * 256; }
+static size_t knn_state_bnp_bytes(int64_t M) { return align256((size_t)runia_knn16_padded_rows(M) * sizeof(float)); }
 extern "C" size_t runia_knn_bank_state_bytes(int64_t M, int64_t D) {
   if (M <= 0 || D <= 0) return 0;
-  return knn_state_head_bytes(M) + (knn16_bank_ok(M, D) ? runia_knn16_plane_bytes(M, D) : 0);
+  return knn_state_head_bytes(M) + (knn16_bank_ok(M, D) ? knn_state_bnp_bytes(M) + runia_knn16_plane_bytes(M, D) : 0);
 }
 extern "C" int runia_knn_prepare_bank_f32(const float* bank, void* state, size_t state_bytes, int64_t M, int64_t D,
                                           runia_stream_t stream) {
@@ -1033,17 +1331,21 @@ extern "C" int runia_knn_prepare_bank_f32(const float* bank, void* state, size_t
   row_sqnorm_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(bank, bn, M, D, bn_max);
   int rc = runia_check_launch();
   if (rc != RUNIA_OK) return rc;
-  if (knn16_bank_ok(M, D) && state_bytes >= runia_knn_bank_state_bytes(M, D))
-    rc = runia_knn16_split(bank, reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(state) + knn_state_head_bytes(M)), M, D, s);
+  if (knn16_bank_ok(M, D) && state_bytes >= runia_knn_bank_state_bytes(M, D)) {
+    char* st = reinterpret_cast<char*>(state);
+    rc = runia_knn16_split_bank(bank, reinterpret_cast<uint16_t*>(st + knn_state_head_bytes(M) + knn_state_bnp_bytes(M)), bn,
+                                reinterpret_cast<float*>(st + knn_state_head_bytes(M)), M, D, s);
+  }
   return rc;
 }
-// workspace of a call against a prepared bank: one chunk of distances, |q|^2 and (bf16 kernel) the chunk's pieces
+// workspace of a call against a prepared bank: the dense rows, |q|^2 and (bf16 kernel) the filter's buffers and the chunk's pieces
 extern "C" size_t runia_knn_prepared_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {
-  (void)k;
   if (N <= 0 || M <= 0) return 0;
   const int64_t qc = knn_chunk_rows(N, M);
-  const size_t head = ((size_t)(qc * M + qc) * sizeof(float) + 255) / 256 * 256;
-  return head + (knn16_prepared_wanted(N, M, D) ? runia_knn16_plane_bytes(qc, D) : 0);
+  if (!knn16_prepared_wanted(N, M, D)) return align256((size_t)(qc * M + qc) * sizeof(float));
+  const int64_t S = knn16_sample_rows(N, M, k), dr = knn16_dense_rows(qc, S);
+  const Knn16Filter f = knn16_filter_layout(align256((size_t)(dr * M) * sizeof(float)), qc, dr, M, D, S, false);
+  return f.end + runia_knn16_plane_bytes(qc, D);
 }
 extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, const void* state, size_t state_bytes,
                                           float* score, void* workspace, size_t workspace_bytes, int64_t N, int64_t M,
@@ -1070,17 +1372,21 @@ extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, con
   if (qc > kQueryChunk) qc = kQueryChunk;
   float* dist = reinterpret_cast<float*>(workspace);
   float* qn = dist + qc * M;
-  if (N <= kSmallQ && M >= 1024 && qc >= N) {  // a handful of queries: one pass over the bank, exact distances
-    row_sqnorm_kernel<<<runia_rows_grid(N), 64 * kRowWaves, 0, s>>>(q, qn, N, D, nullptr);
-    knn_small_dist_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(q, bank, dist, bn_max, (int)N, M, D);
-    kth_select_range_kernel<<<(unsigned)N, 256, 0, s>>>(dist, q, bank, qn, bn_max, score, N, M, D, k, kRefineRel);
-    return runia_check_launch();
+  if (N <= kSmallQ && M >= 1024 && qc >= N)  // a handful of queries: one pass over the bank, exact distances
+    return knn_small_path(q, bank, score, dist, qn, bn_max, N, M, D, k, s);
+  Knn16Run r16{};
+  if (use16) {
+    const char* st = reinterpret_cast<const char*>(state);
+    r16.S = knn16_sample_rows(N, M, k);
+    r16.dense_rows = knn16_dense_rows(qc, r16.S);
+    r16.ws = reinterpret_cast<char*>(workspace);
+    r16.f = knn16_filter_layout(align256((size_t)(r16.dense_rows * M) * sizeof(float)), qc, r16.dense_rows, M, D, r16.S, false);
+    r16.bn_p = reinterpret_cast<const float*>(st + knn_state_head_bytes(M));
+    r16.bank_planes = reinterpret_cast<const uint16_t*>(st + knn_state_head_bytes(M) + knn_state_bnp_bytes(M));
+    qn = reinterpret_cast<float*>(r16.ws + r16.f.qn);
+    r16.q_planes = reinterpret_cast<uint16_t*>(r16.ws + r16.f.end);
   }
-  const uint16_t* bank_planes = reinterpret_cast<const uint16_t*>(reinterpret_cast<const char*>(state) + knn_state_head_bytes(M));
-  uint16_t* q_planes = use16 ? reinterpret_cast<uint16_t*>(reinterpret_cast<char*>(workspace) +
-                                                           ((size_t)(qc * M + qc) * sizeof(float) + 255) / 256 * 256)
-                             : nullptr;
-  return knn_scan(q, bank, score, dist, qn, bn, bn_max, bank_planes, q_planes, qc, use16, N, M, D, k, s, 1);
+  return knn_scan(q, bank, score, dist, qn, bn, bn_max, use16 ? &r16 : nullptr, qc, N, M, D, k, s, 1);
 }
 
 extern "C" int runia_linear_f32(const float* x, const float* w, const float* bias, float* out, int64_t N, int64_t D,

@@ -1053,3 +1053,42 @@ def test_knn_prepared_bank_scores_the_same_bits(hip, n, m, d):
     finally:
         config.knn_bf16_candidates = True
     assert torch.equal(hip.knn_kth(q, bank, 50, state=state), hip.knn_kth(q, bank, 50))
+
+
+@pytest.mark.gpu
+def test_knn_candidate_filter_overflow_rounds_equal_the_f32_path(hip):
+    """Candidate filter of the bf16 kernel (no Q x M matrix): rows whose list overflows - here EVERY query sits next to
+    3 000 copies of one bank row, more hits below the sampled threshold than a list holds - go to the overflow list and
+    through the dense kernels in rounds of KNN16_DENSE_ROWS rows (4 500 rows: three rounds); rows that do not overflow
+    (the second half of the queries is random) stay on the lists.  Same bits as the f32 kernel either way."""
+    lib = hip.load_library()
+    n, m, d, k = 9000, 8192, 256, 50
+    rng = np.random.default_rng(7)
+    bank = rng.standard_normal((m, d)).astype(np.float32)
+    bank /= np.linalg.norm(bank, axis=1, keepdims=True)
+    bank[1000:4000] = bank[17]
+    q = rng.standard_normal((n, d)).astype(np.float32)
+    q[:4500] = bank[17] + 0.05 * q[:4500] / np.sqrt(d)
+    q /= np.linalg.norm(q, axis=1, keepdims=True)
+    qd, bd = dev(q, torch.float32), dev(bank, torch.float32)
+
+    def run(big):
+        full = lib.runia_knn_workspace_bytes(n, m, d, k)
+        f32_only = (min(n, 8192) * m + min(n, 8192) + m + 4) * 4
+        ws_bytes = full if big else f32_only
+        ws = torch.empty(ws_bytes // 4 + 1, dtype=torch.float32, device="cuda")
+        out = torch.full((n,), 123.0, device="cuda")
+        rc = lib.runia_knn_kth_f32(qd.data_ptr(), bd.data_ptr(), out.data_ptr(), ws.data_ptr(), ws_bytes, n, m, d, k,
+                                   torch.cuda.current_stream().cuda_stream)
+        assert rc == 0
+        return out.cpu().numpy()
+
+    assert lib.runia_knn_piece_products(n, m, d) == 3
+    a, b = run(True), run(False)
+    assert not (a == 123.0).any() and np.array_equal(a, b)
+    rows = [0, 1, 4499, 4500, 8191, 8192, n - 1]
+    assert rel_err(a[rows], oracle.knn_kth_score(bank, q[rows], k, normalize=False)) < 1e-5
+    # against a prepared bank: the same bits again
+    state = hip.knn_prepare_bank(bd)
+    c = hip.knn_kth(qd, bd, k, state=state).cpu().numpy()
+    assert np.array_equal(a, c)
