@@ -41,6 +41,7 @@ constexpr int TQ = 256, TB = 256;            // tile
 [[maybe_unused]] constexpr float kFltMax = 3.4028234663852886e38f;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ unsigned bf16_rne(float x) {  // bf16 bits of x, round to nearest even (NaN stays NaN)
   const unsigned b = __float_as_uint(x);
@@ -273,6 +274,17 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the last (unused) DMA
   // epilogue: C[row = 4 * (lane >> 4) + reg][col = lane & 15] of each 16 x 16 tile
   if constexpr (FILTER) {
+#if defined(KNN16_ABLATE) && KNN16_ABLATE == 1  // (timing experiments only: no epilogue at all)
+    {
+      float t = 0.f;
+#pragma unroll
+      for (int i = 0; i < 8; ++i)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t += (acc[i][j][0] + acc[i][j][1]) + (acc[i][j][2] + acc[i][j][3]);
+      if (t == 123.456f) fo.counts[0] = 1u;
+    }
+    return;
+#endif
     __syncthreads();  // the stage buffers are free: every wave has read its last operands
     float* qn_l = reinterpret_cast<float*>(lds);                 // [256] |q|^2 of the tile's rows
     float* th_l = qn_l + 256;                                    // [256] their thresholds (-inf: no such row)
@@ -325,6 +337,19 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
       b_l[tid] = (n != 0u) ? atomicAdd(&fo.counts[q0 + tid], n) : 0u;  // (rows beyond Q have no hits)
     }
     __syncthreads();
+#if defined(KNN16_ABLATE) && KNN16_ABLATE == 2  // (timing experiments only: hits counted, not stored)
+    return;
+#endif
+    // The hits, each behind the ones before it in its row's list; stored through a buffer descriptor (32-bit offsets: a
+    // chunk's lists are < 4 GB); a row that would run over its list takes the checked form (it overflows anyway).
+    // (Staging the hits in LDS and storing them with whole waves - 7 store instructions per wave instead of ~200 with two
+    // or three lanes active - measured 3 us per tile SLOWER: what the stores cost, ~7 us of a 130 us tile, is not their
+    // instruction count.)
+    const __amdgpu_buffer_rsrc_t lrsrc =
+        __builtin_amdgcn_make_buffer_rsrc(fo.lists, 0, (int)((size_t)Qpad * (size_t)fo.cap * 8u), 0x00020000);
+    unsigned colj[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) colj[j] = (unsigned)(fo.col0 + (int)(m0 + wb * 128 + j * 16 + lrow));
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
       if (maskp[i] == 0u) continue;
@@ -335,14 +360,28 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
         const int rowl = wq * 128 + i * 16 + 4 * lq + r;
         const float qnr = qn_l[rowl];
         unsigned off = b_l[rowl] + (wb ? c_l[2 * rowl] : 0u) + ((exclp[i] >> (8 * r)) & 255u);
-        uint2* lrow_out = fo.lists + (q0 + rowl) * (int64_t)fo.cap;
+        const unsigned row_base = (unsigned)(q0 + rowl) * (unsigned)fo.cap;
+        if (off + (unsigned)__builtin_popcount(m) <= (unsigned)fo.cap) {
+          unsigned voff = (row_base + off) * 8u;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          if ((m >> j) & 1u) {
-            const float dd = fmaxf((qnr + bnv[j]) - 2.0f * acc[i][j][r], 0.f);
-            if (off < (unsigned)fo.cap)
-              lrow_out[off] = make_uint2(__float_as_uint(dd), (unsigned)(fo.col0 + (int)(m0 + wb * 128 + j * 16 + lrow)));
-            ++off;
+          for (int j = 0; j < 8; ++j) {
+            if ((m >> j) & 1u) {
+              const float dd = fmaxf((qnr + bnv[j]) - 2.0f * acc[i][j][r], 0.f);
+#if !(defined(KNN16_ABLATE) && KNN16_ABLATE == 3)  // (timing experiments only: no stores)
+              __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, make_uint2(__float_as_uint(dd), colj[j])), lrsrc,
+                                                    (int)voff, 0, 0);
+#endif
+              voff += 8u;
+            }
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            if ((m >> j) & 1u) {
+              const float dd = fmaxf((qnr + bnv[j]) - 2.0f * acc[i][j][r], 0.f);
+              if (off < (unsigned)fo.cap) fo.lists[row_base + off] = make_uint2(__float_as_uint(dd), colj[j]);
+              ++off;
+            }
           }
         }
       }
@@ -399,14 +438,15 @@ int runia_knn16_split_bank(const float* x, uint16_t* planes, const float* bn, fl
 // of the true k-th distance as of the approximate one).  Dropped products: m.m + h.l + l.h + ... <= 3 * 2^-16 sum|q_k||b_k|
 // <= 3 * 2^-16 |q||b| (each piece is below 2^-8 of the one before; Cauchy-Schwarz), |q||b| <= R / 4, and the distance
 // carries twice the product's error: e <= 2.3e-5 R.  Accumulation: the matrix cores add the 3 * D / 32 staged partial
-// sums of a dot product in f32, each addition within 2^-24 of the running sum's magnitude <= 2 sum|q_k||b_k| <= R / 2, and
-// the 32 products inside an instruction are summed at no less than that accuracy: <= (3 D / 32 + 32) * 2^-24 * R / 2 per
-// dot product, twice that in the distance - 1.3e-5 R at D = 2048 as a worst case (the observed error is ~sqrt of the
-// count: 1e-7 R).  Window = 2 e = 4.6e-5 R + D * 1.2e-8 R, rounded up to 5e-5 + 1.5e-8 D; D is capped where the window
-// would no longer separate neighbours usefully (runia_knn16_max_width: the f32 kernel takes wider rows).
+// sums of a dot product in f32, each addition within 2^-24 of the running sum's magnitude <= sum|q_k||b_k| <= R / 4, and
+// the 32 products inside an instruction are summed at no less than that accuracy: <= (3 D / 32 + 32) * 2^-24 * R / 4 per
+// dot product, twice that in the distance - 6.7e-6 R at D = 2048 as a worst case (what is observed is the square root of
+// the count: 1e-7 R).  Window = 2 e = 4.6e-5 R + (1.9e-6 + 5.6e-9 D) R, rounded up to (4.8e-5 + 5.6e-9 D) R; D is
+// capped (runia_knn16_max_width; the f32 kernel takes wider rows) where the accumulation term would be twice the other:
+// wider windows mean more exact re-measurements per row, not wrong answers.
 int runia_knn16_terms() { return 3; }
 int64_t runia_knn16_max_width() { return 16384; }
-float runia_knn16_refine_rel(int64_t D) { return 5e-5f + 1.5e-8f * (float)D; }
+float runia_knn16_refine_rel(int64_t D) { return 4.8e-5f + 5.6e-9f * (float)D; }
 
 static int knn16_launch_dims(int64_t Q, int64_t M, unsigned* grid) {
   using namespace runia_knn16;

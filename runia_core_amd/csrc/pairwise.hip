@@ -1089,7 +1089,7 @@ int runia_knn16_filter(const uint16_t* qp, const uint16_t* bp, const float* qn, 
 #define KNN16_FILTER_MIN_ROWS 1024  // queries of a call from which the candidate filter is taken (fewer: the dense form)
 #endif
 #ifndef KNN16_DENSE_ROWS
-#define KNN16_DENSE_ROWS 2048  // rows of the dense fallback matrix of the candidate filter (one round of three launches per that many overflowed rows)
+#define KNN16_DENSE_ROWS 8192  // rows of the dense fallback matrix of the candidate filter (one round of three launches per that many overflowed rows)
 #endif
 // the bank side of the bf16 kernel: some thousand rows, wide (but not wider than its window allows) features
 static bool knn16_bank_ok(int64_t M, int64_t D) {
@@ -1151,22 +1151,43 @@ static Knn16Filter knn16_filter_layout(size_t at, int64_t qc, int64_t dense_rows
   f.end = at;
   return f;
 }
-// rows of the dense matrix a bf16 call keeps: the whole chunk in the dense form, the overflow rounds' share with the filter
-static int64_t knn16_dense_rows(int64_t qc, int64_t S) {
-  return (S > 0 && qc > KNN16_DENSE_ROWS) ? (int64_t)KNN16_DENSE_ROWS : qc;
+// Query rows per pass of the bf16 kernel.  Dense form: the f32 kernel's chunk.  With the candidate filter no Q x M matrix
+// limits it, and the main pass - (query tiles) x (bank tiles behind the sample) workgroups, one per compute unit at a
+// time - should END on a full round: among 32 .. 64 query tiles (8 192 .. 16 384 rows) the count whose last round of
+// workgroups is fullest is taken (50 000 bank rows, 2 048 sample rows: 188 bank tiles x 64 = 47.0 rounds of 256; x 32 =
+// 23.5, i.e. 2 % of the pass spent on a half-empty chip).
+static int64_t knn16_chunk_rows(int64_t N, int64_t M, int64_t S) {
+  if (S <= 0) return knn_chunk_rows(N, M);
+  const int64_t nbt = (M - S + 255) / 256, cus = runia_cu_count();
+  int64_t best = 32;
+  double best_fill = 0.0;
+  for (int64_t nqt = 32; nqt <= 64; ++nqt) {
+    const int64_t wgs = nqt * nbt, rounds = (wgs + cus - 1) / cus;
+    const double fill = (double)wgs / (double)(rounds * cus);
+    if (fill > best_fill + 1e-9 || (fill > best_fill - 1e-9 && nqt > best)) { best_fill = fill; best = nqt; }
+  }
+  const int64_t qc = best * 256;
+  return N < qc ? N : qc;
+}
+// rows of the dense matrix a bf16 call keeps: the whole chunk in the dense form; with the filter the share of one overflow
+// round (three launches that end at their first instruction when nothing overflowed: 16 us per round)
+static int64_t knn16_dense_rows(int64_t qc, int64_t M, int64_t S) {
+  if (S <= 0) return qc;
+  int64_t dr = knn_chunk_rows(qc, M);
+  if (dr > KNN16_DENSE_ROWS) dr = KNN16_DENSE_ROWS;
+  return dr;
 }
 
 extern "C" size_t runia_knn_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {
   if (N <= 0 || M <= 0) return 0;
-  const int64_t qc = knn_chunk_rows(N, M);
   // + the bf16 pieces of the bank and of one chunk of queries when the bf16 kernel will be taken; the entry point works
   // with whatever it is given (>= 1 row of distances), but takes the bf16 kernel only with at least this much
   if (knn16_wanted(N, M, D)) {
-    const int64_t S = knn16_sample_rows(N, M, k), dr = knn16_dense_rows(qc, S);
+    const int64_t S = knn16_sample_rows(N, M, k), qc = knn16_chunk_rows(N, M, S), dr = knn16_dense_rows(qc, M, S);
     const Knn16Filter f = knn16_filter_layout(knn16_head_bytes(dr, M), qc, dr, M, D, S, true);
     return f.end + runia_knn16_plane_bytes(M, D) + runia_knn16_plane_bytes(qc, D);
   }
-  return knn_f32_words(qc, M) * sizeof(float);
+  return knn_f32_words(knn_chunk_rows(N, M), M) * sizeof(float);
 }
 
 // The passes of a kNN call once the bank's |b|^2, their maximum and (use16) its bf16 pieces exist - computed by the call
@@ -1215,13 +1236,13 @@ static int knn_scan(const float* q, const float* bank, float* score, float* dist
       const int64_t dr = r16->dense_rows;
       for (int64_t first = 0; first < rows; first += dr) {
         const int64_t cap_rows = (rows - first < dr) ? (rows - first) : dr;
-        knn_gather_rows_kernel<<<(unsigned)(cap_rows < 1024 ? cap_rows : 1024), 256, 0, s>>>(
+        knn_gather_rows_kernel<<<(unsigned)(cap_rows < 256 ? cap_rows : 256), 256, 0, s>>>(
             reinterpret_cast<const uint4*>(r16->q_planes), qn, ov_list, n_ov, (int)first, (int)cap_rows, reinterpret_cast<uint4*>(ov_planes),
             ov_qn, Dp2 / 8);
         rc = runia_knn16_dist(ov_planes, r16->bank_planes, ov_qn, r16->bn_p, dist, cap_rows, M, D,
                               runia_knn16_padded_rows(dr), Mpad, n_ov, (int)first, s);
         if (rc != RUNIA_OK) return rc;
-        kth_select_range_kernel<<<(unsigned)(cap_rows < 4096 ? cap_rows : 4096), 256, 0, s>>>(
+        kth_select_range_kernel<<<(unsigned)(cap_rows < 1024 ? cap_rows : 1024), 256, 0, s>>>(
             dist, q + r0 * D, bank, qn, bn_max, score + r0, cap_rows, M, D, k, rel, pm, ov_list, n_ov, (int)first);
       }
       rc = runia_check_launch();
@@ -1275,9 +1296,9 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
   Knn16Run r16{};
   int64_t dense_rows = qc;
   if (use16) {
-    qc = knn_chunk_rows(N, M);
     r16.S = knn16_sample_rows(N, M, k);
-    r16.dense_rows = dense_rows = knn16_dense_rows(qc, r16.S);
+    qc = knn16_chunk_rows(N, M, r16.S);
+    r16.dense_rows = dense_rows = knn16_dense_rows(qc, M, r16.S);
     r16.ws = reinterpret_cast<char*>(workspace);
     r16.f = knn16_filter_layout(knn16_head_bytes(dense_rows, M), qc, dense_rows, M, D, r16.S, true);
     uint16_t* planes = reinterpret_cast<uint16_t*>(r16.ws + r16.f.end);
@@ -1341,9 +1362,11 @@ extern "C" int runia_knn_prepare_bank_f32(const float* bank, void* state, size_t
 // workspace of a call against a prepared bank: the dense rows, |q|^2 and (bf16 kernel) the filter's buffers and the chunk's pieces
 extern "C" size_t runia_knn_prepared_workspace_bytes(int64_t N, int64_t M, int64_t D, int k) {
   if (N <= 0 || M <= 0) return 0;
-  const int64_t qc = knn_chunk_rows(N, M);
-  if (!knn16_prepared_wanted(N, M, D)) return align256((size_t)(qc * M + qc) * sizeof(float));
-  const int64_t S = knn16_sample_rows(N, M, k), dr = knn16_dense_rows(qc, S);
+  if (!knn16_prepared_wanted(N, M, D)) {
+    const int64_t qc = knn_chunk_rows(N, M);
+    return align256((size_t)(qc * M + qc) * sizeof(float));
+  }
+  const int64_t S = knn16_sample_rows(N, M, k), qc = knn16_chunk_rows(N, M, S), dr = knn16_dense_rows(qc, M, S);
   const Knn16Filter f = knn16_filter_layout(align256((size_t)(dr * M) * sizeof(float)), qc, dr, M, D, S, false);
   return f.end + runia_knn16_plane_bytes(qc, D);
 }
@@ -1366,10 +1389,11 @@ extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, con
   // many query rows per pass as the workspace holds
   const bool use16 = knn16_prepared_wanted(N, M, D) && state_bytes >= runia_knn_bank_state_bytes(M, D) &&
                      workspace_bytes >= runia_knn_prepared_workspace_bytes(N, M, D, k);
-  int64_t qc = use16 ? knn_chunk_rows(N, M) : (int64_t)(workspace_bytes / sizeof(float) / (size_t)(M + 1));
+  const int64_t S16 = use16 ? knn16_sample_rows(N, M, k) : 0;
+  int64_t qc = use16 ? knn16_chunk_rows(N, M, S16) : (int64_t)(workspace_bytes / sizeof(float) / (size_t)(M + 1));
   if (qc < 1) return RUNIA_E_WORKSPACE;
   if (qc > N) qc = N;
-  if (qc > kQueryChunk) qc = kQueryChunk;
+  if (!use16 && qc > kQueryChunk) qc = kQueryChunk;
   float* dist = reinterpret_cast<float*>(workspace);
   float* qn = dist + qc * M;
   if (N <= kSmallQ && M >= 1024 && qc >= N)  // a handful of queries: one pass over the bank, exact distances
@@ -1377,8 +1401,8 @@ extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, con
   Knn16Run r16{};
   if (use16) {
     const char* st = reinterpret_cast<const char*>(state);
-    r16.S = knn16_sample_rows(N, M, k);
-    r16.dense_rows = knn16_dense_rows(qc, r16.S);
+    r16.S = S16;
+    r16.dense_rows = knn16_dense_rows(qc, M, r16.S);
     r16.ws = reinterpret_cast<char*>(workspace);
     r16.f = knn16_filter_layout(align256((size_t)(r16.dense_rows * M) * sizeof(float)), qc, r16.dense_rows, M, D, r16.S, false);
     r16.bn_p = reinterpret_cast<const float*>(st + knn_state_head_bytes(M));
