@@ -376,6 +376,22 @@ int runia_linear_f32(const float* x, const float* w, const float* bias, float* o
 int runia_ash_s_f32(const float* x, float* y, int64_t N, int64_t D, int percentile, runia_stream_t stream);
 int runia_gen_score_f32(const float* logits, float* score, int64_t N, int64_t C, int M, double gamma,
                         runia_stream_t stream);
+/* runia_gen_entropy_f32: generalized_entropy(probs, gamma, M) on rows that already are probabilities - the reference's
+ *   free function (inference/funcs.py:347-375) as its own tests call it (tests/unit_test_baselines.py).
+ * runia_mcd_uncertainty_f32: get_predictive_uncertainty_score / get_mcd_pred_uncertainty_score (inference/funcs.py:
+ *   430-465, 378-427): logits [N * n_mc, C] f32, the n_mc rows of an image consecutive -> pred_h [N] = H[mean_s softmax],
+ *   mi [N] = pred_h - mean_s H[softmax]; probs (optional) [N * n_mc, C] receives the softmax rows (the first value the
+ *   dataloader form returns).  One launch, C <= 4096.
+ * runia_ash_s_rows_f32: ASH-S for rows of any length - ash_s_conv_layer (inference/funcs.py:194-227) on the flattened
+ *   (B, C*H*W) maps and ash_s_linear_layer beyond 4096 features.  y = pruned row * exp(sum / kept sum); `pruned`
+ *   (optional, may be x itself: the reference's view + scatter_ prunes its argument in place) = the pruned row.
+ *   keep_all_when_k_is_zero: NumPy's x[:, -0:] semantics (linear form) instead of torch.topk(k = 0) (conv form). */
+int runia_gen_entropy_f32(const float* probs, float* score, int64_t N, int64_t C, int M, double gamma,
+                          runia_stream_t stream);
+int runia_mcd_uncertainty_f32(const float* logits, float* probs, float* pred_h, float* mi, int64_t N, int n_mc, int64_t C,
+                              runia_stream_t stream);
+int runia_ash_s_rows_f32(const float* x, float* y, float* pruned, int64_t N, int64_t D, int percentile,
+                         int keep_all_when_k_is_zero, runia_stream_t stream);
 /* runia_proj_norm_*: ViM residual norm || (x - u) @ NS ||_2 per row (inference/postprocessors.py:1106):
  *   x [N, D], u [D] (same dtype as x; f32 - f32 is rounded to f32 first, as NumPy), packed_ns = pack(NS [D, n]),
  *   norm [N] f64. */

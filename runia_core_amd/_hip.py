@@ -142,6 +142,9 @@ _SIGNATURES = {
     "runia_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "runia_ash_s_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "runia_gen_score_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
+    "runia_gen_entropy_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
+    "runia_mcd_uncertainty_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "runia_ash_s_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
     "runia_proj_norm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "runia_proj_norm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "runia_proj_sq_workspace_bytes": (c_size_t, [c_int64]),
@@ -845,13 +848,64 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], clip_
 
 
 def ash_s(x: torch.Tensor, percentile: int) -> torch.Tensor:
+    """ASH-S of 2-D activations (``ash_s_linear_layer``): rows of up to 4 096 features in registers (wave per row), longer
+    rows through the radix-select kernel (workgroup per row)."""
     lib = load_library()
     require_gpu()
     assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
     x = x.contiguous()
     y = torch.empty_like(x)
-    _check(lib.runia_ash_s_f32(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], int(percentile), _stream()), "runia_ash_s_f32")
+    if x.shape[1] <= 4096:
+        _check(lib.runia_ash_s_f32(x.data_ptr(), y.data_ptr(), x.shape[0], x.shape[1], int(percentile), _stream()), "runia_ash_s_f32")
+    else:
+        _check(lib.runia_ash_s_rows_f32(x.data_ptr(), y.data_ptr(), None, x.shape[0], x.shape[1], int(percentile), 1, _stream()),
+               "runia_ash_s_rows_f32")
     return y
+
+
+def ash_s_conv(x: torch.Tensor, percentile: int, prune_in_place: bool = True) -> torch.Tensor:
+    """ASH-S of (B, C, H, W) maps (``ash_s_conv_layer``): per sample the k largest of its C*H*W activations are kept and
+    the sample is multiplied by exp(sum / kept sum).  ``prune_in_place``: ``x`` itself is left pruned, as the
+    reference's ``view`` + ``scatter_`` leaves its argument (x must then be contiguous)."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    assert x.is_contiguous() or not prune_in_place
+    xc = x.contiguous()
+    b = xc.shape[0]
+    d = xc.numel() // max(b, 1)
+    y = torch.empty_like(xc)
+    _check(lib.runia_ash_s_rows_f32(xc.data_ptr(), y.data_ptr(), xc.data_ptr() if prune_in_place else None, b, d, int(percentile),
+                                    0, _stream()), "runia_ash_s_rows_f32")
+    return y
+
+
+def gen_entropy(probs: torch.Tensor, gamma: float, m: int) -> torch.Tensor:
+    """``generalized_entropy(probs, gamma, M)`` on rows that already are probabilities -> [N] f32."""
+    lib = load_library()
+    require_gpu()
+    assert probs.is_cuda and probs.dtype == torch.float32 and probs.dim() == 2
+    probs = probs.contiguous()
+    s = torch.empty((probs.shape[0],), dtype=torch.float32, device=probs.device)
+    _check(lib.runia_gen_entropy_f32(probs.data_ptr(), s.data_ptr(), probs.shape[0], probs.shape[1], int(m), float(gamma), _stream()),
+           "runia_gen_entropy_f32")
+    return s
+
+
+def mcd_uncertainty(logits: torch.Tensor, n_mc: int, want_probs: bool = False):
+    """logits [N * n_mc, C] f32 (an image's MC rows consecutive) -> (pred_h [N], mi [N], softmax rows or None): the
+    predictive entropy of the mean distribution and the mutual information, one launch."""
+    lib = load_library()
+    require_gpu()
+    assert logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 2 and logits.shape[0] % n_mc == 0
+    logits = logits.contiguous()
+    n, c = logits.shape[0] // n_mc, logits.shape[1]
+    ph = torch.empty((n,), dtype=torch.float32, device=logits.device)
+    mi = torch.empty((n,), dtype=torch.float32, device=logits.device)
+    probs = torch.empty_like(logits) if want_probs else None
+    _check(lib.runia_mcd_uncertainty_f32(logits.data_ptr(), _ptr(probs), ph.data_ptr(), mi.data_ptr(), n, int(n_mc), c, _stream()),
+           "runia_mcd_uncertainty_f32")
+    return ph, mi, probs
 
 
 def gen_score(logits: torch.Tensor, gamma: float, m: int) -> torch.Tensor:

@@ -265,7 +265,7 @@ constexpr int kGenCompact = 512;  // largest M whose selected probabilities are 
 // 1 M x 10 rows: 0.61 ms with a wave per row (10 of 64 lanes busy) -> 0.14 ms.
 template <int CT>
 __global__ __launch_bounds__(256) void gen_tiny_kernel(const float* __restrict__ logits, float* __restrict__ score, int64_t N,
-                                                        int M, float gamma) {
+                                                        int M, float gamma, int from_probs) {
   for (int64_t row = (int64_t)blockIdx.x * 256 + threadIdx.x; row < N; row += (int64_t)gridDim.x * 256) {
     const float* p = logits + row * CT;
     float v[16];
@@ -275,14 +275,17 @@ __global__ __launch_bounds__(256) void gen_tiny_kernel(const float* __restrict__
       v[j] = p[j];
       m = fmaxf(m, v[j]);
     }
-    float s = 0.f;
+    float s = 1.f;
+    if (!from_probs) {  // (uniform) the rows are logits: softmax first
+      s = 0.f;
 #pragma unroll
-    for (int j = 0; j < CT; ++j) {
-      v[j] = expf(v[j] - m);
-      s += v[j];
+      for (int j = 0; j < CT; ++j) {
+        v[j] = expf(v[j] - m);
+        s += v[j];
+      }
     }
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = (j < CT) ? v[j] / s : 0.f;
+    for (int j = 0; j < 16; ++j) v[j] = (j < CT) ? (from_probs ? v[j] : v[j] / s) : 0.f;
     if (M < CT) runia_entropy::sort_asc<16>(v);  // wave-uniform
     float acc = 0.f;
 #pragma unroll
@@ -296,7 +299,7 @@ __global__ __launch_bounds__(256) void gen_tiny_kernel(const float* __restrict__
 
 template <int NV>
 __global__ __launch_bounds__(64 * kRowWaves) void gen_kernel(const float* __restrict__ logits, float* __restrict__ score,
-                                                   int64_t N, int C, int M, float gamma) {
+                                                   int64_t N, int C, int M, float gamma, int from_probs) {
   __shared__ float gen_sel[kRowWaves][kGenCompact];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += (int64_t)gridDim.x * kRowWaves) {
@@ -310,17 +313,20 @@ __global__ __launch_bounds__(64 * kRowWaves) void gen_kernel(const float* __rest
       m = fmaxf(m, v[t]);
     }
     m = wave_max_f32(m);
-    float s = 0.f;
+    float s = 1.f;
+    if (!from_probs) {  // (uniform) the rows are logits: softmax first
+      s = 0.f;
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
-      v[t] = expf(v[t] - m);  // padding -> 0
-      s += v[t];
+      for (int t = 0; t < NV; ++t) {
+        v[t] = expf(v[t] - m);  // padding -> 0
+        s += v[t];
+      }
+      s = wave_sum_f32(s);
     }
-    s = wave_sum_f32(s);
     unsigned key[NV];
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
-      v[t] = v[t] / s;  // softmax probability
+      v[t] = from_probs ? ((lane + 64 * t < C) ? v[t] : 0.f) : v[t] / s;  // (softmax) probability
       key[t] = (lane + 64 * t < C) ? (__float_as_uint(v[t]) | 0x80000000u) : 0u;  // p >= 0
     }
     float acc = 0.f;
@@ -441,8 +447,8 @@ extern "C" int runia_ash_s_f32(const float* x, float* y, int64_t N, int64_t D, i
   return runia_check_launch();
 }
 
-extern "C" int runia_gen_score_f32(const float* logits, float* score, int64_t N, int64_t C, int M, double gamma,
-                                   runia_stream_t stream) {
+static int gen_rows(const float* logits, float* score, int64_t N, int64_t C, int M, double gamma, int from_probs,
+                    runia_stream_t stream) {
   if (N < 0 || C <= 0 || C > 4096 || M < 1) return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
   if (!logits || !score) return RUNIA_E_INVALID;
@@ -452,7 +458,7 @@ extern "C" int runia_gen_score_f32(const float* logits, float* score, int64_t N,
   const float g = (float)gamma;
   if (C <= 16) {
     const unsigned tg = runia_stream_grid(N, 256);
-#define RUNIA_GEN_TINY(CT) case CT: gen_tiny_kernel<CT><<<tg, 256, 0, s>>>(logits, score, N, M, g); break;
+#define RUNIA_GEN_TINY(CT) case CT: gen_tiny_kernel<CT><<<tg, 256, 0, s>>>(logits, score, N, M, g, from_probs); break;
     switch ((int)C) {
       RUNIA_GEN_TINY(1) RUNIA_GEN_TINY(2) RUNIA_GEN_TINY(3) RUNIA_GEN_TINY(4) RUNIA_GEN_TINY(5) RUNIA_GEN_TINY(6)
       RUNIA_GEN_TINY(7) RUNIA_GEN_TINY(8) RUNIA_GEN_TINY(9) RUNIA_GEN_TINY(10) RUNIA_GEN_TINY(11) RUNIA_GEN_TINY(12)
@@ -461,9 +467,19 @@ extern "C" int runia_gen_score_f32(const float* logits, float* score, int64_t N,
 #undef RUNIA_GEN_TINY
     return runia_check_launch();
   }
-  if (C <= 64) gen_kernel<1><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g);
-  else if (C <= 256) gen_kernel<4><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g);
-  else if (C <= 1024) gen_kernel<16><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g);
-  else gen_kernel<64><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g);
+  if (C <= 64) gen_kernel<1><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
+  else if (C <= 256) gen_kernel<4><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
+  else if (C <= 1024) gen_kernel<16><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
+  else gen_kernel<64><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
   return runia_check_launch();
+}
+
+extern "C" int runia_gen_score_f32(const float* logits, float* score, int64_t N, int64_t C, int M, double gamma,
+                                   runia_stream_t stream) {
+  return gen_rows(logits, score, N, C, M, gamma, 0, stream);
+}
+// generalized_entropy on rows that already are probabilities (the reference's free function, inference/funcs.py:347-375)
+extern "C" int runia_gen_entropy_f32(const float* probs, float* score, int64_t N, int64_t C, int M, double gamma,
+                                     runia_stream_t stream) {
+  return gen_rows(probs, score, N, C, M, gamma, 1, stream);
 }

@@ -6,7 +6,7 @@ on the GPU."""
 from __future__ import annotations
 
 import warnings
-from typing import Dict, Tuple
+from typing import Dict, Tuple, Union
 
 import numpy as np
 import torch
@@ -14,7 +14,21 @@ import torch
 from .. import _hip, config
 from ..device_fit import empirical_precision_device
 
-__all__ = ["mahalanobis_preprocess", "mahalanobis_postprocess", "normalizer", "MahalanobisState", "gmm_fit", "GmmState"]
+__all__ = [
+    "RouteDICE",
+    "ash_s_conv_layer",
+    "ash_s_linear_layer",
+    "gmm_fit",
+    "generalized_entropy",
+    "get_mcd_pred_uncertainty_score",
+    "get_predictive_uncertainty_score",
+    "get_dice_feat_mean_react_percentile",
+    "mahalanobis_preprocess",
+    "mahalanobis_postprocess",
+    "normalizer",
+    "MahalanobisState",
+    "GmmState",
+]
 
 
 def mahalanobis_preprocess(ind_data: Dict[str, np.ndarray], num_classes: int) -> Tuple[np.ndarray, np.ndarray]:
@@ -167,3 +181,127 @@ class GmmState:
     def energy_device(self, x: torch.Tensor) -> torch.Tensor:
         lse, _ = _hip.row_lse_msp(self.log_prob_device(x), True, False)
         return lse
+
+
+# ---- the other free functions of the reference's inference/funcs.py (its __all__, funcs.py:19-30) --------------------
+class RouteDICE(torch.nn.Linear):
+    """Drop-in for the reference's ``RouteDICE`` (``inference/funcs.py:124-189``): a final linear layer whose weights with a
+    low mean contribution ``info * W`` (below the ``p``-th percentile) are removed.  Same constructor, attributes
+    (``p``, ``info``, ``masked_w``, ``contrib``, ``thresh``) and lazily computed mask; ``forward`` = ``x @ masked_w.T + bias``
+    on the f32 matrix-core kernel (``runia_linear_f32``) instead of the reference's (N, C, D) broadcast product."""
+
+    def __init__(self, in_features: int, out_features: int, bias: bool = True, p: int = 90, conv1x1: bool = False,
+                 info: Union[None, np.ndarray] = None):
+        assert 0 < p < 100, "p must be greater than 0 and less than 100"
+        if info is not None:
+            assert isinstance(info, np.ndarray), "info must be a numpy array or None"
+        super().__init__(in_features, out_features, bias)
+        if conv1x1:
+            self.weight = torch.nn.Parameter(torch.Tensor(out_features, in_features, 1, 1))
+        self.p = p
+        self.info = info
+        self.masked_w = None
+        self.contrib = None
+        self.thresh = None
+
+    def calculate_mask_weight(self):
+        self.contrib = self.info[None, :] * self.weight.data.cpu().numpy()
+        self.thresh = np.percentile(self.contrib, self.p)
+        mask = torch.Tensor((self.contrib > self.thresh))
+        self.masked_w = (self.weight.squeeze().cpu() * mask).to(_hip.require_gpu())
+
+    def forward(self, x):
+        if self.masked_w is None:
+            self.calculate_mask_weight()
+        dev = self.masked_w.device
+        xd = x.detach().to(dev, torch.float32).reshape(-1, x.shape[-1])
+        w = self.masked_w.to(torch.float32).reshape(self.masked_w.shape[0], -1).contiguous()
+        b = None if self.bias is None else self.bias.detach().to(dev, torch.float32).contiguous()
+        out = _hip.linear(xd, w, b)
+        return out.reshape(*x.shape[:-1], out.shape[-1])
+
+
+def ash_s_conv_layer(x: torch.Tensor, percentile: int = 65):
+    """ASH-S for (B, C, H, W) maps (reference ``inference/funcs.py:194-227``): keep the
+    ``k = n - int(np.round(n * percentile / 100))`` largest activations of each sample, zero the rest and multiply the
+    sample by ``exp(sum before / sum after)``.  Like the reference - whose ``view`` + ``scatter_`` write through to the
+    argument - a contiguous ``x`` is left PRUNED (not scaled); the scaled tensor is returned, on ``x``'s device."""
+    assert x.dim() == 4
+    assert 0 <= percentile <= 100
+    if x.is_cuda and x.dtype == torch.float32 and x.is_contiguous():
+        return _hip.ash_s_conv(x, percentile, True)
+    xd = x.detach().to(_hip.require_gpu(), torch.float32).contiguous()
+    y = _hip.ash_s_conv(xd, percentile, True)
+    if x.is_contiguous():
+        with torch.no_grad():
+            x.copy_(xd.to(x.device, x.dtype))
+    return y.to(x.device, x.dtype)
+
+
+def ash_s_linear_layer(x: np.ndarray, percentile: int = 85):
+    """ASH-S for 2-D activations (reference ``inference/funcs.py:230-261``), NumPy in, NumPy out.  Every kept activation
+    stays at its own index (the reference scatters ``np.partition``'s values at ``np.argpartition``'s indices, which
+    permutes them within a row when the two orders differ - INTEGRATION.md, known divergences)."""
+    assert x.ndim == 2
+    assert 0 <= percentile <= 100
+    y = _hip.to_host(_hip.ash_s(_hip.to_device(np.ascontiguousarray(x), torch.float32), percentile))
+    return y.astype(x.dtype, copy=False) if np.issubdtype(x.dtype, np.floating) else y
+
+
+def generalized_entropy(probs, gamma, M):
+    """``-sum over the M largest probabilities of p^gamma (1 - p)^gamma`` per row (reference
+    ``inference/funcs.py:347-375``); computed in f32 on the device, returned in the dtype of ``probs``."""
+    arr = probs.detach().cpu().numpy() if isinstance(probs, torch.Tensor) else np.asarray(probs)
+    s = _hip.to_host(_hip.gen_entropy(_hip.to_device(np.ascontiguousarray(arr), torch.float32), float(gamma), int(M)))
+    return s.astype(arr.dtype, copy=False) if np.issubdtype(arr.dtype, np.floating) else s
+
+
+def get_predictive_uncertainty_score(input_samples: torch.Tensor, mcd_nro_samples: int) -> Tuple[torch.Tensor, torch.Tensor]:
+    """Predictive entropy and mutual information of MC-dropout outputs (reference ``inference/funcs.py:430-465``):
+    ``input_samples`` (N * n_mc, C) logits, an image's n_mc rows consecutive -> ``(pred_h (N,), mi (N,))`` f32 tensors on
+    the input's device.  One row-streaming launch (``runia_mcd_uncertainty_f32``)."""
+    assert input_samples.shape[0] % mcd_nro_samples == 0, (
+        "Input tensor first dimension must be " "divisible by the mcd_nro_samples"
+    )
+    x = input_samples.detach().to(_hip.require_gpu(), torch.float32)
+    ph, mi, _ = _hip.mcd_uncertainty(x, int(mcd_nro_samples), False)
+    return ph.to(input_samples.device), mi.to(input_samples.device)
+
+
+def get_mcd_pred_uncertainty_score(dnn_model: torch.nn.Module, input_dataloader, mcd_nro_samples: int = 2
+                                   ) -> Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """The dataloader form (reference ``inference/funcs.py:378-427``): ``mcd_nro_samples`` forward passes per batch, then
+    the same kernel -> ``(softmax samples (N, n_mc, C), pred_h (N,), mi (N,))`` on the device.  As upstream the passes of
+    a batch are concatenated in the order they were made, so batches of ONE image give image-major rows."""
+    device = _hip.require_gpu()
+    outs = []
+    with torch.no_grad():
+        for image, _ in input_dataloader:
+            image = image.to(device)
+            for _s in range(mcd_nro_samples):
+                outs.append(dnn_model(image))
+        logits = torch.cat(outs, dim=0).to(device, torch.float32)
+        ph, mi, probs = _hip.mcd_uncertainty(logits, int(mcd_nro_samples), True)
+    return probs.reshape(-1, mcd_nro_samples, logits.shape[1]), ph, mi
+
+
+def get_dice_feat_mean_react_percentile(dnn_model: torch.nn.Module, ind_dataloader, react_percentile: int = 90
+                                        ) -> Tuple[np.ndarray, float]:
+    """DICE expected activations and the ReAct clipping threshold (reference ``inference/funcs.py:468-495``): the
+    model's feature maps are average-pooled per channel on the device (``runia_map_reduce_f32``), their mean over the
+    dataset and the ``react_percentile``-th percentile of all pooled activations (NumPy's linear interpolation, as
+    upstream) come back as ``(ndarray (C,), float)``."""
+    assert 0 < react_percentile < 100, "react_percentile must be greater than 0 and less than 100"
+    feat_log = []
+    dnn_model.eval()
+    assert dnn_model.dice_precompute
+    device = _hip.require_gpu()
+    with torch.no_grad():
+        for inputs, _targets in ind_dataloader:
+            outputs = dnn_model(inputs.to(device)).to(torch.float32)
+            b, c, h, w = outputs.shape
+            rows = _hip.map_reduce(outputs.contiguous(), h, w, "mean")          # (b*c, h): mean over W
+            pooled = _hip.map_reduce(rows.contiguous(), 1, h, "mean").reshape(b, c)  # mean over H
+            feat_log.append(_hip.to_host(pooled))
+    feat_log_array = np.array(feat_log).squeeze()
+    return feat_log_array.mean(0), np.percentile(feat_log_array, react_percentile)

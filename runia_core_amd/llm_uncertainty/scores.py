@@ -21,7 +21,7 @@ import torch
 
 from .. import _hip
 
-__all__ = ["eigen_score", "semantic_entropy"]
+__all__ = ["eigen_score", "normalized_entropy", "semantic_entropy", "perplexity", "generation_entropy"]
 
 
 def _construct_embedding_matrix(hidden_states: Tuple[torch.Tensor, ...], token_index: int = -1, layer_index: int = 15) -> torch.Tensor:
@@ -87,3 +87,32 @@ def semantic_entropy(model, tokenizer, texts: List[str]) -> Tuple[float, Dict[in
         if p > 0:
             entropy -= p * math.log(p)
     return float(entropy), clusters
+
+
+# ---- scalar scores of one generation (host-side torch on the few hundred numbers a generation yields; reference
+# llm_uncertainty/scores.py:69-85, 121-152) --------------------------------------------------------------------------
+def normalized_entropy(log_probs: torch.Tensor) -> float:
+    """Length-normalised entropy over sequences of token log-probabilities (``-inf`` = padding)."""
+    n = len(log_probs)
+    entropy = 0.0
+    for seq in log_probs:
+        valid = seq != -float("inf")
+        entropy += torch.sum(seq[valid]) / torch.sum(valid)
+    return (-entropy / n).item()
+
+
+def perplexity(log_probs) -> float:
+    """``-mean(log_probs)`` of one sequence (what the reference calls perplexity)."""
+    return -torch.mean(log_probs).item()
+
+
+def generation_entropy(logits) -> float:
+    """Entropy of every generated token's distribution (HuggingFace ``outputs.scores``, first batch element),
+    normalised by ``log(vocabulary)`` and averaged over the tokens."""
+    entropies = []
+    for logit in logits:
+        p = torch.softmax(logit[0], dim=-1).cpu()
+        log_p = torch.clamp(p, min=1e-12).log()
+        entropy = -(p * log_p).sum() / torch.log(torch.tensor(p.shape[-1], dtype=torch.float32))
+        entropies.append(entropy.item())
+    return float(sum(entropies) / len(entropies)) if entropies else float("nan")

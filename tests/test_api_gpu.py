@@ -1230,3 +1230,118 @@ def test_larex_inference_fc_layer_type():
     assert z.shape == (n * n_mc, dflat)
     exp, _ = oracle.larem_pipeline(z, n_mc, comp, pca.mean_, pca.explained_variance_, md.feats_mean, md.precision)
     assert s.shape == (n,) and rel_err(s, exp) < 1e-9
+
+
+# ---- round 4: the free functions of inference/funcs.py (fixtures: tools/make_goldens_r4.py, the reference's own file run by path)
+@pytest.mark.gpu
+def test_funcs_mirror_against_reference_run_fixture():
+    from runia_core_amd.inference import (ash_s_conv_layer, ash_s_linear_layer, generalized_entropy,
+                                          get_dice_feat_mean_react_percentile, get_mcd_pred_uncertainty_score,
+                                          get_predictive_uncertainty_score)
+
+    g = load_npz("ref_funcs_r4.npz")
+    # ash_s_linear_layer: tie-free rows; the reference's scatter quirk (values of np.partition at the indices of
+    # np.argpartition) permutes kept values inside some rows, so rows are compared as sorted multisets + by their support
+    for tag in ("a", "b"):
+        x, pct, ref = g[f"ashl_{tag}_x"], int(g[f"ashl_{tag}_pct"]), g[f"ashl_{tag}_y"]
+        got = ash_s_linear_layer(x.copy(), pct)
+        assert got.dtype == ref.dtype and got.shape == ref.shape
+        assert np.array_equal(got != 0, ref != 0)
+        assert rel_err(np.sort(got, axis=1), np.sort(ref, axis=1)) < 1e-5
+        assert rel_err(got, oracle.ash_s_defined(x, pct)) < 1e-5
+    # ash_s_conv_layer: output and the argument left pruned in place, on a CPU tensor (as the reference's callers hold)
+    # and on a device tensor
+    for tag in ("a", "b"):
+        x, pct = g[f"ashc_{tag}_x"], int(g[f"ashc_{tag}_pct"])
+        for on_gpu in (False, True):
+            xin = torch.from_numpy(x.copy())
+            xin = xin.cuda() if on_gpu else xin
+            y = ash_s_conv_layer(xin, pct)
+            assert y.device == xin.device and y.shape == xin.shape
+            assert rel_err(y.cpu().numpy(), g[f"ashc_{tag}_y"]) < 1e-5
+            assert np.array_equal(xin.cpu().numpy(), g[f"ashc_{tag}_x_after"])
+    # generalized_entropy: dtype of the probabilities kept
+    for tag in ("a", "b", "c"):
+        p, (gamma, m), ref = g[f"gen_{tag}_p"], g[f"gen_{tag}_gm"], g[f"gen_{tag}_s"]
+        got = generalized_entropy(p, float(gamma), int(m))
+        assert got.dtype == ref.dtype and rel_err(got, ref) < 1e-5
+        assert rel_err(generalized_entropy(torch.from_numpy(p), float(gamma), int(m)), ref) < 1e-5
+    # pred_h / mi: heads of 10 (lane per image), 43, 100 and 1000 classes (wave per image); 2 ... 32 MC samples
+    for tag in ("a", "b", "c", "d"):
+        logits, n_mc = torch.from_numpy(g[f"pu_{tag}_logits"]), int(g[f"pu_{tag}_nmc"])
+        ph, mi = get_predictive_uncertainty_score(logits, n_mc)
+        assert ph.dtype == torch.float32 and ph.device == logits.device
+        assert rel_err(ph.numpy(), g[f"pu_{tag}_pred_h"]) < 1e-5 and rel_err(mi.numpy(), g[f"pu_{tag}_mi"]) < 1e-5
+        ph2, mi2 = get_predictive_uncertainty_score(logits.cuda(), n_mc)
+        assert ph2.is_cuda and np.array_equal(ph2.cpu().numpy(), ph.numpy()) and np.array_equal(mi2.cpu().numpy(), mi.numpy())
+    # the dataloader form, fed the MC outputs the reference's model produced (recorded through a forward hook)
+    rows = torch.from_numpy(g["mcd_logits"])
+    n_mc = int(g["mcd_nmc"])
+
+    class Replay(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.i = 0
+
+        def forward(self, image):
+            out = rows[self.i: self.i + 1].to(image.device)
+            self.i += 1
+            return out
+
+    loader = [(torch.zeros(1, 3, 4, 4), torch.zeros(1)) for _ in range(rows.shape[0] // n_mc)]
+    samples, ph, mi = get_mcd_pred_uncertainty_score(Replay(), loader, n_mc)
+    assert samples.shape == g["mcd_samples"].shape
+    assert rel_err(samples.cpu().numpy(), g["mcd_samples"]) < 1e-5
+    assert rel_err(ph.cpu().numpy(), g["mcd_pred_h"]) < 1e-5 and rel_err(mi.cpu().numpy(), g["mcd_mi"]) < 1e-5
+
+    # DICE info + ReAct threshold with the reference's toy model
+    class Feat(torch.nn.Module):
+        dice_precompute = True
+
+        def __init__(self):
+            super().__init__()
+            self.conv = torch.nn.Conv2d(3, 12, 3, padding=1)
+
+        def forward(self, x):
+            return torch.relu(self.conv(x))
+
+    fm = Feat()
+    with torch.no_grad():
+        fm.conv.weight.copy_(torch.from_numpy(g["dice_w"]))
+        fm.conv.bias.copy_(torch.from_numpy(g["dice_b"]))
+    fm = fm.cuda()
+    batches = [(torch.from_numpy(g["dice_inputs"][i: i + 1]), torch.zeros(1, dtype=torch.long)) for i in range(g["dice_inputs"].shape[0])]
+    mean, thr = get_dice_feat_mean_react_percentile(fm, batches, 90)
+    assert rel_err(mean, g["dice_mean"]) < 1e-5 and abs(float(thr) - float(g["dice_thr"])) < 1e-5 * max(1.0, abs(float(g["dice_thr"])))
+
+
+@pytest.mark.gpu
+def test_route_dice_forward_and_long_rows():
+    """RouteDICE.forward against its definition in NumPy (the reference's forward calls .cuda() and cannot run in the
+    build container; its arithmetic is pinned through the DICE postprocessor's all-baselines golden), and the
+    radix-select ASH-S kernel on rows longer than the register kernel takes (ties at the threshold included)."""
+    from runia_core_amd.inference import RouteDICE, ash_s_conv_layer, ash_s_linear_layer
+
+    rng = np.random.default_rng(5)
+    info = np.abs(rng.standard_normal(64)).astype(np.float32)
+    layer = RouteDICE(64, 10, bias=True, p=90, info=info)
+    x = rng.standard_normal((33, 64)).astype(np.float32)
+    out = layer(torch.from_numpy(x))
+    w, b = layer.weight.detach().numpy(), layer.bias.detach().numpy()
+    contrib = info[None, :] * w
+    masked = w * (contrib > np.percentile(contrib, 90))
+    assert out.is_cuda and rel_err(out.cpu().numpy(), x @ masked.T + b) < 1e-5
+    assert np.allclose(layer.thresh, np.percentile(contrib, 90)) and np.array_equal(layer.masked_w.detach().cpu().numpy(), masked.astype(np.float32))
+    # long rows: 5 000 features (linear form) and 2 x 128 x 7 x 7 = 6 272 per sample (conv form), with exact ties
+    xl = np.abs(rng.standard_normal((9, 5000))).astype(np.float32) + 0.01
+    xl[:, 100:140] = xl[:, 99:100]  # 41 equal values
+    assert rel_err(ash_s_linear_layer(xl, 85), oracle.ash_s_defined(xl, 85)) < 1e-5
+    xc = np.abs(rng.standard_normal((2, 128, 7, 7))).astype(np.float32) + 0.01
+    flat = xc.reshape(2, -1)
+    k = flat.shape[1] - int(np.round(flat.shape[1] * 65 / 100.0))
+    kept = np.zeros_like(flat)
+    idx = np.argsort(-flat, axis=1, kind="stable")[:, :k]
+    np.put_along_axis(kept, idx, np.take_along_axis(flat, idx, axis=1), axis=1)
+    want = kept * np.exp(flat.sum(1) / kept.sum(1))[:, None]
+    got = ash_s_conv_layer(torch.from_numpy(xc.copy()), 65)
+    assert rel_err(got.numpy().reshape(2, -1), want) < 1e-5
