@@ -287,6 +287,22 @@ int runia_covariance_f32in(const float* x, double* mean, double* cov, void* work
 int runia_roi_align_f32(const float* input, const float* boxes, const int* batch_idx, float* out, int64_t K, int64_t B,
                         int C, int H, int W, int PH, int PW, double spatial_scale, int sampling_ratio, int aligned,
                         runia_stream_t stream);
+/* roi_align folded into the sampler + entropy launch (round 4; _dropblock_rois_get_entropy, feature_extraction/
+ * object_level.py:312-367, as ONE pass from the hooked feature map to the per-ROI entropies - the (K, C, PH, PW) tensor is
+ * never written).  runia_nchw_to_nhwc_f32: the hooked map [B, C, H*W] -> [B, H*W, C] once per image batch (channel = lane:
+ * every bilinear tap of a wave is one contiguous run).  runia_roi_mc_entropy_f32: feat_nhwc [B, H, W, C], boxes [K, 4] xyxy,
+ * batch_idx [K] or NULL (B == 1), draws / workspace as runia_mc_entropy_f32 (workspace:
+ * runia_roi_mc_entropy_workspace_bytes: the keep-flag table + 16 bytes per sample row and sample column of every ROI) -> h [K, C] f64,
+ * the same bits as runia_roi_align_f32 followed by runia_mc_entropy_f32.  Supported (runia_roi_mc_entropy_supported): the
+ * fused sampler's map shapes with sampling_ratio 1 or 2; others take the two calls. */
+int runia_nchw_to_nhwc_f32(const float* in, float* out, int64_t B, int C, int64_t HW, runia_stream_t stream);
+int runia_roi_mc_entropy_supported(int PH, int PW, int n_mc, int k, int sampling_ratio);
+size_t runia_roi_mc_entropy_workspace_bytes(int64_t K, int PH, int PW, int n_mc, int sampling_ratio);
+int runia_roi_mc_entropy_f32(const float* feat_nhwc, const float* boxes, const int* batch_idx, const float* rand,
+                             int64_t rand_image_stride, double* h, float* z_out, void* workspace, size_t workspace_bytes,
+                             int64_t K, int64_t B, int C, int H, int W, int PH, int PW, double spatial_scale,
+                             int sampling_ratio, int aligned, int n_mc, double drop_prob, int block_size, int k,
+                             double min_dist, runia_stream_t stream);
 
 /* Symmetric eigen-decomposition without a vendor solver: two-sided cyclic Jacobi, f64, parallel ordering.  What
  * scipy.linalg.pinvh (EmpiricalCovariance.fit, inference/postprocessors.py:213-220, inference/funcs.py:52-66), the

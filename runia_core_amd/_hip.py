@@ -139,6 +139,14 @@ _SIGNATURES = {
         [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_int, c_int, c_int, c_double, c_int, c_int,
          c_void_p],
     ),
+    "runia_nchw_to_nhwc_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
+    "runia_roi_mc_entropy_supported": (c_int, [c_int, c_int, c_int, c_int, c_int]),
+    "runia_roi_mc_entropy_workspace_bytes": (c_size_t, [c_int64, c_int, c_int, c_int, c_int]),
+    "runia_roi_mc_entropy_f32": (
+        c_int,
+        [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_int, c_int,
+         c_int, c_int, c_int, c_double, c_int, c_int, c_int, c_double, c_int, c_int, c_double, c_void_p],
+    ),
     "runia_linear_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_float, c_void_p]),
     "runia_ash_s_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_void_p]),
     "runia_gen_score_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
@@ -1077,3 +1085,57 @@ def roi_align(x: torch.Tensor, boxes: torch.Tensor, output_size, spatial_scale: 
                                    int(pw), float(spatial_scale), int(sampling_ratio), 1 if aligned else 0, _stream()),
            "runia_roi_align_f32")
     return out
+
+
+def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
+    """x [B, C, H, W] f32 -> [B, H, W, C] f32 (a contiguous copy in channels-last order; the ROI source of
+    :func:`roi_mc_entropy`: 64 channels of a wave read a bilinear tap as one contiguous run)."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 4
+    x = x.contiguous()
+    b, c, h, w = x.shape
+    out = torch.empty((b, h, w, c), dtype=torch.float32, device=x.device)
+    _check(lib.runia_nchw_to_nhwc_f32(x.data_ptr(), out.data_ptr(), b, c, h * w, _stream()), "runia_nchw_to_nhwc_f32")
+    return out
+
+
+def roi_mc_entropy_supported(ph: int, pw: int, n_mc: int, k: int, sampling_ratio: int) -> bool:
+    return bool(load_library().runia_roi_mc_entropy_supported(int(ph), int(pw), int(n_mc), int(k), int(sampling_ratio)))
+
+
+def roi_mc_entropy(x_nhwc: torch.Tensor, boxes: torch.Tensor, output_size, spatial_scale: float, sampling_ratio: int,
+                   aligned: bool, rand: Union[torch.Tensor, CounterDraws, None], n_mc: int, drop_prob: float, block_size: int, k: int,
+                   min_dist: float = 1e-5, batch_idx: Optional[torch.Tensor] = None, return_samples: bool = False):
+    """``roi_align`` -> per-ROI ``MCSamplerModule`` -> per-dimension entropy in ONE pass from the feature map (NHWC,
+    :func:`nchw_to_nhwc`): x_nhwc [B, H, W, C], boxes [K, 4] xyxy, rand [K, n_mc, PH, PW] -> h [K, C] f64.  The
+    (K, C, PH, PW) tensor of ``roi_align`` is never written; same bits as ``roi_align`` + :func:`mc_entropy`.  Calls of
+    more than 65 535 ROIs are cut in slices."""
+    lib = load_library()
+    require_gpu()
+    assert x_nhwc.is_cuda and x_nhwc.dtype == torch.float32 and x_nhwc.dim() == 4 and x_nhwc.is_contiguous()
+    b, hh, ww, c = x_nhwc.shape
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else tuple(output_size)
+    boxes = boxes.to(device=x_nhwc.device, dtype=torch.float32).contiguous()
+    kk = boxes.shape[0]
+    if batch_idx is not None:
+        batch_idx = batch_idx.to(device=x_nhwc.device, dtype=torch.int32).contiguous()
+    if isinstance(rand, CounterDraws):
+        rand = _explicit_counter_draws(rand, kk, n_mc, ph, pw)  # (same bits as the in-kernel generator)
+    if rand is not None:
+        rand = rand.to(device=x_nhwc.device, dtype=torch.float32).contiguous()
+        assert rand.shape == (kk, n_mc, ph, pw)
+    h = torch.empty((kk, c), dtype=torch.float64, device=x_nhwc.device)
+    z = torch.empty((kk * n_mc, c), dtype=torch.float32, device=x_nhwc.device) if return_samples else None
+    step = 65535
+    for k0 in range(0, kk, step):
+        n = min(step, kk - k0)
+        ws_bytes = int(lib.runia_roi_mc_entropy_workspace_bytes(n, ph, pw, n_mc, sampling_ratio))
+        ws = torch.empty(max(ws_bytes, 16), dtype=torch.uint8, device=x_nhwc.device)
+        _check(lib.runia_roi_mc_entropy_f32(
+            x_nhwc.data_ptr(), boxes[k0:].data_ptr(), None if batch_idx is None else batch_idx[k0:].data_ptr(),
+            None if rand is None else rand[k0:].data_ptr(), n_mc * ph * pw, h[k0:].data_ptr(),
+            None if z is None else z[k0 * n_mc:].data_ptr(), ws.data_ptr(), ws_bytes, n, b, c, hh, ww, int(ph), int(pw),
+            float(spatial_scale), int(sampling_ratio), 1 if aligned else 0, int(n_mc), float(drop_prob), int(block_size), int(k),
+            float(min_dist), _stream()), "runia_roi_mc_entropy_f32")
+    return (h, z) if return_samples else h

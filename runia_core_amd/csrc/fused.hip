@@ -226,7 +226,85 @@ __global__ __launch_bounds__(64 * kMaskBitsWaves) void mc_mask_bits_kernel(const
 #endif
 constexpr int kK1Block = K1_BLOCK;  // channels (threads) per workgroup: 185 us vs 199 us with 256 at N = 10 000
 
-template <int HT, int WT, int NP, int K, bool FULL, bool ENTROPY = true>
+// ---- ROI source of K1 (BASELINE config 4, reference feature_extraction/object_level.py:340-349 + 312-367): instead of a
+// (K, C, PH, PW) tensor that roi_align wrote, a thread builds its PH x PW map in registers from the feature map itself.
+// `x` of the kernel then points at a RoiSource (written by roi_sample_table_kernel, roi.hip): the feature map in NHWC
+// (channel = lane: every bilinear tap of a wave is one contiguous 4 * 64-byte run) and, per ROI, a SEPARABLE table of its
+// bilinear samples - per sample row (ph, iy): byte offsets of the two map rows and the weights hy, ly; per sample column
+// (pw, ix): byte offsets of the two map columns and hx, lx; two bit masks of the rows / columns
+// more than a pixel outside the map (their samples contribute 0) - 480 bytes for 7x7 bins of 2x2 samples,
+// wave-uniform, read through the scalar cache.  (A table of all 196 samples with their four offsets and four products,
+// 6.3 KB per ROI, kept every vector instruction out of the weights but streamed 376 MB per 60 000 ROIs through the scalar
+// cache: 7 of the 11 ms the launch took.)  A bin is the sum of its G x G samples in (iy, ix) order, each
+// (hy hx) v1 + (hy lx) v2 + (ly hx) v3 + (ly lx) v4, divided by G * G: the arithmetic of roi_align_kernel, same bits
+// (tests/test_api_gpu.py).  The taps are buffer loads with the sample's offset as the scalar operand: no vector instruction
+// goes into addressing.  What bounds the launch is the bytes of the taps through the vector L1 (48 GB per 60 000 ROIs x 256
+// channels at ~5.6 TB/s; the L1 only catches the reuse between neighbouring samples of a row): the four taps of a sample
+// as ONE 16-byte load from a map of quads (f[y][x], f[y][x+1], f[y+1][x], f[y+1][x+1]) moved the same bytes with a quarter
+// of the load instructions and measured 11.1 ms against 8.5 (no reuse left for the L1); staging a ROI's footprint in LDS
+// (each pixel read once, 3.5 x fewer bytes) is what would come next.
+struct RoiSource {
+  const float* nhwc;      // [B, H, W, C]
+  const unsigned* table;  // per ROI: 8 dwords (image, row mask, column mask, 0 ...) + (PH * G + PW * G) x 4 dwords
+  int64_t image_bytes;    // H * W * C * 4
+  int C;
+  int roi_dwords;         // 8 + 4 * (PH * G + PW * G)
+};
+
+template <int HT, int WT, int G>
+__device__ __forceinline__ void roi_load_map(float (&u)[HT * WT], const RoiSource* __restrict__ src, int64_t roi, int c) {
+  // the table is read through the constant address space: loads the compiler may keep on the scalar unit (through a
+  // plain pointer loaded from memory it reads the wave-uniform entries with vector loads and wraps every tap in a
+  // readfirstlane loop)
+  typedef const __attribute__((address_space(4))) unsigned* cptr;
+  cptr tab = (cptr)(src->table + roi * (int64_t)src->roi_dwords);  // wave-uniform
+  const unsigned image = tab[0], row_out = tab[1], col_out = tab[2];
+  const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
+      const_cast<float*>(src->nhwc) + (int64_t)image * (src->image_bytes / 4), 0, (int)src->image_bytes, 0x00020000);
+  const int voff = c * 4;
+  cptr rows = tab + 8, cols = tab + 8 + 4 * (HT * G);
+  constexpr float count = (float)(G * G);
+#ifndef ROI_BIN_MAJOR
+#define ROI_BIN_MAJOR 0
+#endif
+  float acc[HT * WT];
+#pragma unroll
+  for (int p = 0; p < HT * WT; ++p) acc[p] = 0.f;
+  auto sample = [&](int sy, int sx) {
+    const unsigned oy_lo = rows[4 * sy], oy_hi = rows[4 * sy + 1];
+    const float hy = __uint_as_float(rows[4 * sy + 2]), ly = __uint_as_float(rows[4 * sy + 3]);
+    const unsigned ox_lo = cols[4 * sx], ox_hi = cols[4 * sx + 1];
+    const float hx = __uint_as_float(cols[4 * sx + 2]), lx = __uint_as_float(cols[4 * sx + 3]);
+    // (wave-uniform; outside: offsets are 0 in the table, the value read is replaced by 0 - no branch, the loads move freely)
+    const bool inside = (((row_out >> sy) | (col_out >> sx)) & 1u) == 0u;
+    const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_lo + ox_lo), 0));
+    const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_lo + ox_hi), 0));
+    const float v3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_hi + ox_lo), 0));
+    const float v4 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_hi + ox_hi), 0));
+    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
+    return inside ? w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4 : 0.f;
+  };
+  // a bin receives its samples in (iy, ix) order in either loop order
+  if constexpr (ROI_BIN_MAJOR) {
+#pragma unroll
+    for (int ph = 0; ph < HT; ++ph)
+#pragma unroll
+      for (int pw = 0; pw < WT; ++pw)
+#pragma unroll
+        for (int iy = 0; iy < G; ++iy)
+#pragma unroll
+          for (int ix = 0; ix < G; ++ix) acc[ph * WT + pw] += sample(ph * G + iy, pw * G + ix);
+  } else {
+#pragma unroll
+    for (int sy = 0; sy < HT * G; ++sy)
+#pragma unroll
+      for (int sx = 0; sx < WT * G; ++sx) acc[(sy / G) * WT + (sx / G)] += sample(sy, sx);
+  }
+#pragma unroll
+  for (int p = 0; p < HT * WT; ++p) u[p] = acc[p] / count;
+}
+
+template <int HT, int WT, int NP, int K, bool FULL, bool ENTROPY = true, int ROI_G = 0>
 #ifdef K1_WAVES
 __attribute__((amdgpu_waves_per_eu(K1_WAVES, 8)))
 #endif
@@ -253,7 +331,9 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
   const float* zhs = mk + n_mc * HW;
   const float* zls = zhs + n_mc;
   float u[HW];
-  {
+  if constexpr (ROI_G > 0) {
+    roi_load_map<HT, WT, ROI_G>(u, reinterpret_cast<const RoiSource*>(x), img, c);
+  } else {
     // 16-byte loads at a 4*HW-byte lane stride: measured faster than staging the block's contiguous run
     // through LDS (214 vs 271 us at N = 10 000, profiles/README.md) - the kernel is VALU-bound, not HBM-bound
     const float* xc = x + (img * C + c) * (int64_t)HW;
@@ -977,6 +1057,65 @@ extern "C" int runia_mc_entropy_f32(const float* x, const float* rnd, int64_t ra
     return rc;
   return runia_mc_entropy_from_table_f32(x, workspace, workspace_bytes, h, z_out, zero_fill, N, C, H, W, n_mc, k,
                                          min_dist, stream);
+}
+
+// ---- ROI source (config 4): roi_align folded into K1's load ------------------------------------------------------------
+int runia_roi_sample_table(const float* feat_nhwc, const float* boxes, const int* batch_idx, void* table, size_t table_bytes,
+                           int64_t K, int64_t B, int C, int H, int W, int PH, int PW, double spatial_scale, int G, int aligned,
+                           hipStream_t s);  // roi.hip
+size_t runia_roi_sample_table_bytes(int64_t K, int PH, int PW, int G);
+
+extern "C" int runia_roi_mc_entropy_supported(int PH, int PW, int n_mc, int k, int sampling_ratio) {
+  // the table path's map shapes with an odd or even side up to 8 and one or four samples per bin (what the reference's
+  // extractor is configured with; adaptive sampling - ratio <= 0 - has a per-ROI sample count: roi_align + K1 then)
+  return runia_mc_entropy_supported(PH, PW, n_mc, k) && (sampling_ratio == 1 || sampling_ratio == 2) && PH * PW > 4;
+}
+extern "C" size_t runia_roi_mc_entropy_workspace_bytes(int64_t K, int PH, int PW, int n_mc, int sampling_ratio) {
+  if (K <= 0 || sampling_ratio < 1) return 0;
+  const size_t masks = (runia_mc_entropy_workspace_bytes(K, PH, PW, n_mc) + 255) / 256 * 256;
+  return masks + runia_roi_sample_table_bytes(K, PH, PW, sampling_ratio);
+}
+extern "C" int runia_roi_mc_entropy_f32(const float* feat_nhwc, const float* boxes, const int* batch_idx, const float* rnd,
+                                        int64_t rand_image_stride, double* h, float* z_out, void* workspace,
+                                        size_t workspace_bytes, int64_t K, int64_t B, int C, int H, int W, int PH, int PW,
+                                        double spatial_scale, int sampling_ratio, int aligned, int n_mc, double drop_prob,
+                                        int block_size, int k, double min_dist, runia_stream_t stream) {
+  if (K < 0 || B <= 0 || C <= 0 || H <= 0 || W <= 0 || n_mc < 2 || n_mc > kMaxMC || block_size < 1 || k < 1 || k >= n_mc)
+    return RUNIA_E_INVALID;
+  if (K == 0) return RUNIA_OK;
+  if (!feat_nhwc || !boxes || !h || K > 65535 || (B > 1 && !batch_idx)) return RUNIA_E_INVALID;
+  if (!runia_roi_mc_entropy_supported(PH, PW, n_mc, k, sampling_ratio)) return RUNIA_E_INVALID;
+  if ((int64_t)H * W * C * 4 >= ((int64_t)1 << 31)) return RUNIA_E_INVALID;  // one image's map behind a 32-bit buffer
+  if (drop_prob != 0.0 && !rnd) return RUNIA_E_INVALID;
+  if (!workspace || (((uintptr_t)workspace) & 15) != 0 ||
+      workspace_bytes < runia_roi_mc_entropy_workspace_bytes(K, PH, PW, n_mc, sampling_ratio))
+    return RUNIA_E_WORKSPACE;
+  const size_t masks = (runia_mc_entropy_workspace_bytes(K, PH, PW, n_mc) + 255) / 256 * 256;
+  if (int rc = runia_mc_mask_table_f32(rnd, rand_image_stride, workspace, masks, K, PH, PW, n_mc, drop_prob, block_size, stream))
+    return rc;
+  char* tab = reinterpret_cast<char*>(workspace) + masks;
+  hipStream_t s = as_stream(stream);
+  if (int rc = runia_roi_sample_table(feat_nhwc, boxes, batch_idx, tab, workspace_bytes - masks, K, B, C, H, W, PH, PW,
+                                      spatial_scale, sampling_ratio, aligned, s))
+    return rc;
+  const float* table = reinterpret_cast<const float*>(workspace);
+  const float* src = reinterpret_cast<const float*>(tab);  // the RoiSource at the head of the sample table
+  const double ct = digamma_diff(n_mc, k), inv_n = 1.0 / (double)n_mc;
+  const unsigned grid = (unsigned)(((K + 7) / 8) * 8 * ((C + kK1Block - 1) / kK1Block));
+#define RUNIA_ROI_MCE(HH, WW, NPP, KK, GG)                                                                         \
+  if (PH == HH && PW == WW && n_mc <= NPP && n_mc > NPP / 2 && k == KK && sampling_ratio == GG) {                  \
+    if (n_mc == NPP)                                                                                               \
+      mc_entropy_kernel<HH, WW, NPP, KK, true, true, GG><<<grid, kK1Block, 0, s>>>(src, table, h, z_out, nullptr,  \
+                                                                                   K, C, n_mc, min_dist, ct, inv_n); \
+    else                                                                                                           \
+      mc_entropy_kernel<HH, WW, NPP, KK, false, true, GG><<<grid, kK1Block, 0, s>>>(src, table, h, z_out, nullptr, \
+                                                                                    K, C, n_mc, min_dist, ct, inv_n); \
+    return runia_check_launch();                                                                                   \
+  }
+  RUNIA_ROI_MCE(7, 7, 16, 5, 2) RUNIA_ROI_MCE(7, 7, 32, 5, 2) RUNIA_ROI_MCE(7, 7, 16, 5, 1) RUNIA_ROI_MCE(7, 7, 32, 5, 1)
+  RUNIA_ROI_MCE(4, 4, 16, 5, 2) RUNIA_ROI_MCE(4, 4, 32, 5, 2) RUNIA_ROI_MCE(8, 8, 16, 5, 2) RUNIA_ROI_MCE(8, 8, 32, 5, 2)
+#undef RUNIA_ROI_MCE
+  return RUNIA_E_INVALID;
 }
 
 // ---- throughput mode: the DropBlock draws come from the counter generator inside K0 (philox.hpp) ----------------

@@ -56,7 +56,144 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
   }
 }
 
+// ---- roi_align folded into the sampler's load (fused.hip, roi_load_map) ---------------------------------------------------
+// The feature map in NHWC, so that the 64 channels of a wave read one bilinear tap as one contiguous run.
+__global__ __launch_bounds__(256) void nchw_to_nhwc_kernel(const float* __restrict__ in, float* __restrict__ out, int C,
+                                                            int64_t HW) {
+  __shared__ float tile[64][65];
+  const int64_t b = blockIdx.z;
+  const int64_t p0 = (int64_t)blockIdx.x * 64;
+  const int c0 = blockIdx.y * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int c = c0 + ty + 4 * r;
+    const int64_t p = p0 + tx;
+    tile[ty + 4 * r][tx] = (c < C && p < HW) ? in[(b * C + c) * HW + p] : 0.f;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int64_t p = p0 + ty + 4 * r;
+    const int c = c0 + tx;
+    if (c < C && p < HW) out[(b * HW + p) * C + c] = tile[tx][ty + 4 * r];
+  }
+}
+
+// mirrors RoiSource of fused.hip
+struct RoiSourceHost {
+  const float* quads;
+  const unsigned* table;
+  int64_t image_bytes;
+  int C;
+  int roi_dwords;
+};
+static_assert(sizeof(RoiSourceHost) <= 64, "the source description fits the head of the table");
+
+// One thread per sample row or sample column of a ROI (PH * G rows, then PW * G columns).  The coordinates, the validity
+// test, the clamping and the weights are those of `bilinear` / roi_align_kernel above, expression for expression (they are
+// separable: y and x never meet before the four products).
+__global__ __launch_bounds__(256) void roi_sample_table_kernel(RoiSourceHost src, const float* __restrict__ boxes,
+                                                                const int* __restrict__ batch_idx, unsigned* __restrict__ tab,
+                                                                int64_t K, int C, int H, int W, int PH, int PW,
+                                                                float spatial_scale, int G, int aligned) {
+  if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<RoiSourceHost*>(tab) = src;
+  unsigned* roi_tab = tab + 16;  // 64 bytes of RoiSource in front
+  const int nrows = PH * G, ncols = PW * G, per_roi = nrows + ncols, roi_dwords = 8 + 4 * per_roi;
+  const int64_t total = K * per_roi;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
+    const int64_t k = idx / per_roi;
+    const int j = (int)(idx % per_roi);
+    const bool is_row = j < nrows;
+    const int sidx = is_row ? j : j - nrows;
+    const int bin = sidx / G, sub = sidx % G;
+    const float* box = boxes + k * 4;
+    const float offset = aligned ? 0.5f : 0.f;
+    const float lo = box[is_row ? 1 : 0] * spatial_scale - offset, hi = box[is_row ? 3 : 2] * spatial_scale - offset;
+    float extent = hi - lo;
+    if (!aligned) extent = fmaxf(extent, 1.f);
+    const int P = is_row ? PH : PW, L = is_row ? H : W;
+    const float bin_sz = extent / (float)P;
+    float t = lo + (float)bin * bin_sz + ((float)sub + 0.5f) * bin_sz / (float)G;
+    unsigned* hd = roi_tab + k * (int64_t)roi_dwords;
+    unsigned* e = hd + 8 + 4 * j;
+    if (j == 0) {
+      hd[0] = (unsigned)(batch_idx ? batch_idx[k] : 0);
+#pragma unroll
+      for (int q = 3; q < 8; ++q) hd[q] = 0u;
+    }
+    const bool outside = (t < -1.0f || t > (float)L);
+    // the masks of a ROI are assembled by the threads of its rows / columns: ballot over the lanes that share the ROI
+    // would need them in one wave; instead every thread recomputes nothing and the masks are written by atomics on a
+    // word the j == 0 thread may not have cleared yet -> they are built in a second, tiny pass below (mask_kernel)
+    if (outside) {
+      e[0] = 0u; e[1] = 0u; e[2] = 0u; e[3] = 0x7fc00000u;  // NaN in `l` marks the entry for the mask pass
+      continue;
+    }
+    if (t <= 0.f) t = 0.f;
+    int low = (int)t, high;
+    if (low >= L - 1) { high = low = L - 1; t = (float)low; } else { high = low + 1; }
+    const float l = t - (float)low, h = 1.f - l;
+    const unsigned step = is_row ? (unsigned)W * (unsigned)C * 4u : (unsigned)C * 4u;
+    e[0] = (unsigned)low * step;
+    e[1] = (unsigned)high * step;
+    e[2] = __float_as_uint(h);
+    e[3] = __float_as_uint(l);
+  }
+}
+
+// row / column masks of every ROI (bit = the sample row / column lies more than a pixel outside the map)
+__global__ __launch_bounds__(256) void roi_sample_mask_kernel(unsigned* __restrict__ tab, int64_t K, int nrows, int ncols) {
+  unsigned* roi_tab = tab + 16;
+  const int roi_dwords = 8 + 4 * (nrows + ncols);
+  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < K; k += (int64_t)gridDim.x * 256) {
+    unsigned* hd = roi_tab + k * (int64_t)roi_dwords;
+    unsigned rm = 0u, cm = 0u;
+    for (int j = 0; j < nrows; ++j) {
+      unsigned* e = hd + 8 + 4 * j;
+      if (e[3] == 0x7fc00000u) { rm |= 1u << j; e[3] = 0u; }
+    }
+    for (int j = 0; j < ncols; ++j) {
+      unsigned* e = hd + 8 + 4 * (nrows + j);
+      if (e[3] == 0x7fc00000u) { cm |= 1u << j; e[3] = 0u; }
+    }
+    hd[1] = rm;
+    hd[2] = cm;
+  }
+}
+
 }  // namespace
+
+size_t runia_roi_sample_table_bytes(int64_t K, int PH, int PW, int G) {
+  return 64 + (size_t)K * (size_t)(8 + 4 * (PH * G + PW * G)) * 4;
+}
+
+int runia_roi_sample_table(const float* feat_nhwc, const float* boxes, const int* batch_idx, void* table, size_t table_bytes,
+                           int64_t K, int64_t B, int C, int H, int W, int PH, int PW, double spatial_scale, int G, int aligned,
+                           hipStream_t s) {
+  (void)B;
+  if (table_bytes < runia_roi_sample_table_bytes(K, PH, PW, G) || PH * G > 32 || PW * G > 32) return RUNIA_E_WORKSPACE;
+  RoiSourceHost src;
+  src.quads = feat_nhwc;
+  src.table = reinterpret_cast<const unsigned*>(table) + 16;
+  src.image_bytes = (int64_t)H * W * C * 4;
+  src.C = C;
+  src.roi_dwords = 8 + 4 * (PH * G + PW * G);
+  const int64_t total = K * (PH * G + PW * G);
+  roi_sample_table_kernel<<<runia_stream_grid(total, 256), 256, 0, s>>>(src, boxes, batch_idx, reinterpret_cast<unsigned*>(table),
+                                                                        K, C, H, W, PH, PW, (float)spatial_scale, G, aligned);
+  roi_sample_mask_kernel<<<runia_stream_grid(K, 256), 256, 0, s>>>(reinterpret_cast<unsigned*>(table), K, PH * G, PW * G);
+  return runia_check_launch();
+}
+
+extern "C" int runia_nchw_to_nhwc_f32(const float* in, float* out, int64_t B, int C, int64_t HW, runia_stream_t stream) {
+  if (B < 0 || C <= 0 || HW <= 0 || B > 65535) return RUNIA_E_INVALID;
+  if (B == 0) return RUNIA_OK;
+  if (!in || !out) return RUNIA_E_INVALID;
+  const dim3 grid((unsigned)((HW + 63) / 64), (unsigned)((C + 63) / 64), (unsigned)B);
+  nchw_to_nhwc_kernel<<<grid, 256, 0, as_stream(stream)>>>(in, out, C, HW);
+  return runia_check_launch();
+}
 
 extern "C" int runia_roi_align_f32(const float* input, const float* boxes, const int* batch_idx, float* out, int64_t K,
                                    int64_t B, int C, int H, int W, int PH, int PW, double spatial_scale,

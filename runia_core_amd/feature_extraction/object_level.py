@@ -67,15 +67,34 @@ def _dropblock_rois_get_entropy(latent_mcd_sample: List[Tensor], output_sizes: T
     """Entropy of the MC-DropBlock means of every detection's ROI-aligned activations: ``(K, C_total)`` (reference
     :312-367; returned as a float32 host ``Tensor`` like ``Tensor(entropies)`` there).  ``rand`` (additive) supplies the
     DropBlock draws ``(K, n_mcd_steps, PH, PW)``; default: the sampler's source, detection after detection, as upstream."""
+    assert n_mcd_steps == mc_sampler.mc_samples, "n_mcd_steps must equal the sampler's mc_samples"
+    active = mc_sampler.training and mc_sampler.drop_prob != 0.0
+    kk = neighbors_for(n_mcd_steps)
+    drop = mc_sampler.drop_prob if active else 0.0
+    sizes = [(s, s) if isinstance(s, int) else tuple(s) for s in output_sizes[:n_hooked_reps]]
+    k = int(torch.as_tensor(boxes).shape[0])
+    redraw = isinstance(rand, _hip.CounterDraws) and rand.redraw_dead_layers  # (lives in the keep-flag kernel of the two-call path)
+    if (mc_sampler.layer_type == "Conv" and k > 0 and len(set(sizes)) == 1 and not redraw
+            and _hip.roi_mc_entropy_supported(sizes[0][0], sizes[0][1], n_mcd_steps, kk, sampling_ratio)):
+        # one pass per hooked layer from the feature map to the entropies: roi_align is folded into the sampler's load
+        # (channels-last copy of the map, per-ROI sample table), the (K, C, PH, PW) tensor is never written
+        ph, pw = sizes[0]
+        dev = _hip.require_gpu()
+        if active and rand is None:
+            rand = mc_sampler.next_draws(k, ph, pw, dev)
+        hs = []
+        for i in range(n_hooked_reps):
+            x = _hip.to_device(latent_mcd_sample[i], torch.float32)
+            hs.append(_hip.roi_mc_entropy(_hip.nchw_to_nhwc(x), torch.as_tensor(boxes, dtype=torch.float32), (ph, pw),
+                                          x.shape[3] / img_shape[1], sampling_ratio, True, rand if active else None,
+                                          n_mcd_steps, drop, mc_sampler.block_size, kk, MIN_DIST))
+        h = torch.cat(hs, dim=1) if len(hs) > 1 else hs[0]
+        return h.to(torch.float32).cpu()
     rois = _rois(latent_mcd_sample, output_sizes, boxes, img_shape, sampling_ratio, n_hooked_reps)
     rois = torch.cat(rois, dim=1) if len(rois) > 1 else rois[0]
     k, _, ph, pw = rois.shape
-    assert n_mcd_steps == mc_sampler.mc_samples, "n_mcd_steps must equal the sampler's mc_samples"
-    active = mc_sampler.training and mc_sampler.drop_prob != 0.0
     if active and rand is None:
         rand = mc_sampler.next_draws(k, ph, pw, rois.device)
-    kk = neighbors_for(n_mcd_steps)
-    drop = mc_sampler.drop_prob if active else 0.0
     if mc_sampler.layer_type == "Conv" and _hip.mc_entropy_supported(ph, pw, n_mcd_steps, kk):
         h = _hip.mc_entropy(rois, rand if active else None, n_mcd_steps, drop, mc_sampler.block_size, kk, MIN_DIST)
     else:

@@ -1345,3 +1345,36 @@ def test_route_dice_forward_and_long_rows():
     want = kept * np.exp(flat.sum(1) / kept.sum(1))[:, None]
     got = ash_s_conv_layer(torch.from_numpy(xc.copy()), 65)
     assert rel_err(got.numpy().reshape(2, -1), want) < 1e-5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("osz,sr,n_mc,c", [(7, 2, 16, 256), (7, 2, 32, 100), (7, 1, 12, 64), (4, 2, 16, 300), (8, 2, 32, 65)])
+def test_roi_align_folded_into_the_sampler_equals_the_two_calls(osz, sr, n_mc, c):
+    """runia_roi_mc_entropy_f32 (round 4: roi_align folded into the load of the fused sampler + entropy kernel; channels-last
+    feature map, per-ROI table of bilinear samples read through the scalar cache) against runia_roi_align_f32 followed by
+    runia_mc_entropy_f32: the SAME BITS - entropies and MC samples - for boxes inside, across and beyond the map's
+    border (samples more than a pixel outside contribute 0), two images in the batch, ragged channel counts, 12 / 16 /
+    32 drop layers, one and four samples per bin."""
+    from runia_core_amd import _hip
+
+    rng = np.random.default_rng(osz * 100 + sr * 10 + n_mc)
+    b, hh, ww = 2, 23, 37
+    fm = torch.relu(torch.from_numpy(rng.standard_normal((b, c, hh, ww)).astype(np.float32))).cuda()
+    k = 90
+    xy = rng.uniform(-40, 560, size=(k, 2)).astype(np.float32)
+    wh = rng.uniform(2, 300, size=(k, 2)).astype(np.float32)
+    boxes = torch.from_numpy(np.concatenate([xy, xy + wh], axis=1))
+    boxes[0] = torch.tensor([-500.0, -500.0, -400.0, -300.0])   # wholly outside: every sample contributes 0
+    boxes[1] = torch.tensor([0.0, 0.0, 592.0, 368.0])           # the whole map
+    bidx = torch.from_numpy(rng.integers(0, b, size=k).astype(np.int32))
+    rand = torch.from_numpy(rng.random((k, n_mc, osz, osz)).astype(np.float32)).cuda()
+    scale = ww / 592.0
+    kk = 5
+    rois = _hip.roi_align(fm, boxes.cuda(), osz, scale, sr, True, bidx)
+    h_ref, z_ref = _hip.mc_entropy(rois, rand, n_mc, 0.4, 2, kk, 1e-5, want_samples=True)
+    h, z = _hip.roi_mc_entropy(_hip.nchw_to_nhwc(fm), boxes, osz, scale, sr, True, rand, n_mc, 0.4, 2, kk, 1e-5, batch_idx=bidx,
+                               return_samples=True)
+    assert torch.equal(_hip.nchw_to_nhwc(fm), fm.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(z, z_ref)
+    assert torch.equal(torch.nan_to_num(h, nan=-7.0), torch.nan_to_num(h_ref, nan=-7.0))
+    assert bool(torch.isfinite(h[2:]).any())
