@@ -238,11 +238,13 @@ constexpr int kK1Block = K1_BLOCK;  // channels (threads) per workgroup: 185 us 
 // cache: 7 of the 11 ms the launch took.)  A bin is the sum of its G x G samples in (iy, ix) order, each
 // (hy hx) v1 + (hy lx) v2 + (ly hx) v3 + (ly lx) v4, divided by G * G: the arithmetic of roi_align_kernel, same bits
 // (tests/test_api_gpu.py).  The taps are buffer loads with the sample's offset as the scalar operand: no vector instruction
-// goes into addressing.  What bounds the launch is the bytes of the taps through the vector L1 (48 GB per 60 000 ROIs x 256
-// channels at ~5.6 TB/s; the L1 only catches the reuse between neighbouring samples of a row): the four taps of a sample
-// as ONE 16-byte load from a map of quads (f[y][x], f[y][x+1], f[y+1][x], f[y+1][x+1]) moved the same bytes with a quarter
-// of the load instructions and measured 11.1 ms against 8.5 (no reuse left for the L1); staging a ROI's footprint in LDS
-// (each pixel read once, 3.5 x fewer bytes) is what would come next.
+// goes into addressing.  How it got to 3.6 ms per 60 000 ROIs x 256 channels x 7x7 bins (roi_align 9.4 + K1 1.1 as two
+// launches): a table of all 196 samples (offsets and products, 6.3 KB per ROI) streamed 376 MB through the scalar cache -
+// 11.2 ms, 7 of them scalar-cache misses; the separable table 8.7 ms, every sample's four loads followed by a wait (four
+// loads in flight per wave, ~380 ns each); all 56 taps of a sample row requested before the first is used: 3.6 ms, the
+// vector L1 path now at ~18 TB/s of taps.  (The four taps of a sample as ONE 16-byte load from a map of quads
+// (f[y][x], f[y][x+1], f[y+1][x], f[y+1][x+1]): the same bytes, a quarter of the instructions, no reuse left for the L1 -
+// 11.1 ms in the unpipelined form, not kept.)
 struct RoiSource {
   const float* nhwc;      // [B, H, W, C]
   const unsigned* table;  // per ROI: 8 dwords (image, row mask, column mask, 0 ...) + (PH * G + PW * G) x 4 dwords
@@ -264,41 +266,45 @@ __device__ __forceinline__ void roi_load_map(float (&u)[HT * WT], const RoiSourc
   const int voff = c * 4;
   cptr rows = tab + 8, cols = tab + 8 + 4 * (HT * G);
   constexpr float count = (float)(G * G);
-#ifndef ROI_BIN_MAJOR
-#define ROI_BIN_MAJOR 0
-#endif
+  // The column entries first (offsets stay in scalar registers, the weights move to vector registers: a vector multiply
+  // takes one scalar operand, the row's), then per sample row ALL its taps are requested before the first is used: left
+  // to the compiler every sample's four loads were followed by a wait - four loads in flight per wave, 380 ns each,
+  // 8.7 ms per 60 000 ROIs x 256 channels with the load path a sixth busy.
+  constexpr int SX = WT * G, SY = HT * G;
+  unsigned ox_lo[SX], ox_hi[SX];
+  float hx[SX], lx[SX];
+#pragma unroll
+  for (int sx = 0; sx < SX; ++sx) {
+    ox_lo[sx] = cols[4 * sx];
+    ox_hi[sx] = cols[4 * sx + 1];
+    hx[sx] = __uint_as_float(cols[4 * sx + 2]);
+    lx[sx] = __uint_as_float(cols[4 * sx + 3]);
+  }
   float acc[HT * WT];
 #pragma unroll
   for (int p = 0; p < HT * WT; ++p) acc[p] = 0.f;
-  auto sample = [&](int sy, int sx) {
+#pragma unroll
+  for (int sy = 0; sy < SY; ++sy) {
     const unsigned oy_lo = rows[4 * sy], oy_hi = rows[4 * sy + 1];
     const float hy = __uint_as_float(rows[4 * sy + 2]), ly = __uint_as_float(rows[4 * sy + 3]);
-    const unsigned ox_lo = cols[4 * sx], ox_hi = cols[4 * sx + 1];
-    const float hx = __uint_as_float(cols[4 * sx + 2]), lx = __uint_as_float(cols[4 * sx + 3]);
-    // (wave-uniform; outside: offsets are 0 in the table, the value read is replaced by 0 - no branch, the loads move freely)
-    const bool inside = (((row_out >> sy) | (col_out >> sx)) & 1u) == 0u;
-    const float v1 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_lo + ox_lo), 0));
-    const float v2 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_lo + ox_hi), 0));
-    const float v3 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_hi + ox_lo), 0));
-    const float v4 = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_hi + ox_hi), 0));
-    const float w1 = hy * hx, w2 = hy * lx, w3 = ly * hx, w4 = ly * lx;
-    return inside ? w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4 : 0.f;
-  };
-  // a bin receives its samples in (iy, ix) order in either loop order
-  if constexpr (ROI_BIN_MAJOR) {
+    const bool row_in = ((row_out >> sy) & 1u) == 0u;
+    float t[SX][4];
 #pragma unroll
-    for (int ph = 0; ph < HT; ++ph)
+    for (int sx = 0; sx < SX; ++sx) {
+      t[sx][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_lo + ox_lo[sx]), 0));
+      t[sx][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_lo + ox_hi[sx]), 0));
+      t[sx][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_hi + ox_lo[sx]), 0));
+      t[sx][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_hi + ox_hi[sx]), 0));
+    }
+    __builtin_amdgcn_sched_barrier(0);  // (the loads above stay above)
 #pragma unroll
-      for (int pw = 0; pw < WT; ++pw)
-#pragma unroll
-        for (int iy = 0; iy < G; ++iy)
-#pragma unroll
-          for (int ix = 0; ix < G; ++ix) acc[ph * WT + pw] += sample(ph * G + iy, pw * G + ix);
-  } else {
-#pragma unroll
-    for (int sy = 0; sy < HT * G; ++sy)
-#pragma unroll
-      for (int sx = 0; sx < WT * G; ++sx) acc[(sy / G) * WT + (sx / G)] += sample(sy, sx);
+    for (int sx = 0; sx < SX; ++sx) {
+      // (wave-uniform; outside: offsets are 0 in the table, the value read is replaced by 0 - no branch around a load)
+      const bool inside = row_in && ((col_out >> sx) & 1u) == 0u;
+      const float w1 = hy * hx[sx], w2 = hy * lx[sx], w3 = ly * hx[sx], w4 = ly * lx[sx];
+      const float val = inside ? w1 * t[sx][0] + w2 * t[sx][1] + w3 * t[sx][2] + w4 * t[sx][3] : 0.f;
+      acc[(sy / G) * WT + (sx / G)] += val;  // a bin receives its samples in (iy, ix) order
+    }
   }
 #pragma unroll
   for (int p = 0; p < HT * WT; ++p) u[p] = acc[p] / count;
