@@ -704,6 +704,8 @@ def main():
                                    "cpu_rows_per_s": c3.get("cpu_baseline", {}).get("value")}
             torch.cuda.empty_cache()
             stages["cfg4_lared"] = bw.run_cfg4_lared(device)
+            torch.cuda.empty_cache()
+            stages["cfg4_from_feature_maps"] = bw.run_cfg4_from_maps(device)
             stages["seconds"] = round(time.perf_counter() - t_s, 1)
             out["stages"] = stages
         except Exception as e:  # a reported extra; its failure must not lose the headline measurement
