@@ -234,7 +234,12 @@ def main_cfg3(args, device, rank, world, dist, saved_stdout):
                    "k": bw.K_NN, "mahalanobis_fit_rows": rec["fit_rows"], "entry": "postprocess_device (rows resident in HBM)",
                    "gather": "none (1 GPU)" if dist is None else "one all_gather_into_tensor per postprocessor, compute stream",
                    "gather_ms_per_call": round(rec["gather_ms_per_call"], 4),
-                   "setup_fit_s": round(rec["fit_s"], 2), "setup_broadcast_s": round(rec["broadcast_s"], 3)},
+                   "setup_fit_s": round(rec["fit_s"], 2), "setup_broadcast_s": round(rec["broadcast_s"], 3),
+                   "setup": {"mode": rec.get("fit_mode"), "fit_s": None if rec.get("fit_only_s") is None else round(rec["fit_only_s"], 3),
+                             "fit_s_host_calls": None if rec.get("fit_only_s_host_calls") is None else round(rec["fit_only_s_host_calls"], 3),
+                             "note": "setup() of Mahalanobis (covariance + pinvh of 2048 x 2048), KNN (bank) and Energy on host arrays; "
+                                     "device = covariance on the f64 matrix cores + blocked Jacobi pinvh (runia_core_amd.config.device_fit, "
+                                     "default where a GPU is present), host calls = the reference's scikit-learn / SciPy"}},
         "roofline": {"bound": "mfma",
                      "kernel": ("knn_dist_bf16_kernel" if knn.get("piece_products") else "knn_dist_kernel")
                      + " (+ normaliser, piece split and k-th select with exact re-measurement: the whole kNN stage is timed)",
@@ -309,10 +314,27 @@ def main():
     xtr, rtr = synth_latents(args.train_images, 1234, 0.0, device)
     h_train = probe.entropy(probe.stack(xtr, rtr)).cpu().numpy()
     del xtr, rtr
-    np.random.seed(1234)  # sklearn's randomized SVD draws from the global NumPy state
-    red, pca = rc.apply_pca_ds_split(h_train, N_PCA)
-    md = MDLatentSpace()
-    md.setup(red)
+    from runia_core_amd import config as rc_config
+
+    def fit_cfg2():
+        np.random.seed(1234)  # sklearn's randomized SVD draws from the global NumPy state (the device fit makes the same draw)
+        t_f = time.perf_counter()
+        red_, pca_ = rc.apply_pca_ds_split(h_train, N_PCA)
+        md_ = MDLatentSpace()
+        md_.setup(red_)
+        torch.cuda.synchronize()
+        return red_, pca_, md_, time.perf_counter() - t_f
+
+    red, pca, md, setup_s = fit_cfg2()
+    setup_rec = {"mode": "device" if rc_config.use_device_fit() else "host", "fit_s": round(setup_s, 3),
+                 "what": f"apply_pca_ds_split({h_train.shape[0]} x {h_train.shape[1]} -> {N_PCA}, randomized) + MDLatentSpace.setup"}
+    if rc_config.use_device_fit() and rank == 0 and not args.no_cpu_baseline:
+        before = rc_config.device_fit
+        rc_config.device_fit = False  # the reference's own host calls beside it (reported, not used)
+        try:
+            setup_rec["fit_s_host_calls"] = round(fit_cfg2()[3], 3)
+        finally:
+            rc_config.device_fit = before
     pipe = LaREMPipeline(md, pca, N_MC, DROP_PROB, BLOCK)
 
     n = args.images
@@ -491,7 +513,7 @@ def main():
         infer = LaRExInference(torch.nn.Identity(), md, DROP_PROB, BLOCK, N_MC, MCSamplerModule, pca_transform=pca)
         infer.mc_sampler.use_counter_draws(seed=2026, redraw_dead_layers=True)
         k_api = max(10, min(args.steps, 200))
-        infer.get_scores_from_latents(sets[0][0], to_host=False)  # folds the weights (host eigh): the GPU idles meanwhile
+        infer.get_scores_from_latents(sets[0][0], to_host=False)  # folds the weights (device Jacobi eigh, pipeline.py): the GPU idles meanwhile
         t_spin = time.perf_counter()
         while time.perf_counter() - t_spin < args.clock_warmup:   # ... so bring the clocks back up, as before the main region
             for i in range(50):
@@ -582,7 +604,7 @@ def main():
                              "host-supplied (N,16,4,4) f32 tensors, resident in HBM before the timed region"),
                    "input_sets_rotated": n_sets, "input_bytes_per_set": int(x.numel() * 4 + rand.numel() * 4),
                    "pipelining": "batch i+1 K1 overlaps batch i K2 (two HIP streams)" if args.overlap else "none (one stream)",
-                   "clock_warmup_s": args.clock_warmup,
+                   "clock_warmup_s": args.clock_warmup, "setup": setup_rec,
                    "keep_flag_table": ("built for batch i+1 on a side stream while batch i is scored (prepare_draws)" if k0_ahead
                                        else "built in line on the compute stream"),
                    "gather": ("none (1 GPU)" if not use_dist else

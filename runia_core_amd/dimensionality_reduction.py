@@ -109,7 +109,7 @@ def apply_pca_ds_split(samples: np.ndarray, nro_components: int = 16, svd_solver
     as sklearn, same result) - and a ``FittedPCA`` with the same public attributes is returned."""
     from . import config
 
-    if config.device_fit and isinstance(nro_components, int):
+    if config.use_device_fit() and isinstance(nro_components, int):
         from .device_fit import pca_fit_device, pca_fit_randomized_device
 
         shape = np.shape(samples)

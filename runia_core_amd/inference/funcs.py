@@ -50,7 +50,7 @@ def mahalanobis_preprocess(ind_data: Dict[str, np.ndarray], num_classes: int) ->
         centered.append(class_samples - class_mean[c].reshape(1, -1))
     class_mean = np.stack(class_mean)
     pooled = np.concatenate(centered).astype(np.float32)
-    if config.device_fit:
+    if config.use_device_fit():
         return class_mean, empirical_precision_device(pooled)
     estimator = EmpiricalCovariance(assume_centered=False)
     estimator.fit(pooled)

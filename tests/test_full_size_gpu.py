@@ -197,7 +197,6 @@ def test_fused_larem_from_latents_sizes_and_boundaries(hip, n):
     from runia_core_amd._hip import CounterDraws
 
     sc = pipe.score_latents(x, CounterDraws(5, 1_000_000))
-    assert bool(torch.isfinite(sc).all() | True)  # a fully dropped map is NaN by definition; equality below is the check
     a, b = n - 3333, n - 1
     part = pipe.score_latents(x[a:b].contiguous(), CounterDraws(5, 1_000_000 + a))
     assert torch.equal(torch.nan_to_num(part, nan=1.0), torch.nan_to_num(sc[a:b], nan=1.0))

@@ -28,4 +28,4 @@ for n_comp in (16, 32, 64, 128, 256):
         else:
             err = float(np.max(np.abs(s - ref) / np.maximum(1.0, np.abs(ref))))
         print(f"{n_comp:6d} {mode:>8s} {t1 - t0:10.3f} {t2 - t1:9.3f} {t2 - t0:8.3f}   {err:.1e}", flush=True)
-config.device_fit = False
+config.device_fit = None

@@ -81,8 +81,9 @@ def _rel(a, b):
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
 
 
-def fit_cfg3(device, fit_rows: int, centres, w, b):
+def fit_cfg3(device, fit_rows: int, centres, w, b, time_host_fit: bool = False):
     """setup() of the three postprocessors exactly as a user of the reference would call it (host arrays in)."""
+    from runia_core_amd import config as rc_config
     from runia_core_amd.inference.postprocessors import KNN, Energy, Mahalanobis
 
     t0 = time.perf_counter()
@@ -90,13 +91,30 @@ def fit_cfg3(device, fit_rows: int, centres, w, b):
     f_val, _ = feature_rows(BANK_ROWS, BANK_ROWS + 2 * GEN_BLOCK, 1, device, centres)
     f_val = f_val[:2048]
     tr_host, lab_host, val_host = f_tr.cpu().numpy(), lab_tr.cpu().numpy(), f_val.cpu().numpy()
-    maha = Mahalanobis(flip_sign=False, num_classes=N_CLASSES)
-    maha.setup(tr_host[:fit_rows], train_labels=lab_host[:fit_rows], valid_feats=val_host)
-    knn = KNN(flip_sign=False, k_neighbors=K_NN)
-    knn.setup(tr_host, valid_feats=val_host)
-    energy = Energy(flip_sign=False)
-    energy.setup(logits_of(f_tr[:8192], w, b).cpu().numpy())
-    return {"mahalanobis": maha, "knn": knn, "energy": energy, "fit_s": time.perf_counter() - t0}
+    t_data = time.perf_counter() - t0
+
+    def fit():
+        t1 = time.perf_counter()
+        maha = Mahalanobis(flip_sign=False, num_classes=N_CLASSES)
+        maha.setup(tr_host[:fit_rows], train_labels=lab_host[:fit_rows], valid_feats=val_host)
+        knn = KNN(flip_sign=False, k_neighbors=K_NN)
+        knn.setup(tr_host, valid_feats=val_host)
+        energy = Energy(flip_sign=False)
+        energy.setup(logits_of(f_tr[:8192], w, b).cpu().numpy())
+        torch.cuda.synchronize()
+        return maha, knn, energy, time.perf_counter() - t1
+
+    maha, knn, energy, t_fit = fit()  # as configured (default: the device when there is one)
+    rec = {"mahalanobis": maha, "knn": knn, "energy": energy, "fit_s": t_data + t_fit,
+           "fit_mode": "device" if rc_config.use_device_fit() else "host", "fit_only_s": t_fit}
+    if time_host_fit and rc_config.use_device_fit():  # the reference's own host calls beside it (reported, not used)
+        before = rc_config.device_fit
+        rc_config.device_fit = False
+        try:
+            rec["fit_only_s_host_calls"] = fit()[3]
+        finally:
+            rc_config.device_fit = before
+    return rec
 
 
 def run_cfg3(device, rank: int, world: int, dist, rows_total: int, fit_rows: int, steps: int, warmup: int,
@@ -109,7 +127,7 @@ def run_cfg3(device, rank: int, world: int, dist, rows_total: int, fit_rows: int
     use_dist = dist is not None
     centres = class_centres(device)
     w, b = linear_head(device)
-    fitted = fit_cfg3(device, fit_rows, centres, w, b) if rank == 0 else None
+    fitted = fit_cfg3(device, fit_rows, centres, w, b, time_host_fit=(world == 1 and cpu_legs)) if rank == 0 else None
     t_b = time.perf_counter()
     if use_dist:
         fitted = broadcast_fitted(fitted, src=0)
@@ -170,7 +188,9 @@ def run_cfg3(device, rank: int, world: int, dist, rows_total: int, fit_rows: int
     gather_ms = float(np.mean([x.elapsed_time(y) for x, y in gather_events])) if gather_events else 0.0
     rec = {"elapsed": elapsed, "rows_total": rows_total, "rows_local": n_loc, "steps": steps,
            "ms_per_step": 1e3 * elapsed / steps, "value": rows_total * steps / elapsed, "stage_ms": ms,
-           "gather_ms_per_call": gather_ms, "fit_s": fitted["fit_s"], "broadcast_s": bcast_s, "fit_rows": fit_rows}
+           "gather_ms_per_call": gather_ms, "fit_s": fitted["fit_s"], "broadcast_s": bcast_s, "fit_rows": fit_rows,
+           "fit_mode": fitted.get("fit_mode"), "fit_only_s": fitted.get("fit_only_s"),
+           "fit_only_s_host_calls": fitted.get("fit_only_s_host_calls")}
     if rank != 0:
         return rec
 
