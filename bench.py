@@ -433,6 +433,10 @@ def main():
         step()
     if use_dist:
         assert step().shape == (world * n,)
+    gather_info = None
+    if use_dist:
+        gather_info = {"requested": args.gather_stream, "trial_ms_per_step": None, "one_shot_candidate": one_shot is not None,
+                       "one_shot_agrees_with_rccl": None}
     if use_dist and args.gather_stream == "auto" and not args.overlap:
         # untimed: which placement of the collective is faster on this node?  (one-GPU rehearsal: same stream
         # +9 us, side stream +23 us per step; with real peers the same-stream form also exposes the ring latency)
@@ -449,6 +453,7 @@ def main():
             except _hip.RuniaHipError:
                 agree.zero_()
             dist.all_reduce(agree, op=dist.ReduceOp.MIN)
+            gather_info["one_shot_agrees_with_rccl"] = float(agree.item()) == 1.0
             if float(agree.item()) == 1.0:
                 kinds.append("p2p")
         trial = {k: float("inf") for k in kinds}
@@ -467,6 +472,8 @@ def main():
             trial[kind] = min(trial[kind], float(t_m.item()))
         best = min(kinds, key=lambda k: trial[k])
         gather_mode["kind"] = best if trial[best] < 0.98 * trial["same"] else "same"  # the simplest form unless clearly slower
+        gather_info["trial_ms_per_step"] = {k: round(trial[k] / 30 * 1e3, 4) for k in kinds}
+        gather_info["trial"] = "best of 3 interleaved runs of 30 steps per form, MAX over ranks; a form replaces `same` only if > 2 % faster"
         if rank == 0:
             print("gather trial: " + ", ".join(f"{k} {trial[k] / 30 * 1e3:.4f} ms/step" for k in kinds) +
                   f" -> {gather_mode['kind']}", file=sys.stderr)
@@ -486,9 +493,24 @@ def main():
     elapsed = time.perf_counter() - t0
     last_set = (args.steps - 1) % n_sets
     if use_dist:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        mine = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        parts = [torch.empty_like(mine) for _ in range(world)]
+        dist.all_gather(parts, mine)  # every rank's own clock around the same K steps (the line reports the MAX)
+        every = torch.cat(parts)
+        elapsed = float(every.max().item())
+        gather_info["chosen"] = gather_mode["kind"]
+        gather_info["per_rank_ms_per_step"] = [round(1e3 * float(v) / args.steps, 4) for v in every.tolist()]
+        # the same steps without their collective, right after the timed region: what the gather costs on this node
+        dist.barrier()
+        torch.cuda.synchronize()
+        t_n = time.perf_counter()
+        for i in range(min(args.steps, 200)):
+            step(collective=False)
+        torch.cuda.synchronize()
+        t_n = torch.tensor([time.perf_counter() - t_n], dtype=torch.float64, device=device)
+        dist.all_reduce(t_n, op=dist.ReduceOp.MAX)
+        gather_info["ms_per_step_without_gather"] = round(1e3 * float(t_n.item()) / min(args.steps, 200), 4)
+        gather_info["gather_ms_per_step"] = round(1e3 * elapsed / args.steps - gather_info["ms_per_step_without_gather"], 4)
 
     if one_shot is not None:
         if gather_mode["kind"] == "p2p":
@@ -614,6 +636,8 @@ def main():
                              (" (chosen by the warm-up trial)" if (use_dist and args.gather_stream == "auto") else "")},
         "roofline": roofline,
     }
+    if gather_info is not None:
+        out["gather"] = gather_info
     if api is not None:
         out["api_level"] = api
     if world == 1 and not args.no_cpu_baseline and not counter:

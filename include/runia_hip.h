@@ -379,6 +379,10 @@ int runia_p2p_close(void* peer_buffer);
 int runia_p2p_all_gather(const void* local_shard, size_t shard_bytes, void* out, void* const* peer_buffers, int world,
                          int rank, size_t shard_capacity_bytes, uint64_t seq, int timeout_ms, runia_stream_t stream);
 int runia_p2p_status(void* buffer, int* status);
+/* runia_p2p_debug(1): the launches that follow ASSERT the ordering argument slot reuse rests on - a writer reads, over the
+ * link, the step its peer last copied out of the slot and expects exactly seq - 2; a mismatch sets bit 1 (value 2) of the
+ * status word.  Every rank of a group must switch it alike.  Returns the previous setting; off by default. */
+int runia_p2p_debug(int on);
 
 /* ---- f4  remaining logits/features postprocessors (SURVEY 8f "next #4") ------- *
  * runia_linear_f32: out [N, C] = min(x, clip_max) @ w.T + bias on the f32 matrix cores - the final linear layer

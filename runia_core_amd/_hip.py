@@ -133,6 +133,7 @@ _SIGNATURES = {
     "runia_p2p_all_gather": (
         c_int, [c_void_p, c_size_t, c_void_p, ctypes.POINTER(c_void_p), c_int, c_int, c_size_t, c_uint64, c_int, c_void_p]),
     "runia_p2p_status": (c_int, [c_void_p, ctypes.POINTER(c_int)]),
+    "runia_p2p_debug": (c_int, [c_int]),
     "runia_centred_gram_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
     "runia_roi_align_f32": (
         c_int,

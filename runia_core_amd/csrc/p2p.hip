@@ -27,6 +27,15 @@ constexpr size_t kHeader = 4096;
 constexpr size_t kFlagsBytes = 2 * kMaxRanks * sizeof(unsigned long long);  // 1 024
 constexpr size_t kStatusOff = kFlagsBytes;                                    // u32 status (0 ok, 1 timed out)
 constexpr size_t kDoneOff = kFlagsBytes + 64;                                 // u32 [2][kMaxRanks] block counters
+constexpr size_t kCopyDoneOff = kDoneOff + 2 * kMaxRanks * sizeof(unsigned);  // u32 [2][kMaxRanks] copy-out part counters
+constexpr size_t kAckOff = kCopyDoneOff + 2 * kMaxRanks * sizeof(unsigned);   // u64 [2][kMaxRanks] last step copied out of (slot, source)
+static_assert(kAckOff + 2 * kMaxRanks * sizeof(unsigned long long) <= kHeader, "header layout");
+// Slot reuse rests on an ordering argument (top of the file): rank A overwrites peer B's slot at step s only after A's own
+// step s - 1 launch, which waited for B's flag s - 1, which B's stream raised after B's step s - 2 copy-out.  With the
+// check switched on (runia_p2p_debug) the argument is ASSERTED: every copy-out records the step it finished in the
+// reader's buffer (ack[slot][source]), and a writer reads the peer's ack over the link before it touches the slot - it has
+// to be exactly s - 2, else status bit 1 (value 2) is set.  Costs one remote read per push; off by default.
+std::atomic<int> g_debug{0};
 
 struct PeerTable { char* buf[16]; };  // by value in the kernel arguments (world <= 16)
 
@@ -36,8 +45,13 @@ std::unordered_map<void*, int> g_opened;      // peer mappings of this process
 
 __device__ __forceinline__ void p2p_push(const char* __restrict__ shard, size_t shard_bytes, size_t cap,
                                          const PeerTable& peers, char* self, int world, int rank, unsigned long long seq,
-                                         int blocks_per_peer, int p, int j) {
+                                         int blocks_per_peer, int p, int j, int debug) {
   const int slot = (int)(seq & 1ull);
+  if (debug && j == 0 && threadIdx.x == 0 && seq > 2ull) {  // the peer has copied my step seq - 2 out of this slot
+    const unsigned long long* ack = reinterpret_cast<const unsigned long long*>(peers.buf[p] + kAckOff) + slot * kMaxRanks + rank;
+    if (__hip_atomic_load(ack, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != seq - 2ull)
+      atomicOr(reinterpret_cast<unsigned*>(self + kStatusOff), 2u);
+  }
   char* dst = peers.buf[p] + kHeader + (size_t)slot * (size_t)world * cap + (size_t)rank * cap;
   const size_t chunk = ((shard_bytes + blocks_per_peer - 1) / blocks_per_peer + 15) & ~(size_t)15;
   const size_t lo = (size_t)j * chunk, hi = (lo + chunk < shard_bytes) ? lo + chunk : shard_bytes;
@@ -68,7 +82,7 @@ __device__ __forceinline__ void p2p_push(const char* __restrict__ shard, size_t 
 
 __device__ __forceinline__ void p2p_wait_copy(char* self, char* __restrict__ out, size_t shard_bytes, size_t cap,
                                               int world, unsigned long long seq, long long timeout_ticks, int r, int part,
-                                              int parts) {
+                                              int parts, int debug) {
   const int slot = (int)(seq & 1ull);
   __shared__ int ok;
   if (threadIdx.x == 0) {
@@ -79,7 +93,7 @@ __device__ __forceinline__ void p2p_wait_copy(char* self, char* __restrict__ out
       __builtin_amdgcn_s_sleep(8);
       if (wall_clock64() - t0 > timeout_ticks) {  // a peer never arrived: report, do not hang
         good = 0;
-        atomicExch(reinterpret_cast<unsigned*>(self + kStatusOff), 1u);
+        atomicOr(reinterpret_cast<unsigned*>(self + kStatusOff), 1u);
         break;
       }
     }
@@ -104,6 +118,18 @@ __device__ __forceinline__ void p2p_wait_copy(char* self, char* __restrict__ out
     }
   }
   (void)ok;
+  if (debug) {  // the last part of this shard's copy-out records the step (see g_debug)
+    __threadfence_system();
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      unsigned* cd = reinterpret_cast<unsigned*>(self + kCopyDoneOff) + slot * kMaxRanks + r;
+      if (atomicAdd(cd, 1u) + 1u == (unsigned)parts) {
+        atomicExch(cd, 0u);
+        unsigned long long* ack = reinterpret_cast<unsigned long long*>(self + kAckOff) + slot * kMaxRanks + r;
+        __hip_atomic_store(ack, seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+  }
 }
 
 // ONE launch: blocks [0, world * bpp) push this rank's shard to the peers, blocks [world * bpp, world * bpp + world) wait
@@ -113,15 +139,15 @@ __device__ __forceinline__ void p2p_wait_copy(char* self, char* __restrict__ out
 __global__ __launch_bounds__(256) void p2p_gather_kernel(const char* __restrict__ shard, size_t shard_bytes, size_t cap,
                                                          PeerTable peers, char* self, char* __restrict__ out, int world,
                                                          int rank, unsigned long long seq, int blocks_per_peer,
-                                                         long long timeout_ticks) {
+                                                         long long timeout_ticks, int debug) {
   const int push_blocks = world * blocks_per_peer;
   if ((int)blockIdx.x < push_blocks) {
     p2p_push(shard, shard_bytes, cap, peers, self, world, rank, seq, blocks_per_peer, (int)blockIdx.x / blocks_per_peer,
-             (int)blockIdx.x % blocks_per_peer);
+             (int)blockIdx.x % blocks_per_peer, debug);
   } else {
     const int w = (int)blockIdx.x - push_blocks;  // the copy-out of a shard is cut like its push
     p2p_wait_copy(self, out, shard_bytes, cap, world, seq, timeout_ticks, w / blocks_per_peer, w % blocks_per_peer,
-                  blocks_per_peer);
+                  blocks_per_peer, debug);
   }
 }
 
@@ -224,11 +250,17 @@ extern "C" int runia_p2p_all_gather(const void* local_shard, size_t shard_bytes,
   const long long ticks = (long long)timeout_ms * 100000ll;  // wall_clock64 runs at 100 MHz
   p2p_gather_kernel<<<(unsigned)(2 * world * bpp), 256, 0, s>>>(reinterpret_cast<const char*>(local_shard), shard_bytes,
                                                                      cap, t, self, reinterpret_cast<char*>(out), world, rank,
-                                                                     (unsigned long long)seq, bpp, ticks);
+                                                                     (unsigned long long)seq, bpp, ticks,
+                                                                     g_debug.load(std::memory_order_relaxed));
   return runia_check_launch();
 }
 
-// 0 = every wait so far saw its flags; 1 = a wait timed out (a peer never arrived).  Synchronises the device.
+// Switch the slot-reuse assertion on / off for the launches that follow (every rank of a group alike: the writers read
+// what the readers record).  Returns the previous setting.
+extern "C" int runia_p2p_debug(int on) { return g_debug.exchange(on ? 1 : 0); }
+
+// Bit 0 (1): a wait timed out (a peer never arrived); bit 1 (2): the slot-reuse assertion of runia_p2p_debug failed.
+// 0 = neither so far.  Synchronises the device.
 extern "C" int runia_p2p_status(void* buffer, int* status) {
   if (!status) return RUNIA_E_INVALID;
   {

@@ -353,8 +353,18 @@ class OneShotGather:
 
         status = ctypes.c_int(0)
         _hip._check(self._lib.runia_p2p_status(self._own, ctypes.byref(status)), "runia_p2p_status")
+        if status.value & 2:
+            raise _hip.RuniaHipError("OneShotGather: slot-reuse assertion failed - a slot was overwritten before the peer had "
+                                     "copied the step before last out of it (runia_p2p_debug)")
         if status.value != 0:
             raise _hip.RuniaHipError("OneShotGather: a wait timed out - a peer never delivered its shard")
+
+    @staticmethod
+    def set_debug(on: bool) -> bool:
+        """Switch the slot-reuse assertion of the gather launches on / off (every rank alike); returns the previous setting."""
+        from . import _hip
+
+        return bool(_hip.load_library().runia_p2p_debug(1 if on else 0))
 
     def __del__(self):  # best effort for a gather that was never closed: no collective here, just the local resources
         try:

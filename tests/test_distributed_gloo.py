@@ -21,6 +21,12 @@ def test_shard_bounds_cover_rows_exactly():
                 assert b0 == a1 and a0 <= b0
             per = -(-n // world) if n else 0
             assert all(b - a <= per for a, b in blocks)
+    # the sizes of the driver's runs: cfg3's 1 M rows over 8 GPUs (125 000 each), cfg2's 8 x 10 000, and 9 rows over 8
+    # ranks (blocks of 2: four full, one of a single row, three empty tails)
+    assert [shard_bounds(1_000_000, 8, r) for r in range(8)] == [(125_000 * r, 125_000 * (r + 1)) for r in range(8)]
+    assert [b - a for a, b in (shard_bounds(1_000_001, 8, r) for r in range(8))] == [125_001] * 7 + [124_994]
+    assert [shard_bounds(9, 8, r) for r in range(8)] == [(0, 2), (2, 4), (4, 6), (6, 8), (8, 9), (9, 9), (9, 9), (9, 9)]
+    assert [shard_bounds(80_000, 8, r)[1] - shard_bounds(80_000, 8, r)[0] for r in range(8)] == [10_000] * 8
 
 
 def _free_port():
@@ -70,9 +76,9 @@ def _worker(rank, world, port, n_rows, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("n_rows", [7, 8, 1, 0])
-def test_sharded_scoring_world2_gloo(tmp_path, n_rows):
-    world = 2
+@pytest.mark.parametrize("world,n_rows", [(2, 7), (2, 8), (2, 1), (2, 0), (4, 9), (8, 9), (8, 3)])
+def test_sharded_scoring_gloo(tmp_path, world, n_rows):
+    """world 2, 4 and 8 (the driver's 8-GPU shape: 9 rows = four blocks of two, one single row, three empty tails)."""
     mp.spawn(_worker, args=(world, _free_port(), n_rows, str(tmp_path)), nprocs=world, join=True)
     rows = np.random.default_rng(5).standard_normal((n_rows, 6))
     exp = rows.sum(axis=1)

@@ -1,6 +1,7 @@
-"""Two ranks, real kernels: the N > 1 path of SURVEY 8(e) on the one GPU a test box has.
+"""Two and four ranks, real kernels: the N > 1 path of SURVEY 8(e) on the one GPU a test box has (its process guard allows six
+processes on the card: four ranks + the test runner).
 
-RCCL refuses two ranks on one device, so the two processes share ``cuda:0`` over gloo (score shards are staged through
+RCCL refuses two ranks on one device, so the processes share ``cuda:0`` over gloo (score shards are staged through
 the host by ``gather_scores``); everything else - fitting on rank 0, ``broadcast_fitted`` with the arrays sent as
 tensors, ``shard_bounds``, the HIP kernels on each rank's block, the single gather per postprocessor - is the code an
 8-GPU RCCL job runs.  Sharded scores must equal the unsharded bits (rows are independent and every kernel scores a row
@@ -17,7 +18,7 @@ import torch.multiprocessing as mp
 pytestmark = pytest.mark.gpu
 
 N_MC, C, HW, N_PCA = 16, 64, 4, 16
-SIZES = (1001, 3, 1)  # uneven blocks (501 + 500), a one-row tail, an empty tail shard
+SIZES = (1001, 9, 3, 1)  # uneven blocks, 9 rows (four ranks: 3 + 3 + 3 + 0), fewer rows than ranks: empty tail shards
 
 
 def _free_port():
@@ -85,18 +86,19 @@ def _worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_two_ranks_real_kernels_equal_unsharded_bits(tmp_path):
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_ranks_real_kernels_equal_unsharded_bits(tmp_path, world):
     mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    g0, g1 = np.load(tmp_path / "g0.npz"), np.load(tmp_path / "g1.npz")
+    gs = [np.load(tmp_path / f"g{r}.npz") for r in range(world)]
+    g0 = gs[0]
     for n in SIZES:
         for name, dt in (("larem", np.float64), ("maha", np.float64), ("knn", np.float32)):
             full = g0[f"{name}_full_{n}"]
             assert full.shape == (n,) and full.dtype == dt and np.isfinite(full).all()
-            for g in (g0, g1):
+            for g in gs:
                 got = g[f"{name}_{n}"]
-                assert got.dtype == dt and np.array_equal(got, full), (name, n)
-        for g in (g0, g1):
+                assert got.dtype == dt and np.array_equal(got, full), (name, n, world)
+        for g in gs:
             assert g[f"knn_host_{n}"].dtype == np.float32 and np.array_equal(g[f"knn_host_{n}"], g0[f"knn_full_{n}"])
 
 
@@ -110,10 +112,11 @@ def _p2p_worker(rank, world, port, out_dir):
         from runia_core_amd.distributed import OneShotGather, gather_scores, shard_bounds
 
         ok = True
+        OneShotGather.set_debug(True)  # every launch asserts that the slot it overwrites was copied out two steps ago
         g64 = OneShotGather(5000, torch.float64, timeout_ms=5000)
         g32 = OneShotGather(300_000, torch.float32, timeout_ms=5000)
         kept = []
-        for step, n in enumerate((10_000, 9_999, 7, 2, 10_000, 10_000, 3)):
+        for step, n in enumerate((5_000 * world, 9_999, 7, 2, 5_000 * world, 5_000 * world, 3, 1)):
             a, b = shard_bounds(n, world, rank)
             full = torch.arange(n, dtype=torch.float64, device="cuda") * 0.5 + 1000.0 * step
             got = g64(full[a:b].clone(), n)
@@ -123,13 +126,14 @@ def _p2p_worker(rank, world, port, out_dir):
             if len(kept) >= 2:  # a gathered vector stays valid until the call after the next one
                 prev_got, prev_full = kept[-2]
                 ok = ok and bool(torch.equal(prev_got, prev_full))
-        for step, n in enumerate((600_000, 599_999, 1)):  # several copy blocks per peer; an odd shard (4-byte granularity)
+        # several copy blocks per peer; an odd shard (4-byte granularity); cfg3's shard of an 8-GPU job (125 000 rows per rank)
+        for step, n in enumerate((600_000 // 2 * world, 599_999, 1, 125_000 * world, 9)):
             a, b = shard_bounds(n, world, rank)
             full = (torch.arange(n, dtype=torch.float32, device="cuda") % 4093) + step
             got = g32(full[a:b].clone(), n)
             ok = ok and bool(torch.equal(got, full))
         # back-to-back calls without any host synchronisation in between
-        n = 10_000
+        n = 5_000 * world
         a, b = shard_bounds(n, world, rank)
         outs = []
         for i in range(40):
@@ -140,7 +144,7 @@ def _p2p_worker(rank, world, port, out_dir):
         g64.check()
         g32.check()
         try:
-            g64(torch.zeros(6000, dtype=torch.float64, device="cuda"), 12_000)
+            g64(torch.zeros(6000, dtype=torch.float64, device="cuda"), 6_000 * world)
             refused = False
         except ValueError:
             refused = True
@@ -151,11 +155,13 @@ def _p2p_worker(rank, world, port, out_dir):
         dist.destroy_process_group()
 
 
-def test_one_shot_p2p_gather_two_ranks(tmp_path):
+@pytest.mark.parametrize("world", [2, 4])
+def test_one_shot_p2p_gather_ranks(tmp_path, world):
     """`OneShotGather` (csrc/p2p.hip: shards written straight into the peers' IPC-mapped buffers + flags, then a wait-and-copy
-    launch) between two processes sharing the GPU: equal to `gather_scores`, even / uneven / tiny / multi-block shards, f64
-    and f32, 40 calls in flight without a host synchronisation, status clean, capacity overflow refused."""
-    world = 2
+    launch) between two and four processes sharing the GPU: equal to `gather_scores`, even / uneven / tiny / empty / multi-block
+    shards (9 rows and 1 row over four ranks; cfg3's 125 000-row shards), f64 and f32, 40 calls in flight without a host
+    synchronisation, status clean - including the slot-reuse assertion of runia_p2p_debug, switched on for every launch -,
+    capacity overflow refused."""
     mp.spawn(_p2p_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
     for r in range(world):
         g = np.load(tmp_path / f"p{r}.npz")
