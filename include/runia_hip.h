@@ -177,6 +177,11 @@ int runia_knn_kth_f32(const float* q, const float* bank, float* score, void* wor
  *   train [M, D] f64, x [N, D] f64, score [N] f64 */
 int runia_kde_score_f64(const double* train, const double* x, double* score, int64_t M, int64_t N,
                         int64_t D, double bandwidth, runia_stream_t stream);
+/* runia_kde_score_kernel_f64: the same log-density for every kernel sklearn's KernelDensity offers (DetectorKDE(kernel=...)
+ * forwards any, inference/postprocessors.py:78-128): kind 0 gaussian (= runia_kde_score_f64), 1 tophat, 2 epanechnikov,
+ * 3 exponential, 4 linear, 5 cosine, with sklearn's normalisation; a query with no training row in range scores -inf. */
+int runia_kde_score_kernel_f64(const double* train, const double* x, double* score, int64_t M, int64_t N, int64_t D,
+                               double bandwidth, int kind, runia_stream_t stream);
 /* The same log-density with the pair distances on the f64 matrix cores, |x - t|^2 = |x|^2 + |t|^2 - 2 x.t (for
  * wide embeddings, D > 64): packed_train_t = runia_pack_weights_f64 of train^T [D, M] and train_sqnorm [M] =
  * runia_row_sqnorm_f64(train), both made once at setup; workspace: N doubles (the query norms).  The logsumexp over

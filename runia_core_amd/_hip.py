@@ -60,6 +60,7 @@ _SIGNATURES = {
     ),
     "runia_row_lse_msp_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "runia_l2_normalize_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "runia_kde_score_kernel_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_double, c_int, c_void_p]),
     "runia_knn_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int64, c_int]),
     "runia_knn_piece_products": (c_int, [c_int64, c_int64, c_int64]),
     "runia_knn_bank_state_bytes": (c_size_t, [c_int64, c_int64]),
@@ -1140,3 +1141,20 @@ def roi_mc_entropy(x_nhwc: torch.Tensor, boxes: torch.Tensor, output_size, spati
             float(spatial_scale), int(sampling_ratio), 1 if aligned else 0, int(n_mc), float(drop_prob), int(block_size), int(k),
             float(min_dist), _stream()), "runia_roi_mc_entropy_f32")
     return (h, z) if return_samples else h
+
+
+KDE_KERNELS = ("gaussian", "tophat", "epanechnikov", "exponential", "linear", "cosine")
+
+
+def kde_score_kernel(train: torch.Tensor, x: torch.Tensor, bandwidth: float, kernel: str) -> torch.Tensor:
+    """log-density of ``x`` [N, D] under a kernel density estimate on ``train`` [M, D] (both f64) for any of sklearn's
+    kernels (``KDE_KERNELS``) with sklearn's normalisation -> [N] f64."""
+    lib = load_library()
+    require_gpu()
+    assert kernel in KDE_KERNELS, f"unknown kernel {kernel!r}"
+    assert train.is_cuda and x.is_cuda and train.dtype == torch.float64 and x.dtype == torch.float64
+    train, x = train.contiguous(), x.contiguous()
+    s = torch.empty((x.shape[0],), dtype=torch.float64, device=x.device)
+    _check(lib.runia_kde_score_kernel_f64(train.data_ptr(), x.data_ptr(), s.data_ptr(), train.shape[0], x.shape[0], train.shape[1],
+                                          float(bandwidth), KDE_KERNELS.index(kernel), _stream()), "runia_kde_score_kernel_f64")
+    return s

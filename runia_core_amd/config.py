@@ -23,3 +23,10 @@ def use_device_fit() -> bool:
 # scores are the same bits either way; False keeps the f32 matrix-core kernel (by handing the entry point the smaller
 # workspace).
 knn_bf16_candidates = True
+
+# BASELINE config 1 ("MSP postprocessor, 10k test images on CPU, no GPU"): there is NO silent CPU fallback anywhere in
+# this package - scoring without a GPU raises RuniaHipError.  This switch is the explicit exception for the logits
+# family only (MSP, Energy): set it to True on a box without a GPU and their scores come from the reference's own host
+# calls (scipy.special.softmax / logsumexp, inference/postprocessors.py:549, 606).  Ignored where a GPU is present
+# (the HIP kernels always run there); every other postprocessor still raises without one.
+host_logits_without_gpu = False

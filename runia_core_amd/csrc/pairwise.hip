@@ -798,6 +798,47 @@ __global__ __launch_bounds__(256) void kde_kernel(const double* __restrict__ tra
   }
 }
 
+// The other kernels sklearn's KernelDensity offers (DetectorKDE(kernel=...) forwards any of them, reference
+// inference/postprocessors.py:78-128): tophat, epanechnikov, exponential, linear, cosine - values in [0, 1], so the
+// density is a plain f64 sum over the training rows (one wave per training row, fixed order), then one log.
+// KIND: 1 tophat [d < h], 2 epanechnikov 1 - d^2 / h^2, 3 exponential exp(-d / h), 4 linear 1 - d / h, 5 cosine
+// cos(pi d / 2 h); compact kernels are 0 from d >= h on (sklearn's strict d < h).  No training row in range: log(0) = -inf.
+template <int KIND>
+__global__ __launch_bounds__(256) void kde_other_kernel(const double* __restrict__ train, const double* __restrict__ x,
+                                                         double* __restrict__ score, int64_t M, int64_t N, int64_t D, double h,
+                                                         double log_norm) {
+  extern __shared__ double xs[];  // D doubles
+  __shared__ double wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  for (int64_t row = blockIdx.x; row < N; row += gridDim.x) {
+    __syncthreads();
+    for (int64_t i = tid; i < D; i += 256) xs[i] = x[row * D + i];
+    __syncthreads();
+    double s = 0.0;
+    for (int64_t m = wave; m < M; m += 4) {
+      const double* t = train + m * D;
+      double acc = 0.0;
+      for (int64_t i = lane; i < D; i += 64) {
+        const double d = xs[i] - t[i];
+        acc += d * d;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) acc += shfl_xor_f64(acc, o);
+      const double dist = sqrt(acc);
+      double kv;
+      if (KIND == 1) kv = dist < h ? 1.0 : 0.0;
+      else if (KIND == 2) kv = dist < h ? 1.0 - (dist * dist) / (h * h) : 0.0;
+      else if (KIND == 3) kv = exp(-dist / h);
+      else if (KIND == 4) kv = dist < h ? 1.0 - dist / h : 0.0;
+      else kv = dist < h ? cos(0.5 * M_PI * dist / h) : 0.0;
+      s += kv;
+    }
+    if (lane == 0) wsum[wave] = s;
+    __syncthreads();
+    if (tid == 0) score[row] = log((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + log_norm;
+  }
+}
+
 // Gaussian KDE for D <= 64 (the regime where the reference's tree evaluation is converged): one thread
 // owns one query with its D coordinates in registers; training rows are staged through LDS and read as broadcasts;
 // the four waves of a workgroup take a quarter of every staged tile each and merge their (max, sum) pairs at the end.
@@ -1468,6 +1509,51 @@ extern "C" int runia_kde_score_f64(const double* train, const double* x, double*
     const size_t shmem = (size_t)D * sizeof(double);
     if (shmem > 64 * 1024) return RUNIA_E_INVALID;
     kde_kernel<<<runia_stream_grid(N, 1), 256, shmem, s>>>(train, x, score, M, N, D, nh, log_norm);
+  }
+  return runia_check_launch();
+}
+
+// log of sklearn's kernel normalisation (neighbors/_binary_tree.pxi.tp, _log_kernel_norm): -factor - d log h
+static double kde_log_norm(int kind, int64_t D, double h) {
+  const double d = (double)D, log_pi = log(M_PI), log_2pi = log(2.0 * M_PI);
+  auto logVn = [&](double n) { return 0.5 * n * log_pi - lgamma(0.5 * n + 1.0); };  // volume of the unit n-ball
+  auto logSn = [&](double n) { return log_2pi + logVn(n - 1.0); };                   // surface of the unit n-sphere
+  double factor = 0.0;
+  switch (kind) {
+    case 0: factor = 0.5 * d * log_2pi; break;
+    case 1: factor = logVn(d); break;
+    case 2: factor = logVn(d) + log(2.0 / (d + 2.0)); break;
+    case 3: factor = logSn(d - 1.0) + lgamma(d); break;
+    case 4: factor = logVn(d) - log(d + 1.0); break;
+    default: {
+      double tmp = 2.0 / M_PI;
+      for (int64_t k = 1; k < D + 1; k += 2) {
+        factor += tmp;
+        tmp *= -(d - (double)k) * (d - (double)k - 1.0) * (2.0 / M_PI) * (2.0 / M_PI);
+      }
+      factor = log(factor) + logSn(d - 1.0);
+    }
+  }
+  return -factor - d * log(h);
+}
+
+extern "C" int runia_kde_score_kernel_f64(const double* train, const double* x, double* score, int64_t M, int64_t N,
+                                          int64_t D, double bandwidth, int kind, runia_stream_t stream) {
+  if (kind == 0) return runia_kde_score_f64(train, x, score, M, N, D, bandwidth, stream);
+  if (M <= 0 || N < 0 || D <= 0 || !(bandwidth > 0.0) || kind < 0 || kind > 5) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!train || !x || !score) return RUNIA_E_INVALID;
+  const size_t shmem = (size_t)D * sizeof(double);
+  if (shmem > 64 * 1024) return RUNIA_E_INVALID;
+  const double log_norm = -log((double)M) + kde_log_norm(kind, D, bandwidth);
+  hipStream_t s = as_stream(stream);
+  const unsigned grid = runia_stream_grid(N, 1);
+  switch (kind) {
+    case 1: kde_other_kernel<1><<<grid, 256, shmem, s>>>(train, x, score, M, N, D, bandwidth, log_norm); break;
+    case 2: kde_other_kernel<2><<<grid, 256, shmem, s>>>(train, x, score, M, N, D, bandwidth, log_norm); break;
+    case 3: kde_other_kernel<3><<<grid, 256, shmem, s>>>(train, x, score, M, N, D, bandwidth, log_norm); break;
+    case 4: kde_other_kernel<4><<<grid, 256, shmem, s>>>(train, x, score, M, N, D, bandwidth, log_norm); break;
+    default: kde_other_kernel<5><<<grid, 256, shmem, s>>>(train, x, score, M, N, D, bandwidth, log_norm); break;
   }
   return runia_check_launch();
 }

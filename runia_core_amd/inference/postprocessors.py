@@ -67,8 +67,8 @@ class DetectorKDE:
     construction; up to D ~ 20 they agree at 1e-5.  Numbers and tests: INTEGRATION.md "Known divergences"."""
 
     def __init__(self, train_embeddings, save_path=None, kernel="gaussian", bandwidth=1.0) -> None:
-        if kernel != "gaussian":
-            raise NotImplementedError("DetectorKDE on MI355X implements the gaussian kernel (the reference default)")
+        if kernel not in _hip.KDE_KERNELS:  # sklearn's KernelDensity raises for anything else as well
+            raise ValueError(f"invalid kernel: '{kernel}'")
         self.kernel = kernel
         self.bandwidth = bandwidth
         self.train_embeddings = train_embeddings
@@ -91,6 +91,8 @@ class DetectorKDE:
     def score_samples_device(self, x: Tensor) -> Tensor:
         train = self._train()
         d, n_rows = train.shape[1], x.shape[0]
+        if self.kernel != "gaussian":  # tophat / epanechnikov / exponential / linear / cosine: one direct kernel
+            return _hip.kde_score_kernel(train, x.to(torch.float64), float(self.bandwidth), self.kernel)
         if d >= 24 or (d >= 12 and n_rows <= 16384):
             # pair distances as |x|^2 + |t|^2 - 2 x.t on the f64 matrix cores, online logsumexp (8 192 x 10 000 pairs:
             # 0.27 / 0.38 / 0.88 ms at D = 32 / 64 / 256 against 0.56 / 1.85 / 21.5 ms for the direct kernels).  At
@@ -386,6 +388,11 @@ def _restore_dtype(scores: Tensor, src) -> np.ndarray:
     return out.astype(want, copy=False) if want in (np.float32, np.float64) else out
 
 
+def _host_logits() -> bool:
+    """True only when the caller switched ``config.host_logits_without_gpu`` on AND no GPU is present (BASELINE config 1)."""
+    return bool(config.host_logits_without_gpu) and not torch.cuda.is_available()
+
+
 @register_postprocessor("energy", postprocessor_input=["logits"])
 class Energy(OodPostprocessor):
     """Energy score: ``logsumexp(logits, axis=1)``."""
@@ -393,6 +400,10 @@ class Energy(OodPostprocessor):
     def _score(self, data) -> np.ndarray:
         if isinstance(data, Tensor):
             data = data.detach()
+        if _host_logits():  # explicit opt-in on a GPU-less box (config.host_logits_without_gpu): the reference's own call
+            from scipy.special import logsumexp
+
+            return logsumexp(data.cpu().numpy() if isinstance(data, Tensor) else data, axis=1)
         lse, _ = _hip.row_lse_msp(_logits_to_device(data), True, False)
         return _restore_dtype(lse, data)
 
@@ -416,6 +427,10 @@ class MSP(OodPostprocessor):
     def _score(self, data) -> np.ndarray:
         if isinstance(data, Tensor):
             data = data.detach()
+        if _host_logits():  # explicit opt-in on a GPU-less box (config.host_logits_without_gpu): the reference's own call
+            from scipy.special import softmax
+
+            return np.max(softmax(data.cpu().numpy() if isinstance(data, Tensor) else data, axis=1), axis=1)
         _, msp = _hip.row_lse_msp(_logits_to_device(data), False, True)
         return _restore_dtype(msp, data)
 

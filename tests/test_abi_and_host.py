@@ -511,3 +511,39 @@ def test_funcs_mirror_host_contract():
         ash_s_linear_layer(np.zeros(5, dtype=np.float32))
     with pytest.raises(AssertionError, match="divisible by the mcd_nro_samples"):
         get_predictive_uncertainty_score(torch.zeros(7, 3), 2)
+
+
+def test_cfg1_msp_on_a_gpu_less_box_is_an_explicit_opt_in(ref_vectors=None):
+    """BASELINE config 1 (MSP on 10 000 x 10 logits, "on CPU, no GPU"): by default scoring without a GPU raises (no silent
+    fallback); with ``config.host_logits_without_gpu = True`` MSP / Energy make the reference's own SciPy calls on such
+    a box - checked against the reference-run fixture - and nothing else gains a host path."""
+    if torch.cuda.is_available():
+        pytest.skip("the switch is ignored where a GPU is present")
+    from runia_core_amd import config
+    from runia_core_amd.inference import MSP, Energy
+
+    g = load_npz("ref_energy_msp.npz")
+    rng = np.random.default_rng(1)
+    logits = rng.standard_normal((10_000, 10)).astype(np.float32)
+    with pytest.raises(_hip.RuniaHipError):
+        MSP(flip_sign=False).setup(logits)
+    config.host_logits_without_gpu = True
+    try:
+        p = MSP(flip_sign=False)
+        p.setup(logits)
+        s = p.postprocess(logits)
+        assert s.dtype == np.float32 and s.shape == (10_000,) and p._setup_flag and np.isfinite(p.threshold)
+        e = np.exp(logits - logits.max(1, keepdims=True))
+        assert np.allclose(s, (e / e.sum(1, keepdims=True)).max(1), rtol=1e-6)
+        for nm in ("c1000", "c10"):  # what the reference itself returned for these logits (tools/make_goldens.py): same call, same bits
+            x = g[f"{nm}_logits"]
+            for cls, sn in ((Energy, "energy"), (MSP, "msp")):
+                q = cls(flip_sign=False)
+                q.setup(x[:64])
+                assert np.array_equal(q.postprocess(x), g[f"{nm}_{sn}_scores"]) and q.threshold == float(g[f"{nm}_{sn}_threshold"])
+        from runia_core_amd.inference import KNN
+
+        with pytest.raises(_hip.RuniaHipError):  # nothing else gains a host path
+            KNN(flip_sign=False, k_neighbors=5).setup(logits[:100], valid_feats=logits[:10])
+    finally:
+        config.host_logits_without_gpu = False
