@@ -171,13 +171,14 @@ __global__ __launch_bounds__(256) void radix_scatter_kernel(const uint64_t* __re
 
 // ---- curve: cumulative positives and the previous run end of every run end ------------------------------------------------
 // tile pass 1: (label sum, index of the last run end) of every tile
-__global__ __launch_bounds__(256) void tile_summary_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
-                                                           int64_t n, unsigned* __restrict__ tile_sum,
-                                                           int* __restrict__ tile_end, unsigned* __restrict__ tile_cnt) {
+__device__ __forceinline__ void tile_summary_body(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
+                                                  int64_t n, unsigned* __restrict__ tile_sum, int* __restrict__ tile_end,
+                                                  unsigned* __restrict__ tile_cnt, unsigned tile) {
   __shared__ unsigned ssum[4], scnt[4];
   __shared__ int send[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t t0 = (int64_t)blockIdx.x * kTile;
+  const int64_t t0 = (int64_t)tile * kTile;
+  __syncthreads();  // (a caller that loops over tiles reuses the arrays above)
   unsigned s = 0u, cnt = 0u;
   int e = -1;
 #pragma unroll
@@ -197,16 +198,21 @@ __global__ __launch_bounds__(256) void tile_summary_kernel(const uint64_t* __res
   if (lane == 0) { ssum[wave] = s; send[wave] = e; scnt[wave] = cnt; }
   __syncthreads();
   if (tid == 0) {
-    tile_sum[blockIdx.x] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
-    tile_end[blockIdx.x] = max(max(send[0], send[1]), max(send[2], send[3]));
-    tile_cnt[blockIdx.x] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
+    tile_sum[tile] = ssum[0] + ssum[1] + ssum[2] + ssum[3];
+    tile_end[tile] = max(max(send[0], send[1]), max(send[2], send[3]));
+    tile_cnt[tile] = scnt[0] + scnt[1] + scnt[2] + scnt[3];
   }
+}
+__global__ __launch_bounds__(256) void tile_summary_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
+                                                           int64_t n, unsigned* __restrict__ tile_sum,
+                                                           int* __restrict__ tile_end, unsigned* __restrict__ tile_cnt) {
+  tile_summary_body(keys, lab, n, tile_sum, tile_end, tile_cnt, blockIdx.x);
 }
 
 // exclusive scan of the tile summaries (sum: +, end: max) by one wave, 64 tiles per trip
-__global__ void tile_scan_kernel(unsigned* __restrict__ tile_sum, int* __restrict__ tile_end,
-                                 unsigned* __restrict__ tile_cnt, int64_t ntiles) {
-  if (blockIdx.x != 0 || threadIdx.x >= 64) return;
+__device__ __forceinline__ void tile_scan_body(unsigned* __restrict__ tile_sum, int* __restrict__ tile_end,
+                                               unsigned* __restrict__ tile_cnt, int64_t ntiles) {
+  if (threadIdx.x >= 64) return;
   const int lane = threadIdx.x;
   unsigned cs = 0u, cc = 0u;
   int ce = -1;
@@ -236,14 +242,18 @@ __global__ void tile_scan_kernel(unsigned* __restrict__ tile_sum, int* __restric
     ce = max(ce, __shfl(m, 63, 64));
   }
 }
+__global__ void tile_scan_kernel(unsigned* __restrict__ tile_sum, int* __restrict__ tile_end,
+                                 unsigned* __restrict__ tile_cnt, int64_t ntiles) {
+  if (blockIdx.x == 0) tile_scan_body(tile_sum, tile_end, tile_cnt, ntiles);
+}
 
 // tile pass 2: tps[i] (inclusive) for every element; prev_end[i] for every run end
-__global__ __launch_bounds__(256) void tile_prefix_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
-                                                          int64_t n, const unsigned* __restrict__ tile_sum,
-                                                          const int* __restrict__ tile_end,
-                                                          const unsigned* __restrict__ tile_cnt, unsigned* __restrict__ tps,
-                                                          int* __restrict__ prev_end, unsigned* __restrict__ tps_out,
-                                                          unsigned* __restrict__ fps_out, int64_t* __restrict__ n_points) {
+__device__ __forceinline__ void tile_prefix_body(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
+                                                 int64_t n, const unsigned* __restrict__ tile_sum,
+                                                 const int* __restrict__ tile_end, const unsigned* __restrict__ tile_cnt,
+                                                 unsigned* __restrict__ tps, int* __restrict__ prev_end,
+                                                 unsigned* __restrict__ tps_out, unsigned* __restrict__ fps_out,
+                                                 int64_t* __restrict__ n_points, unsigned tile) {
   // tps_out / fps_out (optional): torchmetrics' _binary_clf_curve - cumulative true / false positives at the end of every
   // run of equal scores, in descending score order (entry r belongs to the run end of rank r)
   __shared__ unsigned wsum[4], wcnt[4];
@@ -251,8 +261,9 @@ __global__ __launch_bounds__(256) void tile_prefix_kernel(const uint64_t* __rest
   __shared__ unsigned carry_sum, carry_cnt;
   __shared__ int carry_end;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int64_t t0 = (int64_t)blockIdx.x * kTile;
-  if (tid == 0) { carry_sum = tile_sum[blockIdx.x]; carry_end = tile_end[blockIdx.x]; carry_cnt = tile_cnt[blockIdx.x]; }
+  const int64_t t0 = (int64_t)tile * kTile;
+  __syncthreads();  // (a caller that loops over tiles reuses the carries)
+  if (tid == 0) { carry_sum = tile_sum[tile]; carry_end = tile_end[tile]; carry_cnt = tile_cnt[tile]; }
   __syncthreads();
   for (int c = 0; c < kItems; ++c) {
     const int64_t i = t0 + c * 256 + tid;
@@ -302,15 +313,24 @@ __global__ __launch_bounds__(256) void tile_prefix_kernel(const uint64_t* __rest
   }
 }
 
+__global__ __launch_bounds__(256) void tile_prefix_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
+                                                          int64_t n, const unsigned* __restrict__ tile_sum,
+                                                          const int* __restrict__ tile_end,
+                                                          const unsigned* __restrict__ tile_cnt, unsigned* __restrict__ tps,
+                                                          int* __restrict__ prev_end, unsigned* __restrict__ tps_out,
+                                                          unsigned* __restrict__ fps_out, int64_t* __restrict__ n_points) {
+  tile_prefix_body(keys, lab, n, tile_sum, tile_end, tile_cnt, tps, prev_end, tps_out, fps_out, n_points, blockIdx.x);
+}
+
 struct MetricsAccum {
   double roc_sum;            // sum of (fpr_j - fpr_{j-1}) * (tpr_j + tpr_{j-1})   (f32 terms)
   double pr_sum;             // sum of (recall_{j-1} - recall_j) * (precision_{j-1} + precision_j) and the end-point term
   unsigned long long fpr95_idx;  // smallest run-end index with tpr >= 0.95
 };
 
-__global__ __launch_bounds__(256) void curve_terms_kernel(const uint64_t* __restrict__ keys, int64_t n,
-                                                          const unsigned* __restrict__ tps, const int* __restrict__ prev_end,
-                                                          MetricsAccum* __restrict__ acc) {
+__device__ __forceinline__ void curve_terms_body(const uint64_t* __restrict__ keys, int64_t n,
+                                                 const unsigned* __restrict__ tps, const int* __restrict__ prev_end,
+                                                 MetricsAccum* __restrict__ acc, unsigned block, unsigned blocks) {
   __shared__ double sroc[4], spr[4];
   __shared__ unsigned long long sidx[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -318,7 +338,7 @@ __global__ __launch_bounds__(256) void curve_terms_kernel(const uint64_t* __rest
   const float Nn = (float)((unsigned)n - tps[n - 1]);
   double roc = 0.0, pr = 0.0;
   unsigned long long first = ~0ull;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + tid; i < n; i += (int64_t)gridDim.x * 256) {
+  for (int64_t i = (int64_t)block * 256 + tid; i < n; i += (int64_t)blocks * 256) {
     if (!(i == n - 1 || keys[i] != keys[i + 1])) continue;
     const int p = prev_end[i];
     const float tp = (float)tps[i], fp = (float)((unsigned)(i + 1) - tps[i]);
@@ -346,10 +366,21 @@ __global__ __launch_bounds__(256) void curve_terms_kernel(const uint64_t* __rest
     atomicMin(&acc->fpr95_idx, min(min(sidx[0], sidx[1]), min(sidx[2], sidx[3])));
   }
 }
+__global__ __launch_bounds__(256) void curve_terms_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                          const unsigned* __restrict__ tps, const int* __restrict__ prev_end,
+                                                          MetricsAccum* __restrict__ acc) {
+  curve_terms_body(keys, n, tps, prev_end, acc, blockIdx.x, gridDim.x);
+}
 
+__device__ __forceinline__ void finalize_body(const MetricsAccum* __restrict__ acc, const unsigned* __restrict__ tps, int64_t n,
+                                              double* __restrict__ out);
 __global__ void finalize_kernel(const MetricsAccum* __restrict__ acc, const unsigned* __restrict__ tps, int64_t n,
                                 double* __restrict__ out) {
   if (threadIdx.x != 0 || blockIdx.x != 0) return;
+  finalize_body(acc, tps, n, out);
+}
+__device__ __forceinline__ void finalize_body(const MetricsAccum* __restrict__ acc, const unsigned* __restrict__ tps, int64_t n,
+                                              double* __restrict__ out) {
   const float Nn = (float)((unsigned)n - tps[n - 1]);
   out[0] = (double)(float)(acc->roc_sum * 0.5);                // trapz(tpr, fpr), reported as float32 like torchmetrics
   const unsigned long long i = acc->fpr95_idx;
@@ -359,6 +390,16 @@ __global__ void finalize_kernel(const MetricsAccum* __restrict__ acc, const unsi
   // recall axis; sklearn.metrics.auc flips the sign of a decreasing axis
   out[2] = (double)(float)(-(acc->pr_sum * 0.5));
 }
+
+// ---- why the step stays a chain of launches (round 4) ------------------------------------------------------------------
+// The whole step was written as ONE persistent launch - every workgroup resident, the phases above behind grid-wide
+// barriers, a radix pass as one phase with a decoupled look-back over (aggregate | inclusive) words - and measured
+// 7.6 ms per 2 M scores against 0.44 ms for the launches, 0.26 ms per 20 000 against 0.23: on this chip a kernel boundary IS
+// the cheap grid barrier.  tools/microbench/grid_barrier.hip: arrive (one agent-scope atomic add) + spin costs 0.8 us for
+// 5 workgroups, 11 us for 256, 21 us for 512 (atomics on one word retire at ~45 ns each), and with the two
+// __threadfence() a barrier needs to publish plain stores across the eight L2s 2.5 / 40 / 90 us; the look-back of 256
+// digit counters by 256 threads is serial over the predecessors, up to G - 1 of them when G tiles start together.  A
+// dependent launch costs ~7.5 us.  Not kept.
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
@@ -410,6 +451,9 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
   MetricsAccum* acc = reinterpret_cast<MetricsAccum*>(w + L.accum);
   unsigned* flag = reinterpret_cast<unsigned*>(w + L.flag);
   hipStream_t s = as_stream(stream);
+  // f32 scores widened to f64 have 29 zero mantissa bits at the bottom: the three lowest digits are the same for every
+  // key, so those passes would move nothing
+  const int first_pass = (sizeof(T) == 4) ? 3 : 0;
   if (hipMemsetAsync(flag, 0, 4, s) != hipSuccess) return RUNIA_E_LAUNCH;
   if (hipMemsetAsync(acc, 0, 16, s) != hipSuccess) return RUNIA_E_LAUNCH;
   if (hipMemsetAsync(&acc->fpr95_idx, 0xFF, 8, s) != hipSuccess) return RUNIA_E_LAUNCH;
@@ -417,9 +461,6 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
   range_check_kernel<T><<<(sgrid < 1024u ? sgrid : 1024u), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag);
   make_keys_kernel<T><<<sgrid, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, keys[0], labs[0]);
   int cur = 0;
-  // f32 scores widened to f64 have 29 zero mantissa bits at the bottom: the three lowest digits are the same for every
-  // key, so those passes would move nothing
-  const int first_pass = (sizeof(T) == 4) ? 3 : 0;
   for (int pass = first_pass; pass < 8; ++pass) {
     const int shift = 8 * pass;
     radix_hist_kernel<<<L.nblocks, 256, 0, s>>>(keys[cur], n, shift, table, L.nblocks);
