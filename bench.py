@@ -579,8 +579,10 @@ def main():
             traffic_src = ("profiles/pmc_traffic.json: rocprofv3 --pmc FETCH_SIZE (x2, gfx950) + WRITE_SIZE, separate "
                            f"passes of this command ({rec.get('profile', 'see profiles/README.md')}); not measured in this run")
             if "valu_insts_per_launch" in rec:
-                # VALU-issue floor: instructions x 4 issue cycles / 1024 SIMDs / 2.4 GHz (MI355X_MICROARCH.md)
-                floor_ms = rec["valu_insts_per_launch"] * imgs_per_launch / rec.get("images_per_launch", 10000) * 4 / 1024 / 2.4e9 * 1e3
+                # VALU-issue floor: instructions x 4 issue cycles / 1024 SIMDs / the clock the kernel holds (measured:
+                # GRBM_GUI_ACTIVE / 8 over the launches' durations, profiles/r4_cfg2_pmc_summary.json; 2.4 GHz if not recorded)
+                clock_ghz = float(rec.get("clock_ghz_held", 2.4))
+                floor_ms = rec["valu_insts_per_launch"] * imgs_per_launch / rec.get("images_per_launch", 10000) * 4 / 1024 / (clock_ghz * 1e9) * 1e3
                 # ... and at what K1's own instruction mix costs on gfx950 when every instruction reads three different
                 # registers and kinds alternate (tools/microbench/valu_issue.hip, profiles/README.md): 4.46 cycles
                 floor_mix_ms = floor_ms * 4.46 / 4.0
@@ -588,6 +590,7 @@ def main():
                         "floor_ms": round(floor_ms, 4), "frac_of_floor": round(floor_ms / kernel_ms, 4),
                         "floor_ms_at_measured_mix_cost": round(floor_mix_ms, 4),
                         "frac_of_floor_at_measured_mix_cost": round(floor_mix_ms / kernel_ms, 4),
+                        "clock_ghz": clock_ghz, "clock_source": rec.get("clock_source", "nominal"),
                         "cycles_per_instruction": {"nominal": 4.0, "measured_for_this_mix": 4.46,
                                                    "source": "profiles/r2_valu_issue_microbench.txt"},
                         "source": "SQ_INSTS_VALU, same profile"}

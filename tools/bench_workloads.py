@@ -219,6 +219,20 @@ def run_cfg3(device, rank: int, world: int, dist, rows_total: int, fit_rows: int
         stages["knn"]["note"] = ("candidate distances from bf16 piece products (csrc/knn_bf16.hip), `achieved` counts every executed "
                                  "product; the score is the exactly re-measured f32 distance")
     stages["mahalanobis"]["shape"] = f"{n_loc}x{D_FEAT} f32, {N_CLASSES} classes, f64 quadratic forms"
+    # bytes past the L2 from the PMC passes of this command (profiles/pmc_traffic.json, "stages"), scaled to this rank's rows
+    try:
+        import json as _json
+
+        pmc = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")))["stages"]
+        for name, per in (("mahalanobis", "rows_per_launch"), ("knn", "queries_per_launch"), ("energy_c1000", "rows_per_launch")):
+            e = pmc[name]
+            stages[name]["traffic"] = int(e["bytes_per_launch"] * n_loc / e[per])
+            stages[name]["traffic_source"] = f"profiles/pmc_traffic.json stages.{name} ({e['kernel']}): 2 x FETCH_SIZE + WRITE_SIZE per launch, scaled by rows; not measured in this run"
+            for extra in ("matrix_pipe_busy_share", "clock_ghz_held"):
+                if extra in e:
+                    stages[name][extra] = e[extra]
+    except Exception:
+        pass
     stages["energy_c1000"]["shape"] = f"{n_loc}x{N_LOGITS} f32"
     stages["energy_c10"]["shape"] = f"{n_loc}x{N_CLASSES} f32"
     rec["stages"] = stages
