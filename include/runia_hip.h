@@ -110,6 +110,17 @@ int runia_md_score_f32(const float* x, const float* mean, const double* packed_p
                        int64_t N, int64_t n, runia_stream_t stream);
 int runia_md_score_f32x_f64mean(const float* x, const double* mean, const double* packed_p,
                                 double* score, int64_t N, int64_t n, runia_stream_t stream);
+/* The same scores (bit for bit) with a workspace (round 4): for few rows of wide features - MD on un-reduced 2048-d features,
+ * one image at a time - the 256-column blocks of a 16-row tile go to separate workgroups and a second launch adds their
+ * products in the one-launch kernel's order (0.9 -> 0.1 ms at <= 512 rows x 2048).  runia_md_score_workspace_bytes returns
+ * 0 where the one launch is taken anyway (then NULL / 0 may be passed). */
+size_t runia_md_score_workspace_bytes(int64_t N, int64_t n);
+int runia_md_score_ws_f64(const double* x, const double* mean, const double* packed_p, double* score, void* workspace,
+                          size_t workspace_bytes, int64_t N, int64_t n, runia_stream_t stream);
+int runia_md_score_ws_f32(const float* x, const float* mean, const double* packed_p, double* score, void* workspace,
+                          size_t workspace_bytes, int64_t N, int64_t n, runia_stream_t stream);
+int runia_md_score_ws_f32x_f64mean(const float* x, const double* mean, const double* packed_p, double* score,
+                                   void* workspace, size_t workspace_bytes, int64_t N, int64_t n, runia_stream_t stream);
 
 /* ---- a6  class-conditional Mahalanobis ------------------------------------ *
  * Replaces mahalanobis_postprocess (inference/funcs.py:69-102): for each row and

@@ -48,6 +48,10 @@ _SIGNATURES = {
     "runia_md_score_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "runia_md_score_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "runia_md_score_f32x_f64mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "runia_md_score_workspace_bytes": (c_size_t, [c_int64, c_int64]),
+    "runia_md_score_ws_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
+    "runia_md_score_ws_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
+    "runia_md_score_ws_f32x_f64mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
     "runia_mahalanobis_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "runia_mahalanobis_workspace_bytes_classes": (c_size_t, [c_int64, c_int64, c_int]),
     "runia_mahalanobis_score_f32": (
@@ -487,15 +491,19 @@ def md_score(x: torch.Tensor, mean: torch.Tensor, packed_p: torch.Tensor) -> tor
     nrow, n = x.shape
     if x.dtype == torch.float64:
         mean = mean.to(torch.float64)
-        fn = lib.runia_md_score_f64
+        fn = lib.runia_md_score_ws_f64
     elif mean.dtype == torch.float32:
-        fn = lib.runia_md_score_f32
+        fn = lib.runia_md_score_ws_f32
     else:
         mean = mean.to(torch.float64)
-        fn = lib.runia_md_score_f32x_f64mean
+        fn = lib.runia_md_score_ws_f32x_f64mean
     mean = mean.contiguous()
     s = torch.empty((nrow,), dtype=torch.float64, device=x.device)
-    _check(fn(x.data_ptr(), mean.data_ptr(), packed_p.data_ptr(), s.data_ptr(), nrow, n, _stream()), "runia_md_score")
+    # few rows of wide features: column blocks on separate workgroups + a replay launch (same bits, see runia_hip.h)
+    ws_bytes = int(lib.runia_md_score_workspace_bytes(nrow, n))
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    _check(fn(x.data_ptr(), mean.data_ptr(), packed_p.data_ptr(), s.data_ptr(), _ptr(ws), ws_bytes, nrow, n, _stream()),
+           "runia_md_score_ws")
     return s
 
 

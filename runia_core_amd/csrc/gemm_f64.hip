@@ -53,6 +53,9 @@ struct GemmArgs {
   // EPI_MAHA, few row tiles: one workgroup per (row tile, 256-column block); the (block, wave, row, class) partial sums go
   // to maha_part [n_blocks][4][N][C] and maha_split_finish_kernel adds them up in the unsplit kernel's order
   double* maha_part;
+  // EPI_ROWDOT (MD), few row tiles: one workgroup per (row tile, 256-column block) stores its products (d P)_j d_j to md_vals
+  // [tile][block][thread][RT * 4][NCT]; md_replay_kernel adds them up per lane in the unsplit kernel's order
+  double* md_vals;
   // outputs
   double* out;          // EPI_PCA / EPI_STORE: [N, n] (ld = n); EPI_ROWDOT / EPI_ROWNORM / EPI_KDE: [N]
 };
@@ -196,8 +199,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   const int64_t NT = n_pad / 16;
   const int64_t nchunks = k_padded(g.K) / KC;
   int64_t tile_id = blockIdx.x, cb_begin = 0, cb_end = n_pad / BN;
-  if constexpr (EPI == EPI_MAHA || EPI == EPI_KDE) {
-    if ((EPI == EPI_MAHA) ? (g.maha_part != nullptr) : (g.kde_vals != nullptr)) {  // column-split launch (uniform)
+  if constexpr (EPI == EPI_MAHA || EPI == EPI_KDE || EPI == EPI_ROWDOT) {
+    if ((EPI == EPI_MAHA) ? (g.maha_part != nullptr) : (EPI == EPI_KDE) ? (g.kde_vals != nullptr) : (g.md_vals != nullptr)) {  // column-split launch (uniform)
       const int64_t nb = n_pad / BN;
       tile_id = blockIdx.x / nb;
       cb_begin = blockIdx.x % nb;
@@ -309,6 +312,25 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
             kde_online_update<NCT>(val, rowmax[a][r], rowdot[a][r]);
           }
         }
+    } else if (EPI == EPI_ROWDOT && g.md_vals) {  // column-split launch: the products go to memory, md_replay_kernel adds them
+      const TA* x = reinterpret_cast<const TA*>(g.x);
+#pragma unroll
+      for (int a = 0; a < RT; ++a)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) {
+          const int64_t col = (ctbase + c) * 16 + li;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int64_t row = r0 + 16 * a + lg + 4 * r;
+            double prod = 0.0;  // (a term the unsplit kernel skips: adding +0.0 leaves its running sum as it is)
+            if (row < g.N && col < g.n) {
+              const TA xv = x[row * g.ldx + col];
+              const double d = g.sub ? sub_promote<TA, TS>(xv, reinterpret_cast<const TS*>(g.sub)[col]) : (double)xv;
+              prod = acc[a][c][r] * d;
+            }
+            g.md_vals[(((tile_id * (n_pad / BN) + cb) * 256 + tid) * (RT * 4) + (a * 4 + r)) * NCT + c] = prod;
+          }
+        }
     } else
 #pragma unroll
     for (int a = 0; a < RT; ++a) {
@@ -373,6 +395,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     kde_merge_store<RT>(rowdot, rowmax, lds_part, lds_part2, wave, li, lg, tid, r0, g.N, g.addc, g.out);
   }
   if constexpr (EPI == EPI_ROWDOT || EPI == EPI_ROWNORM) {
+    if (EPI == EPI_ROWDOT && g.md_vals) return;
 #pragma unroll
     for (int a = 0; a < RT; ++a)
 #pragma unroll
@@ -626,6 +649,77 @@ extern "C" int runia_md_score_f32(const float* x, const float* mean, const doubl
 extern "C" int runia_md_score_f32x_f64mean(const float* x, const double* mean, const double* packed_p,
                                            double* score, int64_t N, int64_t n, runia_stream_t stream) {
   return md_impl<float, double>(x, mean, packed_p, score, N, n, stream);
+}
+
+// Few rows of wide features (MD on un-reduced 2048-d features, one image at a time): a 16-row tile walks the whole 33.5 MB
+// precision matrix on ONE compute unit (0.9 ms at any batch <= 512 rows).  With a workspace the 256-column blocks of a tile go
+// to separate workgroups, which store their products (d P)_j d_j, and a second launch adds them per lane in the unsplit kernel's
+// order (blocks in order, the lane's four column tiles in order, then the same 16-lane and 4-wave sums): the same bits.
+__global__ __launch_bounds__(256) void md_replay_kernel(const double* __restrict__ vals, double* __restrict__ out, int64_t N,
+                                                         int64_t nb) {
+  constexpr int NCT = 4;
+  __shared__ double lds_part[4][16];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int li = lane & 15, lg = lane >> 4;
+  const int64_t r0 = (int64_t)blockIdx.x * 16;
+  double rowdot[4] = {0.0, 0.0, 0.0, 0.0};
+  for (int64_t cb = 0; cb < nb; ++cb) {
+    const double* src = vals + (((int64_t)blockIdx.x * nb + cb) * 256 + tid) * (4 * NCT);
+#pragma unroll
+    for (int c = 0; c < NCT; ++c)  // the unsplit epilogue visits (column tile, register) in this order
+#pragma unroll
+      for (int r = 0; r < 4; ++r) rowdot[r] += src[r * NCT + c];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r) {
+    double v = rowdot[r];
+    v += shfl_xor_f64(v, 1);
+    v += shfl_xor_f64(v, 2);
+    v += shfl_xor_f64(v, 4);
+    v += shfl_xor_f64(v, 8);
+    if (li == 0) lds_part[wave][lg + 4 * r] = v;
+  }
+  __syncthreads();
+  if (tid < 16) {
+    const int64_t row = r0 + tid;
+    if (row < N) out[row] = -(((lds_part[0][tid] + lds_part[1][tid]) + lds_part[2][tid]) + lds_part[3][tid]);
+  }
+}
+
+static bool md_split_wanted(int64_t N, int64_t n) { return (N + 15) / 16 < runia_cu_count() && n_padded(n) / BN > 1; }
+extern "C" size_t runia_md_score_workspace_bytes(int64_t N, int64_t n) {
+  if (N <= 0 || n <= 0 || !md_split_wanted(N, n)) return 0;
+  return (size_t)(((N + 15) / 16) * (n_padded(n) / BN) * 256 * 16) * sizeof(double);
+}
+template <typename TA, typename TS>
+static int md_ws_impl(const TA* x, const TS* mean, const double* packed_p, double* score, void* workspace, size_t workspace_bytes,
+                      int64_t N, int64_t n, runia_stream_t stream) {
+  const size_t need = runia_md_score_workspace_bytes(N, n);
+  if (need == 0 || !workspace || workspace_bytes < need || N <= 0 || !x || !score || !mean || !packed_p)
+    return md_impl<TA, TS>(x, mean, packed_p, score, N, n, stream);  // (large batches, narrow features, no workspace: the one launch)
+  GemmArgs g{};
+  g.x = x; g.ldx = n; g.packed = packed_p; g.N = N; g.K = n; g.n = n;
+  g.sub = mean; g.out = score;
+  g.md_vals = reinterpret_cast<double*>(workspace);
+  hipStream_t s = as_stream(stream);
+  const int64_t tiles = (N + 15) / 16, nb = n_padded(n) / BN;
+  gemm_rows_kernel<TA, TS, EPI_ROWDOT, 1, 4><<<(unsigned)(tiles * nb), 256, 0, s>>>(g);
+  md_replay_kernel<<<(unsigned)tiles, 256, 0, s>>>(g.md_vals, score, N, nb);
+  return runia_check_launch();
+}
+extern "C" int runia_md_score_ws_f64(const double* x, const double* mean, const double* packed_p, double* score,
+                                     void* workspace, size_t workspace_bytes, int64_t N, int64_t n, runia_stream_t stream) {
+  return md_ws_impl<double, double>(x, mean, packed_p, score, workspace, workspace_bytes, N, n, stream);
+}
+extern "C" int runia_md_score_ws_f32(const float* x, const float* mean, const double* packed_p, double* score, void* workspace,
+                                     size_t workspace_bytes, int64_t N, int64_t n, runia_stream_t stream) {
+  return md_ws_impl<float, float>(x, mean, packed_p, score, workspace, workspace_bytes, N, n, stream);
+}
+extern "C" int runia_md_score_ws_f32x_f64mean(const float* x, const double* mean, const double* packed_p, double* score,
+                                              void* workspace, size_t workspace_bytes, int64_t N, int64_t n,
+                                              runia_stream_t stream) {
+  return md_ws_impl<float, double>(x, mean, packed_p, score, workspace, workspace_bytes, N, n, stream);
 }
 
 // ViM residual: || (x - u) @ NS ||_2 per row (reference inference/postprocessors.py:1106): x - u follows NumPy's

@@ -1091,6 +1091,107 @@ __global__ __launch_bounds__(256) void linear_few_rows_kernel(const float* __res
   if (D % KCH) acc = fmaf(0.f, 0.f, acc);  // the zero padding of the last 32-chunk (only turns a -0 into +0)
   out[idx] = acc + (bias ? bias[c] : 0.f);
 }
+
+// Some tens to hundreds of rows (9 ... 512: a batch of a service, the proposals of an image): the matrix-core kernel has one
+// 128-row tile against C / 128 column tiles - 8 workgroups for 1000 classes, each walking all of K alone (64 ... 512 rows x
+// 2048 -> 1000: 203-226 us).  Here a workgroup takes 64 rows x 16 classes (63 workgroups per 64 rows at 1000 classes): rows
+// and weights staged 64 k at a time through LDS (two buffers, the next chunk's loads in flight during the arithmetic), a
+// thread = one row x four classes, and every (row, class) is again ONE f32 fma chain in the matrix-core kernel's k order -
+// same bits as inside a large batch.  (A wave per 64 classes x 8 rows with the weights streamed per lane - no LDS - ran
+// 249-270 us: one wave per compute unit and a latency chain of 512 load groups.)
+constexpr int kLinearMidRows = 512;
+constexpr int kMidRows = 64, kMidCls = 16, kMidK = 64, kMidPitch = kMidK + 4;  // pitch 68 floats: rows 16-byte aligned, 68 mod 32 = 4
+__global__ __launch_bounds__(256) void linear_mid_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                              const float* __restrict__ bias, float* __restrict__ out,
+                                                              int64_t N, int64_t D, int64_t C, float clip_max) {
+  __shared__ __attribute__((aligned(16))) float xs[2][kMidRows][kMidPitch];
+  __shared__ __attribute__((aligned(16))) float ws[2][kMidCls][kMidPitch];
+  const int tid = threadIdx.x;
+  const int row_l = tid & 63, cq = tid >> 6;  // thread: row row_l, classes 4 cq .. 4 cq + 3 of the tile (a wave shares its classes)
+  const int64_t r0 = (int64_t)blockIdx.y * kMidRows, c0 = (int64_t)blockIdx.x * kMidCls;
+  const bool vec = ((D & 3) == 0) && ((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0;
+  // staging: 64 rows x 64 k = 1024 float4 (4 per thread), 16 classes x 64 k = 256 float4 (1 per thread); zeros beyond D / N / C
+  auto fetch = [&](int64_t k0, float4 (&xr)[4], float4& wr) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u, rr = idx >> 4, kq = (idx & 15) * 4;
+      const int64_t row = r0 + rr, k = k0 + kq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (row < N) {
+        const float* p = x + row * D + k;
+        if (vec && k + 4 <= D) v = *reinterpret_cast<const float4*>(p);
+        else {
+          if (k < D) v.x = p[0];
+          if (k + 1 < D) v.y = p[1];
+          if (k + 2 < D) v.z = p[2];
+          if (k + 3 < D) v.w = p[3];
+        }
+      }
+      xr[u] = v;
+    }
+    {
+      const int cc = tid >> 4, kq = (tid & 15) * 4;
+      const int64_t cls = c0 + cc, k = k0 + kq;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (cls < C) {
+        const float* p = w + cls * D + k;
+        if (vec && k + 4 <= D) v = *reinterpret_cast<const float4*>(p);
+        else {
+          if (k < D) v.x = p[0];
+          if (k + 1 < D) v.y = p[1];
+          if (k + 2 < D) v.z = p[2];
+          if (k + 3 < D) v.w = p[3];
+        }
+      }
+      wr = v;
+    }
+  };
+  auto clipf = [&](float v) { return (v > clip_max) ? clip_max : v; };  // np.clip keeps a NaN activation
+  auto stash = [&](int buf, const float4 (&xr)[4], const float4& wr) {
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int idx = tid + 256 * u, rr = idx >> 4, kq = (idx & 15) * 4;
+      *reinterpret_cast<float4*>(&xs[buf][rr][kq]) = make_float4(clipf(xr[u].x), clipf(xr[u].y), clipf(xr[u].z), clipf(xr[u].w));
+    }
+    *reinterpret_cast<float4*>(&ws[buf][tid >> 4][(tid & 15) * 4]) = wr;
+  };
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  const int64_t nchunks = (D + kMidK - 1) / kMidK;
+  float4 xr[4], wr;
+  fetch(0, xr, wr);
+  int buf = 0;
+  for (int64_t ch = 0; ch < nchunks; ++ch) {
+    stash(buf, xr, wr);
+    __syncthreads();
+    if (ch + 1 < nchunks) fetch((ch + 1) * kMidK, xr, wr);
+    // groups of four k that start beyond D do not exist in the matrix-core kernel's chain (its zero padding ends at the
+    // 32-chunk; see the fma(0, 0, acc) below); a partial group's missing k are zeros, as staged
+    const int64_t kleft = D - ch * kMidK;
+    const int groups = (int)((kleft >= kMidK) ? kMidK / 4 : (kleft + 3) / 4);
+    for (int g = 0; g < groups; ++g) {
+      const float4 xv = *reinterpret_cast<const float4*>(&xs[buf][row_l][4 * g]);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float4 wv = *reinterpret_cast<const float4*>(&ws[buf][4 * cq + j][4 * g]);  // (one address per wave: broadcast)
+        acc[j] = fmaf(xv.x, wv.x, acc[j]);
+        acc[j] = fmaf(xv.z, wv.z, acc[j]);
+        acc[j] = fmaf(xv.y, wv.y, acc[j]);
+        acc[j] = fmaf(xv.w, wv.w, acc[j]);
+      }
+    }
+    buf ^= 1;  // (the next stash goes to the other buffer; the barrier of the next trip orders it against this trip's reads)
+  }
+  const int64_t row = r0 + row_l;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const int64_t cls = c0 + 4 * cq + j;
+    if (row < N && cls < C) {
+      float a = acc[j];
+      if (D % KCH) a = fmaf(0.f, 0.f, a);  // the zero padding of the last 32-chunk (only turns a -0 into +0)
+      out[row * C + cls] = a + (bias ? bias[cls] : 0.f);
+    }
+  }
+}
 }  // namespace
 
 // 1-D grid of knn_dist_kernel for Q x M: whole super-tiles, a multiple of 8 of them
@@ -1481,6 +1582,11 @@ extern "C" int runia_linear_f32(const float* x, const float* w, const float* bia
   }
   if (N <= kLinearFewRows) {
     linear_few_rows_kernel<<<(unsigned)((N * C + 255) / 256), 256, 0, s>>>(x, w, bias, out, N, D, C, clip_max);
+    return runia_check_launch();
+  }
+  if (N <= kLinearMidRows) {
+    const dim3 grid((unsigned)((C + kMidCls - 1) / kMidCls), (unsigned)((N + kMidRows - 1) / kMidRows));
+    linear_mid_rows_kernel<<<grid, 256, 0, s>>>(x, w, bias, out, N, D, C, clip_max);
     return runia_check_launch();
   }
   const int64_t qt = (N + TQ - 1) / TQ;

@@ -995,17 +995,18 @@ def test_mahalanobis_small_batches_split_columns_and_keep_the_bits(hip, d, c):
 
 @pytest.mark.parametrize("d,c,clip", [(2048, 1000, float("inf")), (512, 100, 0.8), (300, 37, float("inf")), (33, 17, 1.0)])
 def test_linear_few_rows_score_the_bits_of_a_batch(hip, d, c, clip):
-    """Up to 8 rows take one thread per (row, class) with the matrix-core kernel's fma chain (k order 0, 2, 1, 3 within
-    every four: v_mfma_f32_32x32x2_f32 is an exact fma chain) instead of its 128 x 128 tiles: same bits as inside a batch,
-    with and without bias and ReAct clip, widths that are not multiples of 4 or 32, NaN activations kept."""
+    """Up to 8 rows take one thread per (row, class), 9 ... 512 rows a wave per 64 classes x 8 rows (round 4), each with the
+    matrix-core kernel's fma chain (k order 0, 2, 1, 3 within every four: v_mfma_f32_32x32x2_f32 is an exact fma chain)
+    instead of its 128 x 128 tiles: same bits as inside a batch of 2 000 rows (the matrix-core kernel), with and without bias
+    and ReAct clip, widths that are not multiples of 4 or 32, NaN activations kept."""
     torch.manual_seed(d + c)
-    x = torch.randn(300, d, device="cuda")
+    x = torch.randn(2000, d, device="cuda")
     x[3, 5] = float("nan")
     w = torch.randn(c, d, device="cuda") * 0.1
     b = torch.randn(c, device="cuda")
     for bias in (b, None):
         whole = hip.linear(x, w, bias, clip)
-        for a0, b0 in ((0, 1), (3, 4), (10, 18), (292, 300)):
+        for a0, b0 in ((0, 1), (3, 4), (10, 18), (292, 300), (0, 9), (1, 65), (700, 1000), (1488, 2000), (3, 516)):
             few = hip.linear(x[a0:b0].contiguous(), w, bias, clip)
             same = (few == whole[a0:b0]) | (torch.isnan(few) & torch.isnan(whole[a0:b0]))
             assert bool(same.all()), (a0, b0, bias is None)
@@ -1092,3 +1093,32 @@ def test_knn_candidate_filter_overflow_rounds_equal_the_f32_path(hip):
     state = hip.knn_prepare_bank(bd)
     c = hip.knn_kth(qd, bd, k, state=state).cpu().numpy()
     assert np.array_equal(a, c)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n_feat", [2048, 300, 257])
+def test_md_few_rows_column_split_scores_the_bits_of_the_one_launch(hip, n_feat):
+    """runia_md_score_ws_* (round 4): for few rows of wide features the 256-column blocks of a 16-row tile run on separate
+    workgroups and a replay launch adds their products in the one-launch kernel's order - the same bits as
+    runia_md_score_* (which large batches still take), for f64 rows, f32 rows with an f32 and with an f64 mean, ragged
+    widths and row counts; and the oracle."""
+    lib = hip.load_library()
+    rng = np.random.default_rng(n_feat)
+    a = rng.standard_normal((n_feat, n_feat))
+    prec = a @ a.T / n_feat + np.eye(n_feat)
+    packed = hip.pack_weights(dev(prec, torch.float64))
+    mean = rng.standard_normal(n_feat)
+    for n_rows in (1, 7, 16, 100, 513):
+        x = rng.standard_normal((n_rows, n_feat))
+        assert lib.runia_md_score_workspace_bytes(n_rows, n_feat) > 0
+        for xdt, mdt, one in ((torch.float64, torch.float64, lib.runia_md_score_f64), (torch.float32, torch.float32, lib.runia_md_score_f32),
+                              (torch.float32, torch.float64, lib.runia_md_score_f32x_f64mean)):
+            xd, md = dev(x, xdt), dev(mean, mdt)
+            got = hip.md_score(xd, md, packed)
+            ref = torch.empty(n_rows, dtype=torch.float64, device="cuda")
+            assert one(xd.data_ptr(), md.data_ptr(), packed.data_ptr(), ref.data_ptr(), n_rows, n_feat,
+                       torch.cuda.current_stream().cuda_stream) == 0
+            assert torch.equal(got, ref), (n_rows, xdt, mdt)
+        xo, mo = x.astype(np.float32).astype(np.float64), mean
+        assert rel_err(got.cpu().numpy(), -np.einsum("ij,jk,ik->i", xo - mo, prec, xo - mo)) < 1e-9
+    assert lib.runia_md_score_workspace_bytes(100000, n_feat) == 0 and lib.runia_md_score_workspace_bytes(64, 200) == 0
