@@ -155,7 +155,7 @@ for t in range(a.rounds):
     # (the same entry point takes the bf16 kernel when the workspace holds the planes; both feed the exact f32
     #  re-measurement, so the scores have to agree bit for bit; a few rows against the oracle)
     if t % 3 == 0:
-        nq2 = int(rng.choice([1024, 1300, 2048, 3000]))
+        nq2 = int(rng.choice([1024, 1300, 2048, 3000, 9000, 17000]))  # (9 000 / 17 000: two chunks of the candidate filter)
         m2 = int(rng.choice([4096, 5000, 8192, 12001]))
         d2 = int(rng.choice([256, 300, 512, 1000, 2048]))
         k2 = int(rng.choice([1, 5, 50, 200, 513, 1500]))  # > 512: the three-read selection; 1500 < every bank size here
@@ -168,14 +168,23 @@ for t in range(a.rounds):
         else:
             bank2 /= np.linalg.norm(bank2, axis=1, keepdims=True)
             q2 /= np.linalg.norm(q2, axis=1, keepdims=True)
-        if rng.random() < 0.5:
+        dup = rng.random()
+        if dup < 0.5:
             bank2[m2 // 3: m2 // 3 + 300] = bank2[7]  # copied rows: ties around the k-th distance
             q2[:20] = bank2[100:120]                  # exact hits
+        elif dup < 0.7:
+            # more copies than a candidate list holds, and a crowd of queries next to them: those rows overflow their lists
+            # and go through the dense kernels (several overflow rounds when more than 8 192 of them do)
+            bank2[m2 // 4: m2 // 4 + 3000] = bank2[7]
+            nn = nq2 // 2
+            q2[:nn] = bank2[7] + 0.05 * q2[:nn] * np.abs(bank2[7]).mean()
+            if not scale_rows:
+                q2[:nn] /= np.linalg.norm(q2[:nn], axis=1, keepdims=True)
         lib = _hip.load_library()
         qd, bd = dev(q2), dev(bank2)
         outs = []
         full = lib.runia_knn_workspace_bytes(nq2, m2, d2, k2)
-        f32_only = (nq2 * m2 + nq2 + m2 + 4) * 4
+        f32_only = (min(nq2, 8192) * m2 + min(nq2, 8192) + m2 + 4) * 4
         for ws_bytes in (full, f32_only):
             ws = torch.empty(ws_bytes // 4 + 1, dtype=torch.float32, device="cuda")
             o = torch.full((nq2,), 123.0, device="cuda")
