@@ -2,8 +2,9 @@
 // out-of-distribution (negative) score set, as get_auroc_results computes them through torchmetrics' binary
 // auroc / roc / precision_recall_curve and sklearn.metrics.auc (reference evaluation/metrics.py:37-100; torchmetrics'
 // _binary_clf_curve: descending sort, one curve point per run of equal scores, cumulative true / false positives).
-// Everything stays on the device: a stable LSD radix sort of the 64-bit keys (8 passes of 8 bits), a scan of the labels and
-// of the run ends, and the trapezoid sums.
+// Everything stays on the device: the sort of the 64-bit keys (round 4: one split into 4 096 buckets that are linear in the
+// score + a sort per bucket, 10 launches; the stable LSD radix sort of rounds 2-3, 8 passes of 8 bits and ~31 launches, is
+// kept behind -DMETRICS_MSD=0), a scan of the labels and of the run ends, and the trapezoid sums.
 //
 // Reference behaviour that is reproduced on purpose (the oracle pins it with the reference's goldens):
 //   * if any score lies outside [0, 1] (or is NaN) every score goes through a sigmoid first - in the dtype of the
@@ -391,6 +392,356 @@ __device__ __forceinline__ void finalize_body(const MetricsAccum* __restrict__ a
   out[2] = (double)(float)(-(acc->pr_sum * 0.5));
 }
 
+// ---- round 4: the sort as ONE most-significant-digit split + a sort per bucket (10 launches instead of ~31) ---------------
+// The step is bound by its DEPENDENT LAUNCHES (~7.5 us each), not by bytes: 8 least-significant-digit passes x 3 launches
+// moved every key 8 times to order 2 M keys.  Here: the probe also finds the range of the finite scores; a key's bucket (of
+// 4 096) is linear in its (squashed) score over that range (msd_bucket); one launch counts the buckets while it makes the keys, one scans them, one scatters
+// (per tile: bucket counts in LDS, ONE global atomic per non-empty (tile, bucket) reserves its range - a hot bucket costs a
+// tile one atomic, not one per key), and one sorts every bucket where it lies: up to 2 048 keys by a bitonic network in
+// LDS, a larger bucket (a heavily skewed score set) by a stable 8-bit radix sort that one workgroup runs over the bucket in
+// global memory - slow but bounded, and the grid needs no second look.  The order inside a run of equal keys is irrelevant
+// to the curve (a run is one point), so neither the scatter nor the network has to be stable.
+#ifndef METRICS_MSD_BITS
+#define METRICS_MSD_BITS 12
+#endif
+#ifndef METRICS_SCAT_ITEMS
+#define METRICS_SCAT_ITEMS 32
+#endif
+constexpr int kMsdBits = METRICS_MSD_BITS, kMsdBuckets = 1 << kMsdBits;
+
+struct MsdState {                 // device words of the split (cleared by the step's one memset)
+  unsigned long long nkmin;       // ~(smallest key of the raw, FINITE scores): a maximum, so that it starts at 0 too
+  unsigned long long kmax;        // their largest key
+  unsigned hist[kMsdBuckets];
+  unsigned cursor[kMsdBuckets];
+  unsigned start[kMsdBuckets + 1];
+  unsigned done_blocks;           // curve_terms: the last block to finish writes the three scalars
+};
+
+template <typename T>
+__device__ __forceinline__ uint64_t score_key(T v, bool squash) {
+  if (squash) v = (T)1 / ((T)1 + exp(-v));  // torch.sigmoid in the dtype of the scores
+  return sortable_desc((double)v + 0.0);     // (-0.0 and +0.0 share a key: one tie group, as torchmetrics)
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void msd_probe_kernel(const T* __restrict__ ind, int64_t n_ind, const T* __restrict__ ood,
+                                                        int64_t n_ood, unsigned* __restrict__ any_outside, MsdState* st,
+                                                        MetricsAccum* __restrict__ acc) {
+  __shared__ unsigned long long smin[4], smax[4];
+  if (blockIdx.x == 0 && threadIdx.x == 0) acc->fpr95_idx = ~0ull;  // (a minimum: the step's one memset left 0 there)
+  bool bad = false;
+  unsigned long long mn = ~0ull, mx = 0ull;  // key range of the raw, finite scores (no exp here: see MsdRange)
+  const int64_t n = n_ind + n_ood;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+    const T v = (i < n_ind) ? ind[i] : ood[i - n_ind];
+    bad = bad || !(v >= (T)0 && v <= (T)1);
+    if (v - v == (T)0) {  // finite
+      const unsigned long long k = score_key<T>(v, false);
+      mn = k < mn ? k : mn;
+      mx = k > mx ? k : mx;
+    }
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long a = ((unsigned long long)__shfl_xor((unsigned)(mn >> 32), o, 64) << 32) | __shfl_xor((unsigned)mn, o, 64);
+    const unsigned long long b = ((unsigned long long)__shfl_xor((unsigned)(mx >> 32), o, 64) << 32) | __shfl_xor((unsigned)mx, o, 64);
+    mn = a < mn ? a : mn;
+    mx = b > mx ? b : mx;
+  }
+  if (lane == 0) { smin[wave] = mn; smax[wave] = mx; }
+  const bool any_bad = __syncthreads_or(bad);
+  if (threadIdx.x == 0) {
+    if (any_bad && __atomic_load_n(any_outside, __ATOMIC_RELAXED) == 0u) atomicOr(any_outside, 1u);
+    unsigned long long a = smin[0], b = smax[0];
+    for (int w = 1; w < 4; ++w) { a = smin[w] < a ? smin[w] : a; b = smax[w] > b ? smax[w] : b; }
+    atomicMax(&st->nkmin, ~a);
+    atomicMax(&st->kmax, b);
+  }
+}
+
+// Bucket of a key: LINEAR in the (squashed) score over the range of the finite scores - the bit patterns of doubles are not
+// spread evenly (the 12 bits below the keys' common prefix are mostly exponent: one bucket per binade, half of a normal
+// score set in one of them).  b = (int)((largest - v) * scale) is monotone in v (a subtraction, a product with a positive
+// factor and a truncation are), so the buckets follow the key order; the keys descend with the scores and the sigmoid is
+// monotone, so the range of the squashed scores is [sigmoid(smallest), sigmoid(largest)] - two exps per workgroup instead of
+// one per score in the probe.  +inf and NaN keys at the low end of the key space go to the first bucket, -inf and NaN keys
+// at the high end to the last (the sort inside a bucket uses the whole key).
+__device__ __forceinline__ double unkey(uint64_t k) {  // inverse of sortable_desc
+  uint64_t b = ~k;
+  b = (b >> 63) ? (b & 0x7fffffffffffffffull) : ~b;
+  return __longlong_as_double((long long)b);
+}
+struct MsdRange { double hi, scale; };
+template <typename T>
+__device__ __forceinline__ MsdRange msd_range(const MsdState* st, bool squash) {
+  MsdRange r{0.0, 0.0};
+  const unsigned long long lo_k = ~st->nkmin, hi_k = st->kmax;
+  if (lo_k > hi_k) return r;  // (no finite score)
+  T v_hi = (T)unkey(lo_k), v_lo = (T)unkey(hi_k);  // largest / smallest finite score
+  if (squash) { v_hi = (T)1 / ((T)1 + exp(-v_hi)); v_lo = (T)1 / ((T)1 + exp(-v_lo)); }
+  r.hi = (double)v_hi;
+  const double span = (double)v_hi - (double)v_lo;
+  r.scale = (span > 0.0 && span < __builtin_inf()) ? (double)kMsdBuckets / span : 0.0;
+  return r;
+}
+__device__ __forceinline__ unsigned msd_bucket(uint64_t key, const MsdRange& r) {
+  const double v = unkey(key);
+  if (!(v - v == 0.0)) return (key >> 63) ? (unsigned)(kMsdBuckets - 1) : 0u;  // inf / NaN: by the end of the key space they lie at
+  const double x = (r.hi - v) * r.scale;
+  const int b = (x >= (double)(kMsdBuckets - 1)) ? kMsdBuckets - 1 : (x > 0.0 ? (int)x : 0);
+  return (unsigned)b;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void msd_keys_kernel(const T* __restrict__ ind, int64_t n_ind, const T* __restrict__ ood,
+                                                       int64_t n_ood, const unsigned* __restrict__ any_outside, MsdState* st,
+                                                       uint64_t* __restrict__ keys, uint8_t* __restrict__ labels) {
+  __shared__ unsigned lh[kMsdBuckets];
+  const bool squash = *any_outside != 0u;
+  const MsdRange rg = msd_range<T>(st, squash);
+  for (int b = threadIdx.x; b < kMsdBuckets; b += 256) lh[b] = 0u;
+  __syncthreads();
+  const int64_t n = n_ind + n_ood;
+  const int64_t t0 = (int64_t)blockIdx.x * kTile;
+#pragma unroll 4
+  for (int c = 0; c < kItems; ++c) {
+    const int64_t i = t0 + c * 256 + threadIdx.x;
+    if (i < n) {
+      const T v = (i < n_ind) ? ind[i] : ood[i - n_ind];
+      const uint64_t key = score_key<T>(v, squash);
+      keys[i] = key;
+      labels[i] = (i < n_ind) ? 1 : 0;
+      atomicAdd(&lh[msd_bucket(key, rg)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kMsdBuckets; b += 256) {
+    const unsigned c = lh[b];
+    if (c) atomicAdd(&st->hist[b], c);
+  }
+}
+
+__global__ __launch_bounds__(256) void msd_scan_kernel(MsdState* st) {  // one workgroup: start[b] = keys in the buckets before b
+  __shared__ unsigned wsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  constexpr int PER = kMsdBuckets / 256;
+  unsigned v[PER], tot = 0u;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { v[j] = st->hist[tid * PER + j]; tot += v[j]; }
+  unsigned x = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wsum[wave] = x;
+  __syncthreads();
+  unsigned off = x - tot;
+  for (int w = 0; w < wave; ++w) off += wsum[w];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { st->start[tid * PER + j] = off; off += v[j]; }
+  if (tid == 255) st->start[kMsdBuckets] = off;
+}
+
+constexpr int kScatItems = METRICS_SCAT_ITEMS, kScatTile = 256 * kScatItems;  // 8 192 keys per workgroup: ~2 per (tile, bucket)
+template <typename T>
+__global__ __launch_bounds__(256) void msd_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint8_t* __restrict__ lab_in,
+                                                          uint64_t* __restrict__ keys_out, uint8_t* __restrict__ lab_out, int64_t n,
+                                                          const unsigned* __restrict__ any_outside, MsdState* st) {
+  __shared__ unsigned cnt[kMsdBuckets];   // keys of this tile per bucket, then the tile's first slot in the bucket
+  const MsdRange rg = msd_range<T>(st, *any_outside != 0u);
+  for (int b = threadIdx.x; b < kMsdBuckets; b += 256) cnt[b] = 0u;
+  __syncthreads();
+  const int64_t t0 = (int64_t)blockIdx.x * kScatTile;
+  uint64_t key[kScatItems];
+  unsigned slot[kScatItems];  // bucket << 16 | rank of the key among the tile's keys of that bucket (< 16 384)
+  static_assert(kScatTile <= 65536 && kMsdBits <= 16, "bucket and rank share a word");
+#pragma unroll
+  for (int c = 0; c < kScatItems; ++c) {
+    const int64_t i = t0 + c * 256 + threadIdx.x;
+    key[c] = (i < n) ? keys_in[i] : 0ull;
+    const unsigned b = msd_bucket(key[c], rg);
+    slot[c] = (b << 16) | ((i < n) ? atomicAdd(&cnt[b], 1u) : 0u);
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kMsdBuckets; b += 256) {
+    const unsigned c = cnt[b];
+    cnt[b] = c ? st->start[b] + atomicAdd(&st->cursor[b], c) : 0u;  // ONE global atomic per non-empty (tile, bucket)
+  }
+  __syncthreads();
+#pragma unroll
+  for (int c = 0; c < kScatItems; ++c) {
+    const int64_t i = t0 + c * 256 + threadIdx.x;
+    if (i < n) {
+      const unsigned pos = cnt[slot[c] >> 16] + (slot[c] & 0xffffu);
+      keys_out[pos] = key[c];
+      lab_out[pos] = lab_in[i];
+    }
+  }
+}
+
+// Buckets 4 g .. 4 g + 3 belong to workgroup g.  First every wave sorts "its" bucket if it holds at most kMsdWaveCap keys: a
+// bitonic network in the wave's own LDS slice, wave-synchronous (no workgroup barrier).  Per 2 M keys (4 096 buckets of ~490):
+// 97 us; a workgroup per bucket with 45 barrier-separated rounds 173 us; a wave-level stable 8-bit radix sort over the bytes
+// in which a bucket's keys differ (two LDS copies of the bucket: half the occupancy) 168 us.  Then the workgroup together
+// takes each of its buckets that is larger.
+constexpr int kMsdWaveCap = 1024;
+template <typename T>
+__global__ __launch_bounds__(256) void msd_bucket_sort_kernel(uint64_t* __restrict__ keys, uint8_t* __restrict__ labs,
+                                                              uint64_t* __restrict__ alt_keys, uint8_t* __restrict__ alt_labs,
+                                                              const unsigned* __restrict__ any_outside, const MsdState* st) {
+  __shared__ uint64_t sk_all[4][kMsdWaveCap];
+  __shared__ uint8_t sl_all[4][kMsdWaveCap];
+  __shared__ unsigned base[256];
+  __shared__ unsigned wcnt[4][256];
+  __shared__ unsigned dsum[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  (void)any_outside;
+  {
+    const int b = 4 * blockIdx.x + wave;
+    const unsigned lo = st->start[b], nb = st->start[b + 1] - lo;
+    if (nb >= 2u && nb <= (unsigned)kMsdWaveCap) {  // (wave-uniform)
+      uint64_t* sk = sk_all[wave];
+      uint8_t* sl = sl_all[wave];
+      unsigned m = 2u;
+      while (m < nb) m <<= 1;  // network size: the next power of two, padded with the largest key
+      for (unsigned i = lane; i < m; i += 64) {
+        sk[i] = (i < nb) ? keys[lo + i] : ~0ull;
+        sl[i] = (i < nb) ? labs[lo + i] : 0;
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      for (unsigned k2 = 2u; k2 <= m; k2 <<= 1) {
+        for (unsigned j = k2 >> 1; j > 0u; j >>= 1) {
+          for (unsigned t = lane; t < (m >> 1); t += 64) {  // pair t: i = the index with bit j clear
+            const unsigned i = ((t & ~(j - 1u)) << 1) | (t & (j - 1u)), p = i | j;
+            const bool up = (i & k2) == 0u;
+            const uint64_t a = sk[i], c = sk[p];
+            if ((a > c) == up) {
+              sk[i] = c; sk[p] = a;
+              const uint8_t la = sl[i]; sl[i] = sl[p]; sl[p] = la;
+            }
+          }
+          __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+        }
+      }
+      for (unsigned i = lane; i < nb; i += 64) { keys[lo + i] = sk[i]; labs[lo + i] = sl[i]; }
+    }
+  }
+  for (int b = 4 * blockIdx.x; b < 4 * (int)blockIdx.x + 4; ++b) {
+    const unsigned lo = st->start[b], nb = st->start[b + 1] - lo;
+    if (nb <= (unsigned)kMsdWaveCap) continue;  // (uniform)
+    // a bucket that does not fit a wave's LDS slice: stable 8-bit radix passes over the bits below the bucket digit, by this
+    // workgroup alone, between the bucket's range in `keys` and the same range of the other buffer
+    // the bits in which the bucket's keys differ at all (a bucket of equal keys - saturated sigmoids, a constant score set -
+    // needs no pass): OR of key ^ first key over the bucket
+    __shared__ unsigned long long diff_s;
+    __syncthreads();
+    if (tid == 0) diff_s = 0ull;
+    __syncthreads();
+    {
+      const uint64_t k0 = keys[lo];
+      unsigned long long d = 0ull;
+      for (unsigned i = tid; i < nb; i += 256) d |= keys[lo + i] ^ k0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+        d |= ((unsigned long long)__shfl_xor((unsigned)(d >> 32), o, 64) << 32) | __shfl_xor((unsigned)d, o, 64);
+      if (lane == 0 && d) atomicOr(&diff_s, d);
+    }
+    __syncthreads();
+    const unsigned long long diff = diff_s;
+    const int low_bits = diff ? 64 - __builtin_clzll(diff) : 0;
+    const int first_bit = diff ? (__builtin_ctzll(diff) & ~7) : 0;
+    uint64_t* src_k = keys + lo;
+    uint8_t* src_l = labs + lo;
+    uint64_t* dst_k = alt_keys + lo;
+    uint8_t* dst_l = alt_labs + lo;
+    int moved = 0;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int shift = first_bit; shift < low_bits; shift += 8) {
+      __syncthreads();
+      base[tid] = 0u;
+      __syncthreads();
+      for (unsigned i = tid; i < nb; i += 256) atomicAdd(&base[(unsigned)(src_k[i] >> shift) & 255u], 1u);
+      __syncthreads();
+      {
+        const unsigned v = base[tid];
+        unsigned x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned y = __shfl_up(x, o, 64);
+          if (lane >= o) x += y;
+        }
+        if (lane == 63) dsum[wave] = x;
+        __syncthreads();
+        unsigned woff = 0u;
+        for (int w = 0; w < wave; ++w) woff += dsum[w];
+        base[tid] = woff + x - v;
+      }
+#pragma unroll
+      for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0u;
+      __syncthreads();
+      for (unsigned i0 = 0; i0 < nb; i0 += 256) {  // chunks in order: the pass is stable
+        const unsigned i = i0 + tid;
+        const bool valid = i < nb;
+        const uint64_t key = valid ? src_k[i] : 0ull;
+        const unsigned d = (unsigned)(key >> shift) & 255u;
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+          const uint64_t bal = __ballot((d >> bb) & 1u);
+          same &= ((d >> bb) & 1u) ? bal : ~bal;
+        }
+        const unsigned rank_in_wave = (unsigned)__popcll(same & lt_mask);
+        if (valid && rank_in_wave == 0u) wcnt[wave][d] = (unsigned)__popcll(same);
+        __syncthreads();
+        if (valid) {
+          unsigned off = base[d] + rank_in_wave;
+          for (int w = 0; w < wave; ++w) off += wcnt[w][d];
+          dst_k[off] = key;
+          dst_l[off] = src_l[i];
+        }
+        __syncthreads();
+        base[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0u;
+        __syncthreads();
+      }
+      __threadfence_block();
+      uint64_t* tk = src_k; src_k = dst_k; dst_k = tk;
+      uint8_t* tl = src_l; src_l = dst_l; dst_l = tl;
+      moved ^= 1;
+    }
+    __syncthreads();
+    if (moved)  // an odd number of passes left the bucket in the other buffer
+      for (unsigned i = tid; i < nb; i += 256) { keys[lo + i] = src_k[i]; labs[lo + i] = src_l[i]; }
+    __syncthreads();
+  }
+}
+
+// curve terms + (the last block to finish) the three scalars: one launch instead of two
+__global__ __launch_bounds__(256) void curve_terms_finalize_kernel(const uint64_t* __restrict__ keys, int64_t n,
+                                                                   const unsigned* __restrict__ tps, const int* __restrict__ prev_end,
+                                                                   MetricsAccum* __restrict__ acc, MsdState* st, double* __restrict__ out) {
+  __shared__ int last;
+  curve_terms_body(keys, n, tps, prev_end, acc, blockIdx.x, gridDim.x);
+  __threadfence();
+  __syncthreads();
+  if (threadIdx.x == 0) last = (atomicAdd(&st->done_blocks, 1u) + 1u == gridDim.x) ? 1 : 0;
+  __syncthreads();
+  if (last && threadIdx.x == 0) {
+    __threadfence();
+    MetricsAccum a;
+    a.roc_sum = __hip_atomic_load(&acc->roc_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.pr_sum = __hip_atomic_load(&acc->pr_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.fpr95_idx = __hip_atomic_load(&acc->fpr95_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    finalize_body(&a, tps, n, out);
+  }
+}
+
 // ---- why the step stays a chain of launches (round 4) ------------------------------------------------------------------
 // The whole step was written as ONE persistent launch - every workgroup resident, the phases above behind grid-wide
 // barriers, a radix pass as one phase with a decoupled look-back over (aggregate | inclusive) words - and measured
@@ -399,12 +750,12 @@ __device__ __forceinline__ void finalize_body(const MetricsAccum* __restrict__ a
 // 5 workgroups, 11 us for 256, 21 us for 512 (atomics on one word retire at ~45 ns each), and with the two
 // __threadfence() a barrier needs to publish plain stores across the eight L2s 2.5 / 40 / 90 us; the look-back of 256
 // digit counters by 256 threads is serial over the predecessors, up to G - 1 of them when G tiles start together.  A
-// dependent launch costs ~7.5 us.  Not kept.
+// dependent launch costs ~7.5 us.  Not kept; what did shorten the step is fewer passes over the keys (above).
 
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, dtot, tile_sum, tile_end, tile_cnt, accum, flag, total;
+  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, dtot, tile_sum, tile_end, tile_cnt, accum, flag, msd, total;
   unsigned nblocks;
 };
 
@@ -425,6 +776,7 @@ Layout make_layout(int64_t n) {
   L.tile_cnt = o; o += align256((size_t)L.nblocks * 4);
   L.accum = o; o += align256(sizeof(MetricsAccum));
   L.flag = o; o += 256;
+  L.msd = o; o += align256(sizeof(MsdState));  // (accum, flag and msd are contiguous: one memset clears them)
   L.total = o;
   return L;
 }
@@ -454,6 +806,27 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
   // f32 scores widened to f64 have 29 zero mantissa bits at the bottom: the three lowest digits are the same for every
   // key, so those passes would move nothing
   const int first_pass = (sizeof(T) == 4) ? 3 : 0;
+#ifndef METRICS_MSD
+#define METRICS_MSD 1
+#endif
+  if (METRICS_MSD) {
+    MsdState* st = reinterpret_cast<MsdState*>(w + L.msd);
+    // one memset: accumulators, flag and split state (10 launches in all)
+    if (hipMemsetAsync(acc, 0, (L.msd - L.accum) + sizeof(MsdState), s) != hipSuccess) return RUNIA_E_LAUNCH;
+    const unsigned sgrid = runia_stream_grid(n, 256);
+    // (every workgroup ends in atomics on three words, ~45 ns each on one word: 256 workgroups, not 1 024)
+    msd_probe_kernel<T><<<(sgrid < 256u ? sgrid : 256u), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, acc);
+    msd_keys_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, keys[0], labs[0]);
+    msd_scan_kernel<<<1, 256, 0, s>>>(st);
+    msd_scatter_kernel<T><<<(unsigned)((n + kScatTile - 1) / kScatTile), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, flag, st);
+    msd_bucket_sort_kernel<T><<<kMsdBuckets / 4, 256, 0, s>>>(keys[1], labs[1], keys[0], labs[0], flag, st);  // (four buckets per workgroup)
+    tile_summary_kernel<<<L.nblocks, 256, 0, s>>>(keys[1], labs[1], n, tile_sum, tile_end, tile_cnt);
+    tile_scan_kernel<<<1, 64, 0, s>>>(tile_sum, tile_end, tile_cnt, L.nblocks);
+    tile_prefix_kernel<<<L.nblocks, 256, 0, s>>>(keys[1], labs[1], n, tile_sum, tile_end, tile_cnt, tps, prev_end, tps_out, fps_out,
+                                                 n_points);
+    curve_terms_finalize_kernel<<<(sgrid < 512u ? sgrid : 512u), 256, 0, s>>>(keys[1], n, tps, prev_end, acc, st, out3);
+    return runia_check_launch();
+  }
   if (hipMemsetAsync(flag, 0, 4, s) != hipSuccess) return RUNIA_E_LAUNCH;
   if (hipMemsetAsync(acc, 0, 16, s) != hipSuccess) return RUNIA_E_LAUNCH;
   if (hipMemsetAsync(&acc->fpr95_idx, 0xFF, 8, s) != hipSuccess) return RUNIA_E_LAUNCH;

@@ -711,11 +711,16 @@ def test_device_metrics_reference_goldens(ref_vectors):
     assert (a, f, p) == pytest.approx(oracle.auroc_fpr95_aupr(ind, ood), abs=2e-7)
 
 
-@pytest.mark.parametrize("case", ["f64_far", "f64_unit", "f32", "ties", "saturated", "tiny", "big"])
+@pytest.mark.parametrize("case", ["f64_far", "f64_unit", "f32", "ties", "saturated", "tiny", "big", "clustered", "clustered_unit",
+                                  "constant", "infinite", "two"])
 def test_device_metrics_vs_oracle(case):
     """Device sort + scan metrics against the oracle's restatement of torchmetrics / sklearn: scores inside [0, 1] (no
     sigmoid), far outside (f64 sigmoid), float32 scores (f32 sigmoid), heavy ties, LaREM-like scores whose sigmoid
-    underflows to 0 (everything below -745 ties, as in the reference), 3 + 2 scores, and 1.2 M + 0.9 M scores."""
+    underflows to 0 (everything below -745 ties, as in the reference), 3 + 2 scores, and 1.2 M + 0.9 M scores.  Round 4
+    (the sort is a split into 4 096 buckets that are linear in the score + a sort per bucket): 300 000 scores inside a
+    relative 1e-9 of each other next to a few outliers, squashed and inside [0, 1] - ONE bucket holds them, its keys differ in
+    their low bytes only: the single-workgroup radix path; a constant score set (no bit differs: no pass); infinite scores
+    (the end buckets); 1 + 1 scores."""
     from runia_core_amd.evaluation.metrics import auroc_fpr95_aupr_device
 
     rng = np.random.default_rng(abs(hash(case)) % 1000)
@@ -731,6 +736,19 @@ def test_device_metrics_vs_oracle(case):
         ind, ood = -200 - 300 * rng.random(6000), -400 - 900 * rng.random(6000)
     elif case == "tiny":
         ind, ood = np.array([0.9, 0.4, 0.7]), np.array([0.1, 0.4])
+    elif case == "clustered":
+        ind = np.concatenate([3.0 + 1e-9 * rng.random(200_000), [-50.0, 40.0, 3.0]])
+        ood = np.concatenate([3.0 + 1e-9 * rng.random(100_000) - 2e-10, [-60.0, 3.0]])
+    elif case == "clustered_unit":
+        ind = np.concatenate([0.5 + 1e-10 * rng.random(150_000), [0.0, 1.0]])
+        ood = np.concatenate([0.5 + 1e-10 * rng.random(150_000) - 3e-11, [0.0, 0.25]])
+    elif case == "constant":
+        ind, ood = np.full(5000, 0.25), np.full(70_000, 0.25)
+    elif case == "infinite":
+        ind = np.concatenate([rng.standard_normal(3000), [np.inf, np.inf, -np.inf]])
+        ood = np.concatenate([rng.standard_normal(3000) - 1, [np.inf, -np.inf, -np.inf]])
+    elif case == "two":
+        ind, ood = np.array([0.3]), np.array([0.7])
     else:
         ind, ood = rng.standard_normal(1_200_000) + 0.3, rng.standard_normal(900_000) - 0.3
     got = auroc_fpr95_aupr_device(ind, ood)
