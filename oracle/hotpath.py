@@ -51,6 +51,9 @@ __all__ = [
     "larem_pipeline",
     "ash_s_linear_layer",
     "ash_s_defined",
+    "ash_s_conv_defined",
+    "predictive_uncertainty",
+    "kde_score_kernel",
     "linear_energy",
     "react_threshold",
     "react_score",
@@ -717,6 +720,77 @@ def generalized_entropy(probs: np.ndarray, gamma: float, M: int) -> np.ndarray:
     """inference/funcs.py:347-375."""
     probs_sorted = np.sort(probs, axis=1)[:, -M:]
     return -np.sum(probs_sorted**gamma * (1 - probs_sorted) ** gamma, axis=1)
+
+
+def ash_s_conv_defined(x: np.ndarray, percentile: int = 65):
+    """ash_s_conv_layer (inference/funcs.py:194-227) on (B, C, H, W) maps: per sample the k = n - round(n * p / 100) largest of
+    its C*H*W activations kept (torch.topk + scatter_: each at its own index; ties at the threshold: lowest index first here),
+    the sample multiplied by exp(sum before / sum after).  Returns (scaled, pruned): the reference leaves its argument pruned."""
+    b = x.shape[0]
+    flat = np.asarray(x, dtype=np.float32).reshape(b, -1)
+    n = flat.shape[1]
+    k = n - int(np.round(n * percentile / 100.0))
+    pruned = np.zeros_like(flat)
+    if k > 0:
+        idx = np.argsort(-flat, axis=1, kind="stable")[:, :k]
+        np.put_along_axis(pruned, idx, np.take_along_axis(flat, idx, axis=1), axis=1)
+    s1 = flat.sum(axis=1, dtype=np.float32)
+    s2 = pruned.sum(axis=1, dtype=np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        scaled = pruned * np.exp(s1 / s2).astype(np.float32)[:, None]
+    return scaled.reshape(x.shape), pruned.reshape(x.shape)
+
+
+def predictive_uncertainty(logits: np.ndarray, n_mc: int):
+    """get_predictive_uncertainty_score (inference/funcs.py:430-465): logits (N * n_mc, C), an image's rows consecutive.
+    softmax per row; pred_h = -sum(mean_s p * log(mean_s p)); mi = pred_h - mean_s(-sum(p log p)); float32 as torch (the sums
+    here are float64 and rounded once: the reference's float32 sums differ from them by their own rounding, ~1e-7)."""
+    x = np.asarray(logits, dtype=np.float32)
+    assert x.shape[0] % n_mc == 0
+    e = np.exp(x - x.max(axis=1, keepdims=True))
+    p = (e / e.sum(axis=1, keepdims=True, dtype=np.float32)).astype(np.float32)
+    p3 = p.reshape(-1, n_mc, x.shape[1])
+    mean = (p3.sum(axis=1, dtype=np.float32) / np.float32(n_mc)).astype(np.float32)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        pred_h = -(mean * np.log(mean)).sum(axis=1, dtype=np.float64)
+        h_s = -(p3 * np.log(p3)).sum(axis=2, dtype=np.float64)
+    exp_h = h_s.mean(axis=1)
+    return pred_h.astype(np.float32), (pred_h - exp_h).astype(np.float32)
+
+
+def kde_score_kernel(train: np.ndarray, x: np.ndarray, bandwidth: float, kernel: str) -> np.ndarray:
+    """sklearn.neighbors.KernelDensity(kernel=..., bandwidth=h).fit(train).score_samples(x) by its definition (what
+    DetectorKDE(kernel=...) forwards to, inference/postprocessors.py:78-128; kernels and normalisation of
+    sklearn/neighbors/_binary_tree.pxi.tp): log(sum_i K(|x - t_i| / h)) - log N + log_norm(kernel, d, h); compact kernels
+    are 0 from |x - t| >= h on."""
+    from scipy.special import gammaln
+
+    train, x = np.asarray(train, np.float64), np.asarray(x, np.float64)
+    m, d = train.shape
+    h = float(bandwidth)
+    dist = np.sqrt(((x[:, None, :] - train[None]) ** 2).sum(-1))
+    log_vn = lambda n: 0.5 * n * np.log(np.pi) - gammaln(0.5 * n + 1)
+    log_sn = lambda n: np.log(2 * np.pi) + log_vn(n - 1)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        if kernel == "gaussian":
+            kv, factor = np.exp(-0.5 * (dist / h) ** 2), 0.5 * d * np.log(2 * np.pi)
+        elif kernel == "tophat":
+            kv, factor = (dist < h).astype(np.float64), log_vn(d)
+        elif kernel == "epanechnikov":
+            kv, factor = np.where(dist < h, 1.0 - (dist * dist) / (h * h), 0.0), log_vn(d) + np.log(2.0 / (d + 2.0))
+        elif kernel == "exponential":
+            kv, factor = np.exp(-dist / h), log_sn(d - 1) + gammaln(d)
+        elif kernel == "linear":
+            kv, factor = np.where(dist < h, 1.0 - dist / h, 0.0), log_vn(d) - np.log(d + 1.0)
+        elif kernel == "cosine":
+            f, tmp = 0.0, 2.0 / np.pi
+            for k in range(1, d + 1, 2):
+                f += tmp
+                tmp *= -(d - k) * (d - k - 1) * (2.0 / np.pi) ** 2
+            kv, factor = np.where(dist < h, np.cos(0.5 * np.pi * dist / h), 0.0), np.log(f) + log_sn(d - 1)
+        else:
+            raise ValueError(kernel)
+        return np.log(kv.sum(axis=1)) - np.log(m) - factor - d * np.log(h)
 
 
 def gen_score(logits: np.ndarray, gamma: float, M: int) -> np.ndarray:

@@ -468,3 +468,28 @@ def test_vim_fixture():
     assert rel_err(u, g["vim_u"]) < 1e-6 and abs(alpha - float(g["vim_alpha"])) < 1e-6 * abs(alpha)
     got = oracle.vim_score(g["test"], g["logits_test"], g["vim_u"], g["vim_NS"], float(g["vim_alpha"]))
     assert rel_err(got, g["vim_scores"]) < 1e-6  # float32 arithmetic in the reference for float32 features
+
+
+def test_round4_restatements_against_the_reference_run_fixture():
+    """oracle.predictive_uncertainty / ash_s_conv_defined / generalized_entropy against what the reference's own functions
+    returned (tests/golden/ref_funcs_r4.npz, tools/make_goldens_r4.py), and oracle.kde_score_kernel against scikit-learn's
+    KernelDensity (the call DetectorKDE forwards) where its tree is converged."""
+    g = load_npz("ref_funcs_r4.npz")
+    for tag in ("a", "b", "c", "d"):
+        ph, mi = oracle.predictive_uncertainty(g[f"pu_{tag}_logits"], int(g[f"pu_{tag}_nmc"]))
+        assert rel_err(ph, g[f"pu_{tag}_pred_h"]) < 2e-6 and rel_err(mi, g[f"pu_{tag}_mi"]) < 2e-6
+    for tag in ("a", "b"):
+        y, pruned = oracle.ash_s_conv_defined(g[f"ashc_{tag}_x"], int(g[f"ashc_{tag}_pct"]))
+        assert rel_err(y, g[f"ashc_{tag}_y"]) < 2e-6 and np.array_equal(pruned, g[f"ashc_{tag}_x_after"])
+    for tag in ("a", "b", "c"):
+        gamma, m = g[f"gen_{tag}_gm"]
+        assert rel_err(oracle.generalized_entropy(g[f"gen_{tag}_p"], float(gamma), int(m)), g[f"gen_{tag}_s"]) < 1e-6
+    from sklearn.neighbors import KernelDensity
+
+    rng = np.random.default_rng(5)
+    train, x = rng.standard_normal((400, 3)), rng.standard_normal((60, 3))
+    for kernel in ("gaussian", "tophat", "epanechnikov", "exponential", "linear", "cosine"):
+        ref = KernelDensity(kernel=kernel, bandwidth=0.9).fit(train).score_samples(x)
+        got = oracle.kde_score_kernel(train, x, 0.9, kernel)
+        ok = np.isfinite(got) & (ref > -30)
+        assert ok.sum() > 40 and rel_err(got[ok], ref[ok]) < 1e-9, kernel
