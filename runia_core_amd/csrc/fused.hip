@@ -301,7 +301,11 @@ __device__ __forceinline__ void roi_load_map(float (&u)[HT * WT], const RoiSourc
     for (int sx = 0; sx < SX; ++sx) {
       // (wave-uniform; outside: offsets are 0 in the table, the value read is replaced by 0 - no branch around a load)
       const bool inside = row_in && ((col_out >> sx) & 1u) == 0u;
+#if defined(ROI_ABLATE) && ROI_ABLATE == 3  // (timing experiments only: no weight products)
+      const float w1 = hy, w2 = ly, w3 = hx[sx], w4 = lx[sx];
+#else
       const float w1 = hy * hx[sx], w2 = hy * lx[sx], w3 = ly * hx[sx], w4 = ly * lx[sx];
+#endif
       const float val = inside ? w1 * t[sx][0] + w2 * t[sx][1] + w3 * t[sx][2] + w4 * t[sx][3] : 0.f;
       acc[(sy / G) * WT + (sx / G)] += val;  // a bin receives its samples in (iy, ix) order
     }

@@ -93,7 +93,10 @@ class DetectorKDE:
         d, n_rows = train.shape[1], x.shape[0]
         if self.kernel != "gaussian":  # tophat / epanechnikov / exponential / linear / cosine: one direct kernel
             return _hip.kde_score_kernel(train, x.to(torch.float64), float(self.bandwidth), self.kernel)
-        if d >= 24 or (d >= 12 and n_rows <= 16384):
+        if d >= 24 or (d >= 12 and n_rows <= 16384) or n_rows <= 2048:
+            # (few rows, any width: a 64-query group of the direct kernel walks the whole training set on ONE compute unit -
+            # 0.28-0.57 ms for 1 ... 512 rows against 10 000 training rows at D = 2 ... 23; the matrix-core form with its
+            # column blocks on separate workgroups 0.12-0.14 ms, tools/ablate/run_kde_few_rows.py)
             # pair distances as |x|^2 + |t|^2 - 2 x.t on the f64 matrix cores, online logsumexp (8 192 x 10 000 pairs:
             # 0.27 / 0.38 / 0.88 ms at D = 32 / 64 / 256 against 0.56 / 1.85 / 21.5 ms for the direct kernels).  At
             # D = 16 the direct kernel wins on large batches (65 536 rows: 1.47 vs 1.84 ms) and loses on small ones,
