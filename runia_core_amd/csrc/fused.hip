@@ -283,31 +283,49 @@ __device__ __forceinline__ void roi_load_map(float (&u)[HT * WT], const RoiSourc
   float acc[HT * WT];
 #pragma unroll
   for (int p = 0; p < HT * WT; ++p) acc[p] = 0.f;
+  // The two pixel rows of a sample row stay in registers: sample rows are 1/G of a bin apart, so on a box of fewer than
+  // 2 * SY feature rows the next sample row uses the same two pixel rows again (no load) or the upper one becomes the lower
+  // (SX * 2 loads instead of SX * 4).  Which of the three it is depends on the table alone (wave-uniform), and a pixel read
+  // once is the pixel read twice: the same bits as one load per tap.
+  float tl[SX][2], th[SX][2];
+  unsigned cur_lo = 0xffffffffu, cur_hi = 0xffffffffu;  // (no pixel row starts at this byte offset)
 #pragma unroll
   for (int sy = 0; sy < SY; ++sy) {
     const unsigned oy_lo = rows[4 * sy], oy_hi = rows[4 * sy + 1];
     const float hy = __uint_as_float(rows[4 * sy + 2]), ly = __uint_as_float(rows[4 * sy + 3]);
     const bool row_in = ((row_out >> sy) & 1u) == 0u;
-    float t[SX][4];
+    if (oy_lo != cur_lo || oy_hi != cur_hi) {
+      if (oy_lo == cur_hi) {
 #pragma unroll
-    for (int sx = 0; sx < SX; ++sx) {
-      t[sx][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_lo + ox_lo[sx]), 0));
-      t[sx][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_lo + ox_hi[sx]), 0));
-      t[sx][2] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_hi + ox_lo[sx]), 0));
-      t[sx][3] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_hi + ox_hi[sx]), 0));
+        for (int sx = 0; sx < SX; ++sx) { tl[sx][0] = th[sx][0]; tl[sx][1] = th[sx][1]; }
+      } else {
+#pragma unroll
+        for (int sx = 0; sx < SX; ++sx) {
+          tl[sx][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_lo + ox_lo[sx]), 0));
+          tl[sx][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_lo + ox_hi[sx]), 0));
+        }
+      }
+#pragma unroll
+      for (int sx = 0; sx < SX; ++sx) {
+        th[sx][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_hi + ox_lo[sx]), 0));
+        th[sx][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, (int)(oy_hi + ox_hi[sx]), 0));
+      }
+      cur_lo = oy_lo;
+      cur_hi = oy_hi;
     }
     __builtin_amdgcn_sched_barrier(0);  // (the loads above stay above)
 #pragma unroll
     for (int sx = 0; sx < SX; ++sx) {
       // (wave-uniform; outside: offsets are 0 in the table, the value read is replaced by 0 - no branch around a load)
-      const bool inside = row_in && ((col_out >> sx) & 1u) == 0u;
-#if defined(ROI_ABLATE) && ROI_ABLATE == 3  // (timing experiments only: no weight products)
-      const float w1 = hy, w2 = ly, w3 = hx[sx], w4 = lx[sx];
-#else
+      const unsigned inside = (row_in && ((col_out >> sx) & 1u) == 0u) ? 0xffffffffu : 0u;
       const float w1 = hy * hx[sx], w2 = hy * lx[sx], w3 = ly * hx[sx], w4 = ly * lx[sx];
-#endif
-      const float val = inside ? w1 * t[sx][0] + w2 * t[sx][1] + w3 * t[sx][2] + w4 * t[sx][3] : 0.f;
-      acc[(sy / G) * WT + (sx / G)] += val;  // a bin receives its samples in (iy, ix) order
+      const float in_val = w1 * tl[sx][0] + w2 * tl[sx][1] + w3 * th[sx][0] + w4 * th[sx][1];
+      const float val = __uint_as_float(__float_as_uint(in_val) & inside);  // (a mask, not a branch per sample)
+      float& bin = acc[(sy / G) * WT + (sx / G)];
+      bin += val;  // a bin receives its samples in (iy, ix) order
+      // added NOW: left alone the compiler keeps all SY * SX sample values in registers to add them in pairs at the end
+      // (247 vector registers, two waves per SIMD; the loader needs the bins, two pixel rows and little else)
+      asm volatile("" : "+v"(bin));
     }
   }
 #pragma unroll

@@ -438,6 +438,44 @@ __global__ __launch_bounds__(256) void row_sqnorm_f64_kernel(const double* __res
 // 16-row instantiation runs (N = 10 000: 313 tiles of 32 rows are 1.2 rounds on 256 CUs - PCA transform 75 us, MD
 // 51 us; 625 tiles of 16 rows: 59 and 33 us; LaRED 8 192 x 10 000 x 256: 0.94 -> 0.88 ms).  A row's bits do not depend on
 // the tile height (tests/test_full_size_gpu.py).
+//
+// Last round (round 4).  All workgroups of a launch take the same time, so a grid of 6.1 x (resident workgroups) runs 7
+// rounds, the last one on a tenth of the chip (100 000 x 1024 -> 256: matrix pipe busy 0.72 against the 0.81 of the same
+// kernel on Mahalanobis' 61 rounds).  The whole rounds therefore go first as 32-row tiles and the remaining rows follow
+// as a second launch of units a fraction of that size: 16-row tiles (half a unit; taken when they fit the chip at once),
+// or - KDE / MD with a workspace, see their entry points - one workgroup per (16-row tile, 256-column block).
+template <auto KERNEL>
+static int64_t resident_workgroups() {  // of one instantiation on the current device; cached
+  static int64_t slots = 0;
+  if (slots == 0) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, KERNEL, 256, 0) != hipSuccess || per_cu < 1) per_cu = 1;
+    slots = (int64_t)per_cu * runia_cu_count();
+  }
+  return slots;
+}
+
+// the rows from `first` on, as a problem of its own (every per-row pointer moved; column-split workspaces are not set here)
+template <typename TA>
+static GemmArgs gemm_rows_from(const GemmArgs& g, int64_t first, int64_t out_ld) {
+  GemmArgs t = g;
+  t.x = reinterpret_cast<const TA*>(g.x) + first * g.ldx;
+  t.N = g.N - first;
+  if (g.rown) t.rown = g.rown + first;
+  t.out = g.out + first * out_ld;
+  return t;
+}
+
+// rows [0, return value) are whole rounds of 32-row tiles; 0 = no split (few tiles, or the last round is nearly full)
+template <typename TA, int EPI, typename TS, int NCT>
+static int64_t gemm_whole_round_rows(const GemmArgs& g) {
+  const int64_t tiles = (g.N + BM - 1) / BM;
+  const int64_t slots = resident_workgroups<gemm_rows_kernel<TA, TS, EPI, 2, NCT>>();
+  const int64_t whole = tiles / slots * slots, rest = tiles - whole;
+  if (whole == 0 || rest == 0 || rest * 8 >= slots * 7) return 0;
+  return whole * BM;
+}
+
 template <typename TA, int EPI, typename TS, int NCT>
 int launch_gemm_nct(const GemmArgs& g, hipStream_t s) {
   const int64_t tiles = (g.N + BM - 1) / BM;
@@ -445,6 +483,18 @@ int launch_gemm_nct(const GemmArgs& g, hipStream_t s) {
   if (EPI != EPI_MAHA && tiles < 4 * runia_cu_count()) {
     gemm_rows_kernel<TA, TS, EPI, 1, NCT><<<(unsigned)((g.N + 15) / 16), 256, 0, s>>>(g);
     return runia_check_launch();
+  }
+  if constexpr (EPI != EPI_MAHA) {
+    const int64_t head = gemm_whole_round_rows<TA, EPI, TS, NCT>(g);
+    const int64_t rest16 = (g.N - head + 15) / 16;
+    if (head > 0 && rest16 <= resident_workgroups<gemm_rows_kernel<TA, TS, EPI, 1, NCT>>()) {
+      GemmArgs h = g;
+      h.N = head;
+      gemm_rows_kernel<TA, TS, EPI, 2, NCT><<<(unsigned)(head / BM), 256, 0, s>>>(h);
+      const GemmArgs t = gemm_rows_from<TA>(g, head, (EPI == EPI_PCA || EPI == EPI_STORE) ? g.n : 1);
+      gemm_rows_kernel<TA, TS, EPI, 1, NCT><<<(unsigned)rest16, 256, 0, s>>>(t);
+      return runia_check_launch();
+    }
   }
   gemm_rows_kernel<TA, TS, EPI, 2, NCT><<<(unsigned)tiles, 256, 0, s>>>(g);
   return runia_check_launch();
@@ -783,10 +833,24 @@ __global__ __launch_bounds__(256) void kde_replay_kernel(const double* __restric
 
 // query norms, + the values of the column-split launch when the batch has fewer 16-row tiles than the chip has compute units
 static bool kde_split_wanted(int64_t N, int64_t M) { return (N + 15) / 16 < runia_cu_count() && n_padded(M) / BN > 1; }
+static size_t kde_split_bytes(int64_t rows, int64_t M) {
+  return (size_t)(((rows + 15) / 16) * (n_padded(M) / BN) * 256 * 16) * sizeof(double);
+}
+// Large batches: the rows behind the whole rounds of 32-row tiles (launch_gemm_nct) go through the same column split - units
+// of 1/(2 * blocks) of a 32-row tile instead of a last round on part of the chip (100 000 x 256 against 4 000 rows: 3 125
+// tiles on 512 resident workgroups = 6.1 rounds; 4.40 -> 3.9 ms).  0 = no such rows.
+static int64_t kde_last_round_rows(int64_t N, int64_t M) {
+  if (n_padded(M) / BN < 2 || (N + BM - 1) / BM < 4 * runia_cu_count()) return 0;
+  GemmArgs g{};
+  g.N = N;
+  const int64_t head = gemm_whole_round_rows<double, EPI_KDE, double, 4>(g);
+  return head > 0 ? N - head : 0;
+}
 extern "C" size_t runia_kde_workspace_bytes(int64_t N, int64_t M) {
   if (N <= 0 || M <= 0) return 0;
   size_t bytes = (((size_t)N * sizeof(double)) + 255) / 256 * 256;
-  if (kde_split_wanted(N, M)) bytes += (size_t)(((N + 15) / 16) * (n_padded(M) / BN) * 256 * 16) * sizeof(double);
+  if (kde_split_wanted(N, M)) bytes += kde_split_bytes(N, M);
+  else bytes += kde_split_bytes(kde_last_round_rows(N, M), M);
   return bytes;
 }
 
@@ -816,6 +880,20 @@ extern "C" int runia_kde_score_packed_f64(const double* packed_train_t, const do
     gemm_rows_kernel<double, double, EPI_KDE, 1, 4><<<(unsigned)(tiles * nb), 256, 0, s>>>(g);
     kde_replay_kernel<<<(unsigned)tiles, 256, 0, s>>>(g.kde_vals, score, N, nb, g.addc);
     return runia_check_launch();
+  }
+  if (const int64_t rest = kde_last_round_rows(N, M); rest > 0 && workspace_bytes >= runia_kde_workspace_bytes(N, M)) {
+    hipStream_t s = as_stream(stream);
+    const int64_t head = N - rest, tiles = (rest + 15) / 16, nb = n_padded(M) / BN;
+    if (tiles * nb <= 0x7fffffff) {
+      GemmArgs h = g;
+      h.N = head;
+      gemm_rows_kernel<double, double, EPI_KDE, 2, 4><<<(unsigned)(head / BM), 256, 0, s>>>(h);
+      GemmArgs t = gemm_rows_from<double>(g, head, 1);
+      t.kde_vals = reinterpret_cast<double*>(reinterpret_cast<char*>(workspace) + (((size_t)N * sizeof(double)) + 255) / 256 * 256);
+      gemm_rows_kernel<double, double, EPI_KDE, 1, 4><<<(unsigned)(tiles * nb), 256, 0, s>>>(t);
+      kde_replay_kernel<<<(unsigned)tiles, 256, 0, s>>>(t.kde_vals, t.out, rest, nb, g.addc);
+      return runia_check_launch();
+    }
   }
   return launch_gemm<double, EPI_KDE>(g, as_stream(stream));
 }

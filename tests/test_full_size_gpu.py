@@ -118,7 +118,9 @@ def test_row_gemm_stages_tile_height_does_not_change_bits(hip):
     """The row GEMM kernel (PCA transform, MD, ViM norm, KDE on the matrix cores) runs 16-row tiles below four tiles per
     CU and 32-row tiles above (40 000 rows here: 32-row tiles).  A row's result must not depend on that: slices scored on
     their own (16-row tiles) equal the same rows of the whole batch bit for bit, ragged ends included; sampled rows are
-    checked against the oracle."""
+    checked against the oracle.  Round 4: the rows behind the whole rounds of 32-row tiles run as a second launch of
+    smaller units (16-row tiles; KDE: 16 rows x 256 training rows + replay) - on 256 CUs with two resident workgroups
+    each that boundary is row 32 768 here, and slices across it are compared too."""
     n_rows, d, n = 40_003, 512, 256
     g = torch.Generator(device="cuda").manual_seed(9)
     h = torch.randn(n_rows, d, dtype=torch.float64, device="cuda", generator=g)
@@ -133,7 +135,7 @@ def test_row_gemm_stages_tile_height_does_not_change_bits(hip):
     pp, mdm = hip.pack_weights(dev(prec)), dev(md_mean.ravel())
     y = hip.pca_transform(h, pct, bias, scale, n)
     s = hip.md_score(y, mdm, pp)
-    for lo, hi in ((0, 700), (17_001, 17_050), (39_990, n_rows)):
+    for lo, hi in ((0, 700), (17_001, 17_050), (32_750, 32_800), (39_990, n_rows)):
         y_part = hip.pca_transform(h[lo:hi].contiguous(), pct, bias, scale, n)
         assert torch.equal(y_part, y[lo:hi])
         assert torch.equal(hip.md_score(y_part, mdm, pp), s[lo:hi])
@@ -149,7 +151,8 @@ def test_row_gemm_stages_tile_height_does_not_change_bits(hip):
     x = torch.randn(n_rows, 64, dtype=torch.float64, device="cuda", generator=g)
     st = hip.kde_pack_train(tr)
     kd = hip.kde_score_packed(st, x, 4.0)
-    assert torch.equal(hip.kde_score_packed(st, x[5_000:5_040].contiguous(), 4.0), kd[5_000:5_040])
+    for lo, hi in ((5_000, 5_040), (32_750, 32_800), (n_rows - 40, n_rows)):
+        assert torch.equal(hip.kde_score_packed(st, x[lo:hi].contiguous(), 4.0), kd[lo:hi])
     assert rel_err(kd[:64].cpu().numpy(), oracle.kde_score(tr.cpu().numpy(), x[:64].cpu().numpy(), 4.0)) < 1e-11
 
 
