@@ -1110,6 +1110,9 @@ def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+ROI_FUSED_MAX_IMAGE_BYTES = 1 << 30  # one image's feature map behind a 32-bit buffer, with room for the offsets of outside samples
+
+
 def roi_mc_entropy_supported(ph: int, pw: int, n_mc: int, k: int, sampling_ratio: int) -> bool:
     return bool(load_library().runia_roi_mc_entropy_supported(int(ph), int(pw), int(n_mc), int(k), int(sampling_ratio)))
 

@@ -260,7 +260,7 @@ __device__ __forceinline__ void roi_load_map(float (&u)[HT * WT], const RoiSourc
   // readfirstlane loop)
   typedef const __attribute__((address_space(4))) unsigned* cptr;
   cptr tab = (cptr)(src->table + roi * (int64_t)src->roi_dwords);  // wave-uniform
-  const unsigned image = tab[0], row_out = tab[1], col_out = tab[2];
+  const unsigned image = tab[0];
   const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(
       const_cast<float*>(src->nhwc) + (int64_t)image * (src->image_bytes / 4), 0, (int)src->image_bytes, 0x00020000);
   const int voff = c * 4;
@@ -293,7 +293,6 @@ __device__ __forceinline__ void roi_load_map(float (&u)[HT * WT], const RoiSourc
   for (int sy = 0; sy < SY; ++sy) {
     const unsigned oy_lo = rows[4 * sy], oy_hi = rows[4 * sy + 1];
     const float hy = __uint_as_float(rows[4 * sy + 2]), ly = __uint_as_float(rows[4 * sy + 3]);
-    const bool row_in = ((row_out >> sy) & 1u) == 0u;
     if (oy_lo != cur_lo || oy_hi != cur_hi) {
       if (oy_lo == cur_hi) {
 #pragma unroll
@@ -316,11 +315,9 @@ __device__ __forceinline__ void roi_load_map(float (&u)[HT * WT], const RoiSourc
     __builtin_amdgcn_sched_barrier(0);  // (the loads above stay above)
 #pragma unroll
     for (int sx = 0; sx < SX; ++sx) {
-      // (wave-uniform; outside: offsets are 0 in the table, the value read is replaced by 0 - no branch around a load)
-      const unsigned inside = (row_in && ((col_out >> sx) & 1u) == 0u) ? 0xffffffffu : 0u;
+      // (a sample outside the map: zero weights and taps beyond the buffer, which read as 0 - the table sees to both)
       const float w1 = hy * hx[sx], w2 = hy * lx[sx], w3 = ly * hx[sx], w4 = ly * lx[sx];
-      const float in_val = w1 * tl[sx][0] + w2 * tl[sx][1] + w3 * th[sx][0] + w4 * th[sx][1];
-      const float val = __uint_as_float(__float_as_uint(in_val) & inside);  // (a mask, not a branch per sample)
+      const float val = w1 * tl[sx][0] + w2 * tl[sx][1] + w3 * th[sx][0] + w4 * th[sx][1];
       float& bin = acc[(sy / G) * WT + (sx / G)];
       bin += val;  // a bin receives its samples in (iy, ix) order
       // added NOW: left alone the compiler keeps all SY * SX sample values in registers to add them in pairs at the end
@@ -1113,7 +1110,7 @@ extern "C" int runia_roi_mc_entropy_f32(const float* feat_nhwc, const float* box
   if (K == 0) return RUNIA_OK;
   if (!feat_nhwc || !boxes || !h || K > 65535 || (B > 1 && !batch_idx)) return RUNIA_E_INVALID;
   if (!runia_roi_mc_entropy_supported(PH, PW, n_mc, k, sampling_ratio)) return RUNIA_E_INVALID;
-  if ((int64_t)H * W * C * 4 >= ((int64_t)1 << 31)) return RUNIA_E_INVALID;  // one image's map behind a 32-bit buffer
+  if ((int64_t)H * W * C * 4 >= ((int64_t)1 << 30)) return RUNIA_E_INVALID;  // one image's map behind a 32-bit buffer (RUNIA_ROI_FUSED_MAX_IMAGE_BYTES)
   if (drop_prob != 0.0 && !rnd) return RUNIA_E_INVALID;
   if (!workspace || (((uintptr_t)workspace) & 15) != 0 ||
       workspace_bytes < runia_roi_mc_entropy_workspace_bytes(K, PH, PW, n_mc, sampling_ratio))

@@ -120,14 +120,15 @@ __global__ __launch_bounds__(256) void roi_sample_table_kernel(RoiSourceHost src
     if (j == 0) {
       hd[0] = (unsigned)(batch_idx ? batch_idx[k] : 0);
 #pragma unroll
-      for (int q = 3; q < 8; ++q) hd[q] = 0u;
+      for (int q = 1; q < 8; ++q) hd[q] = 0u;
     }
     const bool outside = (t < -1.0f || t > (float)L);
-    // the masks of a ROI are assembled by the threads of its rows / columns: ballot over the lanes that share the ROI
-    // would need them in one wave; instead every thread recomputes nothing and the masks are written by atomics on a
-    // word the j == 0 thread may not have cleared yet -> they are built in a second, tiny pass below (mask_kernel)
+    // a sample row / column more than a pixel outside the map contributes nothing (roi_align's `continue`): its byte offset is
+    // the size of the image - every tap of it lies beyond the buffer the loader reads through, and such a load returns 0 -
+    // and its weights are 0, so the sample is +0.0 without a test in the loader
     if (outside) {
-      e[0] = 0u; e[1] = 0u; e[2] = 0u; e[3] = 0x7fc00000u;  // NaN in `l` marks the entry for the mask pass
+      e[0] = e[1] = (unsigned)src.image_bytes;
+      e[2] = e[3] = 0u;
       continue;
     }
     if (t <= 0.f) t = 0.f;
@@ -142,26 +143,6 @@ __global__ __launch_bounds__(256) void roi_sample_table_kernel(RoiSourceHost src
   }
 }
 
-// row / column masks of every ROI (bit = the sample row / column lies more than a pixel outside the map)
-__global__ __launch_bounds__(256) void roi_sample_mask_kernel(unsigned* __restrict__ tab, int64_t K, int nrows, int ncols) {
-  unsigned* roi_tab = tab + 16;
-  const int roi_dwords = 8 + 4 * (nrows + ncols);
-  for (int64_t k = (int64_t)blockIdx.x * 256 + threadIdx.x; k < K; k += (int64_t)gridDim.x * 256) {
-    unsigned* hd = roi_tab + k * (int64_t)roi_dwords;
-    unsigned rm = 0u, cm = 0u;
-    for (int j = 0; j < nrows; ++j) {
-      unsigned* e = hd + 8 + 4 * j;
-      if (e[3] == 0x7fc00000u) { rm |= 1u << j; e[3] = 0u; }
-    }
-    for (int j = 0; j < ncols; ++j) {
-      unsigned* e = hd + 8 + 4 * (nrows + j);
-      if (e[3] == 0x7fc00000u) { cm |= 1u << j; e[3] = 0u; }
-    }
-    hd[1] = rm;
-    hd[2] = cm;
-  }
-}
-
 }  // namespace
 
 size_t runia_roi_sample_table_bytes(int64_t K, int PH, int PW, int G) {
@@ -173,6 +154,7 @@ int runia_roi_sample_table(const float* feat_nhwc, const float* boxes, const int
                            hipStream_t s) {
   (void)B;
   if (table_bytes < runia_roi_sample_table_bytes(K, PH, PW, G) || PH * G > 32 || PW * G > 32) return RUNIA_E_WORKSPACE;
+  if ((int64_t)H * W * C * 4 >= (int64_t)1 << 30) return RUNIA_E_INVALID;  // (offsets of outside samples: row + column + channel stay below 2^32)
   RoiSourceHost src;
   src.quads = feat_nhwc;
   src.table = reinterpret_cast<const unsigned*>(table) + 16;
@@ -182,7 +164,6 @@ int runia_roi_sample_table(const float* feat_nhwc, const float* boxes, const int
   const int64_t total = K * (PH * G + PW * G);
   roi_sample_table_kernel<<<runia_stream_grid(total, 256), 256, 0, s>>>(src, boxes, batch_idx, reinterpret_cast<unsigned*>(table),
                                                                         K, C, H, W, PH, PW, (float)spatial_scale, G, aligned);
-  roi_sample_mask_kernel<<<runia_stream_grid(K, 256), 256, 0, s>>>(reinterpret_cast<unsigned*>(table), K, PH * G, PW * G);
   return runia_check_launch();
 }
 

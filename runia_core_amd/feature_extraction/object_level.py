@@ -75,7 +75,8 @@ def _dropblock_rois_get_entropy(latent_mcd_sample: List[Tensor], output_sizes: T
     k = int(torch.as_tensor(boxes).shape[0])
     redraw = isinstance(rand, _hip.CounterDraws) and rand.redraw_dead_layers  # (lives in the keep-flag kernel of the two-call path)
     if (mc_sampler.layer_type == "Conv" and k > 0 and len(set(sizes)) == 1 and not redraw
-            and _hip.roi_mc_entropy_supported(sizes[0][0], sizes[0][1], n_mcd_steps, kk, sampling_ratio)):
+            and _hip.roi_mc_entropy_supported(sizes[0][0], sizes[0][1], n_mcd_steps, kk, sampling_ratio)
+            and all(m[0].numel() * 4 < _hip.ROI_FUSED_MAX_IMAGE_BYTES for m in latent_mcd_sample[:n_hooked_reps])):
         # one pass per hooked layer from the feature map to the entropies: roi_align is folded into the sampler's load
         # (channels-last copy of the map, per-ROI sample table), the (K, C, PH, PW) tensor is never written
         ph, pw = sizes[0]
