@@ -131,6 +131,12 @@ __device__ __forceinline__ void load_a_regs(const GemmArgs& g, int64_t r0, int64
 // one block's NCT values of a lane's accumulator row into the lane's running (max, sum of exp(. - max))
 template <int NCT>
 __device__ __forceinline__ void kde_online_update(const double (&val)[NCT], double& rowmax, double& rowdot) {
+#if defined(KDE_ABLATE) && KDE_ABLATE >= 1  // (timing experiments only: what the epilogue's exponentials cost)
+#pragma unroll
+  for (int c = 0; c < NCT; ++c) rowdot += val[c];
+  rowmax = 0.0;
+  return;
+#endif
   double gmax = -kInfD();
 #pragma unroll
   for (int c = 0; c < NCT; ++c) gmax = fmax(gmax, val[c]);
@@ -216,20 +222,52 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
 #pragma unroll
     for (int r = 0; r < 4; ++r) { rowdot[a][r] = 0.0; rowmax[a][r] = -kInfD(); }
 
+  // EPI_KDE: the tile's row norms once (they were fetched in front of every block's epilogue - a global load's latency per
+  // block and lane); the block's column norms are requested at the head of the block and arrive under its products
+  __shared__ double lds_rown[(EPI == EPI_KDE) ? BM : 1];
+  if constexpr (EPI == EPI_KDE) {
+    if (tid < BM) lds_rown[tid] = (r0 + tid < g.N) ? g.rown[r0 + tid] : 0.0;  // (published by the chunk loop's barriers)
+  }
+  double areg[2 * RT];  // this thread's part of the next staged chunk of rows
+  // weights three k-step pairs ahead (mfma_chunk_ring) wherever the registers allow it: with one pair of look-ahead - 1 024
+  // matrix-pipe cycles at 32 x 256, 512 at 16 x 256 - a fetch that misses the L2 stalls the products (PCA 100 000 x 1024 ->
+  // 256: 0.93 -> 0.83 ms; the Mahalanobis epilogue keeps its 253 registers and the one-pair form)
+#ifndef GEMM_RING
+#define GEMM_RING 1
+#endif
+  constexpr bool RING = GEMM_RING && (EPI != EPI_MAHA);
+  double2 b0[NCT];
+  double2 bring[RING ? 4 : 1][NCT];
+  auto load_b_head = [&](const double2* p) {  // the first k-step pair(s) of a block's weights
+    if constexpr (RING) {
+#pragma unroll
+      for (int j = 0; j < 3; ++j)
+#pragma unroll
+        for (int c = 0; c < NCT; ++c) bring[j][c] = p[j * NT * 64 + c * 64];
+    } else {
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) b0[c] = p[c * 64];
+    }
+  };
   for (int64_t cb = cb_begin; cb < cb_end; ++cb) {
     const int64_t ctbase = cb * 16 + wave * NCT;
+    double cn[(EPI == EPI_KDE) ? NCT : 1];
+    if constexpr (EPI == EPI_KDE) {
+#pragma unroll
+      for (int c = 0; c < NCT; ++c) {
+        const int64_t col = (ctbase + c) * 16 + li;
+        cn[c] = (col < g.n) ? g.coln[col] : 0.0;
+      }
+    }
     d4 acc[RT][NCT];
 #pragma unroll
     for (int a = 0; a < RT; ++a)
 #pragma unroll
       for (int c = 0; c < NCT; ++c) acc[a][c] = (d4){0.0, 0.0, 0.0, 0.0};
     const double2* bp = reinterpret_cast<const double2*>(g.packed) + ctbase * 64 + lane;
-    double2 b0[NCT];
-#pragma unroll
-    for (int c = 0; c < NCT; ++c) b0[c] = bp[c * 64];
+    if (cb == cb_begin) load_b_head(bp);  // (later blocks: requested behind the previous block's last chunk)
 
-    double areg[2 * RT];
-    load_a_regs<TA, TS, RT>(g, r0, 0, tid, areg);
+    if (cb == cb_begin) load_a_regs<TA, TS, RT>(g, r0, 0, tid, areg);
     int buf = 0;
     for (int64_t ch = 0; ch < nchunks; ++ch) {
       {
@@ -239,10 +277,18 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
         for (int q = 0; q < PER; ++q) lds_a[buf][row][kk + q] = areg[q];
       }
       __syncthreads();
+      // the next chunk's rows are requested before this chunk's products; behind the last chunk that is the FIRST chunk of
+      // the next 256-column block (the same rows again), so its latency passes under the products and the epilogue instead
+      // of in front of every block (KDE at K = 256: 8 chunks per block)
       if (ch + 1 < nchunks) load_a_regs<TA, TS, RT>(g, r0, (ch + 1) * KC, tid, areg);
-      mfma_chunk<RT, NCT>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
+      else if (cb + 1 < cb_end) load_a_regs<TA, TS, RT>(g, r0, 0, tid, areg);
+      if constexpr (RING) mfma_chunk_ring<RT, NCT>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, bring);
+      else mfma_chunk<RT, NCT>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
       buf ^= 1;
     }
+    // the next block's first weights travel under this block's epilogue (the look-ahead of the last chunk fetched the zero
+    // padding behind K instead)
+    if (cb + 1 < cb_end) load_b_head(bp + 16 * 64);
 
     // ---- epilogue for this 256-column block ----
     if constexpr (EPI == EPI_MAHA) {
@@ -296,13 +342,12 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
       for (int a = 0; a < RT; ++a)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const int64_t row = r0 + 16 * a + lg + 4 * r;
-          const double rn = (row < g.N) ? g.rown[row] : 0.0;
+          const double rn = lds_rown[16 * a + lg + 4 * r];
           double val[NCT];
 #pragma unroll
           for (int c = 0; c < NCT; ++c) {
             const int64_t col = (ctbase + c) * 16 + li;
-            val[c] = (col < g.n) ? g.alpha * (rn + g.coln[col] - 2.0 * acc[a][c][r]) : -kInfD();
+            val[c] = (col < g.n) ? g.alpha * (rn + cn[c] - 2.0 * acc[a][c][r]) : -kInfD();
           }
           if (g.kde_vals) {  // column-split launch: the values go to memory, kde_replay_kernel does the rest
             double* dst = g.kde_vals + ((((tile_id * (n_pad / BN) + cb) * 256 + tid) * (RT * 4) + (a * 4 + r)) * NCT);
