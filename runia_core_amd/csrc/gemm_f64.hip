@@ -231,11 +231,11 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   double areg[2 * RT];  // this thread's part of the next staged chunk of rows
   // weights three k-step pairs ahead (mfma_chunk_ring) wherever the registers allow it: with one pair of look-ahead - 1 024
   // matrix-pipe cycles at 32 x 256, 512 at 16 x 256 - a fetch that misses the L2 stalls the products (PCA 100 000 x 1024 ->
-  // 256: 0.93 -> 0.83 ms; the Mahalanobis epilogue keeps its 253 registers and the one-pair form)
+  // 256: 0.93 -> 0.83 ms; Mahalanobis 262 144 x 2048: 35.84 -> 35.66 ms, its weights come from the Infinity Cache either way)
 #ifndef GEMM_RING
 #define GEMM_RING 1
 #endif
-  constexpr bool RING = GEMM_RING && (EPI != EPI_MAHA);
+  constexpr bool RING = GEMM_RING != 0;
   double2 b0[NCT];
   double2 bring[RING ? 4 : 1][NCT];
   auto load_b_head = [&](const double2* p) {  // the first k-step pair(s) of a block's weights
@@ -883,7 +883,7 @@ static size_t kde_split_bytes(int64_t rows, int64_t M) {
 }
 // Large batches: the rows behind the whole rounds of 32-row tiles (launch_gemm_nct) go through the same column split - units
 // of 1/(2 * blocks) of a 32-row tile instead of a last round on part of the chip (100 000 x 256 against 4 000 rows: 3 125
-// tiles on 512 resident workgroups = 6.1 rounds; 4.40 -> 3.9 ms).  0 = no such rows.
+// tiles on 512 resident workgroups = 6.1 rounds; 4.40 -> 3.97 ms).  0 = no such rows.
 static int64_t kde_last_round_rows(int64_t N, int64_t M) {
   if (n_padded(M) / BN < 2 || (N + BM - 1) / BM < 4 * runia_cu_count()) return 0;
   GemmArgs g{};
