@@ -249,6 +249,7 @@ __global__ void tile_scan_kernel(unsigned* __restrict__ tile_sum, int* __restric
 }
 
 // tile pass 2: tps[i] (inclusive) for every element; prev_end[i] for every run end
+template <bool RAW = false>  // RAW: the tile summaries as tile_summary_kernel left them - the carries are added up here
 __device__ __forceinline__ void tile_prefix_body(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
                                                  int64_t n, const unsigned* __restrict__ tile_sum,
                                                  const int* __restrict__ tile_end, const unsigned* __restrict__ tile_cnt,
@@ -264,7 +265,28 @@ __device__ __forceinline__ void tile_prefix_body(const uint64_t* __restrict__ ke
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int64_t t0 = (int64_t)tile * kTile;
   __syncthreads();  // (a caller that loops over tiles reuses the carries)
-  if (tid == 0) { carry_sum = tile_sum[tile]; carry_end = tile_end[tile]; carry_cnt = tile_cnt[tile]; }
+  if constexpr (RAW) {
+    // every workgroup adds up the summaries of the tiles before its own (<= 1 024 x 12 bytes from L2, ~1 us side by side)
+    // instead of one wave scanning them in a launch of its own in front of this one (5.6 us + a launch boundary)
+    unsigned ps = 0u, pc = 0u;
+    int pe = -1;
+    for (unsigned t = tid; t < tile; t += 256) { ps += tile_sum[t]; pc += tile_cnt[t]; pe = max(pe, tile_end[t]); }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      ps += __shfl_xor(ps, o, 64);
+      pc += __shfl_xor(pc, o, 64);
+      pe = max(pe, __shfl_xor(pe, o, 64));
+    }
+    if (lane == 0) { wsum[wave] = ps; wcnt[wave] = pc; wend[wave] = pe; }
+    __syncthreads();
+    if (tid == 0) {
+      carry_sum = wsum[0] + wsum[1] + wsum[2] + wsum[3];
+      carry_cnt = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+      carry_end = max(max(wend[0], wend[1]), max(wend[2], wend[3]));
+    }
+  } else {
+    if (tid == 0) { carry_sum = tile_sum[tile]; carry_end = tile_end[tile]; carry_cnt = tile_cnt[tile]; }
+  }
   __syncthreads();
   for (int c = 0; c < kItems; ++c) {
     const int64_t i = t0 + c * 256 + tid;
@@ -322,6 +344,14 @@ __global__ __launch_bounds__(256) void tile_prefix_kernel(const uint64_t* __rest
                                                           unsigned* __restrict__ fps_out, int64_t* __restrict__ n_points) {
   tile_prefix_body(keys, lab, n, tile_sum, tile_end, tile_cnt, tps, prev_end, tps_out, fps_out, n_points, blockIdx.x);
 }
+__global__ __launch_bounds__(256) void tile_prefix_raw_kernel(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ lab,
+                                                              int64_t n, const unsigned* __restrict__ tile_sum,
+                                                              const int* __restrict__ tile_end,
+                                                              const unsigned* __restrict__ tile_cnt, unsigned* __restrict__ tps,
+                                                              int* __restrict__ prev_end, unsigned* __restrict__ tps_out,
+                                                              unsigned* __restrict__ fps_out, int64_t* __restrict__ n_points) {
+  tile_prefix_body<true>(keys, lab, n, tile_sum, tile_end, tile_cnt, tps, prev_end, tps_out, fps_out, n_points, blockIdx.x);
+}
 
 struct MetricsAccum {
   double roc_sum;            // sum of (fpr_j - fpr_{j-1}) * (tpr_j + tpr_{j-1})   (f32 terms)
@@ -331,7 +361,8 @@ struct MetricsAccum {
 
 __device__ __forceinline__ void curve_terms_body(const uint64_t* __restrict__ keys, int64_t n,
                                                  const unsigned* __restrict__ tps, const int* __restrict__ prev_end,
-                                                 MetricsAccum* __restrict__ acc, unsigned block, unsigned blocks) {
+                                                 MetricsAccum* __restrict__ acc, unsigned block, unsigned blocks,
+                                                 MetricsAccum* __restrict__ parts = nullptr) {
   __shared__ double sroc[4], spr[4];
   __shared__ unsigned long long sidx[4];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -339,18 +370,51 @@ __device__ __forceinline__ void curve_terms_body(const uint64_t* __restrict__ ke
   const float Nn = (float)((unsigned)n - tps[n - 1]);
   double roc = 0.0, pr = 0.0;
   unsigned long long first = ~0ull;
-  for (int64_t i = (int64_t)block * 256 + tid; i < n; i += (int64_t)blocks * 256) {
-    if (!(i == n - 1 || keys[i] != keys[i + 1])) continue;
-    const int p = prev_end[i];
-    const float tp = (float)tps[i], fp = (float)((unsigned)(i + 1) - tps[i]);
-    const float tp0 = (p < 0) ? 0.f : (float)tps[p], fp0 = (p < 0) ? 0.f : (float)((unsigned)(p + 1) - tps[p]);
-    const float tpr = tp / P, fpr = fp / Nn, tpr0 = tp0 / P, fpr0 = fp0 / Nn;
-    roc += (double)((fpr - fpr0) * (tpr + tpr0));
-    if (tpr >= 0.95f) first = min(first, (unsigned long long)i);
-    // precision-recall points: this run end and the one before it (the first run end pairs with the (1, 0) end point)
-    const float prec = tp / (tp + fp), rec = tpr;
-    const float prec0 = (p < 0) ? 1.0f : tp0 / (tp0 + fp0), rec0 = (p < 0) ? 0.0f : tpr0;
-    pr += (double)((rec0 - rec) * (prec0 + prec));
+  // four consecutive elements per thread and trip, their loads requested together: a run end costs a chain of two dependent
+  // loads (prev_end[i], then tps[prev_end[i]]), and with one element per trip a thread walked 15 such chains one after the
+  // other at 2 M keys (54 us; the arithmetic is ~5 us)
+  for (int64_t i0 = ((int64_t)block * 256 + tid) * 4; i0 < n; i0 += (int64_t)blocks * 1024) {
+    uint64_t k[5];
+    int pe[4];
+    unsigned tq[4];
+    if (i0 + 4 < n) {
+      const ulonglong2 ka = *reinterpret_cast<const ulonglong2*>(keys + i0), kb = *reinterpret_cast<const ulonglong2*>(keys + i0 + 2);
+      k[0] = ka.x; k[1] = ka.y; k[2] = kb.x; k[3] = kb.y; k[4] = keys[i0 + 4];
+      const int4 pv = *reinterpret_cast<const int4*>(prev_end + i0);
+      pe[0] = pv.x; pe[1] = pv.y; pe[2] = pv.z; pe[3] = pv.w;
+      const uint4 tv = *reinterpret_cast<const uint4*>(tps + i0);
+      tq[0] = tv.x; tq[1] = tv.y; tq[2] = tv.z; tq[3] = tv.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 5; ++j) k[j] = (i0 + j < n) ? keys[i0 + j] : 0ull;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        pe[j] = (i0 + j < n) ? prev_end[i0 + j] : -1;
+        tq[j] = (i0 + j < n) ? tps[i0 + j] : 0u;
+      }
+    }
+    bool end[4];
+    unsigned tq0[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      end[j] = (i0 + j < n) && (i0 + j == n - 1 || k[j] != k[j + 1]);
+      tq0[j] = (end[j] && pe[j] >= 0) ? tps[pe[j]] : 0u;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      if (!end[j]) continue;
+      const int64_t i = i0 + j;
+      const int p = pe[j];
+      const float tp = (float)tq[j], fp = (float)((unsigned)(i + 1) - tq[j]);
+      const float tp0 = (p < 0) ? 0.f : (float)tq0[j], fp0 = (p < 0) ? 0.f : (float)((unsigned)(p + 1) - tq0[j]);
+      const float tpr = tp / P, fpr = fp / Nn, tpr0 = tp0 / P, fpr0 = fp0 / Nn;
+      roc += (double)((fpr - fpr0) * (tpr + tpr0));
+      if (tpr >= 0.95f) first = min(first, (unsigned long long)i);
+      // precision-recall points: this run end and the one before it (the first run end pairs with the (1, 0) end point)
+      const float prec = tp / (tp + fp), rec = tpr;
+      const float prec0 = (p < 0) ? 1.0f : tp0 / (tp0 + fp0), rec0 = (p < 0) ? 0.0f : tpr0;
+      pr += (double)((rec0 - rec) * (prec0 + prec));
+    }
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) {
@@ -362,9 +426,15 @@ __device__ __forceinline__ void curve_terms_body(const uint64_t* __restrict__ ke
   if (lane == 0) { sroc[wave] = roc; spr[wave] = pr; sidx[wave] = first; }
   __syncthreads();
   if (tid == 0) {
-    unsafeAtomicAdd(&acc->roc_sum, ((sroc[0] + sroc[1]) + sroc[2]) + sroc[3]);
-    unsafeAtomicAdd(&acc->pr_sum, ((spr[0] + spr[1]) + spr[2]) + spr[3]);
-    atomicMin(&acc->fpr95_idx, min(min(sidx[0], sidx[1]), min(sidx[2], sidx[3])));
+    const double r = ((sroc[0] + sroc[1]) + sroc[2]) + sroc[3], q = ((spr[0] + spr[1]) + spr[2]) + spr[3];
+    const unsigned long long f = min(min(sidx[0], sidx[1]), min(sidx[2], sidx[3]));
+    if (parts) {  // the workgroup's own record: the last workgroup adds the records up in index order
+      parts[block].roc_sum = r; parts[block].pr_sum = q; parts[block].fpr95_idx = f;
+    } else {
+      unsafeAtomicAdd(&acc->roc_sum, r);
+      unsafeAtomicAdd(&acc->pr_sum, q);
+      atomicMin(&acc->fpr95_idx, f);
+    }
   }
 }
 __global__ __launch_bounds__(256) void curve_terms_kernel(const uint64_t* __restrict__ keys, int64_t n,
@@ -409,13 +479,20 @@ __device__ __forceinline__ void finalize_body(const MetricsAccum* __restrict__ a
 #endif
 constexpr int kMsdBits = METRICS_MSD_BITS, kMsdBuckets = 1 << kMsdBits;
 
-struct MsdState {                 // device words of the split (cleared by the step's one memset)
-  unsigned long long nkmin;       // ~(smallest key of the raw, FINITE scores): a maximum, so that it starts at 0 too
-  unsigned long long kmax;        // their largest key
+constexpr unsigned kProbeBlocks = 256;
+struct ProbeRec { unsigned long long nkmin, kmax; unsigned bad, pad; };
+// device words of the split.  Nothing of it has to be cleared beforehand: the probe's workgroups leave records of their own
+// (no atomics) and clear the counters the later launches add to; the key launch reduces the records (a memset in front of
+// the step was two fill launches, ~10 us)
+struct MsdState {
+  unsigned long long nkmin;       // ~(smallest key of the raw, FINITE scores)   } written by workgroup 0 of the key launch
+  unsigned long long kmax;        // their largest key                           }
+  ProbeRec recs[kProbeBlocks];    // the probe's workgroups
   unsigned hist[kMsdBuckets];
   unsigned cursor[kMsdBuckets];
   unsigned start[kMsdBuckets + 1];
   unsigned done_blocks;           // curve_terms: the last block to finish writes the three scalars
+  unsigned done_group[8 * 32];    // ... counted per residue of the workgroup id mod 8 first (one 128-byte line each)
 };
 
 template <typename T>
@@ -426,20 +503,35 @@ __device__ __forceinline__ uint64_t score_key(T v, bool squash) {
 
 template <typename T>
 __global__ __launch_bounds__(256) void msd_probe_kernel(const T* __restrict__ ind, int64_t n_ind, const T* __restrict__ ood,
-                                                        int64_t n_ood, unsigned* __restrict__ any_outside, MsdState* st,
-                                                        MetricsAccum* __restrict__ acc) {
+                                                        int64_t n_ood, MsdState* st) {
   __shared__ unsigned long long smin[4], smax[4];
-  if (blockIdx.x == 0 && threadIdx.x == 0) acc->fpr95_idx = ~0ull;  // (a minimum: the step's one memset left 0 there)
+  {  // the words later launches add to
+    constexpr unsigned kClear = 2 * kMsdBuckets + 1 + 8 * 32;
+    static_assert(offsetof(MsdState, done_group) + sizeof(unsigned) * 8 * 32 - offsetof(MsdState, hist) == (kClear + kMsdBuckets + 1) * 4,
+                  "hist, cursor, start, done_blocks, done_group are contiguous");
+    unsigned* z = st->hist;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < kClear + kMsdBuckets + 1; i += gridDim.x * 256) z[i] = 0u;
+  }
   bool bad = false;
   unsigned long long mn = ~0ull, mx = 0ull;  // key range of the raw, finite scores (no exp here: see MsdRange)
   const int64_t n = n_ind + n_ood;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-    const T v = (i < n_ind) ? ind[i] : ood[i - n_ind];
-    bad = bad || !(v >= (T)0 && v <= (T)1);
-    if (v - v == (T)0) {  // finite
-      const unsigned long long k = score_key<T>(v, false);
-      mn = k < mn ? k : mn;
-      mx = k > mx ? k : mx;
+  // (four loads in flight per thread and trip: one at a time the 32 trips of a thread at 2 M scores each waited for its load)
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += 4 * stride) {
+    T v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int64_t ij = i + j * stride;
+      v[j] = (ij < n) ? ((ij < n_ind) ? ind[ij] : ood[ij - n_ind]) : (T)0.5;  // (a filler inside [0, 1]; its key is skipped)
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      bad = bad || !(v[j] >= (T)0 && v[j] <= (T)1);
+      if (i + j * stride < n && v[j] - v[j] == (T)0) {  // finite
+        const unsigned long long k = score_key<T>(v[j], false);
+        mn = k < mn ? k : mn;
+        mx = k > mx ? k : mx;
+      }
     }
   }
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -453,12 +545,44 @@ __global__ __launch_bounds__(256) void msd_probe_kernel(const T* __restrict__ in
   if (lane == 0) { smin[wave] = mn; smax[wave] = mx; }
   const bool any_bad = __syncthreads_or(bad);
   if (threadIdx.x == 0) {
-    if (any_bad && __atomic_load_n(any_outside, __ATOMIC_RELAXED) == 0u) atomicOr(any_outside, 1u);
     unsigned long long a = smin[0], b = smax[0];
     for (int w = 1; w < 4; ++w) { a = smin[w] < a ? smin[w] : a; b = smax[w] > b ? smax[w] : b; }
-    atomicMax(&st->nkmin, ~a);
-    atomicMax(&st->kmax, b);
+    st->recs[blockIdx.x] = ProbeRec{~a, b, any_bad ? 1u : 0u, 0u};
   }
+}
+
+// the probe's records -> (any score outside [0, 1], key range); every workgroup of the key launch for itself, workgroup 0
+// also for the launches behind it
+struct ProbeResult { unsigned long long nkmin, kmax; bool squash; };
+__device__ __forceinline__ ProbeResult msd_reduce_probe(MsdState* st, unsigned nrec, unsigned* __restrict__ any_outside) {
+  __shared__ unsigned long long rmin[4], rmax[4];
+  __shared__ unsigned rbad[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  unsigned long long a = 0ull, b = 0ull;
+  unsigned bad = 0u;
+  for (unsigned r = tid; r < nrec; r += 256) {
+    const ProbeRec q = st->recs[r];
+    a = q.nkmin > a ? q.nkmin : a;
+    b = q.kmax > b ? q.kmax : b;
+    bad |= q.bad;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long a2 = ((unsigned long long)__shfl_xor((unsigned)(a >> 32), o, 64) << 32) | __shfl_xor((unsigned)a, o, 64);
+    const unsigned long long b2 = ((unsigned long long)__shfl_xor((unsigned)(b >> 32), o, 64) << 32) | __shfl_xor((unsigned)b, o, 64);
+    a = a2 > a ? a2 : a;
+    b = b2 > b ? b2 : b;
+    bad |= __shfl_xor(bad, o, 64);
+  }
+  if (lane == 0) { rmin[wave] = a; rmax[wave] = b; rbad[wave] = bad; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; ++w) { a = rmin[w] > a ? rmin[w] : a; b = rmax[w] > b ? rmax[w] : b; bad |= rbad[w]; }
+    rmin[0] = a; rmax[0] = b; rbad[0] = bad;
+    if (blockIdx.x == 0) { st->nkmin = a; st->kmax = b; *any_outside = bad; }
+  }
+  __syncthreads();
+  return ProbeResult{rmin[0], rmax[0], rbad[0] != 0u};
 }
 
 // Bucket of a key: LINEAR in the (squashed) score over the range of the finite scores - the bit patterns of doubles are not
@@ -475,9 +599,9 @@ __device__ __forceinline__ double unkey(uint64_t k) {  // inverse of sortable_de
 }
 struct MsdRange { double hi, scale; };
 template <typename T>
-__device__ __forceinline__ MsdRange msd_range(const MsdState* st, bool squash) {
+__device__ __forceinline__ MsdRange msd_range_of(unsigned long long nkmin, unsigned long long kmax, bool squash) {
   MsdRange r{0.0, 0.0};
-  const unsigned long long lo_k = ~st->nkmin, hi_k = st->kmax;
+  const unsigned long long lo_k = ~nkmin, hi_k = kmax;
   if (lo_k > hi_k) return r;  // (no finite score)
   T v_hi = (T)unkey(lo_k), v_lo = (T)unkey(hi_k);  // largest / smallest finite score
   if (squash) { v_hi = (T)1 / ((T)1 + exp(-v_hi)); v_lo = (T)1 / ((T)1 + exp(-v_lo)); }
@@ -485,6 +609,10 @@ __device__ __forceinline__ MsdRange msd_range(const MsdState* st, bool squash) {
   const double span = (double)v_hi - (double)v_lo;
   r.scale = (span > 0.0 && span < __builtin_inf()) ? (double)kMsdBuckets / span : 0.0;
   return r;
+}
+template <typename T>
+__device__ __forceinline__ MsdRange msd_range(const MsdState* st, bool squash) {
+  return msd_range_of<T>(st->nkmin, st->kmax, squash);
 }
 __device__ __forceinline__ unsigned msd_bucket(uint64_t key, const MsdRange& r) {
   const double v = unkey(key);
@@ -496,11 +624,13 @@ __device__ __forceinline__ unsigned msd_bucket(uint64_t key, const MsdRange& r) 
 
 template <typename T>
 __global__ __launch_bounds__(256) void msd_keys_kernel(const T* __restrict__ ind, int64_t n_ind, const T* __restrict__ ood,
-                                                       int64_t n_ood, const unsigned* __restrict__ any_outside, MsdState* st,
-                                                       uint64_t* __restrict__ keys, uint8_t* __restrict__ labels) {
+                                                       int64_t n_ood, unsigned* __restrict__ any_outside, MsdState* st,
+                                                       unsigned n_probe_recs, uint64_t* __restrict__ keys,
+                                                       uint8_t* __restrict__ labels) {
   __shared__ unsigned lh[kMsdBuckets];
-  const bool squash = *any_outside != 0u;
-  const MsdRange rg = msd_range<T>(st, squash);
+  const ProbeResult pr = msd_reduce_probe(st, n_probe_recs, any_outside);
+  const bool squash = pr.squash;
+  const MsdRange rg = msd_range_of<T>(pr.nkmin, pr.kmax, squash);
   for (int b = threadIdx.x; b < kMsdBuckets; b += 256) lh[b] = 0u;
   __syncthreads();
   const int64_t n = n_ind + n_ood;
@@ -523,36 +653,42 @@ __global__ __launch_bounds__(256) void msd_keys_kernel(const T* __restrict__ ind
   }
 }
 
-__global__ __launch_bounds__(256) void msd_scan_kernel(MsdState* st) {  // one workgroup: start[b] = keys in the buckets before b
-  __shared__ unsigned wsum[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  constexpr int PER = kMsdBuckets / 256;
-  unsigned v[PER], tot = 0u;
-#pragma unroll
-  for (int j = 0; j < PER; ++j) { v[j] = st->hist[tid * PER + j]; tot += v[j]; }
-  unsigned x = tot;
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1) {
-    const unsigned y = __shfl_up(x, o, 64);
-    if (lane >= o) x += y;
-  }
-  if (lane == 63) wsum[wave] = x;
-  __syncthreads();
-  unsigned off = x - tot;
-  for (int w = 0; w < wave; ++w) off += wsum[w];
-#pragma unroll
-  for (int j = 0; j < PER; ++j) { st->start[tid * PER + j] = off; off += v[j]; }
-  if (tid == 255) st->start[kMsdBuckets] = off;
-}
-
 constexpr int kScatItems = METRICS_SCAT_ITEMS, kScatTile = 256 * kScatItems;  // 8 192 keys per workgroup: ~2 per (tile, bucket)
 template <typename T>
 __global__ __launch_bounds__(256) void msd_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint8_t* __restrict__ lab_in,
                                                           uint64_t* __restrict__ keys_out, uint8_t* __restrict__ lab_out, int64_t n,
                                                           const unsigned* __restrict__ any_outside, MsdState* st) {
   __shared__ unsigned cnt[kMsdBuckets];   // keys of this tile per bucket, then the tile's first slot in the bucket
+  __shared__ unsigned first[kMsdBuckets]; // keys in the buckets before b
+  __shared__ unsigned wsum[4];
   const MsdRange rg = msd_range<T>(st, *any_outside != 0u);
   for (int b = threadIdx.x; b < kMsdBuckets; b += 256) cnt[b] = 0u;
+  {
+    // the exclusive scan of the bucket counts, by every workgroup for itself (16 KB of counts from L2) instead of by one
+    // workgroup in a launch of its own in front of this one; workgroup 0 leaves it in st->start for the sort
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = kMsdBuckets / 256;
+    unsigned v[PER], tot = 0u;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { v[j] = st->hist[tid * PER + j]; tot += v[j]; }
+    unsigned x = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum[wave] = x;
+    __syncthreads();
+    unsigned off = x - tot;
+    for (int w = 0; w < wave; ++w) off += wsum[w];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      first[tid * PER + j] = off;
+      if (blockIdx.x == 0) st->start[tid * PER + j] = off;
+      off += v[j];
+    }
+    if (blockIdx.x == 0 && tid == 255) st->start[kMsdBuckets] = off;
+  }
   __syncthreads();
   const int64_t t0 = (int64_t)blockIdx.x * kScatTile;
   uint64_t key[kScatItems];
@@ -568,7 +704,7 @@ __global__ __launch_bounds__(256) void msd_scatter_kernel(const uint64_t* __rest
   __syncthreads();
   for (int b = threadIdx.x; b < kMsdBuckets; b += 256) {
     const unsigned c = cnt[b];
-    cnt[b] = c ? st->start[b] + atomicAdd(&st->cursor[b], c) : 0u;  // ONE global atomic per non-empty (tile, bucket)
+    cnt[b] = c ? first[b] + atomicAdd(&st->cursor[b], c) : 0u;  // ONE global atomic per non-empty (tile, bucket)
   }
   __syncthreads();
 #pragma unroll
@@ -722,22 +858,62 @@ __global__ __launch_bounds__(256) void msd_bucket_sort_kernel(uint64_t* __restri
   }
 }
 
-// curve terms + (the last block to finish) the three scalars: one launch instead of two
+// curve terms + (the last block to finish) the three scalars: one launch instead of two.  Every workgroup leaves its sums in
+// a record of its own and counts itself done with ONE atomic (three more on one record - 2 048 atomics on one line at ~15-45 ns
+// each - were most of the launch); the last one adds the records in index order, so the three scalars are the same bits from
+// run to run.
+#ifndef METRICS_CURVE_BLOCKS
+#define METRICS_CURVE_BLOCKS 512
+#endif
+constexpr unsigned kCurveBlocks = METRICS_CURVE_BLOCKS;
 __global__ __launch_bounds__(256) void curve_terms_finalize_kernel(const uint64_t* __restrict__ keys, int64_t n,
                                                                    const unsigned* __restrict__ tps, const int* __restrict__ prev_end,
-                                                                   MetricsAccum* __restrict__ acc, MsdState* st, double* __restrict__ out) {
+                                                                   MetricsAccum* __restrict__ parts, MsdState* st, double* __restrict__ out) {
   __shared__ int last;
-  curve_terms_body(keys, n, tps, prev_end, acc, blockIdx.x, gridDim.x);
-  __threadfence();
-  __syncthreads();
-  if (threadIdx.x == 0) last = (atomicAdd(&st->done_blocks, 1u) + 1u == gridDim.x) ? 1 : 0;
-  __syncthreads();
-  if (last && threadIdx.x == 0) {
+  __shared__ double sroc[4], spr[4];
+  __shared__ unsigned long long sidx[4];
+  curve_terms_body(keys, n, tps, prev_end, nullptr, blockIdx.x, gridDim.x, parts);
+  // (thread 0 wrote the record: it alone fences, below - a release fence is an L2 write-back, and four waves of every
+  // workgroup issuing one was ~70 ns per workgroup of this launch)
+  // "last one out": atomics on ONE word retire at ~60 ns each - 512 workgroups finishing together spent 30 us in that queue.
+  // Eight counters on lines of their own (workgroup id mod 8) take 64 arrivals each side by side; whoever completes a
+  // counter arrives at the common one.
+  if (threadIdx.x == 0) {
+    const unsigned grp = blockIdx.x & 7u, groups = gridDim.x < 8u ? gridDim.x : 8u;
+    const unsigned in_grp = (gridDim.x + 7u - grp) / 8u;
+    int l = 0;
     __threadfence();
+    if (atomicAdd(&st->done_group[grp * 32], 1u) + 1u == in_grp) {
+      __threadfence();
+      l = (atomicAdd(&st->done_blocks, 1u) + 1u == groups) ? 1 : 0;
+    }
+    last = l;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  double roc = 0.0, pr = 0.0;
+  unsigned long long first = ~0ull;
+  for (unsigned b = tid; b < gridDim.x; b += 256) {
+    roc += __hip_atomic_load(&parts[b].roc_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pr += __hip_atomic_load(&parts[b].pr_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    first = min(first, __hip_atomic_load(&parts[b].fpr95_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    roc += shfl_xor_f64(roc, o);
+    pr += shfl_xor_f64(pr, o);
+    const unsigned lo = __shfl_xor((unsigned)first, o, 64), hi = __shfl_xor((unsigned)(first >> 32), o, 64);
+    first = min(first, ((unsigned long long)hi << 32) | lo);
+  }
+  if (lane == 0) { sroc[wave] = roc; spr[wave] = pr; sidx[wave] = first; }
+  __syncthreads();
+  if (tid == 0) {
     MetricsAccum a;
-    a.roc_sum = __hip_atomic_load(&acc->roc_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a.pr_sum = __hip_atomic_load(&acc->pr_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    a.fpr95_idx = __hip_atomic_load(&acc->fpr95_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    a.roc_sum = ((sroc[0] + sroc[1]) + sroc[2]) + sroc[3];
+    a.pr_sum = ((spr[0] + spr[1]) + spr[2]) + spr[3];
+    a.fpr95_idx = min(min(sidx[0], sidx[1]), min(sidx[2], sidx[3]));
     finalize_body(&a, tps, n, out);
   }
 }
@@ -755,7 +931,7 @@ __global__ __launch_bounds__(256) void curve_terms_finalize_kernel(const uint64_
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, dtot, tile_sum, tile_end, tile_cnt, accum, flag, msd, total;
+  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, dtot, tile_sum, tile_end, tile_cnt, accum, flag, msd, parts, total;
   unsigned nblocks;
 };
 
@@ -777,6 +953,7 @@ Layout make_layout(int64_t n) {
   L.accum = o; o += align256(sizeof(MetricsAccum));
   L.flag = o; o += 256;
   L.msd = o; o += align256(sizeof(MsdState));  // (accum, flag and msd are contiguous: one memset clears them)
+  L.parts = o; o += align256(kCurveBlocks * sizeof(MetricsAccum));  // per-workgroup records of the curve-term launch (written before read)
   L.total = o;
   return L;
 }
@@ -811,20 +988,18 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
 #endif
   if (METRICS_MSD) {
     MsdState* st = reinterpret_cast<MsdState*>(w + L.msd);
-    // one memset: accumulators, flag and split state (10 launches in all)
-    if (hipMemsetAsync(acc, 0, (L.msd - L.accum) + sizeof(MsdState), s) != hipSuccess) return RUNIA_E_LAUNCH;
+    // seven launches, nothing cleared beforehand (MsdState)
     const unsigned sgrid = runia_stream_grid(n, 256);
-    // (every workgroup ends in atomics on three words, ~45 ns each on one word: 256 workgroups, not 1 024)
-    msd_probe_kernel<T><<<(sgrid < 256u ? sgrid : 256u), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, acc);
-    msd_keys_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, keys[0], labs[0]);
-    msd_scan_kernel<<<1, 256, 0, s>>>(st);
+    const unsigned pgrid = sgrid < kProbeBlocks ? sgrid : kProbeBlocks;
+    msd_probe_kernel<T><<<pgrid, 256, 0, s>>>(ind, n_ind, ood, n_ood, st);
+    msd_keys_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0]);
     msd_scatter_kernel<T><<<(unsigned)((n + kScatTile - 1) / kScatTile), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, flag, st);
     msd_bucket_sort_kernel<T><<<kMsdBuckets / 4, 256, 0, s>>>(keys[1], labs[1], keys[0], labs[0], flag, st);  // (four buckets per workgroup)
     tile_summary_kernel<<<L.nblocks, 256, 0, s>>>(keys[1], labs[1], n, tile_sum, tile_end, tile_cnt);
-    tile_scan_kernel<<<1, 64, 0, s>>>(tile_sum, tile_end, tile_cnt, L.nblocks);
-    tile_prefix_kernel<<<L.nblocks, 256, 0, s>>>(keys[1], labs[1], n, tile_sum, tile_end, tile_cnt, tps, prev_end, tps_out, fps_out,
-                                                 n_points);
-    curve_terms_finalize_kernel<<<(sgrid < 512u ? sgrid : 512u), 256, 0, s>>>(keys[1], n, tps, prev_end, acc, st, out3);
+    tile_prefix_raw_kernel<<<L.nblocks, 256, 0, s>>>(keys[1], labs[1], n, tile_sum, tile_end, tile_cnt, tps, prev_end, tps_out,
+                                                     fps_out, n_points);
+    curve_terms_finalize_kernel<<<(sgrid < kCurveBlocks ? sgrid : kCurveBlocks), 256, 0, s>>>(
+        keys[1], n, tps, prev_end, reinterpret_cast<MetricsAccum*>(w + L.parts), st, out3);
     return runia_check_launch();
   }
   if (hipMemsetAsync(flag, 0, 4, s) != hipSuccess) return RUNIA_E_LAUNCH;

@@ -1,6 +1,8 @@
 import os, sys, torch, numpy as np
 sys.path.insert(0, os.getcwd())
 from runia_core_amd import _hip
+if os.environ.get('RUNIA_LIB'):
+    _hip._LIB_PATH = os.environ['RUNIA_LIB']
 dev = torch.device("cuda", 0)
 g = torch.Generator(device=dev).manual_seed(3)
 def t(fn, reps=20):
