@@ -357,6 +357,23 @@ def run_cfg4_lared(device, n_props: int = 100_000, n_train: int = 4000, n_mc: in
     return rec
 
 
+def _roi_valu(k: int, c: int, ms: float) -> dict:
+    """Vector-instruction account of the fused ROI launch: instructions per (ROI, 64 channels) and the clock held from the PMC passes
+    of the same command (profiles/pmc_traffic.json), cycles per instruction per SIMD from this run's time."""
+    import json as _json
+    try:
+        e = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")))["stages"][
+            "cfg4_roi_sampler_entropy"]
+    except (OSError, KeyError, ValueError):
+        return {}
+    insts, ghz = float(e["valu_insts_per_wave"]), float(e["clock_ghz_held"])
+    cycles = ms * 1e-3 * ghz * 1e9 * 1024 / (k * (c / 64))
+    return {"insts_per_roi_64ch": insts, "clock_ghz_held": ghz, "cycles_per_inst_per_simd": round(cycles / insts, 2),
+            "floor_ms_at_2p5_cycles": round(k * (c / 64) * insts * 2.5 / 1024 / (ghz * 1e9) * 1e3, 2),
+            "note": "SQ_INSTS_VALU per wave and GRBM_GUI_ACTIVE / 8 / duration from profiles/r4b_cfg4_pmc_summary.json (not measured in this run); "
+                    "2.5 cycles = the issue cost of a plain f32 instruction (tools/microbench/valu_issue.hip), most of this mix"}
+
+
 def run_cfg4_from_maps(device, n_img: int = 100, per_img: int = 1000, c: int = 1024, fh: int = 45, fw: int = 80, n_mc: int = 16,
                        n_pca: int = 256, n_train: int = 4000, reps: int = 2) -> dict:
     """BASELINE configs[3] from where the reference's object-level path starts (feature_extraction/object_level.py:312-367):
@@ -432,7 +449,8 @@ def run_cfg4_from_maps(device, n_img: int = 100, per_img: int = 1000, c: int = 1
            "rows": k, "ms": round(1e3 * wall, 3), "rows_per_s": round(k / wall, 1),
            "channels_last_copy": {"ms": round(ms_t, 4), "bound": "hbm", "achieved": round(2 * fm.numel() * 4 / (ms_t * 1e-3) / 1e9, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s"},
-           "roi_sampler_entropy": {"ms": round(ms_r, 4), "bound": "L1 tap traffic / valu", "taps_TBps": round(taps_gb / ms_r, 2),
+           "roi_sampler_entropy": {"ms": round(ms_r, 4), "bound": "valu-issue", "bilinear_taps_TBps": round(taps_gb / ms_r, 2),
+                                   "valu": _roi_valu(k, c, ms_r),
                                    "roi_tensor_not_written_GB": round(out_gb, 2),
                                    "unfused_roi_tensor_GBps_equiv": round(2 * out_gb / (ms_r * 1e-3), 1),
                                    "note": "one launch per 65 535 proposals: per-ROI sample table + keep-flag table + fused load/sampler/entropy"},
