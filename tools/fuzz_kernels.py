@@ -329,6 +329,38 @@ for t in range(a.rounds):
         same = torch.equal(torch.nan_to_num(h1, nan=-7.0), torch.nan_to_num(h2, nan=-7.0))
         check("roi folded = two calls", (osz, sr, nm, cr, hr, wr, kr), 0.0 if same else 1.0, 0.5)
 
+    if t % 10 == 7:
+        # row GEMM on batches of more than one round of 32-row tiles (round 4: whole rounds first, the rest as smaller units -
+        # 16-row tiles, KDE: column-split units + replay): slices scored alone (16-row tiles) equal the batch bit for bit,
+        # wherever the boundary falls on this device
+        nb_, dd_, nn_ = int(rng.integers(33_000, 140_000)), int(rng.choice([64, 128, 256])), int(rng.choice([16, 64, 256]))
+        nn_ = min(nn_, dd_)
+        gg = torch.Generator(device="cuda").manual_seed(int(rng.integers(1 << 30)))
+        hb = torch.randn(nb_, dd_, dtype=torch.float64, device="cuda", generator=gg)
+        cp = np.linalg.qr(rng.standard_normal((dd_, nn_)))[0]
+        pct_, bias_, scale_ = _hip.pack_weights(dev(cp)), dev(rng.standard_normal(nn_)), dev(rng.random(nn_) + 0.5)
+        yb = _hip.pca_transform(hb, pct_, bias_, scale_, nn_)
+        ab = rng.standard_normal((nn_, nn_))
+        ppb, mmb = _hip.pack_weights(dev(ab @ ab.T / nn_ + np.eye(nn_))), dev(rng.standard_normal(nn_) * 0.1)
+        sb = _hip.md_score(yb, mmb, ppb)
+        trb = torch.randn(int(rng.choice([700, 3000])), nn_, dtype=torch.float64, device="cuda", generator=gg)
+        stb = _hip.kde_pack_train(trb)
+        kb = _hip.kde_score_packed(stb, yb, 4.0)
+        okb = True
+        for lo in (0, 16_384 - 20, 32_768 - 20, 65_536 - 20, 98_304 - 20, nb_ - 40):
+            if lo < 0 or lo + 40 > nb_:
+                continue
+            part = _hip.pca_transform(hb[lo:lo + 40].contiguous(), pct_, bias_, scale_, nn_)
+            okb &= torch.equal(part, yb[lo:lo + 40]) and torch.equal(_hip.md_score(part, mmb, ppb), sb[lo:lo + 40])
+            okb &= torch.equal(_hip.kde_score_packed(stb, part, 4.0), kb[lo:lo + 40])
+        check("row gemm: slices = batch (last-round split)", (nb_, dd_, nn_, trb.shape[0]), 0.0 if okb else 1.0, 0.5)
+        smp = rng.integers(0, nb_, size=48)
+        y_e = (hb[smp].cpu().numpy() @ cp - bias_.cpu().numpy()) / scale_.cpu().numpy()
+        check("row gemm: pca vs numpy (large batch)", (nb_, dd_, nn_), rel(yb[smp].cpu().numpy(), y_e), 1e-10)
+        check("row gemm: kde vs oracle (large batch)", (nb_, nn_, trb.shape[0]),
+              rel(kb[smp].cpu().numpy(), oracle.kde_score(trb.cpu().numpy(), yb[smp].cpu().numpy(), 4.0)), 1e-9)
+        del hb, yb, kb, sb
+
     if (t + 1) % 10 == 0:
         print(f"round {t + 1}/{a.rounds}, mismatches so far: {bad}", flush=True)
 print("fuzz done, mismatches:", bad)
