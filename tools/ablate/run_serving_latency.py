@@ -40,6 +40,8 @@ for n in (1, 8, 64, 512):
 # second table: the other stages of the path on few rows
 tr = torch.randn(10000, 256, dtype=torch.float64, device=dev); kst = _hip.kde_pack_train(tr)
 tr16 = torch.randn(10000, 16, dtype=torch.float64, device=dev)
+from runia_core_amd.inference.postprocessors import DetectorKDE
+det16 = DetectorKDE(tr16.cpu().numpy())
 comp = torch.linalg.qr(torch.randn(512, 256, dtype=torch.float64, device=dev))[0].contiguous(); pct = _hip.pack_weights(comp)
 bias = torch.randn(256, dtype=torch.float64, device=dev)
 a2 = torch.randn(256, 256, dtype=torch.float64, device=dev); p2 = _hip.pack_weights((a2 @ a2.T / 256 + torch.eye(256, dtype=torch.float64, device=dev)).contiguous())
@@ -51,8 +53,8 @@ for n in (1, 8, 64, 512):
     x256 = torch.randn(n, 256, dtype=torch.float64, device=dev); x16 = torch.randn(n, 16, dtype=torch.float64, device=dev)
     h = torch.randn(n, 512, dtype=torch.float64, device=dev); f = torch.randn(n, 2048, device=dev)
     z = torch.randn(n * 16, 512, device=dev); x2048 = torch.randn(n, 2048, dtype=torch.float64, device=dev)
-    print(f"rows {n:4d}:  LaRED(train 10000x256) {t(lambda: _hip.kde_score_packed(kst, x256, 1.0)):8.1f} us   LaRED(10000x16) "
-          f"{t(lambda: _hip.kde_score(tr16, x16, 1.0)):7.1f} us   PCA 512->256 {t(lambda: _hip.pca_transform(h, pct, bias, None, 256)):6.1f} us   "
+    print(f"rows {n:4d}:  LaRED(train 10000x256) {t(lambda: _hip.kde_score_packed(kst, x256, 1.0)):8.1f} us   LaRED(10000x16) direct "
+          f"{t(lambda: _hip.kde_score(tr16, x16, 1.0)):7.1f} us, as DetectorKDE routes it {t(lambda: det16.score_samples_device(x16)):7.1f} us   PCA 512->256 {t(lambda: _hip.pca_transform(h, pct, bias, None, 256)):6.1f} us   "
           f"MD(256) {t(lambda: _hip.md_score(x256, mean2, p2)):6.1f} us   MD(2048) {t(lambda: _hip.md_score(x2048, mean3, p3)):7.1f} us   "
           f"linear 2048->1000 {t(lambda: _hip.linear(f, w1000, b1000)):6.1f} us   entropy per dim (16 x 512) {t(lambda: _hip.kl_entropy_per_dim(z, 16, 5)):6.1f} us",
           flush=True)
