@@ -125,7 +125,8 @@ __global__ __launch_bounds__(256) void roi_sample_table_kernel(RoiSourceHost src
     const bool outside = (t < -1.0f || t > (float)L);
     // a sample row / column more than a pixel outside the map contributes nothing (roi_align's `continue`): its byte offset is
     // the size of the image - every tap of it lies beyond the buffer the loader reads through, and such a load returns 0 -
-    // and its weights are 0, so the sample is +0.0 without a test in the loader
+    // and its weights are 0, so the sample is +0.0 without a test in the loader (the scalar offset is part of the range check
+    // on gfx950: tools/microbench/buffer_soffset_range.hip)
     if (outside) {
       e[0] = e[1] = (unsigned)src.image_bytes;
       e[2] = e[3] = 0u;
