@@ -1235,7 +1235,13 @@ int runia_knn16_filter(const uint16_t* qp, const uint16_t* bp, const float* qn, 
 #endif
 // the bank side of the bf16 kernel: some thousand rows, wide (but not wider than its window allows) features
 static bool knn16_bank_ok(int64_t M, int64_t D) {
-  return KNN_BF16 && M >= 4096 && D >= 256 && D <= runia_knn16_max_width() && runia_knn16_fits(M, D) &&
+// (round 4, with the candidate filter the feature width no longer has to pay for a distance matrix: 65 536 x 50 000 at
+// D = 8 / 16 / 32 / 64 / 128: 5.6 / 5.6 / 5.7 / 6.0 / 6.7 ms against 9.1 / 9.0 / 9.0 / 10.2 / 13.1 for the f32 kernel, same
+// bits, tools/ablate/run_knn_low_d.py; the limit was 256 while the bf16 kernel wrote the matrix too)
+#ifndef KNN16_MIN_D
+#define KNN16_MIN_D 8
+#endif
+  return KNN_BF16 && M >= 4096 && D >= KNN16_MIN_D && D <= runia_knn16_max_width() && runia_knn16_fits(M, D) &&
          runia_knn16_fits(kQueryChunk, D) && 4 * M * 256 <= ((int64_t)1 << 31);  // (chunks of >= 256 queries: whole tiles)
 }
 // Worth the two split passes and the 256 x 256 tiles: a bank of some thousand rows, wide features, a batch of queries, 2^31
