@@ -198,8 +198,9 @@ int runia_kde_score_kernel_f64(const double* train, const double* x, double* sco
  * runia_row_sqnorm_f64(train), both made once at setup; workspace: N doubles (the query norms).  The logsumexp over
  * the M training rows is kept online in the accumulator lanes; no [N, M] matrix is written. */
 int runia_row_sqnorm_f64(const double* x, double* out, int64_t N, int64_t D, runia_stream_t stream);
-/* workspace of runia_kde_score_packed_f64: the N query norms, plus - for batches of fewer 16-row tiles than the chip has
- * compute units - room for the column-split launch (same bits, a fraction of the latency); N doubles are the minimum */
+/* workspace of runia_kde_score_packed_f64: the N query norms, plus room for the column-split units (same bits) that take
+ * either a batch of fewer 16-row tiles than the chip has compute units (a fraction of the latency) or, since ABI 4, the rows
+ * of a large batch behind its last whole round of 32-row tiles (no last round on part of the chip); N doubles are the minimum */
 size_t runia_kde_workspace_bytes(int64_t N, int64_t M);
 int runia_kde_score_packed_f64(const double* packed_train_t, const double* train_sqnorm, const double* x,
                                double* score, void* workspace, size_t workspace_bytes, int64_t M, int64_t N,
