@@ -1419,6 +1419,44 @@ def test_roi_align_folded_into_the_sampler_equals_the_two_calls(osz, sr, n_mc, c
 
 
 @pytest.mark.gpu
+def test_roi_align_folded_into_the_sampler_non_finite_pixels_and_degenerate_boxes():
+    """The fused ROI launch against the two launches where the arithmetic leaves the finite range: NaN and infinite
+    activations in the map (a sample that touches one is NaN / infinite in both forms; a sample OUTSIDE the map must stay
+    0 even next to them: its taps are not read), boxes of zero width / height, a box that is one point, boxes whose two
+    pixel rows coincide at the map's last row (the loader keeps pixel rows in registers across sample rows).  MC samples
+    compared as bit patterns."""
+    from runia_core_amd import _hip
+
+    rng = np.random.default_rng(77)
+    b, c, hh, ww = 2, 70, 9, 13
+    fm = torch.relu(torch.from_numpy(rng.standard_normal((b, c, hh, ww)).astype(np.float32)))
+    fm[0, :, 0, 0] = float("inf")       # the pixel at byte offset 0 (what an unmasked outside tap would have read)
+    fm[0, 3, 4, 5] = float("nan")
+    fm[1, :, hh - 1, ww - 1] = float("-inf")
+    fm = fm.cuda()
+    boxes = torch.tensor([[-300.0, -300.0, -200.0, -250.0],    # wholly outside, image 0 (pixel 0 of that image is inf)
+                          [-20.0, -20.0, 30.0, 30.0],          # across the corner with the infinite pixel
+                          [40.0, 40.0, 40.0, 90.0],            # zero width
+                          [40.0, 40.0, 90.0, 40.0],            # zero height
+                          [55.5, 33.25, 55.5, 33.25],          # a point
+                          [0.0, 120.0, 200.0, 160.0],          # hangs over the last rows: clamped rows coincide
+                          [150.0, 100.0, 260.0, 190.0],        # over the last row / column of image 1 (-inf pixel)
+                          [10.0, 10.0, 120.0, 100.0]], dtype=torch.float32)
+    bidx = torch.tensor([0, 0, 0, 1, 1, 0, 1, 1], dtype=torch.int32)
+    n_mc, osz = 16, 7
+    rand = torch.from_numpy(rng.random((len(boxes), n_mc, osz, osz)).astype(np.float32)).cuda()
+    scale = ww / 208.0
+    rois = _hip.roi_align(fm, boxes.cuda(), osz, scale, 2, True, bidx)
+    h_ref, z_ref = _hip.mc_entropy(rois, rand, n_mc, 0.3, 2, 5, 1e-5, want_samples=True)
+    h, z = _hip.roi_mc_entropy(_hip.nchw_to_nhwc(fm), boxes, osz, scale, 2, True, rand, n_mc, 0.3, 2, 5, 1e-5, batch_idx=bidx,
+                               return_samples=True)
+    assert torch.equal(z.view(torch.int32), z_ref.view(torch.int32))
+    assert torch.equal(torch.nan_to_num(h, nan=-7.0, posinf=-8.0, neginf=-9.0), torch.nan_to_num(h_ref, nan=-7.0, posinf=-8.0, neginf=-9.0))
+    assert bool((rois[0] == 0).all())                      # outside the map: zeros, not inf * 0
+    assert bool(torch.isfinite(z[0]).all()) and bool(torch.isfinite(z[7]).any())
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("kernel", ["tophat", "epanechnikov", "exponential", "linear", "cosine", "gaussian"])
 def test_detector_kde_other_kernels_vs_sklearn(kernel):
     """DetectorKDE(kernel=...) forwards any sklearn kernel (reference inference/postprocessors.py:78-128): the direct kernel
