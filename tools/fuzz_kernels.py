@@ -343,7 +343,7 @@ for t in range(a.rounds):
         ab = rng.standard_normal((nn_, nn_))
         ppb, mmb = _hip.pack_weights(dev(ab @ ab.T / nn_ + np.eye(nn_))), dev(rng.standard_normal(nn_) * 0.1)
         sb = _hip.md_score(yb, mmb, ppb)
-        trb = torch.randn(int(rng.choice([700, 3000])), nn_, dtype=torch.float64, device="cuda", generator=gg)
+        trb = torch.randn(int(rng.choice([200, 700, 3000])), nn_, dtype=torch.float64, device="cuda", generator=gg)
         stb = _hip.kde_pack_train(trb)
         kb = _hip.kde_score_packed(stb, yb, 4.0)
         okb = True
