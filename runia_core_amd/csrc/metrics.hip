@@ -719,17 +719,86 @@ __global__ __launch_bounds__(256) void msd_scatter_kernel(const uint64_t* __rest
 }
 
 // Buckets 4 g .. 4 g + 3 belong to workgroup g.  First every wave sorts "its" bucket if it holds at most kMsdWaveCap keys: a
-// bitonic network in the wave's own LDS slice, wave-synchronous (no workgroup barrier).  Per 2 M keys (4 096 buckets of ~490):
-// 97 us; a workgroup per bucket with 45 barrier-separated rounds 173 us; a wave-level stable 8-bit radix sort over the bytes
-// in which a bucket's keys differ (two LDS copies of the bucket: half the occupancy) 168 us.  Then the workgroup together
-// takes each of its buckets that is larger.
+// bitonic network in the wave's REGISTERS (wave_sort_in_registers; 61 us per 2 M keys in 4 096 buckets of ~490 on average -
+// value-linear buckets of a normal score set hold 0 ... 1 900).  Before it: the same network in the wave's LDS slice, wave-
+// synchronous, 97 us; a workgroup per bucket with 45 barrier-separated rounds 173 us; a wave-level stable 8-bit radix sort over
+// the bytes in which a bucket's keys differ (two LDS copies of the bucket: half the occupancy) 168 us.  Then the workgroup
+// together takes each of its buckets that is larger.
 constexpr int kMsdWaveCap = 1024;
+#ifndef METRICS_REG_SORT
+#define METRICS_REG_SORT 1
+#endif
+// A bucket of up to 64 * PER keys sorted by ONE wave in registers: element e = lane * PER + r, a bitonic network whose
+// exchanges at distance j < PER are compare-and-selects between two of the lane's own registers and whose exchanges at
+// distance j >= PER are two shuffles + a select per element with the lane at distance j / PER (21 of the 45 stages at
+// PER = 8).  The LDS form - every stage two reads, a compare and up to two writes per pair, for keys and for labels, each
+// stage waiting for the last - took 97 us per 2 M keys (4 096 buckets of ~490).  Equal keys never swap (their order does
+// not matter to the curve: a run is one point), so both lanes of a pair decide alike.
+template <int PER>
+__device__ __forceinline__ void wave_sort_in_registers(uint64_t* __restrict__ keys, uint8_t* __restrict__ labs, unsigned lo,
+                                                       unsigned nb, int lane) {
+  constexpr int LOG_PER = (PER == 1) ? 0 : (PER == 2) ? 1 : (PER == 4) ? 2 : (PER == 8) ? 3 : 4, LOG_M = LOG_PER + 6;
+  static_assert((1 << LOG_PER) == PER, "PER is a power of two up to 16");
+  uint64_t k[PER];
+  unsigned l[PER];
+  // (which unsorted key starts in which register does not matter: consecutive lanes read consecutive keys)
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const unsigned e = (unsigned)r * 64u + (unsigned)lane;
+    k[r] = (e < nb) ? keys[lo + e] : ~0ull;  // padding: the largest key, behind every real one
+    l[r] = (e < nb) ? labs[lo + e] : 0u;
+  }
+#pragma unroll
+  for (int lk = 1; lk <= LOG_M; ++lk) {
+#pragma unroll
+    for (int lj = lk - 1; lj >= 0; --lj) {
+      const int k2 = 1 << lk, j = 1 << lj;
+      if (lj < LOG_PER) {  // both elements in this lane
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+          if ((r & j) != 0) continue;
+          // direction: bit k2 of the element index lane * PER + r
+          const bool up = (k2 < PER) ? ((r & k2) == 0) : ((((unsigned)lane * PER) & (unsigned)k2) == 0u);
+          const uint64_t a = k[r], b = k[r | j];
+          const unsigned la = l[r], lb = l[r | j];
+          const bool swap = up ? (a > b) : (a < b);
+          k[r] = swap ? b : a; k[r | j] = swap ? a : b;
+          l[r] = swap ? lb : la; l[r | j] = swap ? la : lb;
+        }
+      } else {  // the partner element sits in the lane at distance j / PER, same register
+        const int dl = j >> LOG_PER;
+        const bool low = (lane & dl) == 0, up = (((unsigned)lane * PER) & (unsigned)k2) == 0u;
+        const bool want_small = (low == up);
+#pragma unroll
+        for (int r = 0; r < PER; ++r) {
+          const uint64_t a = k[r];
+          const uint64_t o = ((uint64_t)(unsigned)__shfl_xor((int)(unsigned)(a >> 32), dl, 64) << 32) |
+                             (uint64_t)(unsigned)__shfl_xor((int)(unsigned)a, dl, 64);
+          const unsigned ol = (unsigned)__shfl_xor((int)l[r], dl, 64);
+          const bool take = want_small ? (a > o) : (a < o);
+          k[r] = take ? o : a;
+          l[r] = take ? ol : l[r];
+        }
+      }
+    }
+  }
+  // (stores straight from the registers, PER consecutive keys per lane; through the wave's LDS slice for consecutive lanes to
+  // write consecutive keys: 183 registers + 42 KB of LDS per workgroup, 211 -> 233 us per 2 M scores)
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const unsigned e = (unsigned)lane * PER + r;
+    if (e < nb) { keys[lo + e] = k[r]; labs[lo + e] = (uint8_t)l[r]; }
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void msd_bucket_sort_kernel(uint64_t* __restrict__ keys, uint8_t* __restrict__ labs,
                                                               uint64_t* __restrict__ alt_keys, uint8_t* __restrict__ alt_labs,
                                                               const unsigned* __restrict__ any_outside, const MsdState* st) {
+#if !METRICS_REG_SORT
   __shared__ uint64_t sk_all[4][kMsdWaveCap];
   __shared__ uint8_t sl_all[4][kMsdWaveCap];
+#endif
   __shared__ unsigned base[256];
   __shared__ unsigned wcnt[4][256];
   __shared__ unsigned dsum[4];
@@ -738,6 +807,15 @@ __global__ __launch_bounds__(256) void msd_bucket_sort_kernel(uint64_t* __restri
   {
     const int b = 4 * blockIdx.x + wave;
     const unsigned lo = st->start[b], nb = st->start[b + 1] - lo;
+#if METRICS_REG_SORT
+    if (nb >= 2u && nb <= (unsigned)kMsdWaveCap) {  // (wave-uniform)
+      if (nb <= 64u) wave_sort_in_registers<1>(keys, labs, lo, nb, lane);
+      else if (nb <= 128u) wave_sort_in_registers<2>(keys, labs, lo, nb, lane);
+      else if (nb <= 256u) wave_sort_in_registers<4>(keys, labs, lo, nb, lane);
+      else if (nb <= 512u) wave_sort_in_registers<8>(keys, labs, lo, nb, lane);
+      else wave_sort_in_registers<16>(keys, labs, lo, nb, lane);
+    }
+#else  // the LDS form of the network (round 4's first cut), kept for comparison
     if (nb >= 2u && nb <= (unsigned)kMsdWaveCap) {  // (wave-uniform)
       uint64_t* sk = sk_all[wave];
       uint8_t* sl = sl_all[wave];
@@ -766,6 +844,7 @@ __global__ __launch_bounds__(256) void msd_bucket_sort_kernel(uint64_t* __restri
       }
       for (unsigned i = lane; i < nb; i += 64) { keys[lo + i] = sk[i]; labs[lo + i] = sl[i]; }
     }
+#endif
   }
   for (int b = 4 * blockIdx.x; b < 4 * (int)blockIdx.x + 4; ++b) {
     const unsigned lo = st->start[b], nb = st->start[b + 1] - lo;
