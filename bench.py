@@ -344,7 +344,7 @@ def main():
     x, rand = sets[0]
     counter = args.draws == "counter"
 
-    k1_events = []  # (start, end) HIP event pairs around every K1 launch of the timed region
+    k1_events_region = []  # (start, end) HIP event pairs around every K1 launch of the timed region
 
     torch.cuda.synchronize()
     inputs_ready = torch.cuda.current_stream().record_event()  # the input sets are resident from here on
@@ -392,8 +392,11 @@ def main():
         """Draws of step number `no` (1-based, as counted by step_no after its increment)."""
         return _hip.CounterDraws(4242 + rank, no * n) if counter else sets[(no - 1) % n_sets][1]
 
-    def step(timed=False, index=0, collective=True):
-        timed = timed and (index % max(1, args.event_every) == 0)
+    k1_events_outside = []  # the same brackets on untimed steps (warm-up, and a short loop right after the timed region)
+
+    def step(timed=False, index=0, collective=True, bracket=False):
+        timed = (timed and (index % max(1, args.event_every) == 0)) or bracket
+        k1_events = k1_events_region if not bracket else k1_events_outside
         j = step_no[0] % n_sets
         step_no[0] += 1
         xs, rs = sets[j]
@@ -430,7 +433,7 @@ def main():
             step(collective=False)
         torch.cuda.synchronize()
     for _ in range(args.warmup):
-        step()
+        step(bracket=not args.overlap)   # the W warm-up steps carry the K1 brackets too (more launches behind avg_launch_ms)
     if use_dist:
         assert step().shape == (world * n,)
     gather_info = None
@@ -483,14 +486,32 @@ def main():
         pending[1] = pipe.prepare_draws(draws_of(1), n, H, W, inputs_ready=inputs_ready)  # untimed, like the inputs being resident: step 1's table
     if use_dist:
         dist.barrier()
+    # Clock readings bracket the timed region (runia_clock_probe: ~30 us of one wave).  Each probe is queued DIRECTLY BEHIND
+    # steps of the same kind with no host synchronisation between - a probe launched after a synchronisation finds the GPU
+    # already idle and reads a clock in transition (tools/microbench/clock_probe.py: 2.16-2.37 GHz there against 2.42-2.44
+    # directly behind the load).  Both sit outside the timed region.
+    for _ in range(3):
+        step(collective=False)
+    probe_before = _hip.clock_probe()
     torch.cuda.synchronize()
+    step_marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]
     t0 = time.perf_counter()
+    step_marks[0].record()
     for i in range(args.steps):
         scores = step(True, i)
+        step_marks[i + 1].record()  # one event record per step on the compute stream: per-step times (min / median / max)
     torch.cuda.synchronize()  # every stream of the device, the gather stream included
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    for i in range(32):  # more K1 launches under brackets, untimed, right after the region (same clocks, same inputs)
+        step(collective=False, bracket=not args.overlap)
+    probe_after = _hip.clock_probe()  # directly behind those steps
+    torch.cuda.synchronize()
+    per_step_ms = [step_marks[i].elapsed_time(step_marks[i + 1]) for i in range(args.steps)]
+    clocks = {"before": _hip.clock_ghz(probe_before), "after": _hip.clock_ghz(probe_after),
+              "how": "runia_clock_probe (shader-clock counter / 100 MHz counter over ~30 us of one wave) queued directly behind 3 "
+                     "untimed steps before the region and behind the 32 bracketed steps after it; idle reads 2.400"}
     last_set = (args.steps - 1) % n_sets
     if use_dist:
         mine = torch.tensor([elapsed], dtype=torch.float64, device=device)
@@ -516,9 +537,12 @@ def main():
         if gather_mode["kind"] == "p2p":
             one_shot.check()   # a wait that gave up on a peer would have produced garbage: fail loudly
         one_shot.close()
-    kernel_ms = float(np.mean([a.elapsed_time(b) for a, b in k1_events])) if k1_events else float('nan')
+    k1_in = [a.elapsed_time(b) for a, b in k1_events_region]
+    k1_out = [a.elapsed_time(b) for a, b in k1_events_outside]
+    k1_all = k1_in + k1_out
+    kernel_ms = float(np.mean(k1_all)) if k1_all else float('nan')
     bracketed_steps = len(range(0, args.steps, max(1, args.event_every)))
-    k1_launches_per_step = max(1, len(k1_events) // max(1, bracketed_steps))
+    k1_launches_per_step = max(1, len(k1_in) // max(1, bracketed_steps))
     if rank != 0:
         gc.enable()
         dist.destroy_process_group()
@@ -613,7 +637,12 @@ def main():
         "valu_issue": valu,
         "step_frac_of_hbm_ceiling": round(value / world / (HBM_PEAK_GBS * 1e9 / ALGO_BYTES_PER_IMAGE), 4),
         "avg_launch_ms": round(kernel_ms, 4),
-        "launches_per_step": k1_launches_per_step, "launches_timed": len(k1_events),
+        "launches_per_step": k1_launches_per_step, "launches_timed": len(k1_all),
+        "launch_ms": {"min": round(min(k1_all), 4), "median": round(float(np.median(k1_all)), 4), "max": round(max(k1_all), 4),
+                      "in_timed_region": {"launches": len(k1_in), "mean": round(float(np.mean(k1_in)), 4) if k1_in else None},
+                      "bracketed_untimed_steps": {"launches": len(k1_out), "mean": round(float(np.mean(k1_out)), 4) if k1_out else None,
+                                                  "where": "the W warm-up steps + 32 steps right after the timed region"}},
+        "clock_ghz_observed": clocks,
     }
 
     # ---------------- parity on a bounded sample + CPU baseline (oracle = checker / baseline only) --
@@ -622,6 +651,10 @@ def main():
         "value": round(value, 1), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "f64", "data": "synthetic",
+        "ms_per_step_stats": {"min": round(min(per_step_ms), 4), "median": round(float(np.median(per_step_ms)), 4),
+                              "max": round(max(per_step_ms), 4), "mean_of_events": round(float(np.mean(per_step_ms)), 4),
+                              "how": "one HIP event per step on the compute stream (rank 0); ms_per_step above is the wall clock / K, MAX over ranks"},
+        "clock_ghz_observed": clocks,
         "config": {"workload": "CIFAR10 ResNet-18 LaREM: 16 MC samples, 512-d latent -> PCA-256, 10000 test images per GPU",
                    "images_per_gpu": n, "mc_samples": N_MC, "latent": [C, H, W], "pca_components": N_PCA,
                    "row_blocks_per_step": k1_launches_per_step, "input_dtype": "f32",
@@ -750,7 +783,9 @@ def main():
             stages["cfg3_step"] = {"rows": c3["rows_total"], "ms": round(c3["ms_per_step"], 3), "rows_per_s": round(c3["value"], 1),
                                    "note": "Mahalanobis + Energy(C=1000) + Energy(C=10) + kNN(k=50) over the same 1M rows = "
                                            "`python bench.py --workload cfg3`, 2 timed steps",
-                                   "cpu_rows_per_s": c3.get("cpu_baseline", {}).get("value")}
+                                   "cpu_rows_per_s": c3.get("cpu_baseline", {}).get("value"),
+                                   "clock_ghz_observed": c3.get("clock_ghz_observed"),
+                                   "timing": "1 untimed pass (0.56 s of the leg's own kernels), then 2 timed passes"}
             torch.cuda.empty_cache()
             stages["cfg4_lared"] = bw.run_cfg4_lared(device)
             torch.cuda.empty_cache()

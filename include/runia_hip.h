@@ -39,6 +39,12 @@ int runia_abi_version(void);
 const char* runia_error_string(int code);
 /* number of visible HIP devices (0 when none; never fails) */
 int runia_device_count(void);
+/* Clock reading for measurement records (no counterpart upstream: bench.py brackets its timed regions with it).  One wave
+ * runs `chain` (16 .. 2^24, rounded up to 16) dependent v_fma_f32 between two readings of the shader-clock counter
+ * (s_memtime) and of the constant 100 MHz counter (s_memrealtime):
+ *   out4[0] = shader-clock ticks, out4[1] = 100 MHz ticks, out4[2] = FMAs executed, out4[3] unused.
+ * Clock held = out4[0] / (out4[1] * 10 ns). */
+int runia_clock_probe(uint64_t* out4, int chain, runia_stream_t stream);
 
 /* ---- a1  MC-dropout latent stacking ------------------------------------- *
  * Replaces MCSamplerModule.forward (feature_extraction/abstract_classes.py:81-101)
@@ -418,7 +424,9 @@ int runia_gen_score_f32(const float* logits, float* score, int64_t N, int64_t C,
  * runia_mcd_uncertainty_f32: get_predictive_uncertainty_score / get_mcd_pred_uncertainty_score (inference/funcs.py:
  *   430-465, 378-427): logits [N * n_mc, C] f32, the n_mc rows of an image consecutive -> pred_h [N] = H[mean_s softmax],
  *   mi [N] = pred_h - mean_s H[softmax]; probs (optional) [N * n_mc, C] receives the softmax rows (the first value the
- *   dataloader form returns).  One launch, C <= 4096.
+ *   dataloader form returns).  One launch: a wave per image with the rows in registers up to C = 4096; wider heads
+ *   (ImageNet-21k, LLM vocabularies) a workgroup per image with the rows re-read from L2 (n_mc <= 4096 there).  The GEN entry
+ *   points take any C the same way.
  * runia_ash_s_rows_f32: ASH-S for rows of any length - ash_s_conv_layer (inference/funcs.py:194-227) on the flattened
  *   (B, C*H*W) maps and ash_s_linear_layer beyond 4096 features.  y = pruned row * exp(sum / kept sum); `pruned`
  *   (optional, may be x itself: the reference's view + scatter_ prunes its argument in place) = the pruned row.

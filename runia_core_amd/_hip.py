@@ -24,6 +24,7 @@ _SIGNATURES = {
     "runia_abi_version": (c_int, []),
     "runia_error_string": (c_char_p, [c_int]),
     "runia_device_count": (c_int, []),
+    "runia_clock_probe": (c_int, [c_void_p, c_int, c_void_p]),
     "runia_mc_stack_f32": (
         c_int,
         [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p],
@@ -255,6 +256,56 @@ def _check(rc: int, what: str) -> None:
         raise RuniaHipError(f"{what} failed: {msg} (code {rc})")
 
 
+def _cuda_tensors(value):
+    """CUDA tensors inside an argument (the argument itself, or the members of a tuple / list such as a packed state)."""
+    if getattr(value, "is_cuda", False) is True:
+        yield value
+    elif isinstance(value, (tuple, list)):
+        for v in value:
+            yield from _cuda_tensors(v)
+
+
+def resolve_device(args, kwargs, exempt=()):
+    """The one device a wrapper call runs on: that of its CUDA tensor arguments (``exempt``: names the wrapper moves to
+    the first tensor's device itself).  Tensors on different devices raise ``RuniaHipError`` - a kernel launched with
+    pointers of two GPUs would fault or, worse, read peer memory silently.  No CUDA tensor -> None (the current device)."""
+    dev, first = None, None
+    for name, value in list(enumerate(args)) + list(kwargs.items()):
+        if name in exempt:
+            continue
+        for t in _cuda_tensors(value):
+            if dev is None:
+                dev, first = t.device, name
+            elif t.device != dev:
+                raise RuniaHipError(f"tensor arguments sit on different devices ({dev} for argument {first!r}, {t.device} for "
+                                    f"argument {name!r}): move them to one GPU before the call")
+    return dev
+
+
+def _device_guard(*exempt):
+    """Run the wrapper with the arguments' GPU as the current device: the launch stream (``_stream``), the workspaces
+    and ``require_gpu()`` then all belong to the device the operands live on, whatever ``torch.cuda.current_device()``
+    was (the reference's users do ``model.to("cuda:1")``, inference/abstract_classes.py:250-255)."""
+    import functools
+    import inspect
+
+    def wrap(fn):
+        names = list(inspect.signature(fn).parameters)
+        skip = {names.index(e) for e in exempt if e in names} | set(exempt)
+
+        @functools.wraps(fn)
+        def guarded(*args, **kwargs):
+            dev = resolve_device(args, kwargs, skip)
+            if dev is None or dev.index is None or dev.index == torch.cuda.current_device():
+                return fn(*args, **kwargs)
+            with torch.cuda.device(dev):
+                return fn(*args, **kwargs)
+
+        return guarded
+
+    return wrap
+
+
 def _stream() -> int:
     return torch.cuda.current_stream().cuda_stream
 
@@ -302,6 +353,7 @@ def to_host(t: torch.Tensor) -> np.ndarray:
 # --------------------------------------------------------------------------------------
 # stage wrappers: device tensors in, device tensors out, stream-ordered, no sync
 # --------------------------------------------------------------------------------------
+@_device_guard()
 def mc_stack(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob: float, block_size: int) -> torch.Tensor:
     """x [N,C,H,W] f32, rand [n_mc,H,W] (shared) or [N,n_mc,H,W] f32 -> [N*n_mc, C] f32."""
     lib = load_library()
@@ -371,6 +423,7 @@ def mc_draws(n: int, n_mc: int, h: int, w: int, seed: int, first_image: int = 0)
     return out
 
 
+@_device_guard()
 def mc_drop_flat(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_prob: float, block_size: int) -> torch.Tensor:
     """``layer_type="FC"/"RPN"`` form of the sampler: x [N,C,H,W] f32 -> [N*n_mc, C*H*W] f32 (no fullmean)."""
     lib = load_library()
@@ -404,6 +457,7 @@ def mc_drop_flat(x: torch.Tensor, rand: Optional[torch.Tensor], n_mc: int, drop_
     return out
 
 
+@_device_guard()
 def map_reduce(x: torch.Tensor, h: int, w: int, mode: str) -> torch.Tensor:
     """x [..., h*w] f32 seen as maps of h x w -> ``mode="mean"``: mean over w, [maps, h]; ``mode="std"``: std over the
     rows of the per-row stds, [maps] (the reductions of ``get_mean_or_fullmean_ls_sample(., "mean")`` and
@@ -419,6 +473,7 @@ def map_reduce(x: torch.Tensor, h: int, w: int, mode: str) -> torch.Tensor:
     return out
 
 
+@_device_guard()
 def kl_entropy_per_dim(z: torch.Tensor, n_mc: int, k: int, min_dist: float = 1e-5) -> torch.Tensor:
     """z [N*n_mc, D] f32 -> h [N, D] f64."""
     lib = load_library()
@@ -435,6 +490,7 @@ def kl_entropy_per_dim(z: torch.Tensor, n_mc: int, k: int, min_dist: float = 1e-
     return h
 
 
+@_device_guard()
 def kl_entropy_joint(z: torch.Tensor, n_mc: int, k: int, min_dist: float = 1e-5) -> torch.Tensor:
     """z [N*n_mc, D] f32 -> h_mvn [N] f64."""
     lib = load_library()
@@ -451,6 +507,7 @@ def kl_entropy_joint(z: torch.Tensor, n_mc: int, k: int, min_dist: float = 1e-5)
     return h
 
 
+@_device_guard()
 def pack_weights(b: torch.Tensor) -> torch.Tensor:
     """B [K, n] f64 (device) -> fragment-ordered copy for the f64 MFMA kernels."""
     lib = load_library()
@@ -464,6 +521,7 @@ def pack_weights(b: torch.Tensor) -> torch.Tensor:
     return packed
 
 
+@_device_guard()
 def pca_transform(x: torch.Tensor, packed_ct: torch.Tensor, bias: torch.Tensor, scale: Optional[torch.Tensor], n: int) -> torch.Tensor:
     """x [N, D] f64/f32 -> y [N, n] f64."""
     lib = load_library()
@@ -481,6 +539,7 @@ def pca_transform(x: torch.Tensor, packed_ct: torch.Tensor, bias: torch.Tensor, 
     return y
 
 
+@_device_guard()
 def md_score(x: torch.Tensor, mean: torch.Tensor, packed_p: torch.Tensor) -> torch.Tensor:
     """x [N, n] (f64 or f32), mean [n] (f64 or f32) -> score [N] f64 = -(x-mean) P (x-mean)^T,
     with ``x - mean`` formed under NumPy's dtype rules (f32 only when both are f32)."""
@@ -507,6 +566,7 @@ def md_score(x: torch.Tensor, mean: torch.Tensor, packed_p: torch.Tensor) -> tor
     return s
 
 
+@_device_guard()
 def mahalanobis_score(x: torch.Tensor, class_mean: torch.Tensor, packed_p: torch.Tensor, mu_p: torch.Tensor,
                       class_loop: bool = False) -> torch.Tensor:
     """x [N, D], class_mean [C, D] (both f32 or both f64) -> score [N] f64.  ``class_loop=True`` hands over the small
@@ -530,6 +590,7 @@ def mahalanobis_score(x: torch.Tensor, class_mean: torch.Tensor, packed_p: torch
     return s
 
 
+@_device_guard()
 def row_lse_msp(logits: torch.Tensor, want_lse: bool = True, want_msp: bool = False):
     """logits [N, C] f32 -> (lse [N] f32 | None, msp [N] f32 | None)."""
     lib = load_library()
@@ -543,6 +604,7 @@ def row_lse_msp(logits: torch.Tensor, want_lse: bool = True, want_msp: bool = Fa
     return lse, msp
 
 
+@_device_guard()
 def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     lib = load_library()
     require_gpu()
@@ -553,6 +615,7 @@ def l2_normalize(x: torch.Tensor) -> torch.Tensor:
     return y
 
 
+@_device_guard()
 def knn_prepare_bank(bank: torch.Tensor) -> torch.Tensor:
     """Once per bank: squared row norms, their maximum and (banks the bf16 kernel can take) the bf16 pieces, as one
     device buffer for ``knn_kth(..., state=)``.  A deployed index scores many batches against the same bank; each call
@@ -567,6 +630,7 @@ def knn_prepare_bank(bank: torch.Tensor) -> torch.Tensor:
     return state
 
 
+@_device_guard()
 def knn_kth(q: torch.Tensor, bank: torch.Tensor, k: int, state: Optional[torch.Tensor] = None) -> torch.Tensor:
     """q [N, D], bank [M, D] (both L2-normalised f32) -> -(k-th smallest squared L2) [N] f32.
     ``state``: ``knn_prepare_bank(bank)`` of the same bank (same scores, without the per-call bank passes)."""
@@ -601,6 +665,7 @@ def knn_kth(q: torch.Tensor, bank: torch.Tensor, k: int, state: Optional[torch.T
     return s
 
 
+@_device_guard()
 def row_sqnorm(x: torch.Tensor) -> torch.Tensor:
     """x [N, D] f64 -> squared row norms [N] f64."""
     lib = load_library()
@@ -612,6 +677,7 @@ def row_sqnorm(x: torch.Tensor) -> torch.Tensor:
     return out
 
 
+@_device_guard()
 def kde_pack_train(train: torch.Tensor):
     """Setup-time state of ``kde_score_packed``: (pack(train_c^T), squared row norms of train_c, M, D, mean) with
     train_c = train - mean(train).  Distances are translation invariant; centring keeps |x|^2 + |t|^2 - 2 x.t
@@ -622,6 +688,7 @@ def kde_pack_train(train: torch.Tensor):
     return pack_weights(tc.t().contiguous()), row_sqnorm(tc), int(train.shape[0]), int(train.shape[1]), mean
 
 
+@_device_guard()
 def kde_score_packed(state, x: torch.Tensor, bandwidth: float = 1.0) -> torch.Tensor:
     """Gaussian-KDE log-density [N] f64 of x [N, D] f64 against a packed training set (matrix-core path)."""
     lib = load_library()
@@ -639,6 +706,7 @@ def kde_score_packed(state, x: torch.Tensor, bandwidth: float = 1.0) -> torch.Te
     return out
 
 
+@_device_guard()
 def kde_score(train: torch.Tensor, x: torch.Tensor, bandwidth: float = 1.0) -> torch.Tensor:
     """train [M, D] f64, x [N, D] f64 -> gaussian-KDE log-density [N] f64."""
     lib = load_library()
@@ -660,6 +728,7 @@ def mc_entropy_supported(h: int, w: int, n_mc: int, k: int) -> bool:
     return bool(load_library().runia_mc_entropy_supported(int(h), int(w), int(n_mc), int(k)))
 
 
+@_device_guard()
 def mc_mask_table(rand: Union[torch.Tensor, CounterDraws, None], n: int, h: int, w: int, n_mc: int, drop_prob: float,
                   block_size: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """K0 alone: the keep-flag table of a batch of ``n`` <= 65 535 images (``runia_mc_mask_table_f32`` / its counter
@@ -693,6 +762,7 @@ def mc_mask_table(rand: Union[torch.Tensor, CounterDraws, None], n: int, h: int,
     return out
 
 
+@_device_guard()
 def mc_entropy(x: torch.Tensor, rand: Union[torch.Tensor, CounterDraws, None], n_mc: int, drop_prob: float, block_size: int, k: int,
                min_dist: float = 1e-5, want_samples: bool = False, out: Optional[torch.Tensor] = None,
                kernel_events: Optional[list] = None, zero_fill: Optional[torch.Tensor] = None,
@@ -797,6 +867,7 @@ def mc_entropy(x: torch.Tensor, rand: Union[torch.Tensor, CounterDraws, None], n
     return (h, z) if want_samples else h
 
 
+@_device_guard()
 def proj_sq_accumulate(h: torch.Tensor, packed_m: torch.Tensor, c: torch.Tensor, r: int, out: torch.Tensor) -> torch.Tensor:
     """``out`` [N] f64 += -|| M h + c ||^2 where ``out`` was zeroed earlier on the stream (``mc_entropy(zero_fill=out)``):
     the score of ``proj_sq_score`` bit for bit, without its workspace and combine launch."""
@@ -812,6 +883,7 @@ def proj_sq_accumulate(h: torch.Tensor, packed_m: torch.Tensor, c: torch.Tensor,
     return out
 
 
+@_device_guard()
 def pca_md_score(h: torch.Tensor, packed_ct: Optional[torch.Tensor], bias: Optional[torch.Tensor],
                  scale: Optional[torch.Tensor], md_mean: torch.Tensor, packed_p: torch.Tensor, n: int,
                  want_projection: bool = False, out: Optional[torch.Tensor] = None):
@@ -835,6 +907,7 @@ def pca_md_score(h: torch.Tensor, packed_ct: Optional[torch.Tensor], bias: Optio
     return (s, y) if want_projection else s
 
 
+@_device_guard()
 def covariance(x: torch.Tensor):
     """x [N, D] f64/f32 (device) -> (mean [D] f64, cov [D, D] f64) = np.cov(x.T, bias=1) with its column means."""
     lib = load_library()
@@ -851,6 +924,7 @@ def covariance(x: torch.Tensor):
     return mean, cov
 
 
+@_device_guard()
 def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], clip_max: float = float("inf")) -> torch.Tensor:
     """logits [N, C] = min(x, clip_max) @ w.T + bias  (x [N, D], w [C, D], all f32 on the device)."""
     lib = load_library()
@@ -865,6 +939,7 @@ def linear(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], clip_
     return out
 
 
+@_device_guard()
 def ash_s(x: torch.Tensor, percentile: int) -> torch.Tensor:
     """ASH-S of 2-D activations (``ash_s_linear_layer``): rows of up to 4 096 features in registers (wave per row), longer
     rows through the radix-select kernel (workgroup per row)."""
@@ -881,6 +956,7 @@ def ash_s(x: torch.Tensor, percentile: int) -> torch.Tensor:
     return y
 
 
+@_device_guard()
 def ash_s_conv(x: torch.Tensor, percentile: int, prune_in_place: bool = True) -> torch.Tensor:
     """ASH-S of (B, C, H, W) maps (``ash_s_conv_layer``): per sample the k largest of its C*H*W activations are kept and
     the sample is multiplied by exp(sum / kept sum).  ``prune_in_place``: ``x`` itself is left pruned, as the
@@ -898,6 +974,7 @@ def ash_s_conv(x: torch.Tensor, percentile: int, prune_in_place: bool = True) ->
     return y
 
 
+@_device_guard()
 def gen_entropy(probs: torch.Tensor, gamma: float, m: int) -> torch.Tensor:
     """``generalized_entropy(probs, gamma, M)`` on rows that already are probabilities -> [N] f32."""
     lib = load_library()
@@ -910,6 +987,7 @@ def gen_entropy(probs: torch.Tensor, gamma: float, m: int) -> torch.Tensor:
     return s
 
 
+@_device_guard()
 def mcd_uncertainty(logits: torch.Tensor, n_mc: int, want_probs: bool = False):
     """logits [N * n_mc, C] f32 (an image's MC rows consecutive) -> (pred_h [N], mi [N], softmax rows or None): the
     predictive entropy of the mean distribution and the mutual information, one launch."""
@@ -926,6 +1004,7 @@ def mcd_uncertainty(logits: torch.Tensor, n_mc: int, want_probs: bool = False):
     return ph, mi, probs
 
 
+@_device_guard()
 def gen_score(logits: torch.Tensor, gamma: float, m: int) -> torch.Tensor:
     lib = load_library()
     require_gpu()
@@ -937,6 +1016,7 @@ def gen_score(logits: torch.Tensor, gamma: float, m: int) -> torch.Tensor:
     return s
 
 
+@_device_guard()
 def proj_norm(x: torch.Tensor, u: torch.Tensor, packed_ns: torch.Tensor, n: int) -> torch.Tensor:
     """|| (x - u) @ NS ||_2 per row -> [N] f64 (x, u both f32 or both f64)."""
     lib = load_library()
@@ -950,6 +1030,7 @@ def proj_norm(x: torch.Tensor, u: torch.Tensor, packed_ns: torch.Tensor, n: int)
     return out
 
 
+@_device_guard()
 def proj_sq_score(h: torch.Tensor, packed_m: torch.Tensor, c: torch.Tensor, r: int, out: Optional[torch.Tensor] = None) -> torch.Tensor:
     """score [N] = -|| M h + c ||^2 (h [N, D] f64, packed_m = pack(M.T), c [r])."""
     lib = load_library()
@@ -966,6 +1047,7 @@ def proj_sq_score(h: torch.Tensor, packed_m: torch.Tensor, c: torch.Tensor, r: i
     return s
 
 
+@_device_guard()
 def ood_metrics(ind_scores: torch.Tensor, ood_scores: torch.Tensor) -> torch.Tensor:
     """Device scores (both f32 or both f64) -> device tensor [3] f64 = (auroc, fpr@95, aupr), InD = positive class
     (``get_auroc_results`` of the reference, evaluation/metrics.py:37-100).  Stream-ordered, no synchronisation."""
@@ -985,6 +1067,7 @@ def ood_metrics(ind_scores: torch.Tensor, ood_scores: torch.Tensor) -> torch.Ten
     return out
 
 
+@_device_guard()
 def ood_clf_curve(ind_scores: torch.Tensor, ood_scores: torch.Tensor):
     """Device scores (both f32 or both f64) -> ``(metrics [3] f64 device, tps [runs] int64 host, fps [runs] int64 host)``:
     torchmetrics' ``_binary_clf_curve`` (cumulative true / false positives at the end of every run of equal scores,
@@ -1009,6 +1092,7 @@ def ood_clf_curve(ind_scores: torch.Tensor, ood_scores: torch.Tensor):
     return out, host[0], host[1]
 
 
+@_device_guard()
 def eigh(a: torch.Tensor, max_sweeps: int = 30, blocked: bool = True):
     """Symmetric eigen-decomposition on the device: a [n, n] f64 -> (eigenvalues [n] ascending, eigenvectors [n, n] as
     columns), like ``numpy.linalg.eigh``.  Cyclic Jacobi sweeps until one applies no rotation; ``blocked`` (default):
@@ -1051,6 +1135,7 @@ def eigh(a: torch.Tensor, max_sweeps: int = 30, blocked: bool = True):
     return w[order], v[:n, :n][:, order].contiguous()
 
 
+@_device_guard()
 def matmul_f64(a: torch.Tensor, b: torch.Tensor, transpose_b: bool = False) -> torch.Tensor:
     lib = load_library()
     require_gpu()
@@ -1065,6 +1150,7 @@ def matmul_f64(a: torch.Tensor, b: torch.Tensor, transpose_b: bool = False) -> t
     return c
 
 
+@_device_guard()
 def centred_gram(e: torch.Tensor, denom: float) -> torch.Tensor:
     """e [n, H] f32 -> Gram matrix [n, n] f64 of the column-centred rows, divided by ``denom``."""
     lib = load_library()
@@ -1077,6 +1163,7 @@ def centred_gram(e: torch.Tensor, denom: float) -> torch.Tensor:
     return g
 
 
+@_device_guard("boxes", "batch_idx")
 def roi_align(x: torch.Tensor, boxes: torch.Tensor, output_size, spatial_scale: float = 1.0, sampling_ratio: int = -1,
               aligned: bool = False, batch_idx: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``torchvision.ops.roi_align``: x [B, C, H, W] f32, boxes [K, 4] f32 (xyxy) -> [K, C, PH, PW] f32 (device)."""
@@ -1097,6 +1184,7 @@ def roi_align(x: torch.Tensor, boxes: torch.Tensor, output_size, spatial_scale: 
     return out
 
 
+@_device_guard()
 def nchw_to_nhwc(x: torch.Tensor) -> torch.Tensor:
     """x [B, C, H, W] f32 -> [B, H, W, C] f32 (a contiguous copy in channels-last order; the ROI source of
     :func:`roi_mc_entropy`: 64 channels of a wave read a bilinear tap as one contiguous run)."""
@@ -1117,6 +1205,7 @@ def roi_mc_entropy_supported(ph: int, pw: int, n_mc: int, k: int, sampling_ratio
     return bool(load_library().runia_roi_mc_entropy_supported(int(ph), int(pw), int(n_mc), int(k), int(sampling_ratio)))
 
 
+@_device_guard("boxes", "batch_idx", "rand")
 def roi_mc_entropy(x_nhwc: torch.Tensor, boxes: torch.Tensor, output_size, spatial_scale: float, sampling_ratio: int,
                    aligned: bool, rand: Union[torch.Tensor, CounterDraws, None], n_mc: int, drop_prob: float, block_size: int, k: int,
                    min_dist: float = 1e-5, batch_idx: Optional[torch.Tensor] = None, return_samples: bool = False):
@@ -1157,6 +1246,7 @@ def roi_mc_entropy(x_nhwc: torch.Tensor, boxes: torch.Tensor, output_size, spati
 KDE_KERNELS = ("gaussian", "tophat", "epanechnikov", "exponential", "linear", "cosine")
 
 
+@_device_guard()
 def kde_score_kernel(train: torch.Tensor, x: torch.Tensor, bandwidth: float, kernel: str) -> torch.Tensor:
     """log-density of ``x`` [N, D] under a kernel density estimate on ``train`` [M, D] (both f64) for any of sklearn's
     kernels (``KDE_KERNELS``) with sklearn's normalisation -> [N] f64."""
@@ -1169,3 +1259,23 @@ def kde_score_kernel(train: torch.Tensor, x: torch.Tensor, bandwidth: float, ker
     _check(lib.runia_kde_score_kernel_f64(train.data_ptr(), x.data_ptr(), s.data_ptr(), train.shape[0], x.shape[0], train.shape[1],
                                           float(bandwidth), KDE_KERNELS.index(kernel), _stream()), "runia_kde_score_kernel_f64")
     return s
+
+
+@_device_guard()
+def clock_probe(chain: int = 8192, device: Optional[torch.device] = None) -> torch.Tensor:
+    """Queue one clock probe (``runia_clock_probe``) on the current stream -> device tensor [4] int64
+    (shader-clock ticks, 100 MHz ticks, FMAs in the chain, 0).  Read it with :func:`clock_ghz` after a synchronisation."""
+    lib = load_library()
+    dev = require_gpu() if device is None else device
+    out = torch.zeros(4, dtype=torch.int64, device=dev)
+    _check(lib.runia_clock_probe(out.data_ptr(), int(chain), _stream()), "runia_clock_probe")
+    return out
+
+
+def clock_ghz(probe: torch.Tensor) -> dict:
+    """Host reading of a finished :func:`clock_probe`: the clock held (GHz), the probe's length and the cycles one
+    dependent f32 FMA took."""
+    t, r, n, _ = (int(v) for v in probe.cpu().tolist())
+    ns = r * 10.0
+    return {"ghz": round(t / ns, 4) if ns > 0 else None, "probe_us": round(ns / 1e3, 2),
+            "cycles_per_dependent_fma": round(t / n, 3) if n else None}

@@ -220,14 +220,151 @@ __global__ __launch_bounds__(256) void ash_s_rows_kernel(const float* x, float* 
   }
 }
 
+// ---- heads wider than the register kernels hold (C > 4 096: ImageNet-21k, LLM vocabularies) ----------------------------------
+// One workgroup per image / row, the row re-read from L2 between the passes (as ash_s_rows_kernel).  Same arithmetic per
+// element as the wave-per-row kernels; the sums over classes run over 256 threads in a fixed order.
+__device__ __forceinline__ float block_max_f32(float v, float* red, int tid) {
+  v = wave_max_f32(v);
+  __syncthreads();
+  if ((tid & 63) == 0) red[tid >> 6] = v;
+  __syncthreads();
+  return fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+}
+
+__global__ __launch_bounds__(256) void mcd_uncertainty_wide_kernel(const float* __restrict__ logits, float* __restrict__ probs,
+                                                                    float* __restrict__ pred_h, float* __restrict__ mi,
+                                                                    int64_t N, int n_mc, int64_t C) {
+  extern __shared__ float row_stats[];  // [2 * n_mc]: max and sum of exp of every MC row of the image
+  __shared__ float red[4];
+  const int tid = threadIdx.x;
+  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
+    float eh = 0.f;
+    for (int s = 0; s < n_mc; ++s) {
+      const float* p = logits + (img * n_mc + s) * C;
+      float m = -INFINITY;
+      for (int64_t j = tid; j < C; j += 256) m = fmaxf(m, p[j]);
+      m = block_max_f32(m, red, tid);
+      float sum = 0.f;
+      for (int64_t j = tid; j < C; j += 256) sum += expf(p[j] - m);
+      sum = block_sum_f32(sum, red, tid);
+      float h = 0.f;
+      for (int64_t j = tid; j < C; j += 256) {
+        const float pr = expf(p[j] - m) / sum;
+        if (probs) probs[(img * n_mc + s) * C + j] = pr;
+        h += pr * logf(pr);
+      }
+      eh -= block_sum_f32(h, red, tid);
+      if (tid == 0) {
+        row_stats[2 * s] = m;
+        row_stats[2 * s + 1] = sum;
+      }
+    }
+    __syncthreads();
+    float ph = 0.f;
+    for (int64_t j = tid; j < C; j += 256) {
+      float mean = 0.f;
+      for (int s = 0; s < n_mc; ++s) mean += expf(logits[(img * n_mc + s) * C + j] - row_stats[2 * s]) / row_stats[2 * s + 1];
+      const float e = mean / (float)n_mc;
+      ph += e * logf(e);
+    }
+    ph = -block_sum_f32(ph, red, tid);
+    if (tid == 0) {
+      pred_h[img] = ph;
+      mi[img] = ph - eh / (float)n_mc;
+    }
+    __syncthreads();  // row_stats is rewritten by the next image
+  }
+}
+
+// GEN on rows of any length: -sum over the M largest probabilities of p^gamma (1 - p)^gamma.  The M-th largest probability by
+// an 8-bit radix select over the row's keys (4 passes), then one pass for the terms above it; ties at the threshold count
+// (M - #above) times, as in gen_kernel.
+__global__ __launch_bounds__(256) void gen_wide_kernel(const float* __restrict__ logits, float* __restrict__ score, int64_t N,
+                                                        int64_t C, int64_t M, float gamma, int from_probs) {
+  __shared__ unsigned hist[256];
+  __shared__ float red[4];
+  __shared__ unsigned sel[2];
+  const int tid = threadIdx.x;
+  for (int64_t row = blockIdx.x; row < N; row += gridDim.x) {
+    const float* p = logits + row * C;
+    float m = 0.f, s = 1.f;
+    if (!from_probs) {  // (uniform) the rows are logits: softmax first
+      m = -INFINITY;
+      for (int64_t j = tid; j < C; j += 256) m = fmaxf(m, p[j]);
+      m = block_max_f32(m, red, tid);
+      s = 0.f;
+      for (int64_t j = tid; j < C; j += 256) s += expf(p[j] - m);
+      s = block_sum_f32(s, red, tid);
+    }
+    auto prob = [&](int64_t j) { return from_probs ? p[j] : expf(p[j] - m) / s; };
+    float acc = 0.f;
+    if (M >= C) {
+      for (int64_t j = tid; j < C; j += 256) {
+        const float pv = prob(j);
+        acc += powf(pv, gamma) * powf(1.0f - pv, gamma);
+      }
+      acc = block_sum_f32(acc, red, tid);
+    } else {
+      unsigned prefix = 0u, want = (unsigned)M;
+      for (int shift = 24; shift >= 0; shift -= 8) {
+        hist[tid] = 0u;
+        __syncthreads();
+        const unsigned himask = (shift == 24) ? 0u : (0xFFFFFFFFu << (shift + 8));
+        for (int64_t j = tid; j < C; j += 256) {
+          const unsigned key = __float_as_uint(prob(j)) | 0x80000000u;  // p >= 0
+          if ((key & himask) == prefix) atomicAdd(&hist[(key >> shift) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+          unsigned r = want;
+          int d8 = 255;
+          for (; d8 > 0; --d8) {
+            if (r <= hist[d8]) break;
+            r -= hist[d8];
+          }
+          sel[0] = (unsigned)d8;
+          sel[1] = r;
+        }
+        __syncthreads();
+        prefix |= sel[0] << shift;
+        want = sel[1];
+        __syncthreads();
+      }
+      // `want` of the entries equal to the threshold belong to the M largest
+      for (int64_t j = tid; j < C; j += 256) {
+        const float pv = prob(j);
+        if ((__float_as_uint(pv) | 0x80000000u) > prefix) acc += powf(pv, gamma) * powf(1.0f - pv, gamma);
+      }
+      acc = block_sum_f32(acc, red, tid);
+      const float pt = __uint_as_float(prefix & 0x7fffffffu);
+      acc += (float)want * (powf(pt, gamma) * powf(1.0f - pt, gamma));
+    }
+    if (tid == 0) score[row] = -acc;
+    __syncthreads();
+  }
+}
+
 }  // namespace
+
+// rowwise.hip: GEN of rows longer than its register kernels hold
+int runia_gen_rows_wide(const float* logits, float* score, int64_t N, int64_t C, int M, double gamma, int from_probs,
+                        hipStream_t s) {
+  gen_wide_kernel<<<(unsigned)(N < 65536 ? N : 65536), 256, 0, s>>>(logits, score, N, C, (int64_t)M, (float)gamma, from_probs);
+  return runia_check_launch();
+}
 
 extern "C" int runia_mcd_uncertainty_f32(const float* logits, float* probs, float* pred_h, float* mi, int64_t N, int n_mc,
                                          int64_t C, runia_stream_t stream) {
-  if (N < 0 || n_mc < 1 || C <= 0 || C > 4096) return RUNIA_E_INVALID;
+  if (N < 0 || n_mc < 1 || C <= 0) return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
   if (!logits || !pred_h || !mi) return RUNIA_E_INVALID;
   hipStream_t s = as_stream(stream);
+  if (C > 4096) {  // workgroup per image, the rows re-read from L2 (any width; n_mc bounded by the LDS table of row statistics)
+    if (n_mc > 4096) return RUNIA_E_INVALID;
+    mcd_uncertainty_wide_kernel<<<(unsigned)(N < 65536 ? N : 65536), 256, 2 * n_mc * sizeof(float), s>>>(logits, probs, pred_h, mi, N,
+                                                                                                        n_mc, C);
+    return runia_check_launch();
+  }
   if (C <= 16) {
     mcd_uncertainty_tiny_kernel<<<runia_stream_grid(N, 256), 256, 0, s>>>(logits, probs, pred_h, mi, N, n_mc, (int)C);
     return runia_check_launch();

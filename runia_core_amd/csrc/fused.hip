@@ -1090,10 +1090,21 @@ int runia_roi_sample_table(const float* feat_nhwc, const float* boxes, const int
                            hipStream_t s);  // roi.hip
 size_t runia_roi_sample_table_bytes(int64_t K, int PH, int PW, int G);
 
+// The fused ROI launch exists for exactly these (PH, PW, register samples NP, k, samples per bin side G): one list feeds both
+// the shape query and the dispatch, so `supported` can never promise a shape the entry point has no kernel for.  n_mc in
+// (NP/2, NP] takes the NP instantiation.  Everything else (adaptive sampling - ratio <= 0 - has a per-ROI sample count; 4x4 /
+// 8x8 bins with one sample; n_mc <= 8) goes through runia_roi_align_f32 + runia_mc_entropy_f32, same bits.
+#define RUNIA_ROI_MCE_SHAPES(X)                                                                                    \
+  X(7, 7, 16, 5, 2) X(7, 7, 32, 5, 2) X(7, 7, 16, 5, 1) X(7, 7, 32, 5, 1)                                          \
+  X(4, 4, 16, 5, 2) X(4, 4, 32, 5, 2) X(8, 8, 16, 5, 2) X(8, 8, 32, 5, 2)
+
 extern "C" int runia_roi_mc_entropy_supported(int PH, int PW, int n_mc, int k, int sampling_ratio) {
-  // the table path's map shapes with an odd or even side up to 8 and one or four samples per bin (what the reference's
-  // extractor is configured with; adaptive sampling - ratio <= 0 - has a per-ROI sample count: roi_align + K1 then)
-  return runia_mc_entropy_supported(PH, PW, n_mc, k) && (sampling_ratio == 1 || sampling_ratio == 2) && PH * PW > 4;
+  if (!runia_mc_entropy_supported(PH, PW, n_mc, k)) return 0;
+#define RUNIA_ROI_HAS(HH, WW, NPP, KK, GG) \
+  if (PH == HH && PW == WW && n_mc <= NPP && n_mc > NPP / 2 && k == KK && sampling_ratio == GG) return 1;
+  RUNIA_ROI_MCE_SHAPES(RUNIA_ROI_HAS)
+#undef RUNIA_ROI_HAS
+  return 0;
 }
 extern "C" size_t runia_roi_mc_entropy_workspace_bytes(int64_t K, int PH, int PW, int n_mc, int sampling_ratio) {
   if (K <= 0 || sampling_ratio < 1) return 0;
@@ -1137,8 +1148,7 @@ extern "C" int runia_roi_mc_entropy_f32(const float* feat_nhwc, const float* box
                                                                                     K, C, n_mc, min_dist, ct, inv_n); \
     return runia_check_launch();                                                                                   \
   }
-  RUNIA_ROI_MCE(7, 7, 16, 5, 2) RUNIA_ROI_MCE(7, 7, 32, 5, 2) RUNIA_ROI_MCE(7, 7, 16, 5, 1) RUNIA_ROI_MCE(7, 7, 32, 5, 1)
-  RUNIA_ROI_MCE(4, 4, 16, 5, 2) RUNIA_ROI_MCE(4, 4, 32, 5, 2) RUNIA_ROI_MCE(8, 8, 16, 5, 2) RUNIA_ROI_MCE(8, 8, 32, 5, 2)
+  RUNIA_ROI_MCE_SHAPES(RUNIA_ROI_MCE)
 #undef RUNIA_ROI_MCE
   return RUNIA_E_INVALID;
 }

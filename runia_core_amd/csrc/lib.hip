@@ -1,7 +1,7 @@
 // Library-level entry points of librunia_hip.so.
 #include "common.hpp"
 
-extern "C" int runia_abi_version(void) { return 4; }
+extern "C" int runia_abi_version(void) { return 5; }
 
 extern "C" const char* runia_error_string(int code) {
   switch (code) {
@@ -18,4 +18,34 @@ extern "C" int runia_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
+}
+
+// ---- clock probe ------------------------------------------------------------------------------------------------
+// One wave runs `chain` dependent v_fma_f32 and reads both free-running counters around them: s_memtime (shader-clock
+// ticks) and s_memrealtime (constant 100 MHz).  bench.py queues it right before and right after every timed region, so the
+// record carries the clock the GPU held there: GHz = shader ticks / (100 MHz ticks * 10 ns).  The probe takes ~20 us of
+// one wave; DVFS moves the clock over milliseconds, so the reading is that of the load the probe follows.
+__global__ void __launch_bounds__(64) clock_probe_kernel(uint64_t* __restrict__ out, int chain) {
+  float a = (float)threadIdx.x * 1e-3f, b = 0.999f, c = 1e-4f;
+  const uint64_t r0 = __builtin_amdgcn_s_memrealtime();
+  const uint64_t t0 = __builtin_amdgcn_s_memtime();
+  for (int i = 0; i < chain; i += 16) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a) : "v"(b), "v"(c));
+  }
+  asm volatile("s_nop 0" ::"v"(a));
+  const uint64_t t1 = __builtin_amdgcn_s_memtime();
+  const uint64_t r1 = __builtin_amdgcn_s_memrealtime();
+  if (threadIdx.x == 0) {
+    out[0] = t1 - t0;
+    out[1] = r1 - r0;
+    out[2] = (uint64_t)((chain + 15) / 16 * 16);
+  }
+  if (a == 123.456f) out[3] = 1;  // keeps the chain alive
+}
+
+extern "C" int runia_clock_probe(uint64_t* out4, int chain, runia_stream_t stream) {
+  if (!out4 || chain < 16 || chain > (1 << 24)) return RUNIA_E_INVALID;
+  hipLaunchKernelGGL(clock_probe_kernel, dim3(1), dim3(64), 0, as_stream(stream), out4, chain);
+  return runia_check_launch();
 }

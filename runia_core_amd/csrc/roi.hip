@@ -26,7 +26,7 @@ __device__ __forceinline__ float bilinear(const float* __restrict__ in, int H, i
 
 __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict__ input, const float* __restrict__ boxes,
                                                         const int* __restrict__ batch_idx, float* __restrict__ out,
-                                                        int64_t total, int C, int H, int W, int PH, int PW,
+                                                        int64_t total, int64_t B, int C, int H, int W, int PH, int PW,
                                                         float spatial_scale, int sampling_ratio, int aligned) {
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (int64_t)gridDim.x * 256) {
     const int pw = (int)(idx % PW), ph = (int)((idx / PW) % PH);
@@ -34,6 +34,10 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const float* __restrict_
     const int64_t k = idx / ((int64_t)PW * PH * C);
     const float* box = boxes + k * 4;
     const int b = batch_idx ? batch_idx[k] : 0;
+    if (b < 0 || b >= B) {  // an image index outside the batch: a defined result (zeros), never a read outside the feature maps
+      out[idx] = 0.f;
+      continue;
+    }
     const float offset = aligned ? 0.5f : 0.f;
     const float x1 = box[0] * spatial_scale - offset, y1 = box[1] * spatial_scale - offset;
     const float x2 = box[2] * spatial_scale - offset, y2 = box[3] * spatial_scale - offset;
@@ -95,7 +99,7 @@ static_assert(sizeof(RoiSourceHost) <= 64, "the source description fits the head
 // separable: y and x never meet before the four products).
 __global__ __launch_bounds__(256) void roi_sample_table_kernel(RoiSourceHost src, const float* __restrict__ boxes,
                                                                 const int* __restrict__ batch_idx, unsigned* __restrict__ tab,
-                                                                int64_t K, int C, int H, int W, int PH, int PW,
+                                                                int64_t K, int64_t B, int C, int H, int W, int PH, int PW,
                                                                 float spatial_scale, int G, int aligned) {
   if (blockIdx.x == 0 && threadIdx.x == 0) *reinterpret_cast<RoiSourceHost*>(tab) = src;
   unsigned* roi_tab = tab + 16;  // 64 bytes of RoiSource in front
@@ -117,12 +121,17 @@ __global__ __launch_bounds__(256) void roi_sample_table_kernel(RoiSourceHost src
     float t = lo + (float)bin * bin_sz + ((float)sub + 0.5f) * bin_sz / (float)G;
     unsigned* hd = roi_tab + k * (int64_t)roi_dwords;
     unsigned* e = hd + 8 + 4 * j;
+    // An image index outside [0, B) would move the loader's buffer descriptor off the feature maps (its own range check then
+    // protects nothing): such a ROI is made of "outside" samples only - every tap beyond the buffer, weights 0 - on image 0,
+    // i.e. the zeros runia_roi_align_f32 writes for it.
+    const int image = batch_idx ? batch_idx[k] : 0;
+    const bool bad_image = image < 0 || image >= B;
     if (j == 0) {
-      hd[0] = (unsigned)(batch_idx ? batch_idx[k] : 0);
+      hd[0] = bad_image ? 0u : (unsigned)image;
 #pragma unroll
       for (int q = 1; q < 8; ++q) hd[q] = 0u;
     }
-    const bool outside = (t < -1.0f || t > (float)L);
+    const bool outside = bad_image || (t < -1.0f || t > (float)L);
     // a sample row / column more than a pixel outside the map contributes nothing (roi_align's `continue`): its byte offset is
     // the size of the image - every tap of it lies beyond the buffer the loader reads through, and such a load returns 0 -
     // and its weights are 0, so the sample is +0.0 without a test in the loader (the scalar offset is part of the range check
@@ -153,7 +162,6 @@ size_t runia_roi_sample_table_bytes(int64_t K, int PH, int PW, int G) {
 int runia_roi_sample_table(const float* feat_nhwc, const float* boxes, const int* batch_idx, void* table, size_t table_bytes,
                            int64_t K, int64_t B, int C, int H, int W, int PH, int PW, double spatial_scale, int G, int aligned,
                            hipStream_t s) {
-  (void)B;
   if (table_bytes < runia_roi_sample_table_bytes(K, PH, PW, G) || PH * G > 32 || PW * G > 32) return RUNIA_E_WORKSPACE;
   if ((int64_t)H * W * C * 4 >= (int64_t)1 << 30) return RUNIA_E_INVALID;  // (offsets of outside samples: row + column + channel stay below 2^32)
   RoiSourceHost src;
@@ -164,7 +172,7 @@ int runia_roi_sample_table(const float* feat_nhwc, const float* boxes, const int
   src.roi_dwords = 8 + 4 * (PH * G + PW * G);
   const int64_t total = K * (PH * G + PW * G);
   roi_sample_table_kernel<<<runia_stream_grid(total, 256), 256, 0, s>>>(src, boxes, batch_idx, reinterpret_cast<unsigned*>(table),
-                                                                        K, C, H, W, PH, PW, (float)spatial_scale, G, aligned);
+                                                                        K, B, C, H, W, PH, PW, (float)spatial_scale, G, aligned);
   return runia_check_launch();
 }
 
@@ -186,6 +194,6 @@ extern "C" int runia_roi_align_f32(const float* input, const float* boxes, const
   if (B > 1 && !batch_idx) return RUNIA_E_INVALID;
   const int64_t total = K * C * PH * PW;
   roi_align_kernel<<<runia_stream_grid(total, 256), 256, 0, as_stream(stream)>>>(
-      input, boxes, batch_idx, out, total, C, H, W, PH, PW, (float)spatial_scale, sampling_ratio, aligned);
+      input, boxes, batch_idx, out, total, B, C, H, W, PH, PW, (float)spatial_scale, sampling_ratio, aligned);
   return runia_check_launch();
 }

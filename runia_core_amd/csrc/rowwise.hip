@@ -447,11 +447,15 @@ extern "C" int runia_ash_s_f32(const float* x, float* y, int64_t N, int64_t D, i
   return runia_check_launch();
 }
 
+int runia_gen_rows_wide(const float* logits, float* score, int64_t N, int64_t C, int M, double gamma, int from_probs,
+                        hipStream_t s);  // funcs_rows.hip
+
 static int gen_rows(const float* logits, float* score, int64_t N, int64_t C, int M, double gamma, int from_probs,
                     runia_stream_t stream) {
-  if (N < 0 || C <= 0 || C > 4096 || M < 1) return RUNIA_E_INVALID;
+  if (N < 0 || C <= 0 || M < 1) return RUNIA_E_INVALID;
   if (N == 0) return RUNIA_OK;
   if (!logits || !score) return RUNIA_E_INVALID;
+  if (C > 4096) return runia_gen_rows_wide(logits, score, N, C, M, gamma, from_probs, as_stream(stream));
   const unsigned grid = runia_rows_grid(N);
   constexpr int kT = 64 * kRowWaves;
   hipStream_t s = as_stream(stream);

@@ -77,7 +77,7 @@ class DetectorKDE:
 
     def density_fit(self):
         self._train_dev = None  # uploaded on first use so that setup works without a GPU
-        self._packed = None     # matrix-core form of the training set (D >= 24), built on first use
+        self._packed = None     # matrix-core form of the training set, built on first use
         return self
 
     def __getstate__(self):
@@ -90,21 +90,18 @@ class DetectorKDE:
 
     def score_samples_device(self, x: Tensor) -> Tensor:
         train = self._train()
-        d, n_rows = train.shape[1], x.shape[0]
         if self.kernel != "gaussian":  # tophat / epanechnikov / exponential / linear / cosine: one direct kernel
             return _hip.kde_score_kernel(train, x.to(torch.float64), float(self.bandwidth), self.kernel)
-        if d >= 24 or (d >= 12 and n_rows <= 16384) or n_rows <= 2048:
-            # (few rows, any width: a 64-query group of the direct kernel walks the whole training set on ONE compute unit -
-            # 0.28-0.57 ms for 1 ... 512 rows against 10 000 training rows at D = 2 ... 23; the matrix-core form with its
-            # column blocks on separate workgroups 0.12-0.14 ms, tools/ablate/run_kde_few_rows.py)
-            # pair distances as |x|^2 + |t|^2 - 2 x.t on the f64 matrix cores, online logsumexp (8 192 x 10 000 pairs:
-            # 0.27 / 0.38 / 0.88 ms at D = 32 / 64 / 256 against 0.56 / 1.85 / 21.5 ms for the direct kernels).  At
-            # D = 16 the direct kernel wins on large batches (65 536 rows: 1.47 vs 1.84 ms) and loses on small ones,
-            # where it has too few 64-query workgroups for the chip (8 192 rows: 0.37 vs 0.29 ms)
-            if self._packed is None:
-                self._packed = _hip.kde_pack_train(train)
-            return _hip.kde_score_packed(self._packed, x.to(torch.float64), float(self.bandwidth))
-        return _hip.kde_score(train, x.to(torch.float64), float(self.bandwidth))
+        # ONE algorithm whatever the batch: pair distances as |x|^2 + |t|^2 - 2 x.t on the f64 matrix cores with an online
+        # logsumexp (runia_kde_score_packed_f64; few rows put its column blocks on separate workgroups and replay them in block
+        # order - the same bits).  A row's score must not depend on the batch it arrives in, nor on how a sharded job cut the
+        # rows (the direct difference kernel used to take batches > 2 048 rows at D < 12 and > 16 384 at D < 24).
+        # Cost of the rule: at D <= 16 the direct kernel is faster on very large batches (65 536 rows at D = 16: 1.47 vs
+        # 1.84 ms) - and slower on small ones (8 192 rows: 0.37 vs 0.29 ms; 1 ... 512 rows: 0.28-0.57 vs 0.12-0.14 ms).
+        # _hip.kde_score (the direct kernel) stays in the C ABI and is tested against the same oracle.
+        if self._packed is None:
+            self._packed = _hip.kde_pack_train(train)
+        return _hip.kde_score_packed(self._packed, x.to(torch.float64), float(self.bandwidth))
 
     def get_density_scores(self, test_embeddings):
         x = _hip.to_device(np.asarray(test_embeddings), torch.float64)

@@ -1419,6 +1419,46 @@ def test_roi_align_folded_into_the_sampler_equals_the_two_calls(osz, sr, n_mc, c
 
 
 @pytest.mark.gpu
+def test_every_roi_shape_the_query_accepts_has_a_kernel_and_the_others_take_the_two_calls():
+    """runia_roi_mc_entropy_supported promised shapes the entry point had no kernel for (output 4 / 8
+    with one sample per bin, 4x4 with 5..8 drop layers).  The query and the dispatch now expand ONE shape list: every
+    (PH, n_mc, sampling_ratio) the query accepts launches and returns the two-call bits, and
+    _dropblock_rois_get_entropy on a shape it refuses still returns the two-call result."""
+    from runia_core_amd import MCSamplerModule, _hip
+    from runia_core_amd.feature_extraction.object_level import _dropblock_rois_get_entropy
+
+    rng = np.random.default_rng(5)
+    fm = torch.relu(torch.from_numpy(rng.standard_normal((1, 64, 12, 17)).astype(np.float32))).cuda()
+    nhwc = _hip.nchw_to_nhwc(fm)
+    xy = rng.uniform(-10, 200, size=(6, 2)).astype(np.float32)
+    boxes = torch.from_numpy(np.concatenate([xy, xy + rng.uniform(8, 120, size=(6, 2)).astype(np.float32)], axis=1))
+    accepted = 0
+    for osz in (2, 4, 7, 8):
+        for sr in (-1, 0, 1, 2, 3):
+            for n_mc in range(5, 33):
+                ok = _hip.roi_mc_entropy_supported(osz, osz, n_mc, 5, sr)
+                if not ok:
+                    continue
+                accepted += 1
+                rand = torch.from_numpy(rng.random((6, n_mc, osz, osz)).astype(np.float32)).cuda()
+                h = _hip.roi_mc_entropy(nhwc, boxes, osz, 17 / 272.0, sr, True, rand, n_mc, 0.3, 2, 5)   # raised RuniaHipError before
+                if n_mc in (9, 16, 17, 32):
+                    rois = _hip.roi_align(fm, boxes.cuda(), osz, 17 / 272.0, sr, True)
+                    h_ref = _hip.mc_entropy(rois, rand, n_mc, 0.3, 2, 5)
+                    assert torch.equal(torch.nan_to_num(h, nan=-7.0), torch.nan_to_num(h_ref, nan=-7.0)), (osz, sr, n_mc)
+    assert accepted == 8 * 12  # 8 listed (shape, samples-per-bin) pairs x n_mc 9..16 / 17..32 -> 24 values each / 2 register sizes
+    for osz, sr, n_mc in ((4, 1, 16), (8, 1, 16), (4, 2, 6), (7, 0, 16)):
+        assert not _hip.roi_mc_entropy_supported(osz, osz, n_mc, 5, sr)
+    # the reference-shaped caller on a shape without a fused kernel: the two calls, as before round 4
+    for osz, sr, n_mc in ((4, 1, 16), (8, 1, 12)):
+        sampler = MCSamplerModule(mc_samples=n_mc, block_size=2, drop_prob=0.3).train().use_counter_draws(seed=3)
+        ent = _dropblock_rois_get_entropy([fm], (osz,), boxes, (192, 272), sr, 1, n_mc, sampler)
+        rois = _hip.roi_align(fm, boxes.cuda(), osz, 17 / 272.0, sr, True)
+        h_ref = _hip.mc_entropy(rois, _hip.CounterDraws(3, 0), n_mc, 0.3, 2, 5).to(torch.float32).cpu()
+        assert torch.equal(torch.nan_to_num(ent, nan=-7.0), torch.nan_to_num(h_ref, nan=-7.0))
+
+
+@pytest.mark.gpu
 def test_roi_align_folded_into_the_sampler_non_finite_pixels_and_degenerate_boxes():
     """The fused ROI launch against the two launches where the arithmetic leaves the finite range: NaN and infinite
     activations in the map (a sample that touches one is NaN / infinite in both forms; a sample OUTSIDE the map must stay
@@ -1454,6 +1494,30 @@ def test_roi_align_folded_into_the_sampler_non_finite_pixels_and_degenerate_boxe
     assert torch.equal(torch.nan_to_num(h, nan=-7.0, posinf=-8.0, neginf=-9.0), torch.nan_to_num(h_ref, nan=-7.0, posinf=-8.0, neginf=-9.0))
     assert bool((rois[0] == 0).all())                      # outside the map: zeros, not inf * 0
     assert bool(torch.isfinite(z[0]).all()) and bool(torch.isfinite(z[7]).any())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("d", [2, 8, 11, 16, 23])
+def test_lared_row_scores_do_not_depend_on_the_batch(d):
+    """DetectorKDE picked its algorithm by batch size (direct kernel above 2 048 rows at D < 12, above 16 384 at
+    D < 24), so a row's bits followed the batch it arrived in and sharded != unsharded.  One algorithm now: the same row
+    scores the same bits alone, in a 2 048-row call, a 2 049-row call, a 20 000-row call and in the shards of a 3-rank cut;
+    and the exact definition (oracle) on top."""
+    from runia_core_amd.distributed import shard_bounds
+    from runia_core_amd.inference.postprocessors import KDELatentSpace
+
+    rng = np.random.default_rng(d)
+    train = rng.standard_normal((3000, d)) + 0.5
+    x = rng.standard_normal((20000, d)) * 1.3
+    kde = KDELatentSpace()
+    kde.setup(train)
+    whole = kde.postprocess(x)
+    for a, b in ((0, 1), (5, 2053), (5, 2054), (0, 16385), (17000, 20000)):
+        assert np.array_equal(kde.postprocess(x[a:b]), whole[a:b]), (a, b)
+    parts = [kde.postprocess(x[slice(*shard_bounds(len(x), 3, r))]) for r in range(3)]
+    assert np.array_equal(np.concatenate(parts), whole)
+    rows = [0, 2048, 2049, 19999]
+    assert rel_err(whole[rows], oracle.kde_score(train, x[rows])) < 1e-10
 
 
 @pytest.mark.gpu

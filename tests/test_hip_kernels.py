@@ -1013,6 +1013,28 @@ def test_linear_few_rows_score_the_bits_of_a_batch(hip, d, c, clip):
             assert bool(same.all()), (a0, b0, bias is None)
 
 
+@pytest.mark.parametrize("c", [4097, 5000, 21841, 128256])
+def test_gen_and_mcd_uncertainty_on_heads_wider_than_4096(hip, c):
+    """runia_gen_score_f32 / runia_gen_entropy_f32 / runia_mcd_uncertainty_f32 refused C > 4 096 (ImageNet-21k,
+    LLM vocabularies) where the reference's torch / NumPy expressions (inference/funcs.py:347-375, 430-465) take any width:
+    workgroup-per-row kernels now, against the oracle, with ties at the GEN threshold and M >= C."""
+    rng = np.random.default_rng(c)
+    n, n_mc = 6, 3
+    lg = (rng.standard_normal((n * n_mc, c)) * 3).astype(np.float32)
+    lg[1, 10:400] = lg[1, 5]      # ties among the largest probabilities
+    lg[2] = 0.25                  # a constant row: every probability ties
+    for m in (1, 100, 4096, c, c + 5):
+        got = hip.gen_score(dev(lg, torch.float32), 0.1, m).cpu().numpy()
+        assert got.dtype == np.float32 and rel_err(got, oracle.gen_score(lg, 0.1, m)) < 1e-5, m
+    pr = np.exp(lg - lg.max(1, keepdims=True)).astype(np.float32)
+    pr /= pr.sum(1, keepdims=True)
+    assert rel_err(hip.gen_entropy(dev(pr, torch.float32), 0.5, 50).cpu().numpy(), oracle.generalized_entropy(pr, 0.5, 50)) < 1e-5
+    ph, mi, probs = hip.mcd_uncertainty(dev(lg, torch.float32), n_mc, want_probs=True)
+    e_ph, e_mi = oracle.predictive_uncertainty(lg, n_mc)
+    assert rel_err(ph.cpu().numpy(), e_ph) < 1e-5 and rel_err(mi.cpu().numpy(), e_mi) < 1e-5
+    assert rel_err(probs.cpu().numpy(), pr) < 1e-6
+
+
 @pytest.mark.parametrize("m,d", [(10000, 256), (3000, 100), (700, 130)])
 def test_kde_few_rows_split_columns_and_keep_the_bits(hip, m, d):
     """LaRED on few rows (fewer 16-row tiles than compute units): the 256-column blocks of a tile go to separate

@@ -76,6 +76,39 @@ def logits_of(f, w, b):
     return out
 
 
+def warm_clocks(fn, seconds: float = 1.0):
+    """Run ``fn`` untimed for ``seconds`` so that the leg's own kernels bring the clocks up after the host-side work before it
+    (a fit or a CPU-baseline leg on the host leaves the GPU idle for seconds; the first passes after are slower by 5-15 %, the
+    HBM-bound ones included).  Ends WITHOUT a synchronisation: the clock probe and the timed reps queue directly behind it."""
+    t = time.perf_counter()
+    n = 0
+    while n < 2 or time.perf_counter() - t < seconds:
+        torch.cuda.synchronize()
+        fn()
+        n += 1
+    return n
+
+
+def spread(values) -> dict:
+    v = [float(x) for x in values]
+    return {"min": round(min(v), 4), "median": round(float(np.median(v)), 4), "max": round(max(v), 4), "reps": len(v)}
+
+
+def clock_bracket():
+    """A clock probe now (queued on the current stream, directly behind whatever was launched last - call it without a
+    synchronisation in between); call the result right after the region's last launch for {"before", "after"} in GHz."""
+    from runia_core_amd import _hip
+
+    before = _hip.clock_probe()
+
+    def done():
+        after = _hip.clock_probe()
+        torch.cuda.synchronize()
+        return {"before": _hip.clock_ghz(before)["ghz"], "after": _hip.clock_ghz(after)["ghz"]}
+
+    return done
+
+
 def _rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
@@ -170,27 +203,33 @@ def run_cfg3(device, rank: int, world: int, dist, rows_total: int, fit_rows: int
 
     for _ in range(max(1, warmup)):
         scores = one_pass(False)
+    from runia_core_amd import _hip
+
+    probe_before = _hip.clock_probe()  # directly behind the warm-up pass
     if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         scores = one_pass(True)
+    probe_after = _hip.clock_probe()   # directly behind the last pass: ~30 us of one wave inside a region of >= 0.5 s
     torch.cuda.synchronize()
     if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t0
+    clocks = {"before": _hip.clock_ghz(probe_before)["ghz"], "after": _hip.clock_ghz(probe_after)["ghz"]}
     if use_dist:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    ms = {name: float(np.mean([x.elapsed_time(y) for x, y in ev])) for name, ev in events.items()}
+    per_rep = {name: [x.elapsed_time(y) for x, y in ev] for name, ev in events.items()}
+    ms = {name: float(np.mean(v)) for name, v in per_rep.items()}
     gather_ms = float(np.mean([x.elapsed_time(y) for x, y in gather_events])) if gather_events else 0.0
     rec = {"elapsed": elapsed, "rows_total": rows_total, "rows_local": n_loc, "steps": steps,
            "ms_per_step": 1e3 * elapsed / steps, "value": rows_total * steps / elapsed, "stage_ms": ms,
            "gather_ms_per_call": gather_ms, "fit_s": fitted["fit_s"], "broadcast_s": bcast_s, "fit_rows": fit_rows,
            "fit_mode": fitted.get("fit_mode"), "fit_only_s": fitted.get("fit_only_s"),
-           "fit_only_s_host_calls": fitted.get("fit_only_s_host_calls")}
+           "fit_only_s_host_calls": fitted.get("fit_only_s_host_calls"), "clock_ghz_observed": clocks}
     if rank != 0:
         return rec
 
@@ -210,7 +249,7 @@ def run_cfg3(device, rank: int, world: int, dist, rows_total: int, fit_rows: int
     for name, (bound, per_row, peak, unit) in work.items():
         rate = n_loc / (ms[name] * 1e-3)
         ach = per_row * rate / (1e9 if bound == "hbm" else 1e12)
-        stages[name] = {"rows": n_loc, "ms": round(ms[name], 4), "rows_per_s": round(rate, 1), "bound": bound,
+        stages[name] = {"rows": n_loc, "ms": round(ms[name], 4), "ms_spread": spread(per_rep[name]), "rows_per_s": round(rate, 1), "bound": bound,
                         "achieved": round(ach, 2), "peak": peak, "unit": unit, "frac": round(ach / peak, 4)}
     stages["knn"]["shape"] = f"{n_loc} queries x bank {BANK_ROWS}x{D_FEAT} f32, k={K_NN} (normaliser + distances + select)"
     if pieces:
@@ -281,7 +320,7 @@ def run_cfg3(device, rank: int, world: int, dist, rows_total: int, fit_rows: int
 
 
 def run_cfg4_lared(device, n_props: int = 100_000, n_train: int = 4000, n_mc: int = 16, d: int = 1024, n_pca: int = 256,
-                   reps: int = 3) -> dict:
+                   reps: int = 10) -> dict:
     """BASELINE configs[3], LaRED leg: per-proposal MC samples (n_props*16, 1024) f32 resident in HBM -> per-dimension
     entropy -> PCA-256 (whitened) -> KDELatentSpace fitted on 4 000 in-distribution proposals."""
     import runia_core_amd as rc
@@ -321,25 +360,27 @@ def run_cfg4_lared(device, n_props: int = 100_000, n_train: int = 4000, n_mc: in
             ev.append(marks)
         return s
 
-    chain()
-    torch.cuda.synchronize()
+    warm_clocks(chain)
     ev = []
+    clocks = clock_bracket()
     t0 = time.perf_counter()
     for _ in range(reps):
         s = chain(ev)
-    torch.cuda.synchronize()
+    clocks = clocks()  # the probe directly behind the last rep (~30 us of one wave), then the synchronisation
     wall = (time.perf_counter() - t0) / reps
-    ms = [float(np.mean([m[i].elapsed_time(m[i + 1]) for m in ev])) for i in range(3)]
+    per = [[m[i].elapsed_time(m[i + 1]) for m in ev] for i in range(3)]
+    ms = [float(np.median(p)) for p in per]   # median of the reps (min / max beside it)
     ent_gbs = (n_mc * d * 4 + d * 8) * n_props / (ms[0] * 1e-3) / 1e9
     pca_tf = 2.0 * d * n_pca * n_props / (ms[1] * 1e-3) / 1e12
     kde_tf = 2.0 * n_train * n_pca * n_props / (ms[2] * 1e-3) / 1e12
     rec = {"shape": f"{n_props} proposals x {n_mc} MC x {d} f32 -> entropy -> PCA-{n_pca} -> KDE on {n_train} train rows",
-           "rows": n_props, "ms": round(1e3 * wall, 4), "rows_per_s": round(n_props / wall, 1),
-           "entropy": {"ms": round(ms[0], 4), "bound": "hbm", "achieved": round(ent_gbs, 1), "peak": HBM_PEAK_GBS,
+           "rows": n_props, "ms": round(1e3 * wall, 4), "rows_per_s": round(n_props / wall, 1), "clock_ghz_observed": clocks,
+           "timing": "0.3 s of the same chain untimed, then the median of %d reps per stage (HIP events)" % reps,
+           "entropy": {"ms": round(ms[0], 4), "ms_spread": spread(per[0]), "bound": "hbm", "achieved": round(ent_gbs, 1), "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": round(ent_gbs / HBM_PEAK_GBS, 4)},
-           "pca": {"ms": round(ms[1], 4), "bound": "mfma_f64", "achieved": round(pca_tf, 2), "peak": F64_MFMA_TF,
+           "pca": {"ms": round(ms[1], 4), "ms_spread": spread(per[1]), "bound": "mfma_f64", "achieved": round(pca_tf, 2), "peak": F64_MFMA_TF,
                    "unit": "TFLOP/s", "frac": round(pca_tf / F64_MFMA_TF, 4)},
-           "kde": {"ms": round(ms[2], 4), "bound": "mfma_f64", "achieved": round(kde_tf, 2), "peak": F64_MFMA_TF,
+           "kde": {"ms": round(ms[2], 4), "ms_spread": spread(per[2]), "bound": "mfma_f64", "achieved": round(kde_tf, 2), "peak": F64_MFMA_TF,
                    "unit": "TFLOP/s", "frac": round(kde_tf / F64_MFMA_TF, 4)}}
     import oracle  # checker / CPU baseline only
 
@@ -375,7 +416,7 @@ def _roi_valu(k: int, c: int, ms: float) -> dict:
 
 
 def run_cfg4_from_maps(device, n_img: int = 100, per_img: int = 1000, c: int = 1024, fh: int = 45, fw: int = 80, n_mc: int = 16,
-                       n_pca: int = 256, n_train: int = 4000, reps: int = 2) -> dict:
+                       n_pca: int = 256, n_train: int = 4000, reps: int = 8) -> dict:
     """BASELINE configs[3] from where the reference's object-level path starts (feature_extraction/object_level.py:312-367):
     hooked feature maps (n_img, 1024, 45, 80) f32 + per_img proposal boxes per image -> roi_align 7x7 (sampling 2) ->
     per-proposal MC DropBlock x 16 -> per-dimension entropy -> PCA-256 -> KDELatentSpace.  The ROI part is ONE launch per
@@ -431,32 +472,37 @@ def run_cfg4_from_maps(device, n_img: int = 100, per_img: int = 1000, c: int = 1
             ev.append(marks)
         return s, h
 
-    chain()
-    torch.cuda.synchronize()
+    warm_clocks(chain)
     ev, ev_roi = [], []
+    clocks = clock_bracket()
     t0 = time.perf_counter()
     for _ in range(reps):
         s, h = chain(ev_roi, ev)
-    torch.cuda.synchronize()
+    clocks = clocks()  # the probe directly behind the last rep (~30 us of one wave), then the synchronisation
     wall = (time.perf_counter() - t0) / reps
-    ms = [float(np.mean([m[i].elapsed_time(m[i + 1]) for m in ev])) for i in range(3)]
-    ms_t = float(np.mean([t[0].elapsed_time(t[1]) for t in ev_roi]))
-    ms_r = float(np.mean([t[1].elapsed_time(t[2]) for t in ev_roi]))
+    per = [[m[i].elapsed_time(m[i + 1]) for m in ev] for i in range(3)]
+    ms = [float(np.median(p)) for p in per]
+    # the ROI leg takes one launch group per slice of 65 535 proposals: sum the slices of a rep, then the median over reps
+    per_rep = len(ev_roi) // reps
+    per_t = [sum(t[0].elapsed_time(t[1]) for t in ev_roi[r * per_rep:(r + 1) * per_rep]) for r in range(reps)]
+    per_r = [sum(t[1].elapsed_time(t[2]) for t in ev_roi[r * per_rep:(r + 1) * per_rep]) for r in range(reps)]
+    ms_t, ms_r = float(np.median(per_t)), float(np.median(per_r))
     taps_gb = k * c * 49 * 4 * 4 * 4 / 1e9                       # 196 bilinear samples x 4 taps x 4 bytes per (proposal, channel)
     out_gb = k * c * 49 * 4 / 1e9                                 # what roi_align would have written (and K1 read)
     rec = {"shape": f"{n_img} maps x {c} ch x {fh}x{fw} f32 + {per_img} boxes each -> roi_align 7x7/2 -> {n_mc} MC DropBlock -> entropy "
                     f"-> PCA-{n_pca} -> KDE on {n_train} train rows",
-           "rows": k, "ms": round(1e3 * wall, 3), "rows_per_s": round(k / wall, 1),
-           "channels_last_copy": {"ms": round(ms_t, 4), "bound": "hbm", "achieved": round(2 * fm.numel() * 4 / (ms_t * 1e-3) / 1e9, 1),
+           "rows": k, "ms": round(1e3 * wall, 3), "rows_per_s": round(k / wall, 1), "clock_ghz_observed": clocks,
+           "timing": "0.3 s of the same chain untimed, then the median of %d reps per stage (HIP events)" % reps,
+           "channels_last_copy": {"ms": round(ms_t, 4), "ms_spread": spread(per_t), "bound": "hbm", "achieved": round(2 * fm.numel() * 4 / (ms_t * 1e-3) / 1e9, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s"},
-           "roi_sampler_entropy": {"ms": round(ms_r, 4), "bound": "valu-issue", "bilinear_taps_TBps": round(taps_gb / ms_r, 2),
+           "roi_sampler_entropy": {"ms": round(ms_r, 4), "ms_spread": spread(per_r), "bound": "valu-issue", "bilinear_taps_TBps": round(taps_gb / ms_r, 2),
                                    "valu": _roi_valu(k, c, ms_r),
                                    "roi_tensor_not_written_GB": round(out_gb, 2),
                                    "unfused_roi_tensor_GBps_equiv": round(2 * out_gb / (ms_r * 1e-3), 1),
                                    "note": "one launch per 65 535 proposals: per-ROI sample table + keep-flag table + fused load/sampler/entropy"},
-           "pca": {"ms": round(ms[1], 4), "bound": "mfma_f64", "achieved": round(2.0 * c * n_pca * k / (ms[1] * 1e-3) / 1e12, 2),
+           "pca": {"ms": round(ms[1], 4), "ms_spread": spread(per[1]), "bound": "mfma_f64", "achieved": round(2.0 * c * n_pca * k / (ms[1] * 1e-3) / 1e12, 2),
                    "peak": F64_MFMA_TF, "unit": "TFLOP/s"},
-           "kde": {"ms": round(ms[2], 4), "bound": "mfma_f64", "achieved": round(2.0 * n_train * n_pca * k / (ms[2] * 1e-3) / 1e12, 2),
+           "kde": {"ms": round(ms[2], 4), "ms_spread": spread(per[2]), "bound": "mfma_f64", "achieved": round(2.0 * n_train * n_pca * k / (ms[2] * 1e-3) / 1e12, 2),
                    "peak": F64_MFMA_TF, "unit": "TFLOP/s"}}
     for key in ("pca", "kde"):
         rec[key]["frac"] = round(rec[key]["achieved"] / rec[key]["peak"], 4)
