@@ -404,7 +404,8 @@ int runia_p2p_all_gather(const void* local_shard, size_t shard_bytes, void* out,
 int runia_p2p_status(void* buffer, int* status);
 /* runia_p2p_debug(1): the launches that follow ASSERT the ordering argument slot reuse rests on - a writer reads, over the
  * link, the step its peer last copied out of the slot and expects exactly seq - 2; a mismatch sets bit 1 (value 2) of the
- * status word.  Every rank of a group must switch it alike.  Returns the previous setting; off by default. */
+ * status word.  The acknowledgements themselves are always recorded, so the check may be switched on at any step of a live
+ * buffer and by the ranks independently.  Returns the previous setting; off by default. */
 int runia_p2p_debug(int on);
 
 /* ---- f4  remaining logits/features postprocessors (SURVEY 8f "next #4") ------- *

@@ -34,7 +34,9 @@ static_assert(kAckOff + 2 * kMaxRanks * sizeof(unsigned long long) <= kHeader, "
 // step s - 1 launch, which waited for B's flag s - 1, which B's stream raised after B's step s - 2 copy-out.  With the
 // check switched on (runia_p2p_debug) the argument is ASSERTED: every copy-out records the step it finished in the
 // reader's buffer (ack[slot][source]), and a writer reads the peer's ack over the link before it touches the slot - it has
-// to be exactly s - 2, else status bit 1 (value 2) is set.  Costs one remote read per push; off by default.
+// to be exactly s - 2, else status bit 1 (value 2) is set.  The acks are always written (local); the switch gates the remote
+// read only, so it may be flipped at any step and need not flip on every rank at once.  Costs one remote read per push; off
+// by default.
 std::atomic<int> g_debug{0};
 
 struct PeerTable { char* buf[16]; };  // by value in the kernel arguments (world <= 16)
@@ -118,7 +120,10 @@ __device__ __forceinline__ void p2p_wait_copy(char* self, char* __restrict__ out
     }
   }
   (void)ok;
-  if (debug) {  // the last part of this shard's copy-out records the step (see g_debug)
+  (void)debug;
+  {  // The last part of this shard's copy-out records the step (see g_debug).  ALWAYS recorded (local atomics only): the
+     // assertion can then be switched on at any step of a live buffer, and by the ranks at different steps, without a false
+     // alarm (acks used to be written only by launches that ran with the check on) - only the remote READ is gated.
     __threadfence_system();
     __syncthreads();
     if (threadIdx.x == 0) {

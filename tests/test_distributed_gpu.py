@@ -127,12 +127,18 @@ def _p2p_worker(rank, world, port, out_dir):
                 prev_got, prev_full = kept[-2]
                 ok = ok and bool(torch.equal(prev_got, prev_full))
         # several copy blocks per peer; an odd shard (4-byte granularity); cfg3's shard of an 8-GPU job (125 000 rows per rank)
+        # the slot-reuse assertion goes off, comes back in the middle of the live buffer's steps on the even ranks only, then on
+        # every rank: the acknowledgements are always recorded, so none of this may raise a false alarm
+        OneShotGather.set_debug(False)
         for step, n in enumerate((600_000 // 2 * world, 599_999, 1, 125_000 * world, 9)):
+            if step == 3:
+                OneShotGather.set_debug(rank % 2 == 0)
             a, b = shard_bounds(n, world, rank)
             full = (torch.arange(n, dtype=torch.float32, device="cuda") % 4093) + step
             got = g32(full[a:b].clone(), n)
             ok = ok and bool(torch.equal(got, full))
         # back-to-back calls without any host synchronisation in between
+        OneShotGather.set_debug(True)
         n = 5_000 * world
         a, b = shard_bounds(n, world, rank)
         outs = []
