@@ -48,10 +48,12 @@ K1_BOUNDARY_BYTES_PER_IMAGE = C * H * W * 4 + N_MC * (H * W + 2) * 4 + C * 8
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", choices=["cfg2", "cfg3"], default="cfg2",
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "larex_eval"], default="cfg2",
                     help="cfg2 (default, the headline metric): LaREM-16MC/PCA-256 from latents, weak scaling.  cfg3: "
                          "BASELINE.json configs[2] - synthetic 1M x 2048 rows through Mahalanobis + Energy + kNN(k=50), "
-                         "the rows sharded over the ranks (strong scaling), one all_gather per postprocessor")
+                         "the rows sharded over the ranks (strong scaling), one all_gather per postprocessor.  larex_eval: the "
+                         "reference's evaluation harness loop (log_evaluate_larex: PCA refit sweep x five latent-space postprocessors x "
+                         "two OoD sets -> AUROC table), one wall clock for the whole sweep; N > 1 runs independent replicas")
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for cfg2, 3 for cfg3)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 10 for cfg2, 1 for cfg3)")
     ap.add_argument("--rows", type=int, default=1_000_000, help="cfg3: rows of the synthetic test set (all ranks together)")
@@ -96,9 +98,9 @@ def parse_args():
                          "stream (runia_core_amd.distributed.OneShotGather)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = 200 if args.workload == "cfg2" else 3
+        args.steps = {"cfg2": 200, "cfg3": 3, "larex_eval": 1}[args.workload]
     if args.warmup is None:
-        args.warmup = 10 if args.workload == "cfg2" else 1
+        args.warmup = {"cfg2": 10, "cfg3": 1, "larex_eval": 1}[args.workload]
     return args
 
 
@@ -261,6 +263,44 @@ def main_cfg3(args, device, rank, world, dist, saved_stdout):
         dist.destroy_process_group()
 
 
+def main_larex(args, device, rank, world, dist, saved_stdout):
+    """--workload larex_eval: a step = one full pass of the reference's evaluation loop (evaluation/latent_space.py:105-207)
+    over train 50 000 / valid 10 000 / two OoD sets of 10 000 x 512 entropies.  The loop does not shard (every fit needs the
+    whole training split): N > 1 runs N independent replicas ("replicas only")."""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_workloads as bw
+
+    log = (lambda m: print(m, file=sys.stderr, flush=True)) if rank == 0 else None
+    rec = bw.run_larex_eval(device, cpu_legs=(rank == 0 and not args.no_cpu_baseline), log=log)
+    if dist is not None:
+        t = torch.tensor([rec["seconds_device_resident"]], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rec["seconds_device_resident"] = float(t.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    sec = rec["seconds_device_resident"]
+    out = {"metric": "OOD scores/sec through the evaluation harness loop (log_evaluate_larex: PCA sweep x 5 latent-space postprocessors x 2 OoD sets)",
+           "value": round(world * rec["rows_scored"] / sec, 1), "unit": "rows scored/s", "n_gpus": world, "steps": 1, "warmup": 1,
+           "ms_per_step": round(1e3 * sec, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f64 (KDE, MD) / f32 (cMD, KNN, GMM), as the reference's postprocessors return", "data": "synthetic",
+           "config": {"workload": "log_evaluate_larex on cfg2-synth entropies (CIFAR10 ResNet-18 LaREx sizes): " + rec["shape"],
+                      "multi_gpu": "replicas only (the loop's fits need the whole training split)"},
+           "roofline": None, "larex_eval": rec}
+    if "cpu_baseline" in rec:
+        out["cpu_baseline"] = {"value": None, "unit": "s (bounded subset, see sample)", "cores": rec["cpu_baseline"]["cores"], "kind": "port",
+                               "sample": rec["cpu_baseline"]["sample"], "seconds": rec["cpu_baseline"]["seconds"],
+                               "device_seconds_same_subset": rec["cpu_baseline"]["device_seconds_same_subset"]}
+    sys.stdout.flush()
+    os.dup2(saved_stdout, 1)
+    print(json.dumps(out), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-pool-child":
         return cpu_pool_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), int(sys.argv[6]))
@@ -308,6 +348,8 @@ def main():
     _hip.require_gpu()
     if args.workload == "cfg3":
         return main_cfg3(args, device, rank, world, dist if use_dist else None, saved_stdout)
+    if args.workload == "larex_eval":
+        return main_larex(args, device, rank, world, dist if use_dist else None, saved_stdout)
 
     # ---------------- setup (untimed): fit PCA-256 + LaREM on in-distribution entropies ----------
     probe = LaREMPipeline(None, None, N_MC, DROP_PROB, BLOCK)
@@ -778,8 +820,10 @@ def main():
             del sets, x, rand
             torch.cuda.empty_cache()
             t_s = time.perf_counter()
-            c3 = bw.run_cfg3(device, 0, 1, None, args.rows, args.fit_rows or 8192, 2, 1, cpu_legs=not args.no_cpu_baseline)
+            cpu = not args.no_cpu_baseline
+            c3 = bw.run_cfg3(device, 0, 1, None, args.rows, args.fit_rows or 8192, 2, 1, cpu_legs=cpu, f4=True)
             stages = dict(c3["stages"])
+            stages["f4"] = c3.get("f4")
             stages["cfg3_step"] = {"rows": c3["rows_total"], "ms": round(c3["ms_per_step"], 3), "rows_per_s": round(c3["value"], 1),
                                    "note": "Mahalanobis + Energy(C=1000) + Energy(C=10) + kNN(k=50) over the same 1M rows = "
                                            "`python bench.py --workload cfg3`, 2 timed steps",
@@ -790,6 +834,14 @@ def main():
             stages["cfg4_lared"] = bw.run_cfg4_lared(device)
             torch.cuda.empty_cache()
             stages["cfg4_from_feature_maps"] = bw.run_cfg4_from_maps(device)
+            torch.cuda.empty_cache()
+            # f-rows: fits, metrics, joint entropy, and the harness loop they exist for
+            stages["fits"] = bw.run_fit_legs(device, bw.class_centres(device), cpu)
+            torch.cuda.empty_cache()
+            stages["metrics"] = bw.run_metrics_leg(device, cpu_legs=cpu)
+            stages["entropy_joint"] = bw.run_entropy_joint_leg(device, cpu_legs=cpu)
+            torch.cuda.empty_cache()
+            stages["larex_eval"] = bw.run_larex_eval(device, cpu_legs=cpu)
             stages["seconds"] = round(time.perf_counter() - t_s, 1)
             out["stages"] = stages
         except Exception as e:  # a reported extra; its failure must not lose the headline measurement

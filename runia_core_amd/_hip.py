@@ -1093,12 +1093,12 @@ def ood_clf_curve(ind_scores: torch.Tensor, ood_scores: torch.Tensor):
 
 
 @_device_guard()
-def eigh(a: torch.Tensor, max_sweeps: int = 30, blocked: bool = True):
+def eigh(a: torch.Tensor, max_sweeps: int = 30, blocked: bool = True, info: Optional[dict] = None):
     """Symmetric eigen-decomposition on the device: a [n, n] f64 -> (eigenvalues [n] ascending, eigenvectors [n, n] as
     columns), like ``numpy.linalg.eigh``.  Cyclic Jacobi sweeps until one applies no rotation; ``blocked`` (default):
     ``runia_eigh_block_sweep_f64`` - 64 x 64 sub-problems in LDS + matrix-core updates, (n/32 - 1) x 2 launches per sweep;
     ``blocked=False``: the scalar-rotation form ``runia_eigh_sweep_f64`` (2 (n - 1) launches per sweep).
-    Setup-time: reads one counter back per sweep."""
+    Setup-time: reads one counter back per sweep.  ``info`` (optional dict) receives ``sweeps`` and ``rotations``."""
     lib = load_library()
     require_gpu()
     assert a.is_cuda and a.dtype == torch.float64 and a.dim() == 2 and a.shape[0] == a.shape[1]
@@ -1120,7 +1120,7 @@ def eigh(a: torch.Tensor, max_sweeps: int = 30, blocked: bool = True):
     off = (-ws.data_ptr()) % 16
     _check(init(work.data_ptr(), v.data_ptr(), size, ws.data_ptr() + off, ws_bytes, _stream()), "runia_eigh_init")
     done = 0
-    for _ in range(max_sweeps):
+    for sweep_no in range(1, max_sweeps + 1):
         _check(sweep(work.data_ptr(), v.data_ptr(), size, ws.data_ptr() + off, ws_bytes, count.data_ptr(), _stream()),
                "runia_eigh_sweep")
         total = int(count.item())
@@ -1129,6 +1129,10 @@ def eigh(a: torch.Tensor, max_sweeps: int = 30, blocked: bool = True):
         done = total
     else:
         raise RuniaHipError(f"the Jacobi sweeps did not converge in {max_sweeps} sweeps (n = {n})")
+    if info is not None:
+        info["sweeps"] = info.get("sweeps", 0) + sweep_no
+        info["rotations"] = info.get("rotations", 0) + done
+        info["calls"] = info.get("calls", 0) + 1
     w = torch.diagonal(work)[:n].clone()
     # ascending order: n scalars, ranked on the host (the convergence loop has synchronised already; no device sort)
     order = torch.from_numpy(np.argsort(w.cpu().numpy(), kind="stable")).to(a.device)
