@@ -82,6 +82,13 @@ int runia_kl_entropy_per_dim_f32(const float* z, double* h, int64_t N, int n_mc,
                                  double min_dist, runia_stream_t stream);
 int runia_kl_entropy_joint_f32(const float* z, double* h_mvn, int64_t N, int n_mc, int64_t D, int k,
                                double min_dist, runia_stream_t stream);
+/* Both outputs of one get_dl_h_z call (evaluation/entropy.py:67-84: the joint entropy AND the per-dimension entropies of every
+ * image) from ONE pass over z: h_mvn [N] f64 and h [N, D] f64 carry the bits of the two entry points above.  The single-read
+ * kernel covers 5 <= n_mc <= 32 with k = 5 (n_mc <= 8 also k = 4) on rows of whole 16-byte (n_mc <= 16) / 8-byte vectors;
+ * runia_kl_entropy_both_fused tells (1 / 0); other shapes run the two kernels one after the other inside the same call. */
+int runia_kl_entropy_both_fused(int n_mc, int64_t D, int k);
+int runia_kl_entropy_both_f32(const float* z, double* h_mvn, double* h, int64_t N, int n_mc, int64_t D, int k,
+                              double min_dist, runia_stream_t stream);
 
 /* ---- dense f64 weights, packed once at setup ------------------------------ *
  * The f64 contractions (PCA projection, quadratic forms) read their constant

@@ -15,8 +15,8 @@ vectors, then one PCA refit + transform per entry of ``n_pca_components``) and `
 * cMD: class means and the pooled float32 centred rows as upstream (:299-316), precision rounded to float32 (:314), the
   quadratic forms of the float32 differences accumulated in float64 and rounded to float32 once (upstream accumulates in
   float32 row by row: its result is this one up to its own ~1e-6 rounding);
-* KNN: ``normalizer`` + k-th smallest squared distance against the normalised bank, distances in float64 by the expansion
-  (the float32 direct differences of ``oracle.knn_kth_score`` - faiss' single-query form - agree to ~1e-7), float32 result;
+* KNN: ``normalizer`` + k-th smallest squared distance against the normalised bank in faiss' single-query float32 arithmetic
+  (``oracle.knn_kth_score``'s), the bank rows to measure picked by float64 BLAS distances first;
 * GMM: ``gmm_fit`` restated in upstream's form (inference/funcs.py:285-344: per-class mean, ``x^T x / (max(n, 2) - 1)``, the
   jitter ladder through exceptions) + ``oracle.gmm_energy``.
 """
@@ -48,17 +48,27 @@ def kde_score_blas(train: np.ndarray, x: np.ndarray, bandwidth: float = 1.0, chu
     return out
 
 
-def knn_kth_blas(bank_normed: np.ndarray, queries: np.ndarray, k: int, chunk: int = 2048) -> np.ndarray:
-    bank = np.asarray(bank_normed, np.float32)
-    if k > bank.shape[0]:
+def knn_kth_blas(bank_normed: np.ndarray, queries: np.ndarray, k: int, chunk: int = 1024) -> np.ndarray:
+    """-(k-th smallest squared L2) per query in faiss' single-query arithmetic (float32 ``sum((q - b)^2)``, what
+    ``oracle.knn_kth_score`` computes for every bank row) at BLAS cost: the bank rows are ranked by float64 distances from the
+    norm expansion, the 2k + 8 nearest are re-measured exactly in float32, the k-th smallest of those is the score (a bank row
+    beyond the 2k + 8 nearest would have to move k + 8 ranks through ~1e-7 of rounding to matter)."""
+    bank = np.ascontiguousarray(bank_normed, dtype=np.float32)
+    m = bank.shape[0]
+    if k > m:
         return np.full(queries.shape[0], -np.float32(H.FLT_MAX), dtype=np.float32)
     b64 = bank.astype(np.float64)
     bn = np.einsum("ij,ij->i", b64, b64)
+    keep = min(m, 2 * k + 8)
     out = np.empty(queries.shape[0], dtype=np.float32)
     for s in range(0, queries.shape[0], chunk):
-        q = np.asarray(H.normalizer(queries[s: s + chunk])).astype(np.float32).astype(np.float64)
-        d2 = np.maximum(np.einsum("ij,ij->i", q, q)[:, None] + bn[None, :] - 2.0 * (q @ b64.T), 0.0)
-        out[s: s + chunk] = -np.partition(d2, k - 1, axis=1)[:, k - 1].astype(np.float32)
+        q32 = np.ascontiguousarray(np.asarray(H.normalizer(queries[s: s + chunk])).astype(np.float32))
+        q = q32.astype(np.float64)
+        d2 = np.einsum("ij,ij->i", q, q)[:, None] + bn[None, :] - 2.0 * (q @ b64.T)
+        cand = np.argpartition(d2, keep - 1, axis=1)[:, :keep]
+        diff = q32[:, None, :] - bank[cand]                                   # (chunk, keep, D) float32
+        exact = (diff * diff).sum(axis=2, dtype=np.float32)
+        out[s: s + chunk] = -np.partition(exact, k - 1, axis=1)[:, k - 1]
     return out
 
 

@@ -36,6 +36,8 @@ _SIGNATURES = {
     "runia_map_reduce_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int, c_int, c_void_p]),
     "runia_kl_entropy_per_dim_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_double, c_void_p]),
     "runia_kl_entropy_joint_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_double, c_void_p]),
+    "runia_kl_entropy_both_fused": (c_int, [c_int, c_int64, c_int]),
+    "runia_kl_entropy_both_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_int, c_double, c_void_p]),
     "runia_packed_weights_bytes": (c_size_t, [c_int64, c_int64]),
     "runia_pack_weights_f64": (c_int, [c_void_p, c_int64, c_int64, c_int64, c_void_p, c_void_p]),
     "runia_pca_transform_f64": (
@@ -505,6 +507,23 @@ def kl_entropy_joint(z: torch.Tensor, n_mc: int, k: int, min_dist: float = 1e-5)
         "runia_kl_entropy_joint_f32",
     )
     return h
+
+
+@_device_guard()
+def kl_entropy_both(z: torch.Tensor, n_mc: int, k: int, min_dist: float = 1e-5):
+    """z [N*n_mc, D] f32 -> (h_mvn [N] f64, h [N, D] f64): both outputs of ``get_dl_h_z`` from one read of the samples
+    (``runia_kl_entropy_both_f32``; same bits as :func:`kl_entropy_joint` and :func:`kl_entropy_per_dim`)."""
+    lib = load_library()
+    require_gpu()
+    assert z.is_cuda and z.dtype == torch.float32 and z.dim() == 2
+    z = z.contiguous()
+    n = z.shape[0] // n_mc
+    d = z.shape[1]
+    h_mvn = torch.empty((n,), dtype=torch.float64, device=z.device)
+    h = torch.empty((n, d), dtype=torch.float64, device=z.device)
+    _check(lib.runia_kl_entropy_both_f32(z.data_ptr(), h_mvn.data_ptr(), h.data_ptr(), n, n_mc, d, k, min_dist, _stream()),
+           "runia_kl_entropy_both_f32")
+    return h_mvn, h
 
 
 @_device_guard()

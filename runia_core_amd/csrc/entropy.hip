@@ -322,11 +322,15 @@ __device__ __forceinline__ double wave_max16(double (&v)[16], int lane) {
   return r;
 }
 
-template <int NP>
+// K1D > 0: the same pass also emits the per-dimension entropies h [N, D] of get_dl_h_z (evaluation/entropy.py:77-82): the thread
+// holds every sample of its VEC dims anyway - one register sort + window scan per dim with entropy_per_dim_kernel's own
+// column code (same bits), so the (N * n_mc, D) samples are read ONCE for both outputs of the call.
+template <int NP, int K1D = 0>
 __global__ __launch_bounds__(256) void entropy_joint_reg_kernel(const float* __restrict__ z,
                                                                  double* __restrict__ h_mvn, int64_t N, int n,
                                                                  int64_t D, int k, double min_dist,
-                                                                 double const_term, double d_over_n) {
+                                                                 double const_term, double d_over_n,
+                                                                 double* __restrict__ h_dim = nullptr, double inv_n = 0.0) {
   constexpr int VEC = joint_vec<NP>();
   constexpr int NPAIRS = NP * (NP - 1) / 2, NGROUPS = (NPAIRS + 15) / 16;
   constexpr int DP = NP + 1;
@@ -349,14 +353,48 @@ __global__ __launch_bounds__(256) void entropy_joint_reg_kernel(const float* __r
       const int64_t dd = d0 + (int64_t)tid * VEC;
       const int64_t d = (dd < D) ? dd : 0;  // D % VEC == 0
       double x[NP][VEC];
+      if constexpr (K1D > 0) {
+        fvec raw[NP];
 #pragma unroll
-      for (int s = 0; s < NP; ++s) {
-        const int sc = (s < n) ? s : n - 1;  // wave-uniform
-        const fvec t = *reinterpret_cast<const fvec*>(base + (int64_t)sc * D + d);
+        for (int s = 0; s < NP; ++s) {
+          const int sc = (s < n) ? s : n - 1;  // wave-uniform
+          raw[s] = *reinterpret_cast<const fvec*>(base + (int64_t)sc * D + d);
+        }
+        if (dd < D) {  // (a lane past the end of the row re-read dims 0..: it has nothing to write)
+          double out[VEC];
 #pragma unroll
-        for (int q = 0; q < VEC; ++q) {
-          my_nan = my_nan || (t[q] != t[q]);
-          x[s][q] = (double)t[q];
+          for (int q = 0; q < VEC; ++q) {
+            float col[NP];
+#pragma unroll
+            for (int s = 0; s < NP; ++s) col[s] = (s < n) ? raw[s][q] : INFINITY;
+            float probe = col[0];  // NaN sample -> NaN entropy, as entropy_per_dim_kernel
+#pragma unroll
+            for (int t = 1; t < NP; ++t) probe += col[t];
+            sort_asc<NP>(col);
+            out[q] = const_term + inv_n * column_log_sum<NP, K1D>(col, n, min_dist);
+            if (probe != probe) out[q] = NAN;
+          }
+          double* dst = h_dim + img * D + dd;
+#pragma unroll
+          for (int q = 0; q < VEC; q += 2) *reinterpret_cast<double2*>(dst + q) = make_double2(out[q], out[q + 1]);
+        }
+#pragma unroll
+        for (int s = 0; s < NP; ++s)
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) {
+            my_nan = my_nan || (raw[s][q] != raw[s][q]);
+            x[s][q] = (double)raw[s][q];
+          }
+      } else {
+#pragma unroll
+        for (int s = 0; s < NP; ++s) {
+          const int sc = (s < n) ? s : n - 1;  // wave-uniform
+          const fvec t = *reinterpret_cast<const fvec*>(base + (int64_t)sc * D + d);
+#pragma unroll
+          for (int q = 0; q < VEC; ++q) {
+            my_nan = my_nan || (t[q] != t[q]);
+            x[s][q] = (double)t[q];
+          }
         }
       }
       {
@@ -501,5 +539,40 @@ extern "C" int runia_kl_entropy_joint_f32(const float* z, double* h_mvn, int64_t
     return RUNIA_E_LAUNCH;
   const unsigned grid = (unsigned)(N < 65535 ? N : 65535);
   entropy_joint_kernel<<<grid, 256, lds, s>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n);
+  return runia_check_launch();
+}
+
+// get_dl_h_z's two outputs from ONE pass over the samples (reference evaluation/entropy.py:67-84 computes both per image):
+// h_mvn [N] = runia_kl_entropy_joint_f32's bits, h [N, D] = runia_kl_entropy_per_dim_f32's bits.  The single-read kernel exists
+// for 5 <= n_mc <= 32 with k = 5 (and n_mc = 5 ... 8 with k = 4), rows of whole aligned vectors; `runia_kl_entropy_both_fused`
+// says whether a shape takes it - every other shape runs the two kernels one after the other (same results, two reads).
+extern "C" int runia_kl_entropy_both_fused(int n_mc, int64_t D, int k) {
+  if (n_mc < 5 || n_mc > 32) return 0;
+  const int vec = n_mc <= 8 ? 4 : (n_mc <= 16 ? JOINT_VEC16 : 2);
+  if (D <= 0 || D % vec != 0) return 0;
+  if (n_mc <= 8) return k == 4 || k == 5;
+  return k == 5;
+}
+
+extern "C" int runia_kl_entropy_both_f32(const float* z, double* h_mvn, double* h, int64_t N, int n_mc, int64_t D, int k,
+                                         double min_dist, runia_stream_t stream) {
+  if (N < 0 || D <= 0 || n_mc < 2 || n_mc > 64 || k < 1 || k >= n_mc || (N > 0 && (!z || !h_mvn || !h)))
+    return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  const int vec = n_mc <= 8 ? 4 : (n_mc <= 16 ? JOINT_VEC16 : 2);
+  if (!runia_kl_entropy_both_fused(n_mc, D, k) || ((uintptr_t)z) % (4 * vec) != 0 || ((uintptr_t)h) % 16 != 0) {
+    if (int rc = runia_kl_entropy_joint_f32(z, h_mvn, N, n_mc, D, k, min_dist, stream)) return rc;
+    return runia_kl_entropy_per_dim_f32(z, h, N, n_mc, D, k, min_dist, stream);
+  }
+  const double ct = digamma_diff(n_mc, k);
+  const double d_over_n = (double)D / (double)n_mc, inv_n = 1.0 / (double)n_mc;
+  hipStream_t s = as_stream(stream);
+  const int64_t lanes = (D / vec + 63) / 64 * 64;
+  const unsigned threads = (unsigned)(lanes < 256 ? lanes : 256);
+  const unsigned grid = (unsigned)(N < 0x7fffffffll ? N : 0x7fffffffll);
+  if (n_mc <= 8 && k == 4) entropy_joint_reg_kernel<8, 4><<<grid, threads, 0, s>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n, h, inv_n);
+  else if (n_mc <= 8) entropy_joint_reg_kernel<8, 5><<<grid, threads, 0, s>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n, h, inv_n);
+  else if (n_mc <= 16) entropy_joint_reg_kernel<16, 5><<<grid, threads, 0, s>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n, h, inv_n);
+  else entropy_joint_reg_kernel<32, 5><<<grid, threads, 0, s>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n, h, inv_n);
   return runia_check_launch();
 }

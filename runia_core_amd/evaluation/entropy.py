@@ -4,6 +4,7 @@ Same signatures and return shapes as the reference's
 ``runia_core/evaluation/entropy.py`` (``get_dl_h_z`` :41-93,
 ``single_image_entropy_calculation`` :20-38); the k-d-tree loops over
 ``entropy_estimators.continuous.get_h`` are replaced by
+``runia_kl_entropy_both_f32`` (one read of the samples for both outputs of ``get_dl_h_z``) and
 ``runia_kl_entropy_per_dim_f32`` / ``runia_kl_entropy_joint_f32``.
 """
 from __future__ import annotations
@@ -36,9 +37,9 @@ def single_image_entropy_calculation(sample: np.ndarray, neighbors: int) -> np.n
 def get_dl_h_z_device(z: Tensor, mcd_samples_nro: int, joint: bool = True):
     """Device-resident form: ``z (N*n_mc, D)`` f32 cuda -> (h_mvn (N,) f64 | None, h_z (N, D) f64)."""
     k = neighbors_for(mcd_samples_nro)
-    h_z = _hip.kl_entropy_per_dim(z, mcd_samples_nro, k, MIN_DIST)
-    h_mvn = _hip.kl_entropy_joint(z, mcd_samples_nro, k, MIN_DIST) if joint else None
-    return h_mvn, h_z
+    if joint:  # both outputs from one read of the samples (runia_kl_entropy_both_f32; same bits as the two kernels)
+        return _hip.kl_entropy_both(z, mcd_samples_nro, k, MIN_DIST)
+    return None, _hip.kl_entropy_per_dim(z, mcd_samples_nro, k, MIN_DIST)
 
 
 def get_dl_h_z(

@@ -270,7 +270,10 @@ class KNNLatentSpace(Postprocessor):
     def setup(self, ind_train_data: np.ndarray, **kwargs) -> None:
         assert ind_train_data.ndim == 2, "ind_train_feats must be 2 dimensional"
         if not self._setup_flag:
-            self.activation_log = np.array([_normalize_host(feat) for feat in ind_train_data])
+            # np.array([normalizer(feat) for feat in ind_train_data]) upstream (:395): one call on the C-contiguous matrix gives
+            # the same bits row for row (np.linalg.norm reduces the contiguous last axis with the same pairwise sum either
+            # way; checked in tests/test_abi_and_host.py) without 50 000 trips through the interpreter (0.2 s per setup)
+            self.activation_log = _normalize_host(np.ascontiguousarray(ind_train_data))
             self.index = FlatL2Bank(ind_train_data.shape[1])
             self.index.add(self.activation_log)
             self._setup_flag = True

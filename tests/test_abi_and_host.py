@@ -461,9 +461,10 @@ def test_every_in_scope_name_of_the_reference_is_exported():
     out_of_scope = {
         "dimensionality_reduction.py": {n: "PaCMAP plotting / embedding (pacmap is not on the scoring path)" for n in
                                         ("plot_samples_pacmap", "fit_pacmap", "apply_pacmap_transform")},
-        "evaluation/metrics.py": {n: "plotting / mlflow / pandas harness around get_auroc_results" for n in
+        "evaluation/metrics.py": {n: "plotting / mlflow / pandas wrangling around get_auroc_results" for n in
                                   ("plot_roc_ood_detector", "save_roc_ood_detector", "save_scores_plots", "get_pred_scores_plots",
-                                   "log_evaluate_postprocessors", "select_and_log_best_larex", "subset_boxes")},
+                                   "subset_boxes")},
+        "evaluation/latent_space.py": {"plot_roc_curves": "matplotlib figure of the results table"},
         "feature_extraction/abstract_classes.py": {n: "detector / model-zoo glue" for n in
                                                    ("Extractor", "ObjectDetectionExtractor", "SUPPORTED_OBJECT_DETECTION_ARCHITECTURES")},
         "feature_extraction/image_level.py": {n: "model-specific extraction loops (the batched FastMCDSamplesExtractor is mirrored)" for n in
@@ -582,3 +583,18 @@ def test_device_guard_refuses_operands_on_two_gpus():
     # a mismatch is refused before anything touches the library or a GPU
     with pytest.raises(_hip.RuniaHipError, match="different devices"):
         _hip.md_score(a0, c1, b0)
+
+
+def test_bank_normalisation_in_one_call_keeps_the_per_row_bits():
+    """KNNLatentSpace.setup normalises the bank with ONE NumPy call on the C-contiguous matrix instead of upstream's
+    per-row list comprehension (inference/postprocessors.py:395): same bits for every row, f32 and f64, odd and even widths,
+    Fortran-ordered input included (made contiguous first)."""
+    from runia_core_amd.inference.postprocessors import _normalize_host
+
+    rng = np.random.default_rng(0)
+    for dt in (np.float32, np.float64):
+        for d in (1, 3, 8, 20, 129, 512, 2048):
+            x = (rng.standard_normal((200, d)) * rng.uniform(0.1, 100)).astype(dt)
+            per_row = np.array([_normalize_host(r) for r in x])
+            assert np.array_equal(_normalize_host(np.ascontiguousarray(x)), per_row)
+            assert np.array_equal(_normalize_host(np.ascontiguousarray(np.asfortranarray(x))), per_row)

@@ -536,6 +536,49 @@ def test_latent_methods_harness_goldens(fit_on, ref_vectors=None):
     assert abs(best["GMM"] - 0.801800012588501) < 1e-6
 
 
+@pytest.mark.parametrize("device_resident", [False, True])
+def test_log_evaluate_larex_reference_goldens(device_resident):
+    """runia_core_amd.evaluation.log_evaluate_larex (round 5: the reference's harness loop, evaluation/latent_space.py:30-221, with
+    its signature) on the inputs of the reference's own test (tests/unit_test_latent_methods.py:36-115): the best-AUROC goldens of
+    KNN / MD / GMM, the row names of the results table, the best-configuration names and the thresholds dict - in the host-array
+    form and in the additive device-resident form (same table values)."""
+    from runia_core_amd.evaluation import log_evaluate_larex
+
+    torch.manual_seed(1)
+    np.random.seed(1)
+    np.random.rand(20, 20)
+    np.random.rand(20)
+    r = lambda m: np.float32(m + np.random.randn(200, 20))  # noqa: E731
+    tr_f, tr_l, tr_z, va_f, va_l, va_z = r(0.5), r(0.5), r(0.4), r(0.5), r(0.5), r(0.4)
+    ood_f, ood_l, ood_z = r(-0.5), r(-0.5), r(-0.4)
+    ind = {"train latent_space_means": tr_z, "valid latent_space_means": va_z, "train labels": np.argmax(tr_l, axis=-1),
+           "valid labels": np.argmax(va_l, axis=-1), "msp": np.max(va_l, axis=1)}
+    ood = {"test_ood latent_space_means": ood_z, "test_ood labels": np.argmax(ood_l, axis=-1)}
+    cfg = {"ood_datasets": ["test_ood"], "n_pca_components": [1, 2, 4], "k_neighbors": 10, "ind_dataset": "test_id"}
+
+    class Cfg:
+        pass
+
+    c = Cfg()
+    for k, v in cfg.items():
+        setattr(c, k, v)
+    df, best, thresholds, ood_out = log_evaluate_larex(c, ["msp"], {"test_ood msp": np.max(ood_l, axis=1)}, ind, ood, "my_run", False,
+                                                       postprocessors=["KNN", "MD", "GMM"], device_resident=device_resident)
+    assert abs(best["KNN"]["auroc"] - 0.9881750345230103) < 1e-6
+    assert abs(best["MD"]["auroc"] - 0.837399959564209) < 1e-6
+    assert abs(best["GMM"]["auroc"] - 0.801800012588501) < 1e-6
+    want_rows = ["test_ood msp"] + [f"test_ood {p}{ext}" for ext in ("", " PCA 1", " PCA 2", " PCA 4") for p in ("KNN", "MD", "GMM")]
+    assert list(df.index) == want_rows and list(df.columns) == ["auroc", "fpr@95", "aupr", "fpr", "tpr"]
+    assert set(best) == {"best", "KNN", "MD", "GMM"} and len(best["best"]) == 3
+    assert set(thresholds) == {best[p]["best_comp"] for p in ("KNN", "MD", "GMM")}
+    for p in ("KNN", "MD", "GMM"):
+        assert f"test_ood {best[p]['best_comp']}" in ood_out and ood_out[f"test_ood {best[p]['best_comp']}"].shape == (200,)
+    if not device_resident:
+        assert isinstance(df.loc["test_ood MD", "fpr"], list) and df.loc["test_ood MD", "tpr"][-1] == 1.0
+    with pytest.raises(NotImplementedError, match="mlflow"):
+        log_evaluate_larex(c, [], {}, ind, ood, "run", True)
+
+
 def test_folded_single_contraction_equals_two_stage():
     """LaREMPipeline's folded weights (score = -||M h + c||^2) against the two-stage kernel and the oracle,
     incl. a rank-deficient precision matrix (pinvh dropped directions) and the no-PCA case."""

@@ -1013,6 +1013,37 @@ def test_linear_few_rows_score_the_bits_of_a_batch(hip, d, c, clip):
             assert bool(same.all()), (a0, b0, bias is None)
 
 
+@pytest.mark.parametrize("n_mc,d,n_img", [(16, 512, 300), (16, 20, 40), (5, 64, 33), (8, 128, 20), (6, 8, 9), (12, 1024, 17), (17, 64, 11),
+                                        (32, 100, 9), (32, 2050, 5), (16, 37, 12), (4, 16, 7), (33, 12, 4), (16, 1028, 3)])
+def test_get_dl_h_z_single_read_equals_the_two_kernels(hip, n_mc, d, n_img):
+    """runia_kl_entropy_both_f32 (round 5): the joint AND the per-dimension entropies of get_dl_h_z (reference
+    evaluation/entropy.py:67-84 returns both from one call) from ONE pass over the samples - the joint kernel's threads hold
+    every sample of their dims in registers and emit the per-dimension columns from there.  Same bits as the two kernels: fused
+    shapes (5 <= n_mc <= 32, whole vectors per row), the fallback shapes (odd D, n_mc = 4 / 33), constant columns (min_dist
+    clip), a NaN sample, lanes past the end of the last chunk (D = 1028: 257 float4 lanes), and the oracle on top."""
+    rng = np.random.default_rng(n_mc * 1000 + d)
+    z = (rng.standard_normal((n_img, 1, d)) + 0.2 * rng.standard_normal((n_img, n_mc, d))).astype(np.float32)
+    z[1, :, :: 7] = z[1, :1, :: 7]        # columns constant over the samples
+    if n_img > 2:
+        z[2, n_mc // 2, d // 3] = np.nan
+    zt = dev(z.reshape(n_img * n_mc, d), torch.float32)
+    k = 5 if n_mc > 5 else n_mc - 1
+    hj, hd = hip.kl_entropy_both(zt, n_mc, k)
+    ej, ed = hip.kl_entropy_joint(zt, n_mc, k), hip.kl_entropy_per_dim(zt, n_mc, k)
+    assert torch.equal(torch.nan_to_num(hj, nan=-7.0), torch.nan_to_num(ej, nan=-7.0))
+    assert torch.equal(torch.nan_to_num(hd, nan=-7.0), torch.nan_to_num(ed, nan=-7.0))
+    fused = bool(hip.load_library().runia_kl_entropy_both_fused(n_mc, d, k))
+    assert fused == (5 <= n_mc <= 32 and d % (4 if n_mc <= 16 else 2) == 0)
+    m = min(n_img, 4)
+    oj, od = oracle.get_dl_h_z(z[:m].reshape(m * n_mc, d), n_mc)
+    ok = np.isfinite(od).all(axis=1)
+    assert rel_err(hd[:m].cpu().numpy()[ok], od[ok]) < 1e-11 and rel_err(hj[:m].cpu().numpy()[ok], np.ravel(oj)[ok]) < 1e-11
+    if n_mc == 8:  # k = 4 has its own instantiation
+        a, b = hip.kl_entropy_both(zt, n_mc, 4)
+        assert torch.equal(torch.nan_to_num(b, nan=-7.0), torch.nan_to_num(hip.kl_entropy_per_dim(zt, n_mc, 4), nan=-7.0))
+        assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(hip.kl_entropy_joint(zt, n_mc, 4), nan=-7.0))
+
+
 @pytest.mark.parametrize("c", [4097, 5000, 21841, 128256])
 def test_gen_and_mcd_uncertainty_on_heads_wider_than_4096(hip, c):
     """runia_gen_score_f32 / runia_gen_entropy_f32 / runia_mcd_uncertainty_f32 refused C > 4 096 (ImageNet-21k,

@@ -493,3 +493,49 @@ def test_round4_restatements_against_the_reference_run_fixture():
         got = oracle.kde_score_kernel(train, x, 0.9, kernel)
         ok = np.isfinite(got) & (ref > -30)
         assert ok.sum() > 40 and rel_err(got[ok], ref[ok]) < 1e-9, kernel
+
+
+# ---------------- harness loop (oracle/harness.py) -------------------------------
+def test_harness_restatements_against_hotpath_and_reference_goldens(ref_vectors):
+    """oracle/harness.py (round 5: the CPU form of log_evaluate_larex's loop): its BLAS-cost forms equal the direct forms of
+    oracle/hotpath.py that the reference's goldens pin - KDE to 1e-12, kNN BIT for bit (candidates by float64 distances, exact
+    float32 re-measurement) -, its cMD reproduces the reference's golden (tests/unit_test_postprocessors.py:291-302), its
+    gmm_fit is the fit the product's gmm_fit returns, and the sweep's best-AUROC values are the reference's harness goldens
+    (tests/unit_test_latent_methods.py:104-115)."""
+    from oracle import harness
+
+    rng = np.random.default_rng(3)
+    tr, x = rng.standard_normal((700, 24)) + 1.0, rng.standard_normal((90, 24)) * 1.3
+    assert rel_err(harness.kde_score_blas(tr, x), oracle.kde_score(tr, x)) < 1e-12
+    bank = oracle.normalizer(tr).astype(np.float32)
+    for k in (1, 7, 50, 700, 701):
+        assert np.array_equal(harness.knn_kth_blas(bank, x, k), oracle.knn_kth_score(bank, x, k)), k
+    # cMD golden
+    f_tr, lab, _ = generate_test_data(seed=42)
+    f_te, _, _ = generate_test_data(seed=43)
+    cm, p32 = harness.cmd_setup(f_tr, lab, 10)
+    got = harness.cmd_score(f_te, cm, p32)
+    exp = _lists(ref_vectors, "cmd_unit")[0]
+    assert got.dtype == np.float32 and rel_err(got, exp) < 1e-5
+    # gmm_fit: upstream's form against the product's restructured fit (same means, same factor, same jitter)
+    from runia_core_amd.inference import gmm_fit
+
+    emb = (rng.standard_normal((400, 12)) + np.arange(4).repeat(100)[:, None]).astype(np.float32)
+    labels = np.arange(4).repeat(100)
+    g_o, j_o = harness.gmm_fit(emb, labels, 5)  # class 4 has no rows
+    g_p, j_p = gmm_fit(torch.Tensor(emb), torch.Tensor(labels), 5)
+    assert j_o == j_p and torch.allclose(g_o.loc, g_p.loc, atol=1e-6) and torch.allclose(g_o.scale_tril, g_p.scale_tril, atol=1e-5)
+    # the harness goldens (KNN / MD / GMM over PCA [1, 2, 4])
+    torch.manual_seed(1)
+    np.random.seed(1)
+    np.random.rand(20, 20)
+    np.random.rand(20)
+    r = lambda m: np.float32(m + np.random.randn(200, 20))  # noqa: E731
+    tr_f, tr_l, tr_z, va_f, va_l, va_z = r(0.5), r(0.5), r(0.4), r(0.5), r(0.5), r(0.4)
+    ood_f, ood_l, ood_z = r(-0.5), r(-0.5), r(-0.4)
+    ind = {"train latent_space_means": tr_z, "valid latent_space_means": va_z, "train labels": np.argmax(tr_l, axis=-1)}
+    table, _ = harness.larex_eval_sweep(ind, {"o latent_space_means": ood_z}, ["o"], [1, 2, 4], ("KNN", "MD", "GMM"), 10, 10)
+    best = {p: max(v[0] for name, v in table.items() if name.split()[1] == p) for p in ("KNN", "MD", "GMM")}
+    assert abs(best["KNN"] - 0.9881750345230103) < 1e-6
+    assert abs(best["MD"] - 0.837399959564209) < 1e-6
+    assert abs(best["GMM"] - 0.801800012588501) < 1e-6
