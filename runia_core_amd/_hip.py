@@ -587,9 +587,11 @@ def md_score(x: torch.Tensor, mean: torch.Tensor, packed_p: torch.Tensor) -> tor
 
 @_device_guard()
 def mahalanobis_score(x: torch.Tensor, class_mean: torch.Tensor, packed_p: torch.Tensor, mu_p: torch.Tensor,
-                      class_loop: bool = False) -> torch.Tensor:
+                      class_loop: bool = False, split: bool = True) -> torch.Tensor:
     """x [N, D], class_mean [C, D] (both f32 or both f64) -> score [N] f64.  ``class_loop=True`` hands over the small
-    workspace only (more than 16 classes then take the per-class loop instead of the matrix-core form; tests)."""
+    workspace only (more than 16 classes then take the per-class loop instead of the matrix-core form; tests).
+    ``split=False`` (up to 16 classes; tests and measurements) hands over NO workspace: the entry point then keeps the
+    one-launch form instead of the column-split launches - the same bits."""
     lib = load_library()
     require_gpu()
     assert x.is_cuda and x.dim() == 2 and x.dtype == class_mean.dtype
@@ -600,10 +602,11 @@ def mahalanobis_score(x: torch.Tensor, class_mean: torch.Tensor, packed_p: torch
     s = torch.empty((nrow,), dtype=torch.float64, device=x.device)
     ws_bytes = lib.runia_mahalanobis_workspace_bytes(nrow, d) if class_loop else lib.runia_mahalanobis_workspace_bytes_classes(nrow, d, c)
     ws = torch.empty((max(ws_bytes, 8) // 8,), dtype=torch.float64, device=x.device)
+    no_ws = (not split) and c <= 16
     fn = lib.runia_mahalanobis_score_f32 if x.dtype == torch.float32 else lib.runia_mahalanobis_score_f64
     _check(
         fn(x.data_ptr(), class_mean.data_ptr(), packed_p.data_ptr(), mu_p.data_ptr(), s.data_ptr(),
-           ws.data_ptr(), ws_bytes, nrow, d, c, _stream()),
+           None if no_ws else ws.data_ptr(), 0 if no_ws else ws_bytes, nrow, d, c, _stream()),
         "runia_mahalanobis_score",
     )
     return s

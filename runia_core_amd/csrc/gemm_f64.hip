@@ -208,8 +208,17 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   if constexpr (EPI == EPI_MAHA || EPI == EPI_KDE || EPI == EPI_ROWDOT) {
     if ((EPI == EPI_MAHA) ? (g.maha_part != nullptr) : (EPI == EPI_KDE) ? (g.kde_vals != nullptr) : (g.md_vals != nullptr)) {  // column-split launch (uniform)
       const int64_t nb = n_pad / BN;
-      tile_id = blockIdx.x / nb;
-      cb_begin = blockIdx.x % nb;
+      if constexpr (EPI == EPI_MAHA) {
+        // block-major: the workgroups resident at any moment (consecutive ids) are consecutive row tiles of the SAME
+        // 256-column block of P, so the block (K x 256 f64: 4 MB at K = 2048, the size of an XCD's L2) is fetched once per
+        // XCD and launch instead of once per row tile
+        const int64_t tiles = (g.N + BM - 1) / BM;
+        tile_id = blockIdx.x % tiles;
+        cb_begin = blockIdx.x / tiles;
+      } else {
+        tile_id = blockIdx.x / nb;
+        cb_begin = blockIdx.x % nb;
+      }
       cb_end = cb_begin + 1;
     }
   }
@@ -984,6 +993,12 @@ __global__ __launch_bounds__(256) void maha_split_finish_kernel(const double* __
   score[row] = best;
 }
 
+// RUNIA_MAHA_SPLIT=0 keeps large batches on the one-launch form (measurements only; same bits either way)
+static bool maha_split_enabled() {
+  static const bool on = [] { const char* e = getenv("RUNIA_MAHA_SPLIT"); return !(e && e[0] == '0'); }();
+  return on;
+}
+
 template <typename TX>
 static int maha_impl(const TX* x, const TX* class_mean, const double* packed_p, const double* mu_p,
                      double* score, void* workspace, size_t workspace_bytes, int64_t N, int64_t D, int C,
@@ -1002,14 +1017,30 @@ static int maha_impl(const TX* x, const TX* class_mean, const double* packed_p, 
     // against a 2048 x 2048 precision took 1.6 ms, 512 rows 1.4 ms.  With the caller's workspace the 256-column blocks
     // of a tile go to separate workgroups (8 x the parallelism at D = 2048) and a finishing launch adds their partial
     // sums in the unsplit kernel's order: a row scores the same bits in a batch of any size.
-    const int64_t tiles = (N + BM - 1) / BM, nb = n_padded(D) / BN;
-    const size_t part_bytes = (size_t)(nb * 4 * N * C) * sizeof(double);
-    if (tiles < runia_cu_count() && nb > 1 && workspace && (((uintptr_t)workspace) & 7) == 0 && workspace_bytes >= part_bytes &&
-        tiles * nb <= 0x7fffffff) {
-      g.maha_part = reinterpret_cast<double*>(workspace);
-      gemm_rows_kernel<TX, double, EPI_MAHA, 2, 4><<<(unsigned)(tiles * nb), 256, 0, s>>>(g);
-      maha_split_finish_kernel<<<(unsigned)((N + 255) / 256), 256, 0, s>>>(g.maha_part, score, N, C, nb);
-      return runia_check_launch();
+    //
+    // Large batches take the same split (round 5), in slices of rows whose partial sums fit the workspace: in the one-launch
+    // form every 32-row workgroup walks the whole packed P (33.5 MB at D = 2048, eight L2s' worth) at its own phase, and the
+    // workgroups sharing an L2 evict each other's blocks - 687 GB of L2 misses per 1 M rows against 8.2 GB of rows
+    // (profiles/r4_cfg3_pmc_summary.json).  Block-major order of the split launch makes the resident workgroups share ONE
+    // 4 MB block at a time; the rows are then read once per block (8 x 8.2 GB, still 10 x less than before).
+    const int64_t nb = n_padded(D) / BN;
+    const size_t per_row = (size_t)(nb * 4 * C) * sizeof(double);
+    if (nb > 1 && workspace && (((uintptr_t)workspace) & 7) == 0 && maha_split_enabled()) {
+      int64_t cap = (int64_t)(workspace_bytes / per_row);
+      if (cap > 65536) cap = 65536;
+      if (cap >= N) cap = N; else cap = cap / BM * BM;  // slices end on tile boundaries
+      const bool few = (N + BM - 1) / BM < runia_cu_count();
+      if (cap >= N || (!few && cap >= 8192)) {
+        for (int64_t r0 = 0; r0 < N; r0 += cap) {
+          GemmArgs t = gemm_rows_from<TX>(g, r0, 1);
+          if (t.N > cap) t.N = cap;
+          const int64_t tiles = (t.N + BM - 1) / BM;
+          t.maha_part = reinterpret_cast<double*>(workspace);
+          gemm_rows_kernel<TX, double, EPI_MAHA, 2, 4><<<(unsigned)(tiles * nb), 256, 0, s>>>(t);
+          maha_split_finish_kernel<<<(unsigned)((t.N + 255) / 256), 256, 0, s>>>(t.maha_part, t.out, t.N, C, nb);
+        }
+        return runia_check_launch();
+      }
     }
     return launch_gemm<TX, EPI_MAHA>(g, s);
   }

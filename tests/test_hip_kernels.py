@@ -974,10 +974,11 @@ def test_knn_handful_of_queries_scores_the_bits_of_a_batch(hip):
 def test_mahalanobis_small_batches_split_columns_and_keep_the_bits(hip, d, c):
     """Few row tiles (< one per compute unit): the 256-column blocks of a tile go to separate workgroups and a finishing
     launch adds their partial sums in the unsplit kernel's order (one row against a 2048 x 2048 precision: 1.6 -> 0.25 ms).
-    A row scores the same bits alone, in a small batch and in a batch large enough for the one-workgroup-per-tile launch;
-    the oracle's class loop on top."""
+    A row scores the same bits alone, in a small batch, in a large batch (round 5: the split launch in block-major order,
+    slices of 65 536 rows - the resident workgroups share one 4 MB block of P instead of walking all of it out of phase) and
+    in the one-workgroup-per-tile launch (``split=False``); the oracle's class loop on top."""
     torch.manual_seed(d + c)
-    n = 9000  # 282 tiles of 32 rows >= 256 compute units: unsplit
+    n = 70000  # more rows than one slice of the split launch (65 536) holds
     a = torch.randn(d, d, dtype=torch.float64)
     prec = (a @ a.T / d + torch.eye(d, dtype=torch.float64)).numpy()
     cm = torch.randn(c, d).numpy().astype(np.float32)
@@ -985,11 +986,14 @@ def test_mahalanobis_small_batches_split_columns_and_keep_the_bits(hip, d, c):
     packed = hip.pack_weights(torch.from_numpy(prec).cuda())
     mu_p = torch.from_numpy(cm.astype(np.float64) @ prec).cuda()
     cmd = torch.from_numpy(cm).cuda()
-    whole = hip.mahalanobis_score(f, cmd, packed, mu_p)
-    for a0, b0 in ((0, 1), (5, 12), (100, 133), (1000, 1512), (2000, 7000)):
+    whole = hip.mahalanobis_score(f, cmd, packed, mu_p)                       # round 5: two slices of block-major split launches
+    one_launch = hip.mahalanobis_score(f, cmd, packed, mu_p, split=False)     # the one-workgroup-per-tile form
+    assert torch.equal(whole, one_launch)
+    for a0, b0 in ((0, 1), (5, 12), (100, 133), (1000, 1512), (2000, 7000), (60000, 70000)):
         part = hip.mahalanobis_score(f[a0:b0].contiguous(), cmd, packed, mu_p)
         assert torch.equal(part, whole[a0:b0]), (a0, b0)
-    rows = [0, 5, 100, 8999]
+        assert torch.equal(hip.mahalanobis_score(f[a0:b0].contiguous(), cmd, packed, mu_p, split=False), part)
+    rows = [0, 5, 100, 65535, 65536, 69999]
     exp = oracle.mahalanobis_score(f[rows].cpu().numpy(), cm, prec, c)
     assert rel_err(whole[rows].cpu().numpy(), exp) < 1e-9
 
