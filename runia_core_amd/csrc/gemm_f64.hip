@@ -993,9 +993,9 @@ __global__ __launch_bounds__(256) void maha_split_finish_kernel(const double* __
   score[row] = best;
 }
 
-// RUNIA_MAHA_SPLIT=0 keeps large batches on the one-launch form (measurements only; same bits either way)
-static bool maha_split_enabled() {
-  static const bool on = [] { const char* e = getenv("RUNIA_MAHA_SPLIT"); return !(e && e[0] == '0'); }();
+// RUNIA_MAHA_SPLIT=1 sends large batches through the column-split launches as well (measurements only; same bits either way)
+static bool maha_split_large() {
+  static const bool on = [] { const char* e = getenv("RUNIA_MAHA_SPLIT"); return e && e[0] == '1'; }();
   return on;
 }
 
@@ -1018,19 +1018,20 @@ static int maha_impl(const TX* x, const TX* class_mean, const double* packed_p, 
     // of a tile go to separate workgroups (8 x the parallelism at D = 2048) and a finishing launch adds their partial
     // sums in the unsplit kernel's order: a row scores the same bits in a batch of any size.
     //
-    // Large batches take the same split (round 5), in slices of rows whose partial sums fit the workspace: in the one-launch
-    // form every 32-row workgroup walks the whole packed P (33.5 MB at D = 2048, eight L2s' worth) at its own phase, and the
-    // workgroups sharing an L2 evict each other's blocks - 687 GB of L2 misses per 1 M rows against 8.2 GB of rows
-    // (profiles/r4_cfg3_pmc_summary.json).  Block-major order of the split launch makes the resident workgroups share ONE
-    // 4 MB block at a time; the rows are then read once per block (8 x 8.2 GB, still 10 x less than before).
+    // Large batches stay on the one launch.  Round 5 measured them on the same split in block-major order (slices of 65 536
+    // rows; RUNIA_MAHA_SPLIT=1 still selects it): the resident workgroups then share ONE 4 MB block of P instead of walking
+    // all 33.5 MB out of phase (687 GB of L2 misses per 1 M rows in the one-launch form, profiles/r4_cfg3_pmc_summary.json) -
+    // and 1 M x 2048 rows took 144.5 ms against 136.1 ms (profiles/r5_maha_split.txt): the rows are read once per block
+    // (8 x 8.2 GB) and every (tile, block) workgroup refills its pipeline, which costs more than the misses did - they are
+    // served by the Infinity Cache under the three-pair look-ahead of the weights.  Same bits either way.
     const int64_t nb = n_padded(D) / BN;
     const size_t per_row = (size_t)(nb * 4 * C) * sizeof(double);
-    if (nb > 1 && workspace && (((uintptr_t)workspace) & 7) == 0 && maha_split_enabled()) {
+    if (nb > 1 && workspace && (((uintptr_t)workspace) & 7) == 0) {
       int64_t cap = (int64_t)(workspace_bytes / per_row);
       if (cap > 65536) cap = 65536;
       if (cap >= N) cap = N; else cap = cap / BM * BM;  // slices end on tile boundaries
       const bool few = (N + BM - 1) / BM < runia_cu_count();
-      if (cap >= N || (!few && cap >= 8192)) {
+      if ((few && cap >= N) || (!few && maha_split_large() && cap >= 8192)) {
         for (int64_t r0 = 0; r0 < N; r0 += cap) {
           GemmArgs t = gemm_rows_from<TX>(g, r0, 1);
           if (t.N > cap) t.N = cap;
