@@ -478,6 +478,7 @@ __device__ __forceinline__ void finalize_body(const MetricsAccum* __restrict__ a
 #define METRICS_SCAT_ITEMS 32
 #endif
 constexpr int kMsdBits = METRICS_MSD_BITS, kMsdBuckets = 1 << kMsdBits;
+constexpr int kScatTileHist = 8192;  // scores per workgroup of the sketch launch
 
 constexpr unsigned kProbeBlocks = 256;
 struct ProbeRec { unsigned long long nkmin, kmax; unsigned bad, pad; };
@@ -488,6 +489,7 @@ struct MsdState {
   unsigned long long nkmin;       // ~(smallest key of the raw, FINITE scores)   } written by workgroup 0 of the key launch
   unsigned long long kmax;        // their largest key                           }
   ProbeRec recs[kProbeBlocks];    // the probe's workgroups
+  unsigned lin[kMsdBuckets];      // round 5: scores per bin of the raw range (msd_lin_hist_kernel), the sketch the buckets are equalised with
   unsigned hist[kMsdBuckets];
   unsigned cursor[kMsdBuckets];
   unsigned start[kMsdBuckets + 1];
@@ -506,10 +508,10 @@ __global__ __launch_bounds__(256) void msd_probe_kernel(const T* __restrict__ in
                                                         int64_t n_ood, MsdState* st) {
   __shared__ unsigned long long smin[4], smax[4];
   {  // the words later launches add to
-    constexpr unsigned kClear = 2 * kMsdBuckets + 1 + 8 * 32;
-    static_assert(offsetof(MsdState, done_group) + sizeof(unsigned) * 8 * 32 - offsetof(MsdState, hist) == (kClear + kMsdBuckets + 1) * 4,
-                  "hist, cursor, start, done_blocks, done_group are contiguous");
-    unsigned* z = st->hist;
+    constexpr unsigned kClear = 3 * kMsdBuckets + 1 + 8 * 32;
+    static_assert(offsetof(MsdState, done_group) + sizeof(unsigned) * 8 * 32 - offsetof(MsdState, lin) == (kClear + kMsdBuckets + 1) * 4,
+                  "lin, hist, cursor, start, done_blocks, done_group are contiguous");
+    unsigned* z = st->lin;
     for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < kClear + kMsdBuckets + 1; i += gridDim.x * 256) z[i] = 0u;
   }
   bool bad = false;
@@ -597,41 +599,122 @@ __device__ __forceinline__ double unkey(uint64_t k) {  // inverse of sortable_de
   b = (b >> 63) ? (b & 0x7fffffffffffffffull) : ~b;
   return __longlong_as_double((long long)b);
 }
+// Round 5: the buckets are linear in the RAW score, not in the squashed one.  The sigmoid turns the smooth score sets the
+// postprocessors actually produce - LaREM's -chi2(256), LaRED's log-densities of -300 ... -2000, energies around 9 - into sets
+// crowded against 0 or 1: value-linear buckets of sigmoid(score) then put nearly every key into ONE bucket, which takes the
+// bounded-but-slow workgroup path (2 M LaREM scores: 81.7 ms against 0.22 ms for N(0, 1) scores; 20 000: 0.75 ms against
+// 0.08).  The sigmoid is monotone, so a bucket index that rises as the raw score falls rises with the key as well: every key of
+// bucket i still sorts before every key of bucket j > i (equal keys - saturated sigmoids - may straddle a boundary, which the
+// order does not mind).  The key launch knows the raw score and leaves the bucket of every key in a 16-bit array for the
+// scatter.  Non-finite scores take the end of the key space their KEY lies at.
 struct MsdRange { double hi, scale; };
-template <typename T>
-__device__ __forceinline__ MsdRange msd_range_of(unsigned long long nkmin, unsigned long long kmax, bool squash) {
+__device__ __forceinline__ MsdRange msd_range_of(unsigned long long nkmin, unsigned long long kmax) {
   MsdRange r{0.0, 0.0};
   const unsigned long long lo_k = ~nkmin, hi_k = kmax;
   if (lo_k > hi_k) return r;  // (no finite score)
-  T v_hi = (T)unkey(lo_k), v_lo = (T)unkey(hi_k);  // largest / smallest finite score
-  if (squash) { v_hi = (T)1 / ((T)1 + exp(-v_hi)); v_lo = (T)1 / ((T)1 + exp(-v_lo)); }
-  r.hi = (double)v_hi;
-  const double span = (double)v_hi - (double)v_lo;
+  const double v_hi = unkey(lo_k), v_lo = unkey(hi_k);  // largest / smallest finite raw score
+  r.hi = v_hi;
+  const double span = v_hi - v_lo;
   r.scale = (span > 0.0 && span < __builtin_inf()) ? (double)kMsdBuckets / span : 0.0;
   return r;
 }
-template <typename T>
-__device__ __forceinline__ MsdRange msd_range(const MsdState* st, bool squash) {
-  return msd_range_of<T>(st->nkmin, st->kmax, squash);
+// position of a finite raw score on the bin axis: [0, kMsdBuckets), rising as the score falls
+__device__ __forceinline__ double msd_lin_pos(double raw, const MsdRange& r) {
+  const double x = (r.hi - raw) * r.scale;
+  constexpr double kTop = (double)kMsdBuckets * (1.0 - 0x1p-52);  // the largest position inside the last bin
+  return (x >= kTop) ? kTop : (x > 0.0 ? x : 0.0);
 }
-__device__ __forceinline__ unsigned msd_bucket(uint64_t key, const MsdRange& r) {
-  const double v = unkey(key);
-  if (!(v - v == 0.0)) return (key >> 63) ? (unsigned)(kMsdBuckets - 1) : 0u;  // inf / NaN: by the end of the key space they lie at
-  const double x = (r.hi - v) * r.scale;
-  const int b = (x >= (double)(kMsdBuckets - 1)) ? kMsdBuckets - 1 : (x > 0.0 ? (int)x : 0);
-  return (unsigned)b;
+// Equalised bucket (round 5).  Raw-linear bins of a bell-shaped score set hold 0 ... 4 x the mean, and a bin beyond the wave
+// sort's 1 024 keys takes the slow workgroup path (2 M N(0, 1) scores: 0.36 ms).  With the bin counts known (`lin`, one
+// histogram launch over the scores), the cumulative count at a score - linear inside its bin - is its approximate RANK; the
+// bucket is that rank cut into kMsdBuckets equal parts.  Monotone in the score (cum[b] + f * cnt[b] <= cum[b + 1] for f < 1;
+// products with positive constants and truncations keep order), so the buckets still follow the key order, and their sizes
+// follow the mean as closely as the density is flat inside one bin.  cum / cnt: this workgroup's LDS copy of the sketch.
+__device__ __forceinline__ unsigned msd_bucket(double raw, uint64_t key, const MsdRange& r, const unsigned* __restrict__ cum,
+                                               const unsigned* __restrict__ cnt, double buckets_per_key) {
+  if (!(raw - raw == 0.0)) {
+    // +inf (its sigmoid is 1.0: the largest key) -> the first bucket, -inf (0.0) -> the last; a NaN keeps the end of the
+    // key space its (squashed) key lies at - NaN keys sort before +inf or behind -inf by their sign bit
+    if (raw == raw) return raw > 0.0 ? 0u : (unsigned)(kMsdBuckets - 1);
+    return (key >> 63) ? (unsigned)(kMsdBuckets - 1) : 0u;
+  }
+  const double x = msd_lin_pos(raw, r);
+  const int b = (int)x;
+  const double rank = (double)cum[b] + (x - (double)b) * (double)cnt[b];
+  const int e = (int)(rank * buckets_per_key);
+  return (unsigned)(e >= kMsdBuckets ? kMsdBuckets - 1 : e);
+}
+
+// the sketch: finite raw scores per linear bin - of every kSketchStride-th score once the set is large (a quarter of 2 M
+// scores still puts ~120 into an average bin; the launch is a pass over the scores with LDS atomics, 19 us -> ~7 at 2 M)
+constexpr int kSketchStride = 4;
+constexpr int64_t kSketchAll = 1 << 17;  // up to here every score is counted
+template <typename T>
+__global__ __launch_bounds__(256) void msd_lin_hist_kernel(const T* __restrict__ ind, int64_t n_ind, const T* __restrict__ ood,
+                                                           int64_t n_ood, unsigned* __restrict__ any_outside, MsdState* st,
+                                                           unsigned n_probe_recs) {
+  __shared__ unsigned lh[kMsdBuckets];
+  const ProbeResult pr = msd_reduce_probe(st, n_probe_recs, any_outside);
+  const MsdRange rg = msd_range_of(pr.nkmin, pr.kmax);
+  for (int b = threadIdx.x; b < kMsdBuckets; b += 256) lh[b] = 0u;
+  __syncthreads();
+  const int64_t n = n_ind + n_ood;
+  const int64_t step = (n > kSketchAll) ? kSketchStride : 1;  // (the grid is sized for the sampled count)
+  const int64_t t0 = (int64_t)blockIdx.x * kScatTileHist;
+#pragma unroll 4
+  for (int c = 0; c < kScatTileHist / 256; ++c) {
+    const int64_t j = t0 + c * 256 + threadIdx.x;
+    const int64_t i = (j >> 8) * step * 256 + (j & 255);  // 256 consecutive scores of every `step`-th run of 256: whole lines, a quarter of them
+    if (i < n) {
+      const double v = (double)((i < n_ind) ? ind[i] : ood[i - n_ind]) + 0.0;
+      if (v - v == 0.0) atomicAdd(&lh[(int)msd_lin_pos(v, rg)], 1u);
+    }
+  }
+  __syncthreads();
+  for (int b = threadIdx.x; b < kMsdBuckets; b += 256) {
+    const unsigned c = lh[b];
+    if (c) atomicAdd(&st->lin[b], c);
+  }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void msd_keys_kernel(const T* __restrict__ ind, int64_t n_ind, const T* __restrict__ ood,
                                                        int64_t n_ood, unsigned* __restrict__ any_outside, MsdState* st,
                                                        unsigned n_probe_recs, uint64_t* __restrict__ keys,
-                                                       uint8_t* __restrict__ labels) {
+                                                       uint8_t* __restrict__ labels, uint16_t* __restrict__ bucket_of) {
   __shared__ unsigned lh[kMsdBuckets];
+  __shared__ unsigned cum[kMsdBuckets], cnt[kMsdBuckets];  // the sketch: finite scores in the bins before b, in bin b
+  __shared__ unsigned wsum_k[4];
   const ProbeResult pr = msd_reduce_probe(st, n_probe_recs, any_outside);
   const bool squash = pr.squash;
-  const MsdRange rg = msd_range_of<T>(pr.nkmin, pr.kmax, squash);
+  const MsdRange rg = msd_range_of(pr.nkmin, pr.kmax);
   for (int b = threadIdx.x; b < kMsdBuckets; b += 256) lh[b] = 0u;
+  unsigned finite_total;
+  {  // exclusive scan of the bin counts, every workgroup for itself (16 KB from L2)
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = kMsdBuckets / 256;
+    unsigned v[PER], tot = 0u;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) { v[j] = st->lin[tid * PER + j]; tot += v[j]; }
+    unsigned x = tot;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const unsigned y = __shfl_up(x, o, 64);
+      if (lane >= o) x += y;
+    }
+    if (lane == 63) wsum_k[wave] = x;
+    __syncthreads();
+    unsigned off = x - tot;
+    for (int w = 0; w < wave; ++w) off += wsum_k[w];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      cum[tid * PER + j] = off;
+      cnt[tid * PER + j] = v[j];
+      off += v[j];
+    }
+    finite_total = wsum_k[0] + wsum_k[1] + wsum_k[2] + wsum_k[3];
+  }
+  const double buckets_per_key = finite_total ? (double)kMsdBuckets / (double)finite_total : 0.0;
   __syncthreads();
   const int64_t n = n_ind + n_ood;
   const int64_t t0 = (int64_t)blockIdx.x * kTile;
@@ -643,7 +726,9 @@ __global__ __launch_bounds__(256) void msd_keys_kernel(const T* __restrict__ ind
       const uint64_t key = score_key<T>(v, squash);
       keys[i] = key;
       labels[i] = (i < n_ind) ? 1 : 0;
-      atomicAdd(&lh[msd_bucket(key, rg)], 1u);
+      const unsigned b = msd_bucket((double)v + 0.0, key, rg, cum, cnt, buckets_per_key);
+      bucket_of[i] = (uint16_t)b;
+      atomicAdd(&lh[b], 1u);
     }
   }
   __syncthreads();
@@ -657,11 +742,10 @@ constexpr int kScatItems = METRICS_SCAT_ITEMS, kScatTile = 256 * kScatItems;  //
 template <typename T>
 __global__ __launch_bounds__(256) void msd_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint8_t* __restrict__ lab_in,
                                                           uint64_t* __restrict__ keys_out, uint8_t* __restrict__ lab_out, int64_t n,
-                                                          const unsigned* __restrict__ any_outside, MsdState* st) {
+                                                          const uint16_t* __restrict__ bucket_of, MsdState* st) {
   __shared__ unsigned cnt[kMsdBuckets];   // keys of this tile per bucket, then the tile's first slot in the bucket
   __shared__ unsigned first[kMsdBuckets]; // keys in the buckets before b
   __shared__ unsigned wsum[4];
-  const MsdRange rg = msd_range<T>(st, *any_outside != 0u);
   for (int b = threadIdx.x; b < kMsdBuckets; b += 256) cnt[b] = 0u;
   {
     // the exclusive scan of the bucket counts, by every workgroup for itself (16 KB of counts from L2) instead of by one
@@ -693,12 +777,12 @@ __global__ __launch_bounds__(256) void msd_scatter_kernel(const uint64_t* __rest
   const int64_t t0 = (int64_t)blockIdx.x * kScatTile;
   uint64_t key[kScatItems];
   unsigned slot[kScatItems];  // bucket << 16 | rank of the key among the tile's keys of that bucket (< 16 384)
-  static_assert(kScatTile <= 65536 && kMsdBits <= 16, "bucket and rank share a word");
+  static_assert(kScatTile <= 65536 && kMsdBits <= 16, "bucket and rank share a word; a bucket index fits the 16-bit array");
 #pragma unroll
   for (int c = 0; c < kScatItems; ++c) {
     const int64_t i = t0 + c * 256 + threadIdx.x;
     key[c] = (i < n) ? keys_in[i] : 0ull;
-    const unsigned b = msd_bucket(key[c], rg);
+    const unsigned b = (i < n) ? (unsigned)bucket_of[i] : 0u;
     slot[c] = (b << 16) | ((i < n) ? atomicAdd(&cnt[b], 1u) : 0u);
   }
   __syncthreads();
@@ -1010,7 +1094,7 @@ __global__ __launch_bounds__(256) void curve_terms_finalize_kernel(const uint64_
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, dtot, tile_sum, tile_end, tile_cnt, accum, flag, msd, parts, total;
+  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, dtot, tile_sum, tile_end, tile_cnt, accum, flag, msd, parts, bucket_of, total;
   unsigned nblocks;
 };
 
@@ -1033,6 +1117,7 @@ Layout make_layout(int64_t n) {
   L.flag = o; o += 256;
   L.msd = o; o += align256(sizeof(MsdState));  // (accum, flag and msd are contiguous: one memset clears them)
   L.parts = o; o += align256(kCurveBlocks * sizeof(MetricsAccum));  // per-workgroup records of the curve-term launch (written before read)
+  L.bucket_of = o; o += align256((size_t)n * 2);                     // bucket of every key (key launch -> scatter)
   L.total = o;
   return L;
 }
@@ -1067,12 +1152,15 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
 #endif
   if (METRICS_MSD) {
     MsdState* st = reinterpret_cast<MsdState*>(w + L.msd);
-    // seven launches, nothing cleared beforehand (MsdState)
+    // eight launches, nothing cleared beforehand (MsdState)
     const unsigned sgrid = runia_stream_grid(n, 256);
     const unsigned pgrid = sgrid < kProbeBlocks ? sgrid : kProbeBlocks;
     msd_probe_kernel<T><<<pgrid, 256, 0, s>>>(ind, n_ind, ood, n_ood, st);
-    msd_keys_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0]);
-    msd_scatter_kernel<T><<<(unsigned)((n + kScatTile - 1) / kScatTile), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, flag, st);
+    const int64_t sketch_n = (n > kSketchAll) ? (n + kSketchStride - 1) / kSketchStride : n;
+    msd_lin_hist_kernel<T><<<(unsigned)((sketch_n + kScatTileHist - 1) / kScatTileHist), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid);
+    uint16_t* bucket_of = reinterpret_cast<uint16_t*>(w + L.bucket_of);
+    msd_keys_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of);
+    msd_scatter_kernel<T><<<(unsigned)((n + kScatTile - 1) / kScatTile), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
     msd_bucket_sort_kernel<T><<<kMsdBuckets / 4, 256, 0, s>>>(keys[1], labs[1], keys[0], labs[0], flag, st);  // (four buckets per workgroup)
     tile_summary_kernel<<<L.nblocks, 256, 0, s>>>(keys[1], labs[1], n, tile_sum, tile_end, tile_cnt);
     tile_prefix_raw_kernel<<<L.nblocks, 256, 0, s>>>(keys[1], labs[1], n, tile_sum, tile_end, tile_cnt, tps, prev_end, tps_out,
