@@ -478,7 +478,7 @@ __device__ __forceinline__ void finalize_body(const MetricsAccum* __restrict__ a
 #define METRICS_SCAT_ITEMS 32
 #endif
 constexpr int kMsdBits = METRICS_MSD_BITS, kMsdBuckets = 1 << kMsdBits;
-constexpr int kScatTileHist = 8192;  // scores per workgroup of the sketch launch
+constexpr int kScatTileHist = 2048;  // scores per workgroup of the sketch launch
 
 constexpr unsigned kProbeBlocks = 256;
 struct ProbeRec { unsigned long long nkmin, kmax; unsigned bad, pad; };
@@ -640,6 +640,7 @@ __device__ __forceinline__ unsigned msd_bucket(double raw, uint64_t key, const M
   }
   const double x = msd_lin_pos(raw, r);
   const int b = (int)x;
+  if (buckets_per_key == 0.0) return (unsigned)b;  // (uniform) no sketch: the raw-linear bin itself
   const double rank = (double)cum[b] + (x - (double)b) * (double)cnt[b];
   const int e = (int)(rank * buckets_per_key);
   return (unsigned)(e >= kMsdBuckets ? kMsdBuckets - 1 : e);
@@ -681,7 +682,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void msd_keys_kernel(const T* __restrict__ ind, int64_t n_ind, const T* __restrict__ ood,
                                                        int64_t n_ood, unsigned* __restrict__ any_outside, MsdState* st,
                                                        unsigned n_probe_recs, uint64_t* __restrict__ keys,
-                                                       uint8_t* __restrict__ labels, uint16_t* __restrict__ bucket_of) {
+                                                       uint8_t* __restrict__ labels, uint16_t* __restrict__ bucket_of, int equalise) {
   __shared__ unsigned lh[kMsdBuckets];
   __shared__ unsigned cum[kMsdBuckets], cnt[kMsdBuckets];  // the sketch: finite scores in the bins before b, in bin b
   __shared__ unsigned wsum_k[4];
@@ -689,8 +690,8 @@ __global__ __launch_bounds__(256) void msd_keys_kernel(const T* __restrict__ ind
   const bool squash = pr.squash;
   const MsdRange rg = msd_range_of(pr.nkmin, pr.kmax);
   for (int b = threadIdx.x; b < kMsdBuckets; b += 256) lh[b] = 0u;
-  unsigned finite_total;
-  {  // exclusive scan of the bin counts, every workgroup for itself (16 KB from L2)
+  unsigned finite_total = 0u;
+  if (equalise) {  // (uniform) exclusive scan of the bin counts, every workgroup for itself (16 KB from L2)
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     constexpr int PER = kMsdBuckets / 256;
     unsigned v[PER], tot = 0u;
@@ -1156,10 +1157,15 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
     const unsigned sgrid = runia_stream_grid(n, 256);
     const unsigned pgrid = sgrid < kProbeBlocks ? sgrid : kProbeBlocks;
     msd_probe_kernel<T><<<pgrid, 256, 0, s>>>(ind, n_ind, ood, n_ood, st);
-    const int64_t sketch_n = (n > kSketchAll) ? (n + kSketchStride - 1) / kSketchStride : n;
-    msd_lin_hist_kernel<T><<<(unsigned)((sketch_n + kScatTileHist - 1) / kScatTileHist), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid);
+    // Small sets (<= 64 keys per bucket on average) skip the sketch: a raw-linear bin of a bell-shaped set holds a few times
+    // the mean, far below the wave sort's 1 024, and the launch would cost them 10 us of their 80
+    const int equalise = n > (int64_t)64 * kMsdBuckets;
+    if (equalise) {
+      const int64_t sketch_n = (n > kSketchAll) ? (n + kSketchStride - 1) / kSketchStride : n;
+      msd_lin_hist_kernel<T><<<(unsigned)((sketch_n + kScatTileHist - 1) / kScatTileHist), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid);
+    }
     uint16_t* bucket_of = reinterpret_cast<uint16_t*>(w + L.bucket_of);
-    msd_keys_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of);
+    msd_keys_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise);
     msd_scatter_kernel<T><<<(unsigned)((n + kScatTile - 1) / kScatTile), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
     msd_bucket_sort_kernel<T><<<kMsdBuckets / 4, 256, 0, s>>>(keys[1], labs[1], keys[0], labs[0], flag, st);  // (four buckets per workgroup)
     tile_summary_kernel<<<L.nblocks, 256, 0, s>>>(keys[1], labs[1], n, tile_sum, tile_end, tile_cnt);

@@ -755,7 +755,7 @@ def test_device_metrics_reference_goldens(ref_vectors):
 
 
 @pytest.mark.parametrize("case", ["f64_far", "f64_unit", "f32", "ties", "saturated", "tiny", "big", "clustered", "clustered_unit",
-                                  "constant", "infinite", "two"])
+                                  "constant", "infinite", "two", "larem_like", "energy_like_f32", "ties_big", "infinite_big"])
 def test_device_metrics_vs_oracle(case):
     """Device sort + scan metrics against the oracle's restatement of torchmetrics / sklearn: scores inside [0, 1] (no
     sigmoid), far outside (f64 sigmoid), float32 scores (f32 sigmoid), heavy ties, LaREM-like scores whose sigmoid
@@ -792,11 +792,23 @@ def test_device_metrics_vs_oracle(case):
         ood = np.concatenate([rng.standard_normal(3000) - 1, [np.inf, -np.inf, -np.inf]])
     elif case == "two":
         ind, ood = np.array([0.3]), np.array([0.7])
+    elif case == "larem_like":      # round 5: -chi2(64) x 3, every score far outside [0, 1] - the sigmoids crowd against 0; the
+        ind = -3.0 * rng.chisquare(64, 220_000)          # buckets follow the RAW score and are equalised with a sketch (> 262 144 scores)
+        ood = -3.4 * rng.chisquare(64, 200_000)
+    elif case == "energy_like_f32":  # float32 energies around 9: float32 sigmoids within 1e-4 of 1.0, heavy ties after the squash
+        ind = (rng.standard_normal(180_000) * 2 + 9).astype(np.float32)
+        ood = (rng.standard_normal(170_000) * 2 + 7).astype(np.float32)
+    elif case == "ties_big":        # 40 distinct values over 400 000 scores: every equalised bucket boundary falls inside a run
+        ind = rng.integers(0, 40, 210_000).astype(np.float64) * 0.37 - 5.0
+        ood = rng.integers(0, 33, 190_000).astype(np.float64) * 0.37 - 6.0
+    elif case == "infinite_big":
+        ind = np.concatenate([rng.standard_normal(200_000) * 4, [np.inf] * 5, [-np.inf] * 3])
+        ood = np.concatenate([rng.standard_normal(150_000) * 4 - 1, [np.inf, -np.inf, -np.inf]])
     else:
         ind, ood = rng.standard_normal(1_200_000) + 0.3, rng.standard_normal(900_000) - 0.3
     got = auroc_fpr95_aupr_device(ind, ood)
     exp = oracle.auroc_fpr95_aupr(ind, ood)
-    tol = 3e-7 if case != "big" else 2e-6  # the reference adds its float32 trapezoid terms in float32
+    tol = 3e-7 if case not in ("big", "larem_like", "energy_like_f32", "ties_big", "infinite_big") else 2e-6  # the reference adds its float32 trapezoid terms in float32
     assert got == pytest.approx(exp, abs=tol), (case, got, exp)
     # device-resident inputs, no host round trip
     import torch as _t
