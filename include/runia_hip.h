@@ -445,6 +445,10 @@ int runia_mcd_uncertainty_f32(const float* logits, float* probs, float* pred_h, 
                               runia_stream_t stream);
 int runia_ash_s_rows_f32(const float* x, float* y, float* pruned, int64_t N, int64_t D, int percentile,
                          int keep_all_when_k_is_zero, runia_stream_t stream);
+/* runia_tril_inverse_f64: inv [batch, D, D] = inverse of the lower-triangular factors tril [batch, D, D] (row-major f64; the strict
+ *   upper triangle of inv is zero).  Setup of the class-wise Gaussians of GMMLatentSpace / DDU (inference/postprocessors.py:
+ *   426-492, 694-786; torch.distributions.MultivariateNormal keeps scale_tril): the precision of a class is inv^T inv. */
+int runia_tril_inverse_f64(const double* tril, double* inv, int64_t batch, int64_t D, runia_stream_t stream);
 /* runia_proj_norm_*: ViM residual norm || (x - u) @ NS ||_2 per row (inference/postprocessors.py:1106):
  *   x [N, D], u [D] (same dtype as x; f32 - f32 is rounded to f32 first, as NumPy), packed_ns = pack(NS [D, n]),
  *   norm [N] f64. */

@@ -162,6 +162,7 @@ _SIGNATURES = {
     "runia_gen_entropy_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_int, c_double, c_void_p]),
     "runia_mcd_uncertainty_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int64, c_void_p]),
     "runia_ash_s_rows_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int, c_int, c_void_p]),
+    "runia_tril_inverse_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "runia_proj_norm_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "runia_proj_norm_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_int64, c_void_p]),
     "runia_proj_sq_workspace_bytes": (c_size_t, [c_int64]),
@@ -1305,3 +1306,15 @@ def clock_ghz(probe: torch.Tensor) -> dict:
     ns = r * 10.0
     return {"ghz": round(t / ns, 4) if ns > 0 else None, "probe_us": round(ns / 1e3, 2),
             "cycles_per_dependent_fma": round(t / n, 3) if n else None}
+
+
+@_device_guard()
+def tril_inverse(tril: torch.Tensor) -> torch.Tensor:
+    """tril [B, D, D] f64 lower-triangular (device) -> their inverses [B, D, D] (``runia_tril_inverse_f64``)."""
+    lib = load_library()
+    require_gpu()
+    assert tril.is_cuda and tril.dtype == torch.float64 and tril.dim() == 3 and tril.shape[1] == tril.shape[2]
+    tril = tril.contiguous()
+    out = torch.empty_like(tril)
+    _check(lib.runia_tril_inverse_f64(tril.data_ptr(), out.data_ptr(), tril.shape[0], tril.shape[1], _stream()), "runia_tril_inverse_f64")
+    return out

@@ -1049,6 +1049,23 @@ def test_get_dl_h_z_single_read_equals_the_two_kernels(hip, n_mc, d, n_img):
         assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(hip.kl_entropy_joint(zt, n_mc, 4), nan=-7.0))
 
 
+@pytest.mark.parametrize("d,batch", [(1, 2), (37, 3), (64, 1), (65, 2), (300, 10), (1024, 2)])
+def test_tril_inverse_of_the_class_factors(hip, d, batch):
+    """runia_tril_inverse_f64 (round 5; setup of GMMLatentSpace / DDU: the Cholesky factors torch's MultivariateNormal keeps,
+    reference inference/postprocessors.py:490, 778): W = L^-1 per class by forward substitution, against the host's triangular
+    solve; W L = I; the strict upper triangle is zero; the precision W^T W equals torch.cholesky_inverse."""
+    rng = np.random.default_rng(d)
+    a = rng.standard_normal((batch, d, 2 * d + 3))
+    cov = a @ a.transpose(0, 2, 1) / (2 * d + 3) + 0.05 * np.eye(d)
+    L = np.linalg.cholesky(cov)
+    w = hip.tril_inverse(dev(L, torch.float64)).cpu().numpy()
+    assert np.allclose(np.triu(w, 1), 0.0)
+    for b in range(batch):
+        assert np.allclose(w[b] @ L[b], np.eye(d), atol=1e-10)
+        ref = torch.cholesky_inverse(torch.from_numpy(L[b])).numpy()
+        assert rel_err(w[b].T @ w[b], ref) < 1e-9 * max(1.0, np.abs(ref).max())
+
+
 @pytest.mark.parametrize("c", [4097, 5000, 21841, 128256])
 def test_gen_and_mcd_uncertainty_on_heads_wider_than_4096(hip, c):
     """runia_gen_score_f32 / runia_gen_entropy_f32 / runia_mcd_uncertainty_f32 refused C > 4 096 (ImageNet-21k,
