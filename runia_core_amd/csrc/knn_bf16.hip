@@ -6,7 +6,7 @@
 // piece products of order <= 2^-8,
 //     q.b ~= m.h + h.m + h.h        (dropped: m.m + h.l + l.h + ... <= 3 * 2^-16 |q||b|),
 // each an exact bf16 product accumulated in f32 by the matrix cores, 3/16 of the f32 contraction's matrix-pipe time.  The
-// result feeds the SAME selection + exact f32 re-measurement as the f32 kernel's distances (pairwise.hip,
+// result feeds the SAME selection + exact f32 re-measurement as the f32 kernel's distances (knn_f32.hip,
 // kth_select_range_kernel), whose window is widened to twice this kernel's error bound (runia_knn16_refine_rel): every
 // bank row that could be the k-th neighbour is re-measured with exact f32 differences, so the caller gets the exactly
 // re-measured k-th distance either way; this kernel only decides which bank rows are looked at.  (All six products of
@@ -409,7 +409,7 @@ __global__ __launch_bounds__(256) void knn_dist_bf16_kernel(const uint16_t* __re
 
 }  // namespace runia_knn16
 
-// ---- host side (called from pairwise.hip) ----
+// ---- host side (called from knn_f32.hip) ----
 int64_t runia_knn16_padded_rows(int64_t rows) { return (rows + 255) / 256 * 256; }
 int64_t runia_knn16_padded_width(int64_t D) { return (D + 31) / 32 * 32; }
 size_t runia_knn16_plane_bytes(int64_t rows, int64_t D) {

@@ -1,207 +1,16 @@
-// Pairwise-distance postprocessors.
-//   a8  kNN   : faiss.IndexFlatL2.search(q, k) -> -(k-th smallest squared L2)
-//               (reference inference/postprocessors.py:417-421, 873-880; faiss-gpu==1.7.2)
-//   a9  LaRED : sklearn KernelDensity(gaussian).score_samples
-//               (reference inference/postprocessors.py:118-128)
+// a8  kNN : faiss.IndexFlatL2.search(q, k) -> -(k-th smallest squared L2)
+//            (reference inference/postprocessors.py:417-421, 873-880; faiss-gpu==1.7.2)
 //
-// kNN = the one f32 dense contraction of the path, on the matrix cores:
-//   d2[q, m] = |q|^2 + |b_m|^2 - 2 q.b_m          (v_mfma_f32_32x32x2_f32, exact-f32 fma chain)
-// A workgroup owns a 128-query x 128-bank-row tile (4 waves x 64x64, i.e. 2x2 MFMA tiles of 32x32 per wave);
-// both operands are K-contiguous rows, staged 32 k at a time into LDS with a 34-float pitch (conflict-free
-// ds_read_b64: one 8-byte read feeds two MFMA k-steps, A and B use the same k permutation).  Distances go to a
-// row-chunked workspace [Qc, M]; the k-th order statistic of each row is then found by an 8-bit radix select over
-// the distance bits (distances are clamped >= 0, so unsigned integer order == float order) - no sort, no top-k list.
-// The tile grid is walked in XCD-aware super-tiles (see knn_dist_kernel).
-#include "common.hpp"
+// kNN = the one f32 dense contraction of the path, on the matrix cores (nt_tile_f32.hpp):
+//   d2[q, m] = |q|^2 + |b_m|^2 - 2 q.b_m
+// Distances go to a row-chunked workspace [Qc, M]; the k-th order statistic of each row is then found by a histogram select
+// over the distance bits and an exact re-measurement of the candidates around it - no sort, no top-k list.  Large problems
+// rank the bank rows by bf16 piece products first (knn_bf16.hip) and never write the Q x M matrix (candidate lists).
+// This file: the selection kernels, the handful-of-queries path, the dispatch and the C entry points.
+#include "nt_tile_f32.hpp"
 #include "knn_perm.hpp"
 
 namespace {
-
-constexpr float kFltMax = 3.4028234663852886e38f;
-typedef float f32x16 __attribute__((ext_vector_type(16)));
-
-constexpr int TQ = 128, TB = 128, KCH = 32, KP = 34;
-#ifndef KNN_SB
-#define KNN_SB 8
-#define KNN_SQ 8
-#endif
-constexpr int kSuperB = KNN_SB, kSuperQ = KNN_SQ;  // super-tile of workgroups that share L2 lines (knn_dist_kernel)
-// Query tiles of a super-tile: kSuperQ, or all of them when the batch has fewer (the super-tile is then kSuperB x nqt
-// workgroups, every one of them with a tile).  Workgroups go to compute units in a fixed rotation: with a batch of one
-// query tile in 8 x 8 super-tiles only every eighth workgroup had a tile, and those landed on one eighth of the compute
-// units (100 queries against 50 000 x 2048: 0.45 ms, as much as 1 000).
-__host__ __device__ inline int knn_super_q(int64_t nqt) { return nqt < kSuperQ ? (int)nqt : kSuperQ; }
-
-// squared row norms; max_bits (optional): running maximum of the norms as an unsigned bit pattern (norms are >= 0)
-__global__ __launch_bounds__(64 * kRowWaves) void row_sqnorm_kernel(const float* __restrict__ x, float* __restrict__ out,
-                                                                    int64_t N, int64_t D, unsigned* __restrict__ max_bits) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const bool vec = ((D & 3) == 0) && ((((uintptr_t)x) & 15) == 0);
-  for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += (int64_t)gridDim.x * kRowWaves) {
-    const float* p = x + row * D;
-    float s = 0.f;
-    if (vec) {
-      // 16-byte loads, four independent partial sums
-      const float4* p4 = reinterpret_cast<const float4*>(p);
-      const int64_t n4 = D >> 2;
-      float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
-      int64_t i = lane;
-      for (; i + 192 < n4; i += 256) {
-        const float4 a = p4[i], b = p4[i + 64], c = p4[i + 128], d = p4[i + 192];
-        s0 = fmaf(a.x, a.x, s0); s0 = fmaf(a.y, a.y, s0); s0 = fmaf(a.z, a.z, s0); s0 = fmaf(a.w, a.w, s0);
-        s1 = fmaf(b.x, b.x, s1); s1 = fmaf(b.y, b.y, s1); s1 = fmaf(b.z, b.z, s1); s1 = fmaf(b.w, b.w, s1);
-        s2 = fmaf(c.x, c.x, s2); s2 = fmaf(c.y, c.y, s2); s2 = fmaf(c.z, c.z, s2); s2 = fmaf(c.w, c.w, s2);
-        s3 = fmaf(d.x, d.x, s3); s3 = fmaf(d.y, d.y, s3); s3 = fmaf(d.z, d.z, s3); s3 = fmaf(d.w, d.w, s3);
-      }
-      for (; i < n4; i += 64) {
-        const float4 a = p4[i];
-        s0 = fmaf(a.x, a.x, s0); s0 = fmaf(a.y, a.y, s0); s0 = fmaf(a.z, a.z, s0); s0 = fmaf(a.w, a.w, s0);
-      }
-      s = (s0 + s1) + (s2 + s3);
-    } else {
-      for (int64_t i = lane; i < D; i += 64) s = fmaf(p[i], p[i], s);
-    }
-    s = wave_sum_f32(s);
-    if (lane == 0) {
-      out[row] = s;
-      // Running maximum of the norms (NaN / inf rows do not set the range).  One returning atomic per row on ONE word
-      // serialises at ~88 per microsecond: 50 000 bank rows took 0.58 ms for 0.08 ms of reading.  The atomic is only
-      // issued when the value beats what the word already holds (a stale read only costs a redundant atomic).
-      if (max_bits && s < INFINITY) {
-        const unsigned b = __float_as_uint(s);
-        if (b > __atomic_load_n(max_bits, __ATOMIC_RELAXED)) atomicMax(max_bits, b);
-      }
-    }
-  }
-}
-
-// stage a [rows x 32] K-chunk of a K-contiguous matrix into LDS (zero filled outside the matrix), in two halves so that
-// the global loads of chunk i+1 are in flight while the matrix cores work on chunk i:
-//   load_chunk : global -> 16 registers per thread (128 rows x 2 halves of 16 floats)
-//   store_chunk: registers -> LDS
-__device__ __forceinline__ void load_chunk(const float* __restrict__ src, int64_t row0, int64_t nrows, int64_t D,
-                                           int64_t k0, float (&v)[16], int tid, bool vec) {
-  const int row = tid >> 1, half = tid & 1;
-  const int64_t gr = row0 + row;
-  const float* p = src + gr * D + k0 + half * 16;
-  if (gr < nrows && vec && k0 + half * 16 + 16 <= D) {
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float4 t = reinterpret_cast<const float4*>(p)[j];
-      v[4 * j] = t.x; v[4 * j + 1] = t.y; v[4 * j + 2] = t.z; v[4 * j + 3] = t.w;
-    }
-  } else {
-#pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = (gr < nrows && k0 + half * 16 + j < D) ? p[j] : 0.f;
-  }
-}
-
-template <bool CLIP>
-__device__ __forceinline__ void store_chunk(const float (&v)[16], float (*dst)[KP], int tid, float clip_max = INFINITY) {
-  const int row = tid >> 1, half = tid & 1;
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    // the clip (ReAct) costs two vector instructions per element: only the instantiation that clips pays for it
-    // np.clip keeps a NaN activation (fminf would return the other operand and hide it)
-    const float a = (CLIP && v[2 * j] > clip_max) ? clip_max : v[2 * j];
-    const float b = (CLIP && v[2 * j + 1] > clip_max) ? clip_max : v[2 * j + 1];
-    *reinterpret_cast<float2*>(&dst[row][half * 16 + 2 * j]) = make_float2(a, b);
-  }
-}
-
-// EPI_DIST  : out[q, m] = max(0, |q|^2 + |b_m|^2 - 2 q.b_m)                  (kNN distances; qn = |q|^2, bn = |b|^2)
-// EPI_LINEAR: out[q, m] = min(x_q, clip).w_m + bias_m                          (final linear layer; bn = bias, qn unused)
-enum NtEpilogue { EPI_DIST = 0, EPI_LINEAR = 1 };
-
-template <int EPI>
-__global__ __launch_bounds__(256) void knn_dist_kernel(const float* __restrict__ q, const float* __restrict__ bank,
-                                                        const float* __restrict__ qn, const float* __restrict__ bn,
-                                                        float* __restrict__ dist, int64_t Q, int64_t M, int64_t D,
-                                                        float clip_max) {
-  __shared__ __attribute__((aligned(16))) float As[TQ][KP];
-  __shared__ __attribute__((aligned(16))) float Bs[TB][KP];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wq = wave >> 1, wb = wave & 1;   // 2 x 2 waves
-  const int li = lane & 31, lh = lane >> 5;
-  // XCD-aware order of the tile grid.  Consecutive workgroup ids go round-robin over the 8 XCDs; here ids i, i + 8,
-  // i + 16, ... (one XCD's share) walk a super-tile of kSuperB bank tiles x kSuperQ query tiles row by row, and the
-  // super-tiles themselves are dealt round-robin to the XCDs.  The 64 workgroups of a super-tile are resident on one
-  // XCD at the same time and sweep K in step, so every 16 KB slice of a query or bank tile is fetched into that L2
-  // once and read 8 times (with the plain (bank tile, query tile) grid a bank tile was fetched again for every query
-  // tile: 64 x 410 MB per 8 192-query chunk).
-  int64_t q0, m0;
-  {
-    const int64_t nbt = (M + TB - 1) / TB, nqt = (Q + TQ - 1) / TQ;
-    const int sq = knn_super_q(nqt), wps = kSuperB * sq;  // workgroups per super-tile (see knn_super_q)
-    const int64_t nqg = (nqt + sq - 1) / sq;
-    const int64_t l = blockIdx.x >> 3;
-    const int64_t st = (l / wps) * 8 + (blockIdx.x & 7);  // super-tile of this workgroup
-    const int r = (int)(l % wps);
-    const int64_t bt = (st / nqg) * kSuperB + r % kSuperB, qt = (st % nqg) * sq + r / kSuperB;
-    if (bt >= nbt || qt >= nqt) return;  // padding of the grid (uniform over the workgroup)
-    q0 = qt * TQ;
-    m0 = bt * TB;
-  }
-  const bool vec = ((D & 3) == 0) && ((((uintptr_t)q) & 15) == 0) && ((((uintptr_t)bank) & 15) == 0);
-  f32x16 acc[2][2];
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
-  float ra[16], rb[16];
-  load_chunk(q, q0, Q, D, 0, ra, tid, vec);
-  load_chunk(bank, m0, M, D, 0, rb, tid, vec);
-  for (int64_t k0 = 0; k0 < D; k0 += KCH) {
-    __syncthreads();  // every wave has finished reading the previous chunk
-    store_chunk<EPI == EPI_LINEAR>(ra, As, tid, clip_max);
-    store_chunk<false>(rb, Bs, tid);
-    __syncthreads();
-    if (k0 + KCH < D) {  // next chunk's loads fly while the matrix cores consume this one
-      load_chunk(q, q0, Q, D, k0 + KCH, ra, tid, vec);
-      load_chunk(bank, m0, M, D, k0 + KCH, rb, tid, vec);
-    }
-#pragma unroll
-    for (int s = 0; s < KCH / 4; ++s) {
-      float2 av[2], bv[2];
-#pragma unroll
-      for (int a = 0; a < 2; ++a) av[a] = *reinterpret_cast<const float2*>(&As[wq * 64 + a * 32 + li][4 * s + 2 * lh]);
-#pragma unroll
-      for (int b = 0; b < 2; ++b) bv[b] = *reinterpret_cast<const float2*>(&Bs[wb * 64 + b * 32 + li][4 * s + 2 * lh]);
-#pragma unroll
-      for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].x, bv[b].x, acc[a][b], 0, 0, 0);
-          acc[a][b] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a].y, bv[b].y, acc[a][b], 0, 0, 0);
-        }
-    }
-  }
-  // epilogue: C[row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)][col = lane&31]
-#pragma unroll
-  for (int a = 0; a < 2; ++a)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
-      const int64_t col = m0 + wb * 64 + b * 32 + li;
-      const float bnv = (col < M && bn) ? bn[col] : 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int64_t row = q0 + wq * 64 + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
-        if (row < Q && col < M) {
-          if constexpr (EPI == EPI_DIST) {
-            const float d = (qn[row] + bnv) - 2.0f * acc[a][b][r];
-            // faiss keeps a max-heap initialised with FLT_MAX and inserts a distance only if it compares smaller: a NaN
-            // or infinite distance is never inserted, i.e. it counts as FLT_MAX (fmaxf alone would turn NaN into 0)
-            dist[row * M + col] = (d == d) ? fminf(fmaxf(d, 0.f), kFltMax) : kFltMax;
-          } else {
-            dist[row * M + col] = acc[a][b][r] + bnv;
-          }
-        }
-      }
-    }
-}
 
 // k-th smallest (1-based) of each row of dist [Q, M]: histogram select, one workgroup per row, followed by an exact
 // refinement.  The norm-expansion distances carry ~K*eps cancellation error (4e-6 at D = 2048), while
@@ -757,450 +566,9 @@ __global__ void fill_kernel(float* p, int64_t n, float v) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) p[i] = v;
 }
 
-// Gaussian KDE log-density, f64: online logsumexp over the training rows, one workgroup per query.
-__global__ __launch_bounds__(256) void kde_kernel(const double* __restrict__ train, const double* __restrict__ x,
-                                                   double* __restrict__ score, int64_t M, int64_t N, int64_t D,
-                                                   double neg_half_inv_h2, double log_norm) {
-  extern __shared__ double xs[];  // D doubles
-  __shared__ double wm[4], wsum[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int64_t row = blockIdx.x; row < N; row += gridDim.x) {
-    __syncthreads();
-    for (int64_t i = tid; i < D; i += 256) xs[i] = x[row * D + i];
-    __syncthreads();
-    double mx = -kInfD(), s = 0.0;  // running max / sum of exp(. - mx), identical on all lanes of a wave
-    for (int64_t m = wave; m < M; m += 4) {
-      const double* t = train + m * D;
-      double acc = 0.0;
-      for (int64_t i = lane; i < D; i += 64) {
-        const double d = xs[i] - t[i];
-        acc += d * d;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += shfl_xor_f64(acc, o);
-      const double v = acc * neg_half_inv_h2;
-      if (v > mx) {
-        s = s * exp(mx - v) + 1.0;
-        mx = v;
-      } else {
-        s += exp(v - mx);
-      }
-    }
-    if (lane == 0) { wm[wave] = mx; wsum[wave] = s; }
-    __syncthreads();
-    if (tid == 0) {
-      double gm = fmax(fmax(wm[0], wm[1]), fmax(wm[2], wm[3]));
-      double gs = 0.0;
-      for (int w = 0; w < 4; ++w)
-        if (wsum[w] > 0.0) gs += wsum[w] * exp(wm[w] - gm);
-      score[row] = log(gs) + gm + log_norm;
-    }
-  }
-}
-
-// The other kernels sklearn's KernelDensity offers (DetectorKDE(kernel=...) forwards any of them, reference
-// inference/postprocessors.py:78-128): tophat, epanechnikov, exponential, linear, cosine - values in [0, 1], so the
-// density is a plain f64 sum over the training rows (one wave per training row, fixed order), then one log.
-// KIND: 1 tophat [d < h], 2 epanechnikov 1 - d^2 / h^2, 3 exponential exp(-d / h), 4 linear 1 - d / h, 5 cosine
-// cos(pi d / 2 h); compact kernels are 0 from d >= h on (sklearn's strict d < h).  No training row in range: log(0) = -inf.
-template <int KIND>
-__global__ __launch_bounds__(256) void kde_other_kernel(const double* __restrict__ train, const double* __restrict__ x,
-                                                         double* __restrict__ score, int64_t M, int64_t N, int64_t D, double h,
-                                                         double log_norm) {
-  extern __shared__ double xs[];  // D doubles
-  __shared__ double wsum[4];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int64_t row = blockIdx.x; row < N; row += gridDim.x) {
-    __syncthreads();
-    for (int64_t i = tid; i < D; i += 256) xs[i] = x[row * D + i];
-    __syncthreads();
-    double s = 0.0;
-    for (int64_t m = wave; m < M; m += 4) {
-      const double* t = train + m * D;
-      double acc = 0.0;
-      for (int64_t i = lane; i < D; i += 64) {
-        const double d = xs[i] - t[i];
-        acc += d * d;
-      }
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) acc += shfl_xor_f64(acc, o);
-      const double dist = sqrt(acc);
-      double kv;
-      if (KIND == 1) kv = dist < h ? 1.0 : 0.0;
-      else if (KIND == 2) kv = dist < h ? 1.0 - (dist * dist) / (h * h) : 0.0;
-      else if (KIND == 3) kv = exp(-dist / h);
-      else if (KIND == 4) kv = dist < h ? 1.0 - dist / h : 0.0;
-      else kv = dist < h ? cos(0.5 * M_PI * dist / h) : 0.0;
-      s += kv;
-    }
-    if (lane == 0) wsum[wave] = s;
-    __syncthreads();
-    if (tid == 0) score[row] = log((wsum[0] + wsum[1]) + (wsum[2] + wsum[3])) + log_norm;
-  }
-}
-
-// Gaussian KDE for D <= 64 (the regime where the reference's tree evaluation is converged): one thread
-// owns one query with its D coordinates in registers; training rows are staged through LDS and read as broadcasts;
-// the four waves of a workgroup take a quarter of every staged tile each and merge their (max, sum) pairs at the end.
-// Per (query, train row): 2*D f64 ops + one f64 exp; logsumexp is kept online per group of 8 rows.
-// Any D <= DP: training rows staged through LDS and read as broadcasts; NW waves share 64 queries and split every
-// staged tile.  NW = 16 (8 at DP = 64: register budget) when the batch has too few 64-query groups to fill the chip.
-template <int DP, int NW>
-__global__ __launch_bounds__(64 * NW) void kde_small_kernel(const double* __restrict__ train,
-                                                             const double* __restrict__ x,
-                                                             double* __restrict__ score, int64_t M, int64_t N, int D,
-                                                             double neg_half_inv_h2, double log_norm) {
-  constexpr int TM = (NW == 4) ? 64 : ((DP <= 32) ? 128 : 64);  // staged training rows (<= 32 KB of LDS)
-  constexpr int RPW = TM / NW;                                   // rows per wave and tile
-  constexpr int GS = (RPW < 8) ? RPW : 8;                        // rows per online-logsumexp group
-  __shared__ double tile[TM][DP];
-  __shared__ double pm[NW][64], ps[NW][64];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int64_t qrow = (int64_t)blockIdx.x * 64 + lane;
-  double xq[DP];
-#pragma unroll
-  for (int i = 0; i < DP; ++i) xq[i] = (qrow < N && i < D) ? x[qrow * D + i] : 0.0;
-  double mx = -kInfD(), sum = 0.0;
-  for (int64_t t0 = 0; t0 < M; t0 += TM) {
-    __syncthreads();
-    for (int i = tid; i < TM * DP; i += 64 * NW) {
-      const int r = i / DP, c = i - r * DP;
-      tile[r][c] = (t0 + r < M && c < D) ? train[(t0 + r) * D + c] : 0.0;
-    }
-    __syncthreads();
-    const int rows = (int)((M - t0 < TM) ? (M - t0) : TM);
-#pragma unroll
-    for (int g = 0; g < RPW / GS; ++g) {  // this wave's share of the tile, GS rows at a time
-      const int r0 = wave * RPW + g * GS;
-      double v[GS];
-      double gmax = -kInfD();
-#pragma unroll
-      for (int j = 0; j < GS; ++j) {
-        double acc = 0.0;
-#pragma unroll
-        for (int i = 0; i < DP; ++i) {
-          const double d = xq[i] - tile[r0 + j][i];
-          acc = fma(d, d, acc);
-        }
-        v[j] = (r0 + j < rows) ? acc * neg_half_inv_h2 : -kInfD();
-        gmax = fmax(gmax, v[j]);
-      }
-      if (gmax > -kInfD()) {
-        const double mnew = fmax(mx, gmax);
-        double part = 0.0;
-#pragma unroll
-        for (int j = 0; j < GS; ++j) part += exp(v[j] - mnew);
-        sum = sum * exp(mx - mnew) + part;
-        mx = mnew;
-      }
-    }
-  }
-  pm[wave][lane] = mx;
-  ps[wave][lane] = sum;
-  __syncthreads();
-  if (wave == 0 && qrow < N) {
-    double gm = pm[0][lane];
-#pragma unroll
-    for (int w = 1; w < NW; ++w) gm = fmax(gm, pm[w][lane]);
-    double gs = 0.0;
-#pragma unroll
-    for (int w = 0; w < NW; ++w)
-      if (ps[w][lane] > 0.0) gs += ps[w][lane] * exp(pm[w][lane] - gm);
-    score[qrow] = log(gs) + gm + log_norm;
-  }
-}
-
-template <int DP>
-void launch_kde_small(const double* train, const double* x, double* score, int64_t M, int64_t N, int D, double nh,
-                      double log_norm, hipStream_t s) {
-  const unsigned qblocks = (unsigned)((N + 63) / 64);
-  const bool few = (int64_t)qblocks < 2 * runia_cu_count();
-  // (training rows through the scalar cache instead of LDS - s_load_dwordx16, SGPR operands - measured 0.355 / 3.81 /
-  //  2.60 ms against 0.365 / 2.90 / 1.84 ms at D = 16 / 32 / 64: not kept)
-  if (few) {  // 16 waves leave 128 VGPRs per lane: enough for D <= 32, not for a 64-wide query -> 8 waves there
-    if constexpr (DP <= 32) kde_small_kernel<DP, 16><<<qblocks, 1024, 0, s>>>(train, x, score, M, N, D, nh, log_norm);
-    else kde_small_kernel<DP, 8><<<qblocks, 512, 0, s>>>(train, x, score, M, N, D, nh, log_norm);
-  } else {
-    kde_small_kernel<DP, 4><<<qblocks, 256, 0, s>>>(train, x, score, M, N, D, nh, log_norm);
-  }
-}
-
 constexpr int64_t kQueryChunk = 8192;  // query rows per distance-workspace pass
 
 }  // namespace
-
-namespace {
-// ---- final linear layer with a small head (C <= 16: CIFAR-10-sized ReAct / DICE / ASH / ViM logits) ---------------------
-// The 128 x 128 matrix-core tile spends 118 of its 128 columns on padding there (1 M x 512 -> 10: 4.3 ms, 0.5 TB/s of
-// rows).  Here a wave takes one row at a time: lane = four adjacent features per 256-feature stripe (16-byte loads), the
-// head's weights come from LDS, the C partial dot products of a row are summed over the wave by the halving exchange of
-// the joint-entropy kernel (v_permlane32_swap / v_permlane16_swap / DPP: ~40 instructions for up to 16 sums) and lane
-// quad c writes logit c.  Row-streaming: 1 M x 512 -> 10 in 0.71 ms (2.9 TB/s of rows).
-constexpr int kSkinnyMaxC = 16;
-constexpr int kSkinnyMaxFloats = 24576;  // C * D floats of weights in LDS (96 KB)
-#ifndef SKINNY_RPW
-#define SKINNY_RPW 16
-#endif
-constexpr int kSkinnyRowsPerWave = SKINNY_RPW;   // consecutive rows a wave works through (amortises the weight staging)
-
-template <int CTRL, int BANKS = 0xf>
-__device__ __forceinline__ float dpp_f32(float old, float v) {
-  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(v), CTRL, 0xf, BANKS, false));
-}
-// 16 per-lane partial sums -> their totals over the wave; lane L ends with slot (L >> 2) & 15
-__device__ __forceinline__ float wave_sum16(float (&v)[16], int lane) {
-#pragma unroll
-  for (int j = 0; j < 8; ++j) {
-    const auto r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 8]), false, false);
-    v[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const auto r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[j]), __float_as_uint(v[j + 4]), false, false);
-    v[j] = __uint_as_float(r[0]) + __uint_as_float(r[1]);
-  }
-  const bool u8 = (lane & 8) != 0, u4 = (lane & 4) != 0;
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {  // lanes i, i ^ 8
-    const float send = u8 ? v[j] : v[j + 2], keep = u8 ? v[j + 2] : v[j];
-    v[j] = keep + dpp_f32<0x128>(send, send);  // row_ror:8
-  }
-  {  // lanes i, i ^ 4
-    const float send = u4 ? v[0] : v[1], keep = u4 ? v[1] : v[0];
-    float recv = dpp_f32<0x124, 0xA>(send, send);  // row_ror:4 into banks 1, 3
-    recv = dpp_f32<0x12C, 0x5>(recv, send);        // row_ror:12 into banks 0, 2
-    v[0] = keep + recv;
-  }
-  float r = v[0];
-  r += dpp_f32<0x4E>(r, r);  // quad_perm:[2,3,0,1]
-  r += dpp_f32<0xB1>(r, r);  // quad_perm:[1,0,3,2]
-  return r;
-}
-
-template <int CT>  // CT = classes rounded up to 4, 8, 12 or 16 (accumulator registers)
-__global__ __launch_bounds__(256) void linear_skinny_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                             const float* __restrict__ bias, float* __restrict__ out,
-                                                             int64_t N, int D, int C, float clip_max) {
-  extern __shared__ __attribute__((aligned(16))) float wl[];  // [C][D]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  for (int i = tid; i < C * D / 4; i += 256) reinterpret_cast<float4*>(wl)[i] = reinterpret_cast<const float4*>(w)[i];
-  __syncthreads();
-  const int n4 = D >> 2;                   // float4 per row
-  const int stripes = (n4 + 63) / 64;
-  const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * kSkinnyRowsPerWave;
-  for (int rr = 0; rr < kSkinnyRowsPerWave; ++rr) {  // (next row's loads issued ahead of this row's sums: 0.71 -> 0.79 ms)
-    const int64_t row = row0 + rr;
-    if (row >= N) break;  // wave-uniform
-    const float4* xr = reinterpret_cast<const float4*>(x + row * D);
-    float acc[16];
-#pragma unroll
-    for (int c = 0; c < 16; ++c) acc[c] = 0.f;
-    for (int st = 0; st < stripes; ++st) {
-      const int i4 = lane + 64 * st;
-      if (i4 < n4) {
-        float4 v = xr[i4];
-        // x > clip ? clip : x keeps a NaN activation, as np.clip and the matmul that follows do upstream
-        v.x = v.x > clip_max ? clip_max : v.x; v.y = v.y > clip_max ? clip_max : v.y;
-        v.z = v.z > clip_max ? clip_max : v.z; v.w = v.w > clip_max ? clip_max : v.w;
-#pragma unroll
-        for (int c = 0; c < CT; ++c) {
-          if (c < C) {
-            const float4 ww = reinterpret_cast<const float4*>(wl + c * D)[i4];
-            acc[c] = fmaf(v.x, ww.x, acc[c]);
-            acc[c] = fmaf(v.y, ww.y, acc[c]);
-            acc[c] = fmaf(v.z, ww.z, acc[c]);
-            acc[c] = fmaf(v.w, ww.w, acc[c]);
-          }
-        }
-      }
-    }
-    const float total = wave_sum16(acc, lane);
-    const int c = (lane >> 2) & 15;
-    if ((lane & 3) == 0 && c < C) out[row * C + c] = total + (bias ? bias[c] : 0.f);
-  }
-}
-}  // namespace
-
-// Final linear layer for a handful of rows (serving one image at a time: 1 row x 2048 -> 1000 took 0.22 ms on the
-// 128 x 128 tiles of the matrix-core kernel, 127 rows of every tile padding): one thread per (row, class) walks the
-// class's weights with ONE f32 fma chain in the k order of the matrix-core kernel - its v_mfma_f32_32x32x2_f32 pairs
-// multiply k = 4s, 4s + 2 and then 4s + 1, 4s + 3 of every four, each instruction an exact fma chain - so a row gets the
-// same bits alone as inside a batch (tests).
-namespace {
-constexpr int kLinearFewRows = 8;
-// (a workgroup of 64 classes x 4 rows with the weights staged 32 k at a time through LDS measured slower - 115 us against
-// 89 for one row x 2048 -> 1000: 16 workgroups, two barriers and one exposed load latency per chunk)
-__global__ __launch_bounds__(256) void linear_few_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                              int64_t N, int64_t D, int64_t C, float clip_max) {
-  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
-  if (idx >= N * C) return;
-  const int64_t row = idx / C, c = idx - row * C;
-  const float* xr = x + row * D;
-  const float* wr = w + c * D;
-  float acc = 0.f;
-  int64_t k0 = 0;
-  if (((D & 3) == 0) && ((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0) {
-    // 16-byte loads, four groups of four in flight
-    const float4* x4 = reinterpret_cast<const float4*>(xr);
-    const float4* w4 = reinterpret_cast<const float4*>(wr);
-    const int64_t n4 = D >> 2;
-    int64_t g4 = 0;
-    for (; g4 + 4 <= n4; g4 += 4) {
-      float4 xa[4], wa[4];
-#pragma unroll
-      for (int u = 0; u < 4; ++u) { xa[u] = x4[g4 + u]; wa[u] = w4[g4 + u]; }
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const float a0 = (xa[u].x > clip_max) ? clip_max : xa[u].x, a1 = (xa[u].y > clip_max) ? clip_max : xa[u].y;
-        const float a2 = (xa[u].z > clip_max) ? clip_max : xa[u].z, a3 = (xa[u].w > clip_max) ? clip_max : xa[u].w;
-        acc = fmaf(a0, wa[u].x, acc);
-        acc = fmaf(a2, wa[u].z, acc);
-        acc = fmaf(a1, wa[u].y, acc);
-        acc = fmaf(a3, wa[u].w, acc);
-      }
-    }
-    k0 = g4 * 4;
-  }
-  for (; k0 + 4 <= D; k0 += 4) {
-    float xv[4], wv[4];
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float v = xr[k0 + j];
-      xv[j] = (v > clip_max) ? clip_max : v;  // np.clip keeps a NaN activation
-      wv[j] = wr[k0 + j];
-    }
-    acc = fmaf(xv[0], wv[0], acc);
-    acc = fmaf(xv[2], wv[2], acc);
-    acc = fmaf(xv[1], wv[1], acc);
-    acc = fmaf(xv[3], wv[3], acc);
-  }
-  if (k0 < D) {  // the last, partial group of four: the missing k are zeros in the matrix-core kernel's staging
-    float xv[4] = {0.f, 0.f, 0.f, 0.f}, wv[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int j = 0; k0 + j < D; ++j) {
-      const float v = xr[k0 + j];
-      xv[j] = (v > clip_max) ? clip_max : v;
-      wv[j] = wr[k0 + j];
-    }
-    acc = fmaf(xv[0], wv[0], acc);
-    acc = fmaf(xv[2], wv[2], acc);
-    acc = fmaf(xv[1], wv[1], acc);
-    acc = fmaf(xv[3], wv[3], acc);
-  }
-  if (D % KCH) acc = fmaf(0.f, 0.f, acc);  // the zero padding of the last 32-chunk (only turns a -0 into +0)
-  out[idx] = acc + (bias ? bias[c] : 0.f);
-}
-
-// Some tens to hundreds of rows (9 ... 512: a batch of a service, the proposals of an image): the matrix-core kernel has one
-// 128-row tile against C / 128 column tiles - 8 workgroups for 1000 classes, each walking all of K alone (64 ... 512 rows x
-// 2048 -> 1000: 203-226 us).  Here a workgroup takes 64 rows x 16 classes (63 workgroups per 64 rows at 1000 classes): rows
-// and weights staged 64 k at a time through LDS (two buffers, the next chunk's loads in flight during the arithmetic), a
-// thread = one row x four classes, and every (row, class) is again ONE f32 fma chain in the matrix-core kernel's k order -
-// same bits as inside a large batch.  (A wave per 64 classes x 8 rows with the weights streamed per lane - no LDS - ran
-// 249-270 us: one wave per compute unit and a latency chain of 512 load groups.)
-constexpr int kLinearMidRows = 512;
-constexpr int kMidRows = 64, kMidCls = 16, kMidK = 64, kMidPitch = kMidK + 4;  // pitch 68 floats: rows 16-byte aligned, 68 mod 32 = 4
-__global__ __launch_bounds__(256) void linear_mid_rows_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                              const float* __restrict__ bias, float* __restrict__ out,
-                                                              int64_t N, int64_t D, int64_t C, float clip_max) {
-  __shared__ __attribute__((aligned(16))) float xs[2][kMidRows][kMidPitch];
-  __shared__ __attribute__((aligned(16))) float ws[2][kMidCls][kMidPitch];
-  const int tid = threadIdx.x;
-  const int row_l = tid & 63, cq = tid >> 6;  // thread: row row_l, classes 4 cq .. 4 cq + 3 of the tile (a wave shares its classes)
-  const int64_t r0 = (int64_t)blockIdx.y * kMidRows, c0 = (int64_t)blockIdx.x * kMidCls;
-  const bool vec = ((D & 3) == 0) && ((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0;
-  // staging: 64 rows x 64 k = 1024 float4 (4 per thread), 16 classes x 64 k = 256 float4 (1 per thread); zeros beyond D / N / C
-  auto fetch = [&](int64_t k0, float4 (&xr)[4], float4& wr) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + 256 * u, rr = idx >> 4, kq = (idx & 15) * 4;
-      const int64_t row = r0 + rr, k = k0 + kq;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (row < N) {
-        const float* p = x + row * D + k;
-        if (vec && k + 4 <= D) v = *reinterpret_cast<const float4*>(p);
-        else {
-          if (k < D) v.x = p[0];
-          if (k + 1 < D) v.y = p[1];
-          if (k + 2 < D) v.z = p[2];
-          if (k + 3 < D) v.w = p[3];
-        }
-      }
-      xr[u] = v;
-    }
-    {
-      const int cc = tid >> 4, kq = (tid & 15) * 4;
-      const int64_t cls = c0 + cc, k = k0 + kq;
-      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (cls < C) {
-        const float* p = w + cls * D + k;
-        if (vec && k + 4 <= D) v = *reinterpret_cast<const float4*>(p);
-        else {
-          if (k < D) v.x = p[0];
-          if (k + 1 < D) v.y = p[1];
-          if (k + 2 < D) v.z = p[2];
-          if (k + 3 < D) v.w = p[3];
-        }
-      }
-      wr = v;
-    }
-  };
-  auto clipf = [&](float v) { return (v > clip_max) ? clip_max : v; };  // np.clip keeps a NaN activation
-  auto stash = [&](int buf, const float4 (&xr)[4], const float4& wr) {
-#pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const int idx = tid + 256 * u, rr = idx >> 4, kq = (idx & 15) * 4;
-      *reinterpret_cast<float4*>(&xs[buf][rr][kq]) = make_float4(clipf(xr[u].x), clipf(xr[u].y), clipf(xr[u].z), clipf(xr[u].w));
-    }
-    *reinterpret_cast<float4*>(&ws[buf][tid >> 4][(tid & 15) * 4]) = wr;
-  };
-  float acc[4] = {0.f, 0.f, 0.f, 0.f};
-  const int64_t nchunks = (D + kMidK - 1) / kMidK;
-  float4 xr[4], wr;
-  fetch(0, xr, wr);
-  int buf = 0;
-  for (int64_t ch = 0; ch < nchunks; ++ch) {
-    stash(buf, xr, wr);
-    __syncthreads();
-    if (ch + 1 < nchunks) fetch((ch + 1) * kMidK, xr, wr);
-    // groups of four k that start beyond D do not exist in the matrix-core kernel's chain (its zero padding ends at the
-    // 32-chunk; see the fma(0, 0, acc) below); a partial group's missing k are zeros, as staged
-    const int64_t kleft = D - ch * kMidK;
-    const int groups = (int)((kleft >= kMidK) ? kMidK / 4 : (kleft + 3) / 4);
-    for (int g = 0; g < groups; ++g) {
-      const float4 xv = *reinterpret_cast<const float4*>(&xs[buf][row_l][4 * g]);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const float4 wv = *reinterpret_cast<const float4*>(&ws[buf][4 * cq + j][4 * g]);  // (one address per wave: broadcast)
-        acc[j] = fmaf(xv.x, wv.x, acc[j]);
-        acc[j] = fmaf(xv.z, wv.z, acc[j]);
-        acc[j] = fmaf(xv.y, wv.y, acc[j]);
-        acc[j] = fmaf(xv.w, wv.w, acc[j]);
-      }
-    }
-    buf ^= 1;  // (the next stash goes to the other buffer; the barrier of the next trip orders it against this trip's reads)
-  }
-  const int64_t row = r0 + row_l;
-#pragma unroll
-  for (int j = 0; j < 4; ++j) {
-    const int64_t cls = c0 + 4 * cq + j;
-    if (row < N && cls < C) {
-      float a = acc[j];
-      if (D % KCH) a = fmaf(0.f, 0.f, a);  // the zero padding of the last 32-chunk (only turns a -0 into +0)
-      out[row * C + cls] = a + (bias ? bias[cls] : 0.f);
-    }
-  }
-}
-}  // namespace
-
-// 1-D grid of knn_dist_kernel for Q x M: whole super-tiles, a multiple of 8 of them
-static inline unsigned knn_dist_grid(int64_t Q, int64_t M) {
-  const int64_t nbt = (M + TB - 1) / TB, nqt = (Q + TQ - 1) / TQ;
-  const int sq = knn_super_q(nqt);
-  const int64_t st = ((nbt + kSuperB - 1) / kSuperB) * ((nqt + sq - 1) / sq);
-  return (unsigned)(((st + 7) / 8) * 8 * kSuperB * sq);
-}
 
 // knn_bf16.hip: candidate distances of large problems from bf16 piece products (6/16 of the f32 kernel's matrix-pipe time)
 int64_t runia_knn16_padded_rows(int64_t rows);
@@ -1559,113 +927,4 @@ extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, con
     r16.q_planes = reinterpret_cast<uint16_t*>(r16.ws + r16.f.end);
   }
   return knn_scan(q, bank, score, dist, qn, bn, bn_max, use16 ? &r16 : nullptr, qc, N, M, D, k, s, 1);
-}
-
-extern "C" int runia_linear_f32(const float* x, const float* w, const float* bias, float* out, int64_t N, int64_t D,
-                                int64_t C, float clip_max, runia_stream_t stream) {
-  if (N < 0 || D <= 0 || C <= 0) return RUNIA_E_INVALID;
-  if (N == 0) return RUNIA_OK;
-  if (!x || !w || !out) return RUNIA_E_INVALID;
-  hipStream_t s = as_stream(stream);
-  if (C <= kSkinnyMaxC && C * D <= kSkinnyMaxFloats && (D & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)w)) & 15) == 0) {
-    const size_t lds = (size_t)C * D * sizeof(float);
-    const int64_t per_wg = 4 * kSkinnyRowsPerWave;
-    const unsigned grid = (unsigned)((N + per_wg - 1) / per_wg);
-#define RUNIA_SKINNY(CT)                                                                                          \
-  {                                                                                                               \
-    static std::atomic<uint64_t> lds_ok{0};                                                                       \
-    if (runia_allow_dynamic_lds(reinterpret_cast<const void*>(linear_skinny_kernel<CT>), 96 * 1024, lds_ok) !=    \
-        RUNIA_OK)                                                                                                 \
-      return RUNIA_E_LAUNCH;                                                                                      \
-    linear_skinny_kernel<CT><<<grid, 256, lds, s>>>(x, w, bias, out, N, (int)D, (int)C, clip_max);               \
-  }
-    if (C <= 4) RUNIA_SKINNY(4)
-    else if (C <= 8) RUNIA_SKINNY(8)
-    else if (C <= 12) RUNIA_SKINNY(12)
-    else RUNIA_SKINNY(16)
-#undef RUNIA_SKINNY
-    return runia_check_launch();
-  }
-  if (N <= kLinearFewRows) {
-    linear_few_rows_kernel<<<(unsigned)((N * C + 255) / 256), 256, 0, s>>>(x, w, bias, out, N, D, C, clip_max);
-    return runia_check_launch();
-  }
-  if (N <= kLinearMidRows) {
-    const dim3 grid((unsigned)((C + kMidCls - 1) / kMidCls), (unsigned)((N + kMidRows - 1) / kMidRows));
-    linear_mid_rows_kernel<<<grid, 256, 0, s>>>(x, w, bias, out, N, D, C, clip_max);
-    return runia_check_launch();
-  }
-  const int64_t qt = (N + TQ - 1) / TQ;
-  for (int64_t t0 = 0; t0 < qt; t0 += 65535) {  // grid.y limit
-    const int64_t tiles = (qt - t0 < 65535) ? (qt - t0) : 65535;
-    const int64_t r0 = t0 * TQ;
-    const int64_t rows = (N - r0 < tiles * TQ) ? (N - r0) : tiles * TQ;
-    knn_dist_kernel<EPI_LINEAR><<<knn_dist_grid(rows, C), 256, 0, s>>>(x + r0 * D, w, nullptr, bias, out + r0 * C, rows, C, D, clip_max);
-  }
-  return runia_check_launch();
-}
-
-extern "C" int runia_kde_score_f64(const double* train, const double* x, double* score, int64_t M, int64_t N,
-                                   int64_t D, double bandwidth, runia_stream_t stream) {
-  if (M <= 0 || N < 0 || D <= 0 || !(bandwidth > 0.0)) return RUNIA_E_INVALID;
-  if (N == 0) return RUNIA_OK;
-  if (!train || !x || !score) return RUNIA_E_INVALID;
-  const double log_norm = -log((double)M) - (double)D * log(bandwidth) - 0.5 * (double)D * log(2.0 * M_PI);
-  const double nh = -0.5 / (bandwidth * bandwidth);
-  hipStream_t s = as_stream(stream);
-  if (D <= 8) launch_kde_small<8>(train, x, score, M, N, (int)D, nh, log_norm, s);
-  else if (D <= 16) launch_kde_small<16>(train, x, score, M, N, (int)D, nh, log_norm, s);
-  else if (D <= 32) launch_kde_small<32>(train, x, score, M, N, (int)D, nh, log_norm, s);
-  else if (D <= 64) launch_kde_small<64>(train, x, score, M, N, (int)D, nh, log_norm, s);
-  else {
-    const size_t shmem = (size_t)D * sizeof(double);
-    if (shmem > 64 * 1024) return RUNIA_E_INVALID;
-    kde_kernel<<<runia_stream_grid(N, 1), 256, shmem, s>>>(train, x, score, M, N, D, nh, log_norm);
-  }
-  return runia_check_launch();
-}
-
-// log of sklearn's kernel normalisation (neighbors/_binary_tree.pxi.tp, _log_kernel_norm): -factor - d log h
-static double kde_log_norm(int kind, int64_t D, double h) {
-  const double d = (double)D, log_pi = log(M_PI), log_2pi = log(2.0 * M_PI);
-  auto logVn = [&](double n) { return 0.5 * n * log_pi - lgamma(0.5 * n + 1.0); };  // volume of the unit n-ball
-  auto logSn = [&](double n) { return log_2pi + logVn(n - 1.0); };                   // surface of the unit n-sphere
-  double factor = 0.0;
-  switch (kind) {
-    case 0: factor = 0.5 * d * log_2pi; break;
-    case 1: factor = logVn(d); break;
-    case 2: factor = logVn(d) + log(2.0 / (d + 2.0)); break;
-    case 3: factor = logSn(d - 1.0) + lgamma(d); break;
-    case 4: factor = logVn(d) - log(d + 1.0); break;
-    default: {
-      double tmp = 2.0 / M_PI;
-      for (int64_t k = 1; k < D + 1; k += 2) {
-        factor += tmp;
-        tmp *= -(d - (double)k) * (d - (double)k - 1.0) * (2.0 / M_PI) * (2.0 / M_PI);
-      }
-      factor = log(factor) + logSn(d - 1.0);
-    }
-  }
-  return -factor - d * log(h);
-}
-
-extern "C" int runia_kde_score_kernel_f64(const double* train, const double* x, double* score, int64_t M, int64_t N,
-                                          int64_t D, double bandwidth, int kind, runia_stream_t stream) {
-  if (kind == 0) return runia_kde_score_f64(train, x, score, M, N, D, bandwidth, stream);
-  if (M <= 0 || N < 0 || D <= 0 || !(bandwidth > 0.0) || kind < 0 || kind > 5) return RUNIA_E_INVALID;
-  if (N == 0) return RUNIA_OK;
-  if (!train || !x || !score) return RUNIA_E_INVALID;
-  const size_t shmem = (size_t)D * sizeof(double);
-  if (shmem > 64 * 1024) return RUNIA_E_INVALID;
-  const double log_norm = -log((double)M) + kde_log_norm(kind, D, bandwidth);
-  hipStream_t s = as_stream(stream);
-  const unsigned grid = runia_stream_grid(N, 1);
-  switch (kind) {
-    case 1: kde_other_kernel<1><<<grid, 256, shmem, s>>>(train, x, score, M, N, D, bandwidth, log_norm); break;
-    case 2: kde_other_kernel<2><<<grid, 256, shmem, s>>>(train, x, score, M, N, D, bandwidth, log_norm); break;
-    case 3: kde_other_kernel<3><<<grid, 256, shmem, s>>>(train, x, score, M, N, D, bandwidth, log_norm); break;
-    case 4: kde_other_kernel<4><<<grid, 256, shmem, s>>>(train, x, score, M, N, D, bandwidth, log_norm); break;
-    default: kde_other_kernel<5><<<grid, 256, shmem, s>>>(train, x, score, M, N, D, bandwidth, log_norm); break;
-  }
-  return runia_check_launch();
 }
