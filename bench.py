@@ -13,8 +13,9 @@ finds its inputs in a cache.
 process, before this process makes any GPU call) and exits with the child's code.
 
 Prints ONE JSON line (rank 0) with the driver's contract plus
-  `roofline`      dominant kernel (K1, sampler + entropy), timed with HIP events on its launch stream inside the timed
-                  region; `achieved` uses BASELINE.md section 4's algorithmic 33 800 B/image;
+  `roofline`      dominant kernel (K1, sampler + entropy), timed inside the timed region with HIP events attached to its
+                  dispatch on its launch stream (the kernel's own start / end timestamps, as rocprofv3's kernel trace
+                  reports them; runia_time_next_launch); `achieved` uses BASELINE.md section 4's algorithmic 33 800 B/image;
   `cpu_baseline`  the CPU oracle in the reference's algorithmic form on a bounded sample, 1 core;
   `cpu_baseline_all_cores`  the same work fanned out per image over a process pool, as the reference's
                   parallel_run=True does (evaluation/entropy.py:86-91);
@@ -628,7 +629,9 @@ def main():
     gc.enable()
 
     # ---------------- roofline of the dominant kernel ------------------------------------------
-    # HIP events bracket K1 alone on its launch stream (pipeline.k1_events).  `achieved` = BASELINE.md section 4's
+    # HIP events attached to K1's dispatch on its launch stream (pipeline.k1_events, _hip._timed_launch_events: the kernel's own
+    # start / end timestamps - an event pair recorded AROUND the launch also counts the ~7 us dispatch gap behind K0, which is
+    # how rounds 3-4 read 0.1113 / 0.1179 ms for a kernel the tracer saw at 0.1073 / 0.1086).  `achieved` = BASELINE.md section 4's
     # algorithmic bytes (33 800 B/image) per launch / that time; the kernel-boundary figure (what K1 itself reads and
     # writes, incl. the f64 entropy rows K2' re-reads) is reported beside it.
     kname = "mc_entropy_kernel"

@@ -45,6 +45,11 @@ int runia_device_count(void);
  *   out4[0] = shader-clock ticks, out4[1] = 100 MHz ticks, out4[2] = FMAs executed, out4[3] unused.
  * Clock held = out4[0] / (out4[1] * 10 ns). */
 int runia_clock_probe(uint64_t* out4, int chain, runia_stream_t stream);
+/* Kernel-only timing of ONE launch (measurement records): the next call of this thread to an entry point with a timed launch
+ * site (runia_mc_entropy_from_table_f32: the dominant kernel of the headline step) attaches the two hipEvent_t to its dispatch
+ * - they then carry the kernel's own start and end timestamps, as rocprofv3's kernel trace does, without the dispatch gap an
+ * event pair recorded around the launch includes.  Both events must exist (have been recorded once); (NULL, NULL) clears. */
+int runia_time_next_launch(void* start_event, void* stop_event);
 
 /* ---- a1  MC-dropout latent stacking ------------------------------------- *
  * Replaces MCSamplerModule.forward (feature_extraction/abstract_classes.py:81-101)

@@ -25,6 +25,7 @@ _SIGNATURES = {
     "runia_error_string": (c_char_p, [c_int]),
     "runia_device_count": (c_int, []),
     "runia_clock_probe": (c_int, [c_void_p, c_int, c_void_p]),
+    "runia_time_next_launch": (c_int, [c_void_p, c_void_p]),
     "runia_mc_stack_f32": (
         c_int,
         [c_void_p, c_void_p, c_int64, c_void_p, c_int64, c_int, c_int, c_int, c_int, c_double, c_int, c_void_p],
@@ -747,6 +748,17 @@ def kde_score(train: torch.Tensor, x: torch.Tensor, bandwidth: float = 1.0) -> t
     return s
 
 
+def _timed_launch_events():
+    """An event pair attached to the NEXT timed launch site (``runia_time_next_launch``): the events then hold the kernel's
+    own start / end timestamps (what rocprofv3's kernel trace reports).  A pair recorded around the launch on the stream also
+    counts the dispatch gap behind the previous kernel: K1 read 117.3 us that way against 109.5 us in the trace of the same run."""
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()  # (creates the underlying events; the launch re-records them)
+    e1.record()
+    _check(load_library().runia_time_next_launch(e0.cuda_event, e1.cuda_event), "runia_time_next_launch")
+    return e0, e1
+
+
 def mc_entropy_supported(h: int, w: int, n_mc: int, k: int) -> bool:
     return bool(load_library().runia_mc_entropy_supported(int(h), int(w), int(n_mc), int(k)))
 
@@ -791,8 +803,9 @@ def mc_entropy(x: torch.Tensor, rand: Union[torch.Tensor, CounterDraws, None], n
                kernel_events: Optional[list] = None, zero_fill: Optional[torch.Tensor] = None,
                table: Optional[torch.Tensor] = None):
     """Fused sampler + entropy: x [N,C,H,W] f32 (+ draws) -> h [N, C] f64 (and optionally the MC samples).
-    ``kernel_events``: if a list, (start, end) HIP event pairs around the sampler + entropy launch alone (the
-    keep-flag table launch before it is left out) are appended - bench.py times the dominant kernel with it.
+    ``kernel_events``: if a list, (start, end) HIP event pairs attached to the dispatch of the sampler + entropy launch
+    (the kernel's own start / end timestamps; the keep-flag table launch before it is left out) are appended - bench.py
+    times the dominant kernel with it.
     ``zero_fill``: optional [N] f64 tensor cleared by the launch (the accumulator of ``proj_sq_accumulate``).
     ``table``: the batch's keep-flag table built earlier by :func:`mc_mask_table` (``rand`` is then ignored)."""
     lib = load_library()
@@ -809,13 +822,11 @@ def mc_entropy(x: torch.Tensor, rand: Union[torch.Tensor, CounterDraws, None], n
         if zero_fill is not None:
             assert zero_fill.is_cuda and zero_fill.dtype == torch.float64 and zero_fill.shape == (n,) and zero_fill.is_contiguous()
         if kernel_events is not None:
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0, e1 = _timed_launch_events()
         _check(lib.runia_mc_entropy_from_table_f32(x.data_ptr(), table.data_ptr(), ws_bytes, h.data_ptr(), _ptr(z),
                                                    _ptr(zero_fill), n, c, hh, ww, n_mc, int(k), float(min_dist), _stream()),
                "runia_mc_entropy_from_table_f32")
         if kernel_events is not None:
-            e1.record()
             kernel_events.append((e0, e1))
         return (h, z) if want_samples else h
     stride = 0
@@ -876,15 +887,13 @@ def mc_entropy(x: torch.Tensor, rand: Union[torch.Tensor, CounterDraws, None], n
                                                 int(block_size), _stream()),
                     "runia_mc_mask_table_f32",
                 )
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            e0.record()
+            e0, e1 = _timed_launch_events()
             _check(
                 lib.runia_mc_entropy_from_table_f32(x.data_ptr() + done * c * hh * ww * 4, ws.data_ptr(), ws_bytes,
                                                     h.data_ptr() + done * c * 8, zp, zf, m, c, hh, ww, n_mc, int(k),
                                                     float(min_dist), _stream()),
                 "runia_mc_entropy_from_table_f32",
             )
-            e1.record()
             kernel_events.append((e0, e1))
         done += m
     return (h, z) if want_samples else h

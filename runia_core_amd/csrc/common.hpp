@@ -1,6 +1,7 @@
 // Shared helpers for the gfx950 scoring kernels (wave = 64 lanes).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include <atomic>
@@ -17,6 +18,18 @@ static inline int runia_check_launch() {
 }
 
 static inline hipStream_t as_stream(runia_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+// runia_time_next_launch (lib.hip): a caller's event pair that the NEXT timed launch site of this thread attaches to its
+// dispatch (hipExtLaunchKernelGGL: the events carry the kernel's own start / end timestamps - what rocprofv3's kernel trace
+// reports - instead of bracketing the launch on the stream, which adds the dispatch gap behind the previous kernel, ~7 us).
+struct RuniaTimedLaunch { hipEvent_t start, stop; };
+RuniaTimedLaunch runia_take_timed_launch();
+#define RUNIA_LAUNCH_TIMED(kernel, grid, block, shmem, stream, ...)                                                    \
+  do {                                                                                                                 \
+    const RuniaTimedLaunch tl_ = runia_take_timed_launch();                                                            \
+    if (tl_.start) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, stream, tl_.start, tl_.stop, 0, __VA_ARGS__); \
+    else hipLaunchKernelGGL(kernel, dim3(grid), dim3(block), shmem, stream, __VA_ARGS__);                              \
+  } while (0)
 
 // Raise a kernel's dynamic-LDS limit once per DEVICE (the attribute belongs to the device that is current when it is set;
 // a process that moves on to another GPU needs it again).  `done` is one static mask per call site: bit = device id.

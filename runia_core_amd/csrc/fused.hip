@@ -1054,11 +1054,11 @@ extern "C" int runia_mc_entropy_from_table_f32(const float* x, const void* works
 #define RUNIA_MCE(HH, WW, NPP, KK)                                                                          \
   if (H == HH && W == WW && n_mc <= NPP && n_mc > NPP / 2 && k == KK && (x16 || (HH * WW) % 4 != 0)) {      \
     if (n_mc == NPP)                                                                                        \
-      mc_entropy_kernel<HH, WW, NPP, KK, true><<<grid, kK1Block, 0, s>>>(x, table, h, z_out, zero_fill, N,  \
-                                                                         C, n_mc, min_dist, ct, inv_n);     \
+      RUNIA_LAUNCH_TIMED((mc_entropy_kernel<HH, WW, NPP, KK, true>), grid, kK1Block, 0, s, x, table, h, z_out, \
+                         zero_fill, N, C, n_mc, min_dist, ct, inv_n);                                       \
     else                                                                                                    \
-      mc_entropy_kernel<HH, WW, NPP, KK, false><<<grid, kK1Block, 0, s>>>(x, table, h, z_out, zero_fill, N, \
-                                                                          C, n_mc, min_dist, ct, inv_n);    \
+      RUNIA_LAUNCH_TIMED((mc_entropy_kernel<HH, WW, NPP, KK, false>), grid, kK1Block, 0, s, x, table, h, z_out, \
+                         zero_fill, N, C, n_mc, min_dist, ct, inv_n);                                       \
     return runia_check_launch();                                                                            \
   }
   RUNIA_MCE_SHAPES(RUNIA_MCE)

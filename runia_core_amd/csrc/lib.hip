@@ -14,6 +14,19 @@ extern "C" const char* runia_error_string(int code) {
   }
 }
 
+// ---- kernel-only timing of one launch ------------------------------------------------------------------------------------
+static thread_local RuniaTimedLaunch g_timed_launch{nullptr, nullptr};
+RuniaTimedLaunch runia_take_timed_launch() {
+  const RuniaTimedLaunch t = g_timed_launch;
+  g_timed_launch = RuniaTimedLaunch{nullptr, nullptr};
+  return t;
+}
+extern "C" int runia_time_next_launch(void* start_event, void* stop_event) {
+  if ((start_event == nullptr) != (stop_event == nullptr)) return RUNIA_E_INVALID;
+  g_timed_launch = RuniaTimedLaunch{reinterpret_cast<hipEvent_t>(start_event), reinterpret_cast<hipEvent_t>(stop_event)};
+  return RUNIA_OK;
+}
+
 extern "C" int runia_device_count(void) {
   int n = 0;
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;

@@ -878,4 +878,21 @@ def run_larex_eval(device, n_train: int = 50_000, n_valid: int = 10_000, n_ood: 
     rec["parity"] = {"max_abs_diff_auroc_fpr95_aupr_by_postprocessor": {k: [float(x) for x in v] for k, v in diffs.items()},
                      "rows_compared": len(table), "note": "device table against the oracle's on the subset (float32 metric values; "
                      "KDE is the exact density on both sides - the reference's tree diverges above D ~ 24, INTEGRATION.md)"}
+    # the same subset with the fits on the HOST (sklearn / SciPy, what the oracle calls): kNN scores are float32 values crowded
+    # near their k-th distance - a PCA fit that differs in the 11th digit (device Jacobi vs LAPACK) moves a few of them by one
+    # float32 step and swaps a handful of the 400 x 400 score pairs (one pair = 6e-6 of AUROC)
+    from runia_core_amd import config as rc_config
+
+    before = rc_config.device_fit
+    rc_config.device_fit = False
+    try:
+        df_hf, _, _, _ = sweep_run(ind_s, ood_s, True, thresholds=False)
+    finally:
+        rc_config.device_fit = before
+    worst = {}
+    for name, (au, fp, ap) in table.items():
+        g = df_hf.loc[name]
+        pp = name.split()[1]
+        worst[pp] = max(worst.get(pp, 0.0), abs(float(g["auroc"]) - au), abs(float(g["fpr@95"]) - fp), abs(float(g["aupr"]) - ap))
+    rec["parity"]["max_abs_diff_with_host_fits"] = {k: float(v) for k, v in worst.items()}
     return rec
