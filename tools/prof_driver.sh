@@ -18,4 +18,5 @@ else
   run sq SQ_INSTS_VALU SQ_WAVES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY
   run mfma SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_MFMA GRBM_GUI_ACTIVE SQ_BUSY_CYCLES
   cd $GRAFT_REPO_ROOT && python3 tools/prof_summarise.py "$out" "$tag" | tail -5
+  rm -rf $out/fetch $out/write $out/sq $out/mfma   # (the per-dispatch counter files of four passes exceed what gpurun copies back)
 fi
