@@ -53,10 +53,6 @@ struct GemmArgs {
   // EPI_MAHA, few row tiles: one workgroup per (row tile, 256-column block); the (block, wave, row, class) partial sums go
   // to maha_part [n_blocks][4][N][C] and maha_split_finish_kernel adds them up in the unsplit kernel's order
   double* maha_part;
-  // EPI_MAHA, one-launch form (round 5): squared Frobenius norm of P (device scalar).  Non-null = every row tile first ranks the
-  // classes by the exact-arithmetic scores 2 x.q_c - mu_c.q_c (a 32 x D x C prologue on the vector ALUs, 0.5 % of the tile's
-  // time) and the epilogue evaluates the f32-difference class term only for the classes that can still win (maha_candidates)
-  const double* maha_pnorm2;
   // EPI_ROWDOT (MD), few row tiles: one workgroup per (row tile, 256-column block) stores its products (d P)_j d_j to md_vals
   // [tile][block][thread][RT * 4][NCT]; md_replay_kernel adds them up per lane in the unsplit kernel's order
   double* md_vals;
@@ -194,104 +190,6 @@ __device__ __forceinline__ void kde_merge_store(double (&rowdot)[RT][4], double 
   }
 }
 
-// ---- Mahalanobis: which classes can still be a row's maximum (round 5) -------------------------------------------------
-// The class term of the epilogue costs ~37 vector instructions per (row, class, 4 columns) and on gfx950 vector instructions and
-// v_mfma_f64 do not overlap: with 10 classes the epilogue was 13 % of the kernel (30.7 ms without it, 35.3 ms with it per
-// 262 144 x 2048 rows, tools/ablate/run_maha_variants.sh).  But only max_c s_c is returned, and
-//     s_c = -(t P t^T) = -x P x^T + (2 x.q_c - mu_c.q_c) - 2 (a P).e_c,     a = x - mu_c, t = fl32(a) = a + e_c, q_c = mu_c P:
-// the first term is the same for every class, the second is a D-long dot product per class, and the last - the part that needs
-// the GEMM's accumulators - is bounded: |e_cj| <= 2^-24 |a_j|, so |2 (a P).e_c| <= 2^-23 ||P||_2 ||a||^2 <= beta :=
-// 2^-22 ||P||_F (||x||^2 + max_c ||mu_c||^2).  A class whose v_c = 2 x.q_c - mu_c.q_c lies more than 2 beta below the best v
-// cannot be the maximum; the others (one class, as a rule) are the row's candidates.  The winner's term is then evaluated exactly
-// as before - same instructions, same order - so the score is the same bits as with all classes evaluated.  More than two
-// candidates (an ill-conditioned P, coinciding class means): the row evaluates every class.
-template <typename TA, int BM_>
-__device__ __forceinline__ void maha_candidates(const GemmArgs& g, int64_t r0, int tid, double* __restrict__ scratch,
-                                                int* __restrict__ cand_n, unsigned char (*cand_cls)[2]) {
-  constexpr int TPRW = 256 / BM_;  // threads per row (8 at 32 rows)
-  const int C = g.n_classes;
-  const int64_t D = g.K;
-  const TA* x = reinterpret_cast<const TA*>(g.x);
-  const TA* mu = reinterpret_cast<const TA*>(g.class_mean);
-  double* v = scratch;                      // [BM][16]  x.q_c
-  double* xx = v + BM_ * kMahaMaxClasses;   // [BM]      ||x||^2
-  double* qc = xx + BM_;                    // [16]      mu_c.q_c
-  double* mm = qc + kMahaMaxClasses;        // [16]      ||mu_c||^2
-  {  // class constants: 16 lanes per class
-    const int c = tid >> 4, l16 = tid & 15;
-    double a = 0.0, b = 0.0;
-    if (c < C)
-      for (int64_t j = l16; j < D; j += 16) {
-        const double m = (double)mu[(int64_t)c * D + j];
-        a = fma(m, g.mu_p[(int64_t)c * D + j], a);
-        b = fma(m, m, b);
-      }
-#pragma unroll
-    for (int o = 1; o < 16; o <<= 1) { a += shfl_xor_f64(a, o); b += shfl_xor_f64(b, o); }
-    if (l16 == 0) { qc[c] = a; mm[c] = b; }
-  }
-  {  // x.q_c and ||x||^2 of the tile's rows: TPRW lanes per row, each a strided share of the columns
-    const int row = tid / TPRW, sub = tid % TPRW;
-    const int64_t gr = r0 + row;
-    double dot[kMahaMaxClasses], sq = 0.0;
-#pragma unroll
-    for (int c = 0; c < kMahaMaxClasses; ++c) dot[c] = 0.0;
-    if (gr < g.N)
-      for (int64_t j = sub; j < D; j += TPRW) {
-        const double xv = (double)x[gr * g.ldx + j];
-        sq = fma(xv, xv, sq);
-#pragma unroll
-        for (int c = 0; c < kMahaMaxClasses; ++c)
-          if (c < C) dot[c] = fma(xv, g.mu_p[(int64_t)c * D + j], dot[c]);  // (uniform predicate)
-      }
-#pragma unroll
-    for (int o = 1; o < TPRW; o <<= 1) {
-      sq += shfl_xor_f64(sq, o);
-#pragma unroll
-      for (int c = 0; c < kMahaMaxClasses; ++c)
-        if (c < C) dot[c] += shfl_xor_f64(dot[c], o);
-    }
-    if (sub == 0) {
-      xx[row] = sq;
-#pragma unroll
-      for (int c = 0; c < kMahaMaxClasses; ++c)
-        if (c < C) v[row * kMahaMaxClasses + c] = dot[c];
-    }
-  }
-  __syncthreads();
-  if (tid < BM_) {
-    int n = 0;
-    unsigned char c0 = 0, c1 = 0;
-    if (r0 + tid < g.N) {
-      double m = -kInfD(), mumax = 0.0;
-      for (int c = 0; c < C; ++c) {
-        const double vc = 2.0 * v[tid * kMahaMaxClasses + c] - qc[c];
-        if (vc == vc) m = fmax(m, vc);  // a class without samples (NaN mean) is never the maximum
-        if (mm[c] == mm[c]) mumax = fmax(mumax, mm[c]);
-      }
-      const double scale = sqrt(*g.maha_pnorm2) * (xx[tid] + mumax);
-      const double window = 0x1p-21 * scale + 1e-11 * (scale + fabs(m));  // 2 beta + the f64 rounding of the two sides
-      if (m > -kInfD() && m < kInfD() && window == window && window < kInfD()) {
-        for (int c = 0; c < C; ++c) {
-          const double vc = 2.0 * v[tid * kMahaMaxClasses + c] - qc[c];
-          if (vc >= m - window) {
-            if (n == 0) c0 = (unsigned char)c;
-            else if (n == 1) c1 = (unsigned char)c;
-            ++n;
-          }
-        }
-        if (n > 2) n = C;  // every class, slot = class
-      } else {
-        n = C;             // non-finite scores: nothing is ruled out
-      }
-    }
-    cand_n[tid] = n;
-    cand_cls[tid][0] = c0;
-    cand_cls[tid][1] = c1;
-  }
-  __syncthreads();
-}
-
 template <typename TA, typename TS, int EPI, int RT = 2, int NCT = 4>
 __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   constexpr int BM = 16 * RT;  // rows per workgroup (shadows the file-level default of 32)
@@ -300,12 +198,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   __shared__ double lds_part2[(EPI == EPI_KDE) ? 4 : 1][BM];
   // EPI_MAHA: per (wave, row, class) partial of sum_j (G_j - (mu_c P)_j)(2 t_j - a_j); every slot is owned by one lane
   __shared__ double lds_cls[(EPI == EPI_MAHA) ? 4 * BM * kMahaMaxClasses : 1];
-  __shared__ int cand_n[(EPI == EPI_MAHA) ? BM : 1];
-  __shared__ unsigned char cand_cls[(EPI == EPI_MAHA) ? BM : 1][2];
-  bool use_cand = false;  // (uniform)
   if constexpr (EPI == EPI_MAHA) {
-    use_cand = g.maha_pnorm2 != nullptr && g.maha_part == nullptr && g.n_classes > 1;
-    if (use_cand) maha_candidates<TA, BM>(g, (int64_t)blockIdx.x * BM, threadIdx.x, lds_cls, cand_n, cand_cls);  // (lds_cls as scratch)
     for (int i = threadIdx.x; i < 4 * BM * kMahaMaxClasses; i += 256) lds_cls[i] = 0.0;
   }
   const int tid = threadIdx.x;
@@ -422,7 +315,15 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     } else
 #endif
     if constexpr (EPI == EPI_MAHA) {
-      // class terms of this 256-column block straight from the accumulators (G = X P never goes to memory):
+      // class terms of this 256-column block straight from the accumulators (G = X P never goes to memory).
+      // Where the kernel's time goes (round 5, 262 144 x 2048 rows, 10 classes, tools/ablate/run_maha_variants.sh): 35.3 ms as
+      // it is (0.79 of the f64 matrix peak), 30.7 ms with this epilogue compiled out (0.91) - ~37 vector instructions per
+      // (row, class, 4 columns), and on gfx950 vector instructions do not overlap v_mfma_f64 (tools/microbench/
+      // mfma_valu_overlap.hip), so the class terms cost their issue time 1:1.  Measured and not kept: 64-row tiles at one wave
+      // per SIMD 40.1 ms (-DMAHA_RT=4), one pair of weight look-ahead instead of three 35.6 ms, the column-split launches in
+      // block-major order 144.5 vs 136.1 ms per 1 M rows, and ranking the classes first so that only the classes that can still
+      // be the maximum get the f32-difference term: 33.2 ms with the ranking for free, 35.3 ms with a 32 x D x C ranking prologue
+      // in this kernel (its loads are latency-bound: 2.1 ms) - profiles/README.md, round 5.
       // for every class c, row partial += (G_j - (mu_c P)_j) * (2 t_j - a_j) over the lane's 4 columns, reduced over the
       // 16 lanes that share a row, added to the (wave, row, class) slot this lane group owns.  ~5 % of the block's MFMA time.
       const TA* xg = reinterpret_cast<const TA*>(g.x);
@@ -439,34 +340,6 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
             xv[a][c][r] = (row < g.N && col < g.n) ? xg[row * g.ldx + col] : (TA)0;
           }
         }
-      if (use_cand) {
-        // the f32-difference term of the row's candidate classes only (the 16 lanes that share a row agree on its list)
-#pragma unroll
-        for (int a = 0; a < RT; ++a)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            const int rr = 16 * a + lg + 4 * r;
-            const int n = cand_n[rr];
-            for (int sl = 0; sl < n; ++sl) {
-              const int cls = (n > 2) ? sl : (int)cand_cls[rr][sl];
-              double part = 0.0;
-#pragma unroll
-              for (int c = 0; c < NCT; ++c) {
-                const int64_t col = (ctbase + c) * 16 + li;
-                const TA mvv = (col < g.n) ? mug[(int64_t)cls * g.K + col] : (TA)0;
-                const double qvv = (col < g.n) ? g.mu_p[(int64_t)cls * g.K + col] : 0.0;
-                const double ad = (double)xv[a][c][r] - (double)mvv;
-                const double td = (double)(TA)(xv[a][c][r] - mvv);
-                part = fma(acc[a][c][r] - qvv, 2.0 * td - ad, part);
-              }
-              part += shfl_xor_f64(part, 1);
-              part += shfl_xor_f64(part, 2);
-              part += shfl_xor_f64(part, 4);
-              part += shfl_xor_f64(part, 8);
-              if (li == 0) lds_cls[(wave * BM + rr) * kMahaMaxClasses + ((n > 2) ? cls : sl)] += part;
-            }
-          }
-      } else
       for (int cls = 0; cls < g.n_classes; ++cls) {
         TA mv[NCT];
         double qv[NCT];
@@ -582,8 +455,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
       const int64_t row = r0 + tid;
       if (row < g.N) {
         double best = -kInfD();
-        const int n_slots = use_cand ? cand_n[tid] : g.n_classes;  // (a candidate row's slots hold its candidates' sums)
-        for (int cls = 0; cls < n_slots; ++cls) {
+        for (int cls = 0; cls < g.n_classes; ++cls) {
           const double t = ((lds_cls[(0 * BM + tid) * kMahaMaxClasses + cls] + lds_cls[(1 * BM + tid) * kMahaMaxClasses + cls]) +
                             lds_cls[(2 * BM + tid) * kMahaMaxClasses + cls]) + lds_cls[(3 * BM + tid) * kMahaMaxClasses + cls];
           double sc = -t;
@@ -1149,32 +1021,9 @@ __global__ __launch_bounds__(256) void maha_split_finish_kernel(const double* __
   score[row] = best;
 }
 
-// squared Frobenius norm of the packed matrix (zero padding included), fixed order: 256 partial sums, then their sum
-__global__ __launch_bounds__(256) void packed_sqnorm_part_kernel(const double* __restrict__ p, int64_t n, double* __restrict__ part) {
-  __shared__ double ws[4];
-  double s = 0.0;
-  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) s = fma(p[i], p[i], s);
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) s += shfl_xor_f64(s, o);
-  if ((threadIdx.x & 63) == 0) ws[threadIdx.x >> 6] = s;
-  __syncthreads();
-  if (threadIdx.x == 0) part[blockIdx.x] = (ws[0] + ws[1]) + (ws[2] + ws[3]);
-}
-__global__ void packed_sqnorm_finish_kernel(const double* __restrict__ part, int n, double* __restrict__ out) {
-  if (threadIdx.x != 0 || blockIdx.x != 0) return;
-  double s = 0.0;
-  for (int i = 0; i < n; ++i) s += part[i];
-  *out = s;
-}
-
 // RUNIA_MAHA_SPLIT=1 sends large batches through the column-split launches as well (measurements only; same bits either way)
 static bool maha_split_large() {
   static const bool on = [] { const char* e = getenv("RUNIA_MAHA_SPLIT"); return e && e[0] == '1'; }();
-  return on;
-}
-
-static bool maha_cand_enabled() {
-  static const bool on = [] { const char* e = getenv("RUNIA_MAHA_CAND"); return !(e && e[0] == '0'); }();
   return on;
 }
 
@@ -1221,14 +1070,6 @@ static int maha_impl(const TX* x, const TX* class_mean, const double* packed_p, 
         }
         return runia_check_launch();
       }
-    }
-    // one launch; with a workspace (257 doubles) the row tiles rank their classes first (maha_candidates) - RUNIA_MAHA_CAND=0
-    // keeps every class in the epilogue (measurements; same bits)
-    if (C > 1 && workspace && (((uintptr_t)workspace) & 7) == 0 && workspace_bytes >= 257 * sizeof(double) && maha_cand_enabled()) {
-      double* pn = reinterpret_cast<double*>(workspace);
-      packed_sqnorm_part_kernel<<<256, 256, 0, s>>>(packed_p, packed_elems(D, D), pn + 1);
-      packed_sqnorm_finish_kernel<<<1, 64, 0, s>>>(pn + 1, 256, pn);
-      g.maha_pnorm2 = pn;
     }
     return launch_gemm<TX, EPI_MAHA>(g, s);
   }
