@@ -748,13 +748,26 @@ def kde_score(train: torch.Tensor, x: torch.Tensor, bandwidth: float = 1.0) -> t
     return s
 
 
+_TIMED_EVENT_POOL: list = []
+
+
+def reserve_timed_events(n: int) -> None:
+    """Create ``n`` event pairs for :func:`_timed_launch_events` now (an event exists only once it has been recorded: two
+    marker packets on the stream per pair), so that a bracketed launch inside a timed region costs no record of its own."""
+    for _ in range(int(n)):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        e1.record()
+        _TIMED_EVENT_POOL.append((e0, e1))
+
+
 def _timed_launch_events():
     """An event pair attached to the NEXT timed launch site (``runia_time_next_launch``): the events then hold the kernel's
     own start / end timestamps (what rocprofv3's kernel trace reports).  A pair recorded around the launch on the stream also
     counts the dispatch gap behind the previous kernel: K1 read 117.3 us that way against 109.5 us in the trace of the same run."""
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()  # (creates the underlying events; the launch re-records them)
-    e1.record()
+    if not _TIMED_EVENT_POOL:
+        reserve_timed_events(1)
+    e0, e1 = _TIMED_EVENT_POOL.pop()
     _check(load_library().runia_time_next_launch(e0.cuda_event, e1.cuda_event), "runia_time_next_launch")
     return e0, e1
 
