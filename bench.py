@@ -87,9 +87,8 @@ def parse_args():
                          "sustained load to reach its working clocks (measured: 0.261 ms/step over the first 10 steps, "
                          "0.205 ms/step over 2000)")
     ap.add_argument("--event-every", type=int, default=8,
-                    help="HIP events bracket the dominant kernel on every n-th timed step (a bracketed step runs the "
-                         "table launch and the kernel as two C calls with two event records between them: ~40 us "
-                         "slower than an unbracketed step, so bracketing every step would tax the metric by 16 %%)")
+                    help="the dominant kernel's dispatch carries HIP events on every n-th timed step (events from a pool "
+                         "created before the region; such a step measured no slower than its neighbours)")
     ap.add_argument("--gather-stream", choices=["auto", "same", "side", "p2p"], default="auto",
                     help="queue the all_gather on the compute stream, or on a second stream behind an event with "
                          "two output buffers in turn (the next step's kernels then start without waiting for it); "
@@ -699,6 +698,8 @@ def main():
         "dtype": "f64", "data": "synthetic",
         "ms_per_step_stats": {"min": round(min(per_step_ms), 4), "median": round(float(np.median(per_step_ms)), 4),
                               "max": round(max(per_step_ms), 4), "mean_of_events": round(float(np.mean(per_step_ms)), 4),
+                              "per_step": [round(v, 4) for v in per_step_ms] if len(per_step_ms) <= 64 else None,
+                              "bracketed_steps": list(range(0, args.steps, max(1, args.event_every))),
                               "how": "one HIP event per step on the compute stream (rank 0); ms_per_step above is the wall clock / K, MAX over ranks"},
         "clock_ghz_observed": clocks,
         "config": {"workload": "CIFAR10 ResNet-18 LaREM: 16 MC samples, 512-d latent -> PCA-256, 10000 test images per GPU",
