@@ -150,3 +150,35 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int o) {
   hi = __shfl_xor(hi, o, 64);
   return __hiloint2double(hi, lo);
 }
+
+// ---- GEN's transcendentals on the transcendental unit (v_exp_f32 / v_log_f32 are base-2 and ~1 ulp) -------------------
+// The library expf / powf cost ~20 / ~170 vector instructions each; the wave-per-row GEN kernel spent half its issue slots
+// in six powf per row (1 M x 1000, M = 100: 3.25 ms).  The raw instructions flush denormal inputs and results, which
+// matters here: with gamma = 0.1 a probability of 1e-40 still contributes 1e-4, so both ends are rescaled.
+__device__ __forceinline__ float exp2_nonpos(float a) {  // 2^a, a <= 0 (or NaN)
+  const bool tiny = a < -126.0f;
+  const float r = __builtin_amdgcn_exp2f(tiny ? a + 64.0f : a);
+  return tiny ? r * 0x1p-64f : r;
+}
+__device__ __forceinline__ float exp_nonpos(float d) { return exp2_nonpos(d * 1.44269504088896341f); }  // e^d, d <= 0
+__device__ __forceinline__ float log2_nonneg(float x) {  // log2 x, x >= 0 (denormals included)
+  const bool tiny = x < 1.17549435e-38f;
+  const float r = __builtin_amdgcn_logf(tiny ? x * 0x1p+32f : x);
+  return tiny ? r - 32.0f : r;
+}
+// e / s from r ~ 1 / s: the product corrected by its remainder is the correctly rounded quotient (three instructions for
+// the ten of an IEEE division).  GEN needs the quotient's bits: (1 - p)^gamma of a winner at p = 1 - 2.5e-7 moves by
+// 2.5 % per ulp of p.
+__device__ __forceinline__ float div_by_rcp(float e, float s, float r) {
+  const float q = e * r;
+  const float q1 = fmaf(fmaf(-q, s, e), r, q);
+  return (q1 == q1) ? q1 : q;  // (inf / NaN operands: the plain product's result)
+}
+// p^gamma * (1 - p)^gamma as one exponential; pow(x, 0) is 1 for every x
+__device__ __forceinline__ float gen_term(float p, float gamma) {
+  if (gamma == 0.f) return 1.f;
+  const float l = log2_nonneg(p) + __builtin_amdgcn_logf(1.0f - p);  // (1 - p is never denormal: >= 2^-24 or 0)
+  const float a = gamma * l;
+  // the argument can be positive (gamma < 0) or below the scaled range: the plain instruction covers both ends (inf / 0)
+  return (a <= 0.f && a >= -180.f) ? exp2_nonpos(a) : __builtin_amdgcn_exp2f(a);
+}

@@ -293,15 +293,16 @@ __global__ __launch_bounds__(256) void gen_wide_kernel(const float* __restrict__
       for (int64_t j = tid; j < C; j += 256) m = fmaxf(m, p[j]);
       m = block_max_f32(m, red, tid);
       s = 0.f;
-      for (int64_t j = tid; j < C; j += 256) s += expf(p[j] - m);
+      for (int64_t j = tid; j < C; j += 256) s += exp_nonpos(p[j] - m);
       s = block_sum_f32(s, red, tid);
     }
-    auto prob = [&](int64_t j) { return from_probs ? p[j] : expf(p[j] - m) / s; };
+    const float rs = 1.0f / s;
+    auto prob = [&](int64_t j) { return from_probs ? p[j] : div_by_rcp(exp_nonpos(p[j] - m), s, rs); };
     float acc = 0.f;
     if (M >= C) {
       for (int64_t j = tid; j < C; j += 256) {
         const float pv = prob(j);
-        acc += powf(pv, gamma) * powf(1.0f - pv, gamma);
+        acc += gen_term(pv, gamma);
       }
       acc = block_sum_f32(acc, red, tid);
     } else {
@@ -333,11 +334,11 @@ __global__ __launch_bounds__(256) void gen_wide_kernel(const float* __restrict__
       // `want` of the entries equal to the threshold belong to the M largest
       for (int64_t j = tid; j < C; j += 256) {
         const float pv = prob(j);
-        if ((__float_as_uint(pv) | 0x80000000u) > prefix) acc += powf(pv, gamma) * powf(1.0f - pv, gamma);
+        if ((__float_as_uint(pv) | 0x80000000u) > prefix) acc += gen_term(pv, gamma);
       }
       acc = block_sum_f32(acc, red, tid);
       const float pt = __uint_as_float(prefix & 0x7fffffffu);
-      acc += (float)want * (powf(pt, gamma) * powf(1.0f - pt, gamma));
+      acc += (float)want * (gen_term(pt, gamma));
     }
     if (tid == 0) score[row] = -acc;
     __syncthreads();

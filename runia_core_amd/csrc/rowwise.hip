@@ -179,28 +179,94 @@ __global__ __launch_bounds__(64 * kRowWaves) void l2_normalize_kernel(const floa
 
 
 // ---- per-row order statistics in registers (ASH-S pruning, GEN top-M) -------------------------------------
-// One wave owns one row; lane l holds elements l, l+64, ...  The k-th largest value is found by a 32-step binary
-// search on the order-preserving integer image of the floats (count(key >= candidate) via per-lane counts and a
-// wave reduction) - no sort, no LDS.
+// One wave owns one row; lane l holds elements l, l+64, ...  The k-th largest value is found by a binary search, bit
+// by bit, on the order-preserving integer image of the floats (count(key >= candidate)) - no sort.
 __device__ __forceinline__ unsigned sort_key(float x) {
   const unsigned u = __float_as_uint(x);
   return (u & 0x80000000u) ? ~u : (u | 0x80000000u);  // ascending in x
 }
 
-template <int NV>
-__device__ __forceinline__ unsigned kth_largest_key(const unsigned (&key)[NV], int k) {
-  unsigned prefix = 0u;
-#pragma unroll 1
-  for (int bit = 31; bit >= 0; --bit) {
-    const unsigned cand = prefix | (1u << bit);
-    // counted on the scalar side: one v_cmp per register, population count and sum of the 64-bit masks in scalar
-    // registers - no per-lane counter, no cross-lane reduction (ASH-S 262 144 x 2048: 1.55 -> 1.46 ms, GEN 1 M x 1000: 9.8 -> 9.0 ms)
-    int cnt = 0;
+// count(key >= cand) on the scalar side: one v_cmp per register, population count and sum of the 64-bit masks in scalar
+// registers - no per-lane counter, no cross-lane reduction (ASH-S 262 144 x 2048: 1.55 -> 1.46 ms, GEN 1 M x 1000: 9.8 -> 9.0 ms)
+template <int R>
+__device__ __forceinline__ int count_ge(const unsigned (&key)[R], unsigned cand) {
+  int cnt = 0;
 #pragma unroll
-    for (int t = 0; t < NV; ++t) cnt += __popcll(__ballot(key[t] >= cand));
-    if (cnt >= k) prefix = cand;  // wave-uniform
+  for (int t = 0; t < R; ++t) cnt += __popcll(__ballot(key[t] >= cand));
+  return cnt;
+}
+
+// The keys that agree with `prefix` above bit `bit` (the range the search has narrowed to), packed through the wave's LDS
+// buffer into R2 registers per lane; empty slots hold 0, which no candidate (>= 1) counts.  The caller knows there are at
+// most 64 * R2 of them.
+template <int R, int R2>
+__device__ __forceinline__ void compact_range(const unsigned (&key)[R], unsigned prefix, int bit, unsigned* buf,
+                                              unsigned (&out)[R2], int lane) {
+  const int sh = bit + 1;  // 1 .. 31
+  int base = 0;
+#pragma unroll
+  for (int t = 0; t < R; ++t) {
+    const bool in = ((key[t] ^ prefix) >> sh) == 0u;
+    const unsigned long long mk = __ballot(in);
+    if (in) buf[base + __popcll(mk & ((1ull << lane) - 1ull))] = key[t];
+    base += __popcll(mk);
   }
-  return prefix;  // key of the k-th largest element
+  __builtin_amdgcn_wave_barrier();
+#pragma unroll
+  for (int r = 0; r < R2; ++r) out[r] = (lane + 64 * r < base) ? buf[lane + 64 * r] : 0u;
+  __builtin_amdgcn_wave_barrier();  // buf is written again by the next compaction / the next row
+}
+
+constexpr int kth_slots(int NV) { return NV >= 8 ? NV / 4 : 0; }  // registers per lane after the first compaction (0: none)
+
+// The step count (cnt_lo - cnt_hi = keys left in the range) is wave-uniform and known from the counts alone, so the
+// search narrows its operand set as it goes: all NV registers until at most 64 * NV/4 keys are left, those - packed
+// through `buf` (64 * NV/4 words of the wave's own LDS) - until at most 64 are left, then one register per lane.  With
+// all 32 steps on all registers the scalar unit was the limit (two scalar instructions per register and step: GEN
+// 1 M x 1000 3.3 ms, ASH-S 1 M x 2048 5.5 ms).
+template <int NV>
+__device__ __forceinline__ unsigned kth_largest_key(const unsigned (&key)[NV], int k, unsigned* buf, int lane) {
+  constexpr int R1 = kth_slots(NV);
+  unsigned prefix = 0u;
+  int bit = 31;
+  if constexpr (R1 == 0) {
+#pragma unroll 1
+    for (; bit >= 0; --bit) {
+      const unsigned cand = prefix | (1u << bit);
+      if (count_ge<NV>(key, cand) >= k) prefix = cand;  // wave-uniform
+    }
+    return prefix;
+  } else {
+    int lo = 64 * NV, hi = 0;  // keys >= prefix, keys >= the range's upper end
+#pragma unroll 1
+    for (; bit >= 0 && lo - hi > 64 * R1; --bit) {
+      const unsigned cand = prefix | (1u << bit);
+      const int cnt = count_ge<NV>(key, cand);
+      if (cnt >= k) { prefix = cand; lo = cnt; } else hi = cnt;
+    }
+    if (bit < 0) return prefix;
+    unsigned k1[R1];
+    compact_range<NV, R1>(key, prefix, bit, buf, k1, lane);
+    int kk = k - hi;  // the rank among the keys that are left
+    lo -= hi;
+    hi = 0;
+#pragma unroll 1
+    for (; bit >= 0 && lo - hi > 64; --bit) {
+      const unsigned cand = prefix | (1u << bit);
+      const int cnt = count_ge<R1>(k1, cand);
+      if (cnt >= kk) { prefix = cand; lo = cnt; } else hi = cnt;
+    }
+    if (bit < 0) return prefix;
+    unsigned k2[1];
+    compact_range<R1, 1>(k1, prefix, bit, buf, k2, lane);
+    kk -= hi;
+#pragma unroll 1
+    for (; bit >= 0; --bit) {
+      const unsigned cand = prefix | (1u << bit);
+      if (count_ge<1>(k2, cand) >= kk) prefix = cand;
+    }
+    return prefix;  // key of the k-th largest element
+  }
 }
 
 // ASH-S for 2-D activations (reference inference/funcs.py:234-261): keep the k = n - round(n*p/100) largest entries
@@ -208,6 +274,7 @@ __device__ __forceinline__ unsigned kth_largest_key(const unsigned (&key)[NV], i
 template <int NV>
 __global__ __launch_bounds__(64 * kRowWaves) void ash_s_kernel(const float* __restrict__ x, float* __restrict__ y, int64_t N,
                                                      int D, int k) {
+  __shared__ unsigned sel_buf[kRowWaves][64 * (kth_slots(NV) ? kth_slots(NV) : 1)];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += (int64_t)gridDim.x * kRowWaves) {
     const float* p = x + row * D;
@@ -224,7 +291,7 @@ __global__ __launch_bounds__(64 * kRowWaves) void ash_s_kernel(const float* __re
     s1 = wave_sum_f32(s1);
     float s2 = 0.f;
     if (k > 0) {
-      const unsigned thr = kth_largest_key<NV>(key, k);
+      const unsigned thr = kth_largest_key<NV>(key, k, sel_buf[wave], lane);
       int gt = 0;
 #pragma unroll
       for (int t = 0; t < NV; ++t) gt += (key[t] > thr);
@@ -280,18 +347,19 @@ __global__ __launch_bounds__(256) void gen_tiny_kernel(const float* __restrict__
       s = 0.f;
 #pragma unroll
       for (int j = 0; j < CT; ++j) {
-        v[j] = expf(v[j] - m);
+        v[j] = exp_nonpos(v[j] - m);
         s += v[j];
       }
     }
+    const float rs = 1.0f / s;
 #pragma unroll
-    for (int j = 0; j < 16; ++j) v[j] = (j < CT) ? (from_probs ? v[j] : v[j] / s) : 0.f;
+    for (int j = 0; j < 16; ++j) v[j] = (j < CT) ? (from_probs ? v[j] : div_by_rcp(v[j], s, rs)) : 0.f;
     if (M < CT) runia_entropy::sort_asc<16>(v);  // wave-uniform
     float acc = 0.f;
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const bool take = (M >= CT) ? (j < CT) : (j >= 16 - M);
-      if (take) acc += powf(v[j], gamma) * powf(1.0f - v[j], gamma);
+      if (take) acc += gen_term(v[j], gamma);
     }
     score[row] = -acc;
   }
@@ -300,7 +368,8 @@ __global__ __launch_bounds__(256) void gen_tiny_kernel(const float* __restrict__
 template <int NV>
 __global__ __launch_bounds__(64 * kRowWaves) void gen_kernel(const float* __restrict__ logits, float* __restrict__ score,
                                                    int64_t N, int C, int M, float gamma, int from_probs) {
-  __shared__ float gen_sel[kRowWaves][kGenCompact];
+  constexpr int kBufWords = (64 * kth_slots(NV) > kGenCompact) ? 64 * kth_slots(NV) : kGenCompact;
+  __shared__ unsigned gen_sel[kRowWaves][kBufWords];  // the selection's packed keys, then the selected probabilities (as bits)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += (int64_t)gridDim.x * kRowWaves) {
     const float* p = logits + row * C;
@@ -318,54 +387,55 @@ __global__ __launch_bounds__(64 * kRowWaves) void gen_kernel(const float* __rest
       s = 0.f;
 #pragma unroll
       for (int t = 0; t < NV; ++t) {
-        v[t] = expf(v[t] - m);  // padding -> 0
+        v[t] = exp_nonpos(v[t] - m);  // padding -> 0
         s += v[t];
       }
       s = wave_sum_f32(s);
     }
+    const float rs = 1.0f / s;
     unsigned key[NV];
 #pragma unroll
     for (int t = 0; t < NV; ++t) {
-      v[t] = from_probs ? ((lane + 64 * t < C) ? v[t] : 0.f) : v[t] / s;  // (softmax) probability
+      v[t] = from_probs ? ((lane + 64 * t < C) ? v[t] : 0.f) : div_by_rcp(v[t], s, rs);  // (softmax) probability
       key[t] = (lane + 64 * t < C) ? (__float_as_uint(v[t]) | 0x80000000u) : 0u;  // p >= 0
     }
     float acc = 0.f;
     if (M >= C) {
 #pragma unroll
       for (int t = 0; t < NV; ++t)
-        if (lane + 64 * t < C) acc += powf(v[t], gamma) * powf(1.0f - v[t], gamma);
+        if (lane + 64 * t < C) acc += gen_term(v[t], gamma);
       acc = wave_sum_f32(acc);
     } else {
-      const unsigned thr = kth_largest_key<NV>(key, M);
+      const unsigned thr = kth_largest_key<NV>(key, M, gen_sel[wave], lane);
       int gt = 0;  // wave-uniform: elements above the threshold
       if (M <= kGenCompact) {
-        // The selected probabilities (< M of the row's C) are packed into LDS first, so that the two powf of a term are
+        // The selected probabilities (< M of the row's C) are packed into LDS first, so that the transcendentals of a term are
         // evaluated for M/64 elements per lane instead of all NV under a mask (C = 1000, M = 100: 2 instead of 16).
-        float* sel = gen_sel[wave];
+        unsigned* sel = gen_sel[wave];
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
           const bool take = key[t] > thr;
           const unsigned long long mk = __ballot(take);
-          if (take) sel[gt + __popcll(mk & ((1ull << lane) - 1ull))] = v[t];
+          if (take) sel[gt + __popcll(mk & ((1ull << lane) - 1ull))] = __float_as_uint(v[t]);
           gt += __popcll(mk);
         }
         __builtin_amdgcn_wave_barrier();
         for (int i = lane; i < gt; i += 64) {
-          const float pv = sel[i];
-          acc += powf(pv, gamma) * powf(1.0f - pv, gamma);
+          const float pv = __uint_as_float(sel[i]);
+          acc += gen_term(pv, gamma);
         }
         __builtin_amdgcn_wave_barrier();  // sel is reused by this wave's next row
       } else {
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
           const bool take = key[t] > thr;
-          if (take) acc += powf(v[t], gamma) * powf(1.0f - v[t], gamma);
+          if (take) acc += gen_term(v[t], gamma);
           gt += __popcll(__ballot(take));
         }
       }
       acc = wave_sum_f32(acc);
       const float pt = __uint_as_float(thr & 0x7fffffffu);
-      acc += (float)(M - gt) * (powf(pt, gamma) * powf(1.0f - pt, gamma));
+      acc += (float)(M - gt) * (gen_term(pt, gamma));
     }
     if (lane == 0) score[row] = -acc;
   }

@@ -311,6 +311,47 @@ def test_gen_score_widths_and_m(hip, c, m):
     lg[5] = 0.0  # ties: every probability equal
     got = hip.gen_score(dev(lg, torch.float32), 0.1, m).cpu().numpy()
     assert got.dtype == np.float32 and rel_err(got, oracle.gen_score(lg, 0.1, m)) < 1e-5
+    for gamma in (1.0, 0.0, 2.5):
+        got = hip.gen_score(dev(lg, torch.float32), gamma, m).cpu().numpy()
+        assert rel_err(got, oracle.gen_score(lg, gamma, m)) < 1e-5, gamma
+    # probabilities in the denormal range and exact zeros still count at gamma = 0.1 (1e-40 ** 0.1 = 1e-4): the kernel's
+    # exponentials and logarithms run on the transcendental unit, whose plain instructions flush both - the rescaled forms
+    # must not.  (Winners stay away from p = 1: (1 - p) ** gamma at p = 1 - 2.5e-7 moves by 2.5 % per ulp of p, i.e. with
+    # the summation order of the softmax denominator, in any implementation.)
+    if c >= 8:
+        tails = np.stack([np.linspace(0.0, -115.0, c), np.concatenate([np.zeros(3), -rng.uniform(88.0, 98.0, c - 3)]),
+                          np.concatenate([np.zeros(2), np.full(c - 2, -300.0)])]).astype(np.float32)
+        tails[0, 1] = 0.0
+        for gamma in (0.1, 1.0):
+            got = hip.gen_score(dev(tails, torch.float32), gamma, m).cpu().numpy()
+            assert rel_err(got, oracle.gen_score(tails, gamma, m)) < 1e-5, gamma
+
+
+@pytest.mark.parametrize("d", [3, 64, 65, 300, 512, 513, 1000, 1024, 2048, 2049, 4096])
+def test_ash_s_selection_widths_ties_and_distributions(hip, d):
+    """The per-row k-th-largest search (bit by bit, the operand set packed down through LDS as the range narrows) over every
+    register count of the kernel, with rows that stress the packing: all values in one binade, heavy ties at the
+    threshold, all equal, mixed signs, a few huge outliers, denormals and zeros - kept SET and scale against the oracle."""
+    rng = np.random.default_rng(d)
+    rows = [np.maximum(rng.standard_normal(d), 0), rng.standard_normal(d), 1.0 + rng.random(d),        # relu, signed, one binade
+            np.round(rng.random(d) * 4) / 4 + 0.25, np.full(d, 0.75), rng.integers(0, 3, d).astype(np.float64) + 0.5,
+            np.exp(rng.standard_normal(d) * 8), rng.random(d) * 1e-41, -rng.random(d) - 0.5,
+            np.where(rng.random(d) < 0.02, 1e30, rng.random(d))]
+    x = np.stack(rows).astype(np.float32)
+    for pct in (0, 10, 50, 65, 90, 99, 100):
+        with np.errstate(all="ignore"):
+            exp = oracle.ash_s_defined(x.copy(), pct)
+        got = hip.ash_s(dev(x, torch.float32), pct).cpu().numpy()
+        ok = np.isfinite(exp)
+        assert np.array_equal(np.isfinite(got), ok), (d, pct)
+        assert np.array_equal((got != 0) & ok, (exp != 0) & ok), (d, pct)  # the same entries are kept
+        assert rel_err(got[ok], exp[ok]) < 1e-4, (d, pct)  # (the factor exp(sum / kept sum) amplifies f32 summation order at 99 %)
+    # GEN's top-M over the same rows taken as probabilities (normalised, non-negative)
+    p = np.abs(x[[0, 2, 3, 4, 5, 6]]).astype(np.float64) + 1e-12
+    p = (p / p.sum(axis=1, keepdims=True)).astype(np.float32)
+    for m in (1, 7, max(1, d // 10), max(1, d // 2), d):
+        got = hip.gen_entropy(dev(p, torch.float32), 0.1, m).cpu().numpy()
+        assert rel_err(got, oracle.generalized_entropy(p, 0.1, m)) < 1e-5, (d, m)
 
 
 @pytest.mark.parametrize("n,d,c", [(1, 4, 1), (65, 512, 10), (1000, 516, 3), (333, 1536, 16), (100, 2048, 12), (70, 512, 17),
