@@ -166,6 +166,7 @@ __device__ __forceinline__ float log2_nonneg(float x) {  // log2 x, x >= 0 (deno
   const float r = __builtin_amdgcn_logf(tiny ? x * 0x1p+32f : x);
   return tiny ? r - 32.0f : r;
 }
+__device__ __forceinline__ float log_nonneg(float x) { return log2_nonneg(x) * 0.693147180559945309f; }  // ln x, x >= 0
 // e / s from r ~ 1 / s: the product corrected by its remainder is the correctly rounded quotient (three instructions for
 // the ten of an IEEE division).  GEN needs the quotient's bits: (1 - p)^gamma of a winner at p = 1 - 2.5e-7 moves by
 // 2.5 % per ulp of p.

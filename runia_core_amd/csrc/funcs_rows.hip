@@ -22,7 +22,8 @@ __device__ __forceinline__ unsigned sort_key_f32(float x) {  // ascending in x
 
 // ---- pred_h / mi ---------------------------------------------------------------------------------------------------
 // One wave per image; lane l holds classes l, l + 64, ...; the rows of an image are n_mc consecutive rows of `logits`
-// (torch.split(samples, n_mc), image-major).  Arithmetic in f32 as torch (softmax = exp(x - max) / sum, p * log(p) with
+// (torch.split(samples, n_mc), image-major).  Arithmetic in f32 as torch (softmax = exp(x - max) / sum - exponentials and logarithms on the transcendental unit, ~1 ulp,
+// denormals kept (common.hpp), the quotient correctly rounded -, p * log(p) with
 // 0 * log(0) = NaN exactly as the reference's torch expression); the sums over classes run over the lanes in a fixed
 // order.
 template <int NV>
@@ -49,19 +50,20 @@ __global__ __launch_bounds__(64 * kRowWaves) void mcd_uncertainty_kernel(const f
       float sum = 0.f;
 #pragma unroll
       for (int t = 0; t < NV; ++t) {
-        v[t] = (lane + 64 * t < C) ? expf(v[t] - m) : 0.f;
+        v[t] = (lane + 64 * t < C) ? exp_nonpos(v[t] - m) : 0.f;
         sum += v[t];
       }
       sum = wave_sum_f32(sum);
+      const float rsum = 1.0f / sum;
       float h = 0.f;
 #pragma unroll
       for (int t = 0; t < NV; ++t) {
         const int j = lane + 64 * t;
         if (j < C) {
-          const float pr = v[t] / sum;
+          const float pr = div_by_rcp(v[t], sum, rsum);
           if (probs) probs[(img * n_mc + s) * (int64_t)C + j] = pr;
           mean[t] += pr;
-          h += pr * logf(pr);
+          h += pr * log_nonneg(pr);
         }
       }
       eh -= wave_sum_f32(h);
@@ -71,7 +73,7 @@ __global__ __launch_bounds__(64 * kRowWaves) void mcd_uncertainty_kernel(const f
     for (int t = 0; t < NV; ++t) {
       if (lane + 64 * t < C) {
         const float e = mean[t] / (float)n_mc;
-        ph += e * logf(e);
+        ph += e * log_nonneg(e);
       }
     }
     ph = -wave_sum_f32(ph);
@@ -103,17 +105,18 @@ __global__ __launch_bounds__(256) void mcd_uncertainty_tiny_kernel(const float* 
       float sum = 0.f;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
-        v[j] = (j < C) ? expf(v[j] - m) : 0.f;
+        v[j] = (j < C) ? exp_nonpos(v[j] - m) : 0.f;
         sum += v[j];
       }
+      const float rsum = 1.0f / sum;
       float h = 0.f;
 #pragma unroll
       for (int j = 0; j < 16; ++j) {
         if (j < C) {
-          const float pr = v[j] / sum;
+          const float pr = div_by_rcp(v[j], sum, rsum);
           if (probs) probs[(img * n_mc + s) * (int64_t)C + j] = pr;
           mean[j] += pr;
-          h += pr * logf(pr);
+          h += pr * log_nonneg(pr);
         }
       }
       eh -= h;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void mcd_uncertainty_tiny_kernel(const float* 
     for (int j = 0; j < 16; ++j) {
       if (j < C) {
         const float e = mean[j] / (float)n_mc;
-        ph += e * logf(e);
+        ph += e * log_nonneg(e);
       }
     }
     pred_h[img] = -ph;
@@ -245,13 +248,14 @@ __global__ __launch_bounds__(256) void mcd_uncertainty_wide_kernel(const float* 
       for (int64_t j = tid; j < C; j += 256) m = fmaxf(m, p[j]);
       m = block_max_f32(m, red, tid);
       float sum = 0.f;
-      for (int64_t j = tid; j < C; j += 256) sum += expf(p[j] - m);
+      for (int64_t j = tid; j < C; j += 256) sum += exp_nonpos(p[j] - m);
       sum = block_sum_f32(sum, red, tid);
+      const float rsum = 1.0f / sum;
       float h = 0.f;
       for (int64_t j = tid; j < C; j += 256) {
-        const float pr = expf(p[j] - m) / sum;
+        const float pr = div_by_rcp(exp_nonpos(p[j] - m), sum, rsum);
         if (probs) probs[(img * n_mc + s) * C + j] = pr;
-        h += pr * logf(pr);
+        h += pr * log_nonneg(pr);
       }
       eh -= block_sum_f32(h, red, tid);
       if (tid == 0) {
@@ -263,9 +267,12 @@ __global__ __launch_bounds__(256) void mcd_uncertainty_wide_kernel(const float* 
     float ph = 0.f;
     for (int64_t j = tid; j < C; j += 256) {
       float mean = 0.f;
-      for (int s = 0; s < n_mc; ++s) mean += expf(logits[(img * n_mc + s) * C + j] - row_stats[2 * s]) / row_stats[2 * s + 1];
+      for (int s = 0; s < n_mc; ++s) {
+        const float sum = row_stats[2 * s + 1];
+        mean += div_by_rcp(exp_nonpos(logits[(img * n_mc + s) * C + j] - row_stats[2 * s]), sum, 1.0f / sum);
+      }
       const float e = mean / (float)n_mc;
-      ph += e * logf(e);
+      ph += e * log_nonneg(e);
     }
     ph = -block_sum_f32(ph, red, tid);
     if (tid == 0) {
