@@ -327,6 +327,26 @@ def test_gen_score_widths_and_m(hip, c, m):
             assert rel_err(got, oracle.gen_score(tails, gamma, m)) < 1e-5, gamma
 
 
+@pytest.mark.parametrize("n,d,dt", [(1, 5, np.float64), (9, 3, np.float32), (300, 70, np.float64), (1000, 127, np.float32),
+                                     (2500, 129, np.float64), (700, 257, np.float32), (5000, 384, np.float32),
+                                     (3001, 2048, np.float32), (513, 1030, np.float64)])
+def test_covariance_tiles_of_the_upper_triangle_mirrored(hip, n, d, dt):
+    """np.cov(x.T, bias=1) from 128 x 128 tile pairs of the upper triangle + the mirroring finish: widths around the tile
+    and vector-load edges, row counts around the split and staging steps, a base pointer off the 16-byte grid, and exact
+    symmetry of the result."""
+    rng = np.random.default_rng(n + d)
+    x = (rng.standard_normal((n, d)) * (0.5 + rng.random(d)) + 3 * rng.standard_normal(d)).astype(dt)
+    exp = np.cov(x.astype(np.float64).T, bias=1).reshape(d, d)
+    for off in (0, 1):
+        buf = torch.empty(n * d + 1, dtype=torch.float32 if dt == np.float32 else torch.float64, device="cuda")
+        xd = buf[off: off + n * d].view(n, d)
+        xd.copy_(torch.from_numpy(x))
+        mean, cov = hip.covariance(xd)
+        c = cov.cpu().numpy()
+        assert rel_err(mean.cpu().numpy(), x.astype(np.float64).mean(0)) < 1e-13
+        assert np.array_equal(c, c.T) and rel_err(c, exp) < 1e-12, (n, d, off)
+
+
 @pytest.mark.parametrize("d", [3, 64, 65, 300, 512, 513, 1000, 1024, 2048, 2049, 4096])
 def test_ash_s_selection_widths_ties_and_distributions(hip, d):
     """The per-row k-th-largest search (bit by bit, the operand set packed down through LDS as the range narrows) over every
