@@ -81,47 +81,86 @@ __device__ __forceinline__ double sub_promote(TA x, TS m) {
   else return (double)x - (double)m;
 }
 
-template <typename TA, typename TS, int RT>
-__device__ __forceinline__ void load_a_regs(const GemmArgs& g, int64_t r0, int64_t kc, int tid, double (&r)[2 * RT]) {
-  constexpr int PER = 2 * RT;              // elements per thread of the (16*RT) x 32 chunk: 4 (32 rows) or 2 (16 rows)
+// This thread's part of a staged (16 RT) x 32 chunk of rows between its loads and its LDS store.  The loads are issued in
+// front of a chunk's matrix instructions and their values first touched behind them (row_chunk_values): widened (f32 rows)
+// or centred at the load, every wave waited out its loads' latency before it multiplied (Mahalanobis on f32 rows: a
+// s_waitcnt + four v_cvt_f64_f32 in front of each chunk's 64 matrix instructions).
+//   mode 1  rows as loaded (interior chunk of an aligned matrix, the common case; uniform over the workgroup)
+//   mode 2  rows and the slice of `sub` as loaded (the same with a mean to subtract)
+//   mode 0  values computed at the load (edges, unaligned matrices): predicated scalar loads
+// (SUB: the epilogues that centre their rows - MD, ViM; the others carry no slot for `sub`.  f64 rows keep the values of
+// mode 0 in x itself.)
+template <typename TA, typename TS, int RT, bool SUB>
+struct RowChunk {
+  static constexpr int PER = 2 * RT;  // elements per thread: 4 (32-row tiles) or 2 (16 rows); 8 for the 64-row experiments
+  TA x[PER];
+  TS m[SUB ? PER : 1];
+  double v[sizeof(TA) == 8 ? 1 : PER];
+  int mode;
+};
+
+template <typename T, int PER>
+__device__ __forceinline__ void load_run(const T* __restrict__ p, T (&r)[PER]) {  // PER consecutive elements, 16-byte loads
+  if constexpr (sizeof(T) == 4 && PER == 2) {
+    const float2 a = *reinterpret_cast<const float2*>(p);
+    r[0] = a.x; r[1] = a.y;
+  } else if constexpr (sizeof(T) == 4) {
+#pragma unroll
+    for (int q = 0; q < PER; q += 4) {
+      const float4 a = *reinterpret_cast<const float4*>(p + q);
+      r[q] = a.x; r[q + 1] = a.y; r[q + 2] = a.z; r[q + 3] = a.w;
+    }
+  } else {
+#pragma unroll
+    for (int q = 0; q < PER; q += 2) {
+      const double2 a = *reinterpret_cast<const double2*>(p + q);
+      r[q] = a.x; r[q + 1] = a.y;
+    }
+  }
+}
+
+template <typename TA, typename TS, int RT, bool SUB>
+__device__ __forceinline__ void load_a_regs(const GemmArgs& g, int64_t r0, int64_t kc, int tid, RowChunk<TA, TS, RT, SUB>& c) {
+  constexpr int PER = 2 * RT;
   constexpr int TPR = KC / PER;            // threads per row: 8 or 16
   const int row = tid / TPR;               // 0 .. 16*RT-1
   const int kk = (tid % TPR) * PER;
   const int64_t gr = r0 + row;
   const int64_t gk = kc + kk;
   const TA* x = reinterpret_cast<const TA*>(g.x);
-  // interior chunk of an aligned matrix (the common case; the condition is uniform over the workgroup): one 16-byte load
-  // (two for f64 rows of a 32-row tile) instead of predicated scalar loads - vector instructions do not overlap the
-  // matrix pipe
-  if (!g.sub && r0 + 16 * RT <= g.N && kc + KC <= g.K && (g.ldx & 3) == 0 && (((uintptr_t)g.x) & 15) == 0) {
-    if constexpr (sizeof(TA) == 4 && PER == 8) {  // (64-row tiles: experiments)
-      const float4 v = *reinterpret_cast<const float4*>(x + gr * g.ldx + gk), w = *reinterpret_cast<const float4*>(x + gr * g.ldx + gk + 4);
-      r[0] = (double)v.x; r[1] = (double)v.y; r[2] = (double)v.z; r[3] = (double)v.w;
-      r[4] = (double)w.x; r[5] = (double)w.y; r[6] = (double)w.z; r[7] = (double)w.w;
-    } else if constexpr (sizeof(TA) == 4 && PER == 4) {
-      const float4 v = *reinterpret_cast<const float4*>(x + gr * g.ldx + gk);
-      r[0] = (double)v.x; r[1] = (double)v.y; r[2] = (double)v.z; r[3] = (double)v.w;
-    } else if constexpr (sizeof(TA) == 4) {
-      const float2 v = *reinterpret_cast<const float2*>(x + gr * g.ldx + gk);
-      r[0] = (double)v.x; r[1] = (double)v.y;
-    } else {
-#pragma unroll
-      for (int q = 0; q < PER; q += 2) {
-        const double2 a = *reinterpret_cast<const double2*>(x + gr * g.ldx + gk + q);
-        r[q] = a.x; r[q + 1] = a.y;
-      }
+  const TS* sub = reinterpret_cast<const TS*>(g.sub);
+  const bool centred = SUB && g.sub != nullptr;
+  // (vector instructions do not overlap the matrix pipe: one 16-byte load - two for f64 rows of a 32-row tile - instead of
+  // predicated scalar loads)
+  if (r0 + 16 * RT <= g.N && kc + KC <= g.K && (g.ldx & 3) == 0 && (((uintptr_t)g.x) & 15) == 0 &&
+      (!centred || (((uintptr_t)g.sub) & 15) == 0)) {
+    load_run<TA, PER>(x + gr * g.ldx + gk, c.x);
+    if constexpr (SUB) {
+      if (centred) load_run<TS, PER>(sub + gk, c.m);
     }
+    c.mode = centred ? 2 : 1;
     return;
   }
+  c.mode = 0;
 #pragma unroll
   for (int q = 0; q < PER; ++q) {
     double v = 0.0;
     if (gr < g.N && gk + q < g.K) {
       const TA xv = x[gr * g.ldx + gk + q];
-      v = g.sub ? sub_promote<TA, TS>(xv, reinterpret_cast<const TS*>(g.sub)[gk + q]) : (double)xv;
+      v = centred ? sub_promote<TA, TS>(xv, sub[gk + q]) : (double)xv;
     }
-    r[q] = v;
+    if constexpr (sizeof(TA) == 8) c.x[q] = v;
+    else c.v[q] = v;
   }
+}
+
+template <typename TA, typename TS, int RT, bool SUB>
+__device__ __forceinline__ double row_chunk_value(const RowChunk<TA, TS, RT, SUB>& c, int q) {
+  if constexpr (SUB) {
+    if (c.mode == 2) return sub_promote<TA, TS>(c.x[q], c.m[q]);
+  }
+  if constexpr (sizeof(TA) == 8) return (double)c.x[q];
+  else return (c.mode == 1) ? (double)c.x[q] : c.v[q];
 }
 
 // One workgroup = 32 rows x all n columns (256 at a time); wave w owns the 64-column slice w of each pass.
@@ -241,7 +280,8 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   if constexpr (EPI == EPI_KDE) {
     if (tid < BM) lds_rown[tid] = (r0 + tid < g.N) ? g.rown[r0 + tid] : 0.0;  // (published by the chunk loop's barriers)
   }
-  double areg[2 * RT];  // this thread's part of the next staged chunk of rows
+  constexpr bool SUB = (EPI == EPI_ROWDOT || EPI == EPI_ROWNORM);
+  RowChunk<TA, TS, RT, SUB> areg;  // this thread's part of the next staged chunk of rows
   // weights three k-step pairs ahead (mfma_chunk_ring) wherever the registers allow it: with one pair of look-ahead - 1 024
   // matrix-pipe cycles at 32 x 256, 512 at 16 x 256 - a fetch that misses the L2 stalls the products (PCA 100 000 x 1024 ->
   // 256: 0.93 -> 0.83 ms; Mahalanobis 262 144 x 2048: 35.84 -> 35.66 ms, its weights come from the Infinity Cache either way)
@@ -280,21 +320,21 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     const double2* bp = reinterpret_cast<const double2*>(g.packed) + ctbase * 64 + lane;
     if (cb == cb_begin) load_b_head(bp);  // (later blocks: requested behind the previous block's last chunk)
 
-    if (cb == cb_begin) load_a_regs<TA, TS, RT>(g, r0, 0, tid, areg);
+    if (cb == cb_begin) load_a_regs<TA, TS, RT, SUB>(g, r0, 0, tid, areg);
     int buf = 0;
     for (int64_t ch = 0; ch < nchunks; ++ch) {
       {
         constexpr int PER = 2 * RT, TPR = KC / PER;
         const int row = tid / TPR, kk = (tid % TPR) * PER;
 #pragma unroll
-        for (int q = 0; q < PER; ++q) lds_a[buf][row][kk + q] = areg[q];
+        for (int q = 0; q < PER; ++q) lds_a[buf][row][kk + q] = row_chunk_value<TA, TS, RT, SUB>(areg, q);
       }
       __syncthreads();
       // the next chunk's rows are requested before this chunk's products; behind the last chunk that is the FIRST chunk of
       // the next 256-column block (the same rows again), so its latency passes under the products and the epilogue instead
       // of in front of every block (KDE at K = 256: 8 chunks per block)
-      if (ch + 1 < nchunks) load_a_regs<TA, TS, RT>(g, r0, (ch + 1) * KC, tid, areg);
-      else if (cb + 1 < cb_end) load_a_regs<TA, TS, RT>(g, r0, 0, tid, areg);
+      if (ch + 1 < nchunks) load_a_regs<TA, TS, RT, SUB>(g, r0, (ch + 1) * KC, tid, areg);
+      else if (cb + 1 < cb_end) load_a_regs<TA, TS, RT, SUB>(g, r0, 0, tid, areg);
       if constexpr (RING) mfma_chunk_ring<RT, NCT>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, bring);
       else mfma_chunk<RT, NCT>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
       buf ^= 1;

@@ -563,9 +563,14 @@ def run_fit_legs(device, centres, cpu_legs: bool = True) -> dict:
     f_tr, _ = feature_rows(0, BANK_ROWS, 1, device, centres)
     n, d = f_tr.shape
     ms_c, sp_c, (mean, cov) = _timed(lambda: _hip.covariance(f_tr), reps=3)
-    rec = {"covariance": _leg(ms_c, sp_c, n, "mfma_f64", 2.0 * d * d, F64_MFMA_TF, "TFLOP/s",
+    nt = (d + 127) // 128
+    executed = 2.0 * (nt * (nt + 1) // 2) * 128 * 128  # per row: the 128 x 128 tile pairs of the upper triangle
+    rec = {"covariance": _leg(ms_c, sp_c, n, "mfma_f64", executed, F64_MFMA_TF, "TFLOP/s",
                               shape=f"{n} x {d} f32 rows -> mean + {d} x {d} f64 covariance (np.cov(X.T, bias=1))",
-                              kernel="col_sum + gram_kernel (full D x D tiles, split over rows) + gram_finish")}
+                              kernel="col_sum + gram_kernel (128 x 128 tile pairs of the upper triangle, split over rows) + "
+                                     "gram_finish (sums the slices, mirrors); `achieved` counts the executed products - "
+                                     "the full square would be 2 D^2 per row",
+                              full_square_equivalent_tflops=round(2.0 * d * d * n / (ms_c * 1e-3) * 1e-12, 2))}
     info = {}
     t0 = time.perf_counter()
     prec = pinvh_device(cov)
