@@ -91,7 +91,7 @@ add("cfg4_from_feature_maps.roi_sampler_entropy", M["roi_sampler_entropy"]["ms"]
      ("mc_mask_bits_kernel<7, 7, 16, false>", 16384), ("mc_mask_bits_kernel<7, 7, 16, false>", 8617), ("roi_sample_table_kernel", None)],
     "two slices of <= 65 535 proposals: sampler launches + keep-flag tables + one sample table (median of both slices)")
 F = stg["fits"]
-add("fits.covariance (50 000 x 2048)", F["covariance"]["ms"], [("gram_kernel<float>", 32, 32), ("col_sum_kernel<float>", 32), ("gram_finish_kernel", None), ("col_mean_finish_kernel", None)])
+add("fits.covariance (50 000 x 2048)", F["covariance"]["ms"], [("gram_kernel<float, true>", 136, 15), ("col_sum_kernel<float>", 8), ("gram_finish_kernel", 2080), ("col_mean_finish_kernel", 32)])
 E = stg["entropy_joint"]
 add("entropy_joint.joint", E["joint"]["ms"], [("entropy_joint_reg_kernel<16, 0>", 10000)])
 add("entropy_joint.per_dim", E["per_dim"]["ms"], [("entropy_per_dim_kernel<16, 5, 4>", 5000)])
