@@ -95,8 +95,11 @@ def apply_pca_ds(train_samples: np.ndarray, test_samples: np.ndarray, nro_compon
     """Fit on ``train_samples``; return (train reduced, test reduced, fitted PCA)."""
     from sklearn.decomposition import PCA
 
+    from .host_threads import host_compute
+
     pca_dim_red = PCA(n_components=nro_components, svd_solver=svd_solver, whiten=whiten)
-    train_ds = pca_dim_red.fit_transform(train_samples)
+    with host_compute():  # (BLAS pools capped at the container's CPU quota)
+        train_ds = pca_dim_red.fit_transform(train_samples)
     test_ds = apply_pca_transform(test_samples, pca_dim_red)
     return train_ds, test_ds, pca_dim_red
 
@@ -126,8 +129,11 @@ def apply_pca_ds_split(samples: np.ndarray, nro_components: int = 16, svd_solver
             return apply_pca_transform(samples, fitted), fitted
     from sklearn.decomposition import PCA
 
+    from .host_threads import host_compute
+
     pca_dim_red = PCA(n_components=nro_components, svd_solver=svd_solver, whiten=whiten)
-    dataset_dim_red = pca_dim_red.fit_transform(samples)
+    with host_compute():  # (BLAS pools capped at the container's CPU quota)
+        dataset_dim_red = pca_dim_red.fit_transform(samples)
     return dataset_dim_red, pca_dim_red
 
 

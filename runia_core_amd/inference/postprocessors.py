@@ -154,8 +154,11 @@ class MDLatentSpace(Postprocessor):
             if config.use_device_fit():
                 self.precision = empirical_precision_device(self.centered_data)
             else:
-                estimator = EmpiricalCovariance(assume_centered=False)
-                estimator.fit(self.centered_data)
+                from ..host_threads import host_compute
+
+                with host_compute():  # (BLAS pools capped at the container's CPU quota)
+                    estimator = EmpiricalCovariance(assume_centered=False)
+                    estimator.fit(self.centered_data)
                 self.precision = estimator.precision_
             self._dev = None
             self._setup_flag = True

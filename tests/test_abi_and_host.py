@@ -598,3 +598,34 @@ def test_bank_normalisation_in_one_call_keeps_the_per_row_bits():
             per_row = np.array([_normalize_host(r) for r in x])
             assert np.array_equal(_normalize_host(np.ascontiguousarray(x)), per_row)
             assert np.array_equal(_normalize_host(np.ascontiguousarray(np.asfortranarray(x))), per_row)
+
+
+def test_host_compute_caps_the_pools_at_the_cpu_quota_and_restores_them(monkeypatch):
+    """Host-side fits (gmm_fit, sklearn fits when device_fit is off) run inside host_threads.host_compute(): torch's intra-op
+    pool - and the BLAS / OpenMP pools where threadpoolctl can drive them - are capped at the container's CPU quota for the
+    duration and put back afterwards; a process already within the quota is left alone."""
+    import torch
+    from runia_core_amd import host_threads
+
+    assert host_threads.usable_cpus() >= 1
+    before = torch.get_num_threads()
+    monkeypatch.setattr(host_threads, "_cgroup_quota", lambda: 1)
+    assert host_threads.usable_cpus() == 1
+    with host_threads.host_compute() as cap:
+        assert cap == 1 and torch.get_num_threads() == 1
+        x = torch.randn(64, 64)
+        assert torch.isfinite(x @ x).all()
+    assert torch.get_num_threads() == before
+    monkeypatch.setattr(host_threads, "_cgroup_quota", lambda: None)  # no quota: nothing to cap
+    with host_threads.host_compute():
+        assert torch.get_num_threads() == before
+    # gmm_fit runs under it and returns the same fit whatever the pool size
+    from runia_core_amd.inference import gmm_fit
+    rng = np.random.default_rng(0)
+    x = torch.from_numpy(rng.standard_normal((300, 6)).astype(np.float32))
+    lab = torch.from_numpy(rng.integers(0, 3, 300))
+    g1, j1 = gmm_fit(x, lab, 3)
+    monkeypatch.setattr(host_threads, "_cgroup_quota", lambda: 1)
+    g2, j2 = gmm_fit(x, lab, 3)
+    assert j1 == j2 and torch.allclose(g1.loc, g2.loc, atol=1e-6) and torch.allclose(g1.scale_tril, g2.scale_tril, atol=1e-5)
+    assert torch.get_num_threads() == before

@@ -585,18 +585,21 @@ def run_fit_legs(device, centres, cpu_legs: bool = True) -> dict:
         import oracle  # checker / CPU baseline only
         from scipy.linalg import pinvh
 
+        from runia_core_amd.host_threads import host_compute, usable_cpus
+
         x_h = f_tr.cpu().numpy()
-        t0 = time.perf_counter()
-        cov_h = np.cov(x_h.astype(np.float64).T, bias=1)
-        t_cov = time.perf_counter() - t0
-        t0 = time.perf_counter()
-        prec_h = pinvh(cov_h)
-        t_pin = time.perf_counter() - t0
+        with host_compute():  # BLAS pools at the container's CPU quota (oversubscribed they are throttled: a slower baseline)
+            t0 = time.perf_counter()
+            cov_h = np.cov(x_h.astype(np.float64).T, bias=1)
+            t_cov = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            prec_h = pinvh(cov_h)
+            t_pin = time.perf_counter() - t0
         rec["covariance"]["max_rel_err"] = _rel(cov.cpu().numpy(), cov_h)
         rec["covariance"]["cpu_ms"] = round(1e3 * t_cov, 1)
         rec["pinvh"]["max_rel_err"] = float(np.max(np.abs(prec.cpu().numpy() - prec_h)) / np.max(np.abs(prec_h)))
         rec["pinvh"]["cpu_ms"] = round(1e3 * t_pin, 1)
-        rec["cpu_form"] = f"np.cov(X.T, bias=1) in f64 + scipy.linalg.pinvh, the reference's calls (EmpiricalCovariance), {os.cpu_count()} host cores visible to BLAS"
+        rec["cpu_form"] = f"np.cov(X.T, bias=1) in f64 + scipy.linalg.pinvh, the reference's calls (EmpiricalCovariance), BLAS on {usable_cpus()} CPUs (the container's quota; {os.cpu_count()} visible)"
     del f_tr
     return rec
 
@@ -881,10 +884,13 @@ def run_larex_eval(device, n_train: int = 50_000, n_valid: int = 10_000, n_ood: 
     for name in ood_names:
         ood_s[f"{name} latent_space_means"], ood_s[f"{name} labels"] = ood[f"{name} latent_space_means"][:c], ood[f"{name} labels"][:c]
     df_s, _, _, t_dev_s = sweep_run(ind_s, ood_s, True, thresholds=False)
+    from runia_core_amd.host_threads import host_compute, usable_cpus
+
     np.random.seed(2024)
-    t0 = time.perf_counter()
-    table, secs = harness.larex_eval_sweep(ind_s, ood_s, ood_names, list(sweep), LAREX_POSTPROCESSORS, N_CLASSES, 50)
-    t_cpu = time.perf_counter() - t0
+    with host_compute():  # BLAS / torch pools at the container's CPU quota
+        t0 = time.perf_counter()
+        table, secs = harness.larex_eval_sweep(ind_s, ood_s, ood_names, list(sweep), LAREX_POSTPROCESSORS, N_CLASSES, 50)
+        t_cpu = time.perf_counter() - t0
     diffs = {}
     for name, (au, fp, ap) in table.items():
         g = df_s.loc[name]
@@ -892,7 +898,7 @@ def run_larex_eval(device, n_train: int = 50_000, n_valid: int = 10_000, n_ood: 
         diffs.setdefault(pp, [0.0, 0.0, 0.0])
         diffs[pp] = [max(diffs[pp][0], abs(float(g["auroc"]) - au)), max(diffs[pp][1], abs(float(g["fpr@95"]) - fp)),
                      max(diffs[pp][2], abs(float(g["aupr"]) - ap))]
-    rec["cpu_baseline"] = {"seconds": round(t_cpu, 2), "cores": os.cpu_count(), "kind": "port",
+    rec["cpu_baseline"] = {"seconds": round(t_cpu, 2), "cores": usable_cpus(), "kind": "port",
                            "sample": f"the same loop on train {a} / valid {b} / 2 x {c} rows (oracle/harness.py: sklearn randomized PCA, NumPy / "
                                      f"BLAS distances, SciPy pinvh, CPU torch Gaussians); the device run of the SAME subset takes {t_dev_s:.2f} s",
                            "seconds_by_part": {k: round(v, 2) for k, v in secs.items()}, "device_seconds_same_subset": round(t_dev_s, 3)}
