@@ -220,20 +220,23 @@ class cMDLatentSpace(Postprocessor):
         if not self._setup_flag:
             from sklearn.covariance import EmpiricalCovariance
 
+            from ..host_threads import host_compute
+
             self.class_mean = []
             centered_data = []
-            for c in range(self.num_classes):
-                class_samples = ind_train_data[ind_train_labels.eq(c)].data
-                if len(class_samples) == 0:
-                    warnings.warn(f"No examples for class {c} to build class-wise Mahalanobis Distance score")
-                self.class_mean.append(class_samples.mean(0))
-                centered_data.append(class_samples - self.class_mean[c].view(1, -1))
-            self.class_mean = torch.stack(self.class_mean)
-            pooled = _hip.to_host(torch.cat(centered_data)).astype(np.float32)
-            if config.use_device_fit():
-                precision = empirical_precision_device(pooled)
-            else:
-                precision = EmpiricalCovariance(assume_centered=False).fit(pooled).precision_
+            with host_compute():  # (the class means are the reference's float32 CPU torch ops: pools at the container's CPU quota)
+                for c in range(self.num_classes):
+                    class_samples = ind_train_data[ind_train_labels.eq(c)].data
+                    if len(class_samples) == 0:
+                        warnings.warn(f"No examples for class {c} to build class-wise Mahalanobis Distance score")
+                    self.class_mean.append(class_samples.mean(0))
+                    centered_data.append(class_samples - self.class_mean[c].view(1, -1))
+                self.class_mean = torch.stack(self.class_mean)
+                pooled = _hip.to_host(torch.cat(centered_data)).astype(np.float32)
+                if config.use_device_fit():
+                    precision = empirical_precision_device(pooled)
+                else:
+                    precision = EmpiricalCovariance(assume_centered=False).fit(pooled).precision_
             self.precision = torch.from_numpy(precision).float()
             self._state = None
             self._setup_flag = True
