@@ -160,7 +160,17 @@ __device__ __forceinline__ float exp2_nonpos(float a) {  // 2^a, a <= 0 (or NaN)
   const float r = __builtin_amdgcn_exp2f(tiny ? a + 64.0f : a);
   return tiny ? r * 0x1p-64f : r;
 }
-__device__ __forceinline__ float exp_nonpos(float d) { return exp2_nonpos(d * 1.44269504088896341f); }  // e^d, d <= 0
+// e^d, d <= 0 (or NaN): d log2(e) = n + r with the product formed once more inside an fma (r is exact to ~3e-8 whatever the
+// size of d; rounding the product first put ~|d| 1e-7 into the exponent: 3e-6 relative at d = -30 - within the 1e-5 contract,
+// but ten times the library's error in a sum over 1 000 classes), 2^r on the transcendental unit, 2^n by v_ldexp_f32 (which
+// also forms denormal results, that v_exp_f32 alone flushes).  Below e^-104.5 the float32 result is 0.
+__device__ __forceinline__ float exp_nonpos(float d) {
+  const float n = __builtin_rintf(d * 1.44269504088896341f);
+  float r = fmaf(d, 1.44269504088896341f, -n);
+  r = fmaf(d, 1.92596299e-8f, r);  // log2(e) - float(log2(e))
+  const float e = ldexpf(__builtin_amdgcn_exp2f(r), (int)n);
+  return (d < -104.5f) ? 0.f : e;  // (also the -inf padding: n = -inf would make r NaN)
+}
 __device__ __forceinline__ float log2_nonneg(float x) {  // log2 x, x >= 0 (denormals included)
   const bool tiny = x < 1.17549435e-38f;
   const float r = __builtin_amdgcn_logf(tiny ? x * 0x1p+32f : x);

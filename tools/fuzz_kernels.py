@@ -231,6 +231,49 @@ for t in range(a.rounds):
     da, pa = int(rng.choice([8, 100, 512, 2048, 3000])), int(rng.choice([0, 50, 85, 90, 100]))
     xa = np.maximum(rng.standard_normal((int(rng.choice([1, 9, 130])), da)), 0).astype(np.float32) + np.float32(0.01)
     check("ash_s", (xa.shape, pa), rel(_hip.ash_s(dev(xa), pa).cpu().numpy(), oracle.ash_s_defined(xa, pa)), 2e-6)
+    # round 5: the k-th-largest search packs its keys down through LDS as the range narrows - rows whose values crowd into
+    # one binade / a few distinct values / carry signs and outliers, at every register count; the kept SET must be the oracle's
+    da2 = int(rng.choice([65, 300, 513, 1000, 1024, 2049, 4096]))
+    kind = int(rng.integers(0, 5))
+    rows2 = int(rng.choice([1, 8, 70]))
+    if kind == 0: xa2 = 1.0 + rng.random((rows2, da2))
+    elif kind == 1: xa2 = np.round(rng.random((rows2, da2)) * 4) / 4 + 0.25
+    elif kind == 2: xa2 = rng.standard_normal((rows2, da2))
+    elif kind == 3: xa2 = np.where(rng.random((rows2, da2)) < 0.02, 1e30, rng.random((rows2, da2)))
+    else: xa2 = np.exp(rng.standard_normal((rows2, da2)) * 8)
+    xa2 = xa2.astype(np.float32)
+    pa2 = int(rng.choice([10, 50, 65, 90]))
+    with np.errstate(all="ignore"):
+        ea2 = oracle.ash_s_defined(xa2.copy(), pa2)
+    ga2 = _hip.ash_s(dev(xa2), pa2).cpu().numpy()
+    fin = np.isfinite(ea2)
+    same_set = np.array_equal(np.isfinite(ga2), fin) and np.array_equal((ga2 != 0) & fin, (ea2 != 0) & fin)
+    check("ash_s kept set (crowded rows)", (xa2.shape, kind, pa2), 0.0 if same_set else 1.0, 0.5)
+    check("ash_s values (crowded rows)", (xa2.shape, kind, pa2), rel(ga2[fin], ea2[fin]), 1e-4)
+    # GEN with the exponent and the softmax's spread drawn too (transcendental-unit exp2 / log2 with both ends rescaled)
+    gam = float(rng.choice([0.05, 0.1, 0.5, 1.0, 2.0]))
+    # (confident rows: (1 - p) ** gamma in float32 moves by gamma * ulp(p) / (1 - p) per ulp of p - the kernel and the float32
+    # oracle both carry that error against the float64 value and which of the two is closer on a row is luck
+    # (tools/debug/gen_peaked.py: the same mean error); rows are accepted as above, the batch by its mean error)
+    lg3 = (rng.standard_normal((512, cg)) * float(rng.choice([1.0, 6.0]))).astype(np.float32)
+    g3 = _hip.gen_score(dev(lg3), gam, mg).cpu().numpy().astype(np.float64)
+    with np.errstate(all="ignore"):
+        o32b = oracle.gen_score(lg3, gam, mg).astype(np.float64)
+        o64b = oracle.gen_score(lg3.astype(np.float64), gam, mg)
+    eg3, eo3 = np.abs(g3 - o64b), np.abs(o32b - o64b)
+    okb = (np.abs(g3 - o32b) <= 1e-5 * np.maximum(1.0, np.abs(o32b))) | (eg3 <= np.maximum(1e-5, 2.0 * eo3))
+    check("gen (gamma, spread drawn): rows off by more than the oracle's own error", (lg3.shape, mg, gam), float(1.0 - okb.mean()), 0.03)
+    # (in units of the scores' size: a sum over 1 500 classes is ~40, one float32 step of it 4e-6)
+    # (the 90th percentile, not the mean: ONE row with its winner an ulp of p away from the oracle's carries an error of 0.1)
+    check("gen (gamma, spread drawn): 90th-percentile error against float64", (lg3.shape, mg, gam),
+          float((np.percentile(eg3, 90) - 1.5 * np.percentile(eo3, 90)) / max(1.0, np.abs(o64b).mean())), 3e-7)
+    # covariance: upper-triangle tile pairs + mirroring finish, widths / row counts around the tile, vector and slice edges
+    nc_, dc_ = int(rng.choice([1, 7, 255, 257, 1000, 4100])), int(rng.choice([1, 3, 64, 127, 129, 200, 260, 516]))
+    xc_ = (rng.standard_normal((nc_, dc_)) * (0.5 + rng.random(dc_)) + 3.0 * rng.standard_normal(dc_)).astype(rng.choice([np.float32, np.float64]))
+    mc_, cc_ = _hip.covariance(dev(xc_))
+    cc_ = cc_.cpu().numpy()
+    check("covariance", (nc_, dc_, xc_.dtype.name), rel(cc_, np.cov(xc_.astype(np.float64).T, bias=1).reshape(dc_, dc_)), 1e-12)
+    check("covariance symmetric", (nc_, dc_), 0.0 if np.array_equal(cc_, cc_.T) else 1.0, 0.5)
 
     # ---- f2: metrics on the device (ties, scores inside and outside [0, 1], both dtypes, uneven set sizes) ----
     ni, no = int(rng.choice([1, 7, 300, 5000, 70_000])), int(rng.choice([1, 9, 400, 4097, 50_000]))
