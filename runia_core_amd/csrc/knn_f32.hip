@@ -148,8 +148,10 @@ __device__ __forceinline__ float exact_sqdist_wave(const float* __restrict__ qr,
 // ONCE and measures it against every query with exact f32 differences - the same per-lane fma chain as
 // exact_sqdist_wave, so the distances are the values the large paths arrive at by re-measurement and a row scores the
 // same bits alone as inside a batch - and adds up the row's squared norm on the way (the selection's range bound).
-constexpr int kSmallQ = 8;
-__global__ __launch_bounds__(64 * kRowWaves) void knn_small_dist_kernel(const float* __restrict__ q,
+// One or two queries: one bank row per wave, the queries read through the L1 (8 KB each) - 73 us of kernel time for one query
+// against 50 000 x 2048 (the LDS form below: 83).
+constexpr int kOneQ = 2;
+__global__ __launch_bounds__(64 * kRowWaves) void knn_one_dist_kernel(const float* __restrict__ q,
                                                                         const float* __restrict__ bank,
                                                                         float* __restrict__ dist,
                                                                         unsigned* __restrict__ bn_max_bits, int Q, int64_t M,
@@ -157,16 +159,16 @@ __global__ __launch_bounds__(64 * kRowWaves) void knn_small_dist_kernel(const fl
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int64_t m = (int64_t)blockIdx.x * kRowWaves + wave; m < M; m += (int64_t)gridDim.x * kRowWaves) {
     const float* br = bank + m * D;
-    float acc[kSmallQ], bsq = 0.f;
+    float acc[kOneQ], bsq = 0.f;
 #pragma unroll
-    for (int j = 0; j < kSmallQ; ++j) acc[j] = 0.f;
+    for (int j = 0; j < kOneQ; ++j) acc[j] = 0.f;
     int64_t i = lane;
     for (; i + 448 < D; i += 512) {
       float ba[8];
 #pragma unroll
       for (int u = 0; u < 8; ++u) ba[u] = br[i + 64 * u];
 #pragma unroll
-      for (int j = 0; j < kSmallQ; ++j) {
+      for (int j = 0; j < kOneQ; ++j) {
         if (j < Q) {  // (uniform)
           const float* qr = q + (int64_t)j * D;
 #pragma unroll
@@ -182,7 +184,7 @@ __global__ __launch_bounds__(64 * kRowWaves) void knn_small_dist_kernel(const fl
     for (; i < D; i += 64) {
       const float b = br[i];
 #pragma unroll
-      for (int j = 0; j < kSmallQ; ++j) {
+      for (int j = 0; j < kOneQ; ++j) {
         if (j < Q) {
           const float df = q[(int64_t)j * D + i] - b;
           acc[j] = fmaf(df, df, acc[j]);
@@ -191,7 +193,7 @@ __global__ __launch_bounds__(64 * kRowWaves) void knn_small_dist_kernel(const fl
       bsq = fmaf(b, b, bsq);
     }
 #pragma unroll
-    for (int j = 0; j < kSmallQ; ++j) {
+    for (int j = 0; j < kOneQ; ++j) {
       if (j < Q) {
         const float d = wave_sum_f32(acc[j]);
         // as the matrix-core kernels' epilogues: a NaN or infinite distance counts as faiss's FLT_MAX fill
@@ -205,6 +207,111 @@ __global__ __launch_bounds__(64 * kRowWaves) void knn_small_dist_kernel(const fl
     }
   }
 }
+
+// Round 5: the queries sit in LDS (staged once per workgroup, which then walks its share of the bank), two bank rows per wave
+// and trip, 16 waves per workgroup.  With the queries read from global memory for every bank row the Q x 32 query loads per
+// row (L1 / L2 latency in front of every group of fmas) outweighed the row's own 32: 8 queries took 150 us of kernel time
+// against 73 for one.  3 to 12 queries whose rows fit 144 KB of LDS take this path (12 x 2048: 148 us of kernel time; from ~14 the padded
+// matrix-core tiles - 164 us whatever the count - are faster).
+constexpr int kSmallQ = 12;
+constexpr int kSmallRows = 2;    // bank rows per wave and trip
+constexpr int kSmallWaves = 16;  // waves per workgroup
+constexpr int64_t kSmallLdsBytes = 144 * 1024;
+__global__ __launch_bounds__(64 * kSmallWaves) void knn_small_dist_kernel(const float* __restrict__ q,
+                                                                          const float* __restrict__ bank,
+                                                                          float* __restrict__ dist,
+                                                                          unsigned* __restrict__ bn_max_bits, int Q, int64_t M,
+                                                                          int64_t D) {
+  extern __shared__ float q_lds[];  // [Q][D]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  {
+    const int64_t total = (int64_t)Q * D;
+    if ((total & 3) == 0 && ((((uintptr_t)q) & 15) == 0)) {
+      for (int64_t t = tid; t < (total >> 2); t += 64 * kSmallWaves)
+        reinterpret_cast<float4*>(q_lds)[t] = reinterpret_cast<const float4*>(q)[t];
+    } else {
+      for (int64_t t = tid; t < total; t += 64 * kSmallWaves) q_lds[t] = q[t];
+    }
+  }
+  __syncthreads();
+  for (int64_t m0 = ((int64_t)blockIdx.x * kSmallWaves + wave) * kSmallRows; m0 < M; m0 += (int64_t)gridDim.x * kSmallWaves * kSmallRows) {
+    const float* br[kSmallRows];
+#pragma unroll
+    for (int r = 0; r < kSmallRows; ++r) br[r] = bank + ((m0 + r < M) ? m0 + r : M - 1) * D;  // (rows past the bank: the last row again, not stored)
+    float acc[kSmallQ][kSmallRows], bsq[kSmallRows];
+#pragma unroll
+    for (int j = 0; j < kSmallQ; ++j)
+#pragma unroll
+      for (int r = 0; r < kSmallRows; ++r) acc[j][r] = 0.f;
+#pragma unroll
+    for (int r = 0; r < kSmallRows; ++r) bsq[r] = 0.f;
+    int64_t i = lane;
+    for (; i + 448 < D; i += 512) {
+      float ba[kSmallRows][8];
+#pragma unroll
+      for (int r = 0; r < kSmallRows; ++r)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) ba[r][u] = br[r][i + 64 * u];
+#pragma unroll
+      for (int j = 0; j < kSmallQ; ++j) {
+        if (j < Q) {  // (uniform)
+          const float* qr = q_lds + (int64_t)j * D + i;
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const float qv = qr[64 * u];
+#pragma unroll
+            for (int r = 0; r < kSmallRows; ++r) {
+              const float df = qv - ba[r][u];
+              acc[j][r] = fmaf(df, df, acc[j][r]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kSmallRows; ++r)
+#pragma unroll
+        for (int u = 0; u < 8; ++u) bsq[r] = fmaf(ba[r][u], ba[r][u], bsq[r]);
+    }
+    for (; i < D; i += 64) {
+      float b[kSmallRows];
+#pragma unroll
+      for (int r = 0; r < kSmallRows; ++r) b[r] = br[r][i];
+#pragma unroll
+      for (int j = 0; j < kSmallQ; ++j) {
+        if (j < Q) {
+          const float qv = q_lds[(int64_t)j * D + i];
+#pragma unroll
+          for (int r = 0; r < kSmallRows; ++r) {
+            const float df = qv - b[r];
+            acc[j][r] = fmaf(df, df, acc[j][r]);
+          }
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < kSmallRows; ++r) bsq[r] = fmaf(b[r], b[r], bsq[r]);
+    }
+#pragma unroll
+    for (int j = 0; j < kSmallQ; ++j) {
+      if (j < Q) {
+#pragma unroll
+        for (int r = 0; r < kSmallRows; ++r) {
+          const float d = wave_sum_f32(acc[j][r]);
+          // as the matrix-core kernels' epilogues: a NaN or infinite distance counts as faiss's FLT_MAX fill
+          if (lane == 0 && m0 + r < M) dist[(int64_t)j * M + m0 + r] = (d == d) ? fminf(d, kFltMax) : kFltMax;
+        }
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < kSmallRows; ++r) {
+      const float bs = wave_sum_f32(bsq[r]);
+      if (lane == 0 && m0 + r < M && bs < INFINITY) {  // NaN / inf rows do not set the range (as row_sqnorm_kernel)
+        const unsigned b = __float_as_uint(bs);
+        if (b > __atomic_load_n(bn_max_bits, __ATOMIC_RELAXED)) atomicMax(bn_max_bits, b);
+      }
+    }
+  }
+}
+static bool knn_small_fits(int64_t N, int64_t M, int64_t D) { return N <= kSmallQ && M >= 1024 && N * D * 4 <= kSmallLdsBytes; }
 
 // `pm`: column m of a distance row is bank row knn_perm_row(m) (the bf16 kernel's piece order; identity otherwise).
 // `row_map` / `n_rows` / `row_first` (the dense fallback of the candidate filter): distance row r belongs to query
@@ -784,7 +891,15 @@ static int knn_scan(const float* q, const float* bank, float* score, float* dist
 static int knn_small_path(const float* q, const float* bank, float* score, float* dist, float* qn, unsigned* bn_max,
                           int64_t N, int64_t M, int64_t D, int k, hipStream_t s) {
   row_sqnorm_kernel<<<runia_rows_grid(N), 64 * kRowWaves, 0, s>>>(q, qn, N, D, nullptr);
-  knn_small_dist_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(q, bank, dist, bn_max, (int)N, M, D);
+  const int lds = (int)(N * D * 4);
+  static std::atomic<uint64_t> lds_ok{0};
+  if (int rc = runia_allow_dynamic_lds(reinterpret_cast<const void*>(knn_small_dist_kernel), (int)kSmallLdsBytes, lds_ok)) return rc;
+  // one workgroup per compute unit (92 registers x 16 waves), each walking its share of the bank: the queries are staged CUs times
+  int64_t grid = runia_cu_count();
+  const int64_t trips = (M + kSmallWaves * kSmallRows - 1) / (kSmallWaves * kSmallRows);
+  if (grid > trips) grid = trips;
+  if (N <= kOneQ) knn_one_dist_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(q, bank, dist, bn_max, (int)N, M, D);
+  else knn_small_dist_kernel<<<(unsigned)grid, 64 * kSmallWaves, lds, s>>>(q, bank, dist, bn_max, (int)N, M, D);
   kth_select_range_kernel<<<(unsigned)N, 256, 0, s>>>(dist, q, bank, qn, bn_max, score, N, M, D, k, kRefineRel,
                                                       knn_perm_identity(), nullptr, nullptr, 0);
   return runia_check_launch();
@@ -828,7 +943,7 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
   unsigned* bn_max = reinterpret_cast<unsigned*>(bn + M);
   if (use16) qn = reinterpret_cast<float*>(r16.ws + r16.f.qn);
   if (hipMemsetAsync(bn_max, 0, sizeof(unsigned), s) != hipSuccess) return RUNIA_E_LAUNCH;
-  if (N <= kSmallQ && M >= 1024 && qc >= N)  // a handful of queries: one pass over the bank, exact distances
+  if (knn_small_fits(N, M, D) && qc >= N)  // a handful of queries: one pass over the bank, exact distances
     return knn_small_path(q, bank, score, dist, qn, bn_max, N, M, D, k, s);
   row_sqnorm_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(bank, bn, M, D, bn_max);
   int rc = runia_check_launch();
@@ -844,9 +959,10 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
 // can take - |b|^2 in piece order and the bf16 pieces.  A call against a prepared bank skips those passes (50 000 x 2048:
 // 0.13 ms of norms + 0.25 ms of splitting, more than the scan itself for some hundred queries); the scores are the same bits.
 #ifndef KNN16_MIN_ROWS_PREPARED
-#define KNN16_MIN_ROWS_PREPARED 64
+#define KNN16_MIN_ROWS_PREPARED 13
 #endif
-// with the bank's pieces already there, the bf16 kernel pays from far fewer queries (its 256-row query tile is padded)
+// with the bank's pieces already there, the bf16 kernel pays from far fewer queries (its 256-row query tile is padded): from
+// the first count the few-query path does not take (50 000 x 2048: 16 queries 373 us on the f32 tiles, 225 us here)
 static bool knn16_prepared_wanted(int64_t N, int64_t M, int64_t D) {
   return knn16_bank_ok(M, D) && N >= KNN16_MIN_ROWS_PREPARED && N * M >= ((int64_t)1 << 29) / D &&
          (M * D >= ((int64_t)1 << 23) || N >= 1000);  // (tools/ablate/run_knn_prepared.py: small banks stay on the f32 kernel)
@@ -912,7 +1028,7 @@ extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, con
   if (!use16 && qc > kQueryChunk) qc = kQueryChunk;
   float* dist = reinterpret_cast<float*>(workspace);
   float* qn = dist + qc * M;
-  if (N <= kSmallQ && M >= 1024 && qc >= N)  // a handful of queries: one pass over the bank, exact distances
+  if (knn_small_fits(N, M, D) && qc >= N)  // a handful of queries: one pass over the bank, exact distances
     return knn_small_path(q, bank, score, dist, qn, bn_max, N, M, D, k, s);
   Knn16Run r16{};
   if (use16) {

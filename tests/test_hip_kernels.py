@@ -991,8 +991,9 @@ def test_knn_config_switch_keeps_the_f32_kernel(hip):
 
 
 def test_knn_handful_of_queries_scores_the_bits_of_a_batch(hip):
-    """Up to 8 queries against a bank of >= 1 024 rows take one pass over the bank with exact f32 distances
-    (knn_small_dist_kernel) instead of the matrix-core tiles.  A row scores the same bits alone, among a handful and
+    """Up to 12 queries against a bank of >= 1 024 rows take one pass over the bank with exact f32 distances
+    (knn_one_dist_kernel for one or two, knn_small_dist_kernel - queries in LDS, two bank rows per wave - beyond) instead of
+    the matrix-core tiles.  A row scores the same bits alone, among a handful and
     inside a large batch (f32 kernel and bf16 candidate kernel), on unit vectors, un-normalised rows, copied bank rows and
     NaN / infinite rows; the oracle on top."""
     rng = np.random.default_rng(21)
@@ -1009,7 +1010,7 @@ def test_knn_handful_of_queries_scores_the_bits_of_a_batch(hip):
         whole = hip.knn_kth(qd, bd, k)                       # bf16 candidate kernel (1 500 x 6 000 x 512)
         mid = hip.knn_kth(qd[:100].contiguous(), bd, k)      # f32 matrix-core kernel
         assert torch.equal(mid, whole[:100]), k
-        for a, b in ((0, 1), (5, 6), (0, 8), (3, 7), (92, 100)):
+        for a, b in ((0, 1), (5, 6), (0, 8), (3, 7), (92, 100), (0, 12), (83, 95), (40, 49), (4, 6), (0, 3)):
             few = hip.knn_kth(qd[a:b].contiguous(), bd, k)   # the handful path
             assert torch.equal(few, whole[a:b]), (k, a, b)
         exp = oracle.knn_kth_score(bank, q[:8], k, normalize=False)
@@ -1029,6 +1030,13 @@ def test_knn_handful_of_queries_scores_the_bits_of_a_batch(hip):
         assert np.isfinite(got).all() and rel_err(got, exp) < 1e-5, k
         many = hip.knn_kth(dev(np.concatenate([q2, q2, q2]), torch.float32), dev(bank2, torch.float32), k).cpu().numpy()
         assert np.array_equal(many[:8], got) and np.array_equal(many[8:16], got), k
+    # bank sizes around the four rows a wave takes per trip
+    for m3 in (1025, 1026, 1027, 2999):
+        b3, q3 = dev(bank2[:m3], torch.float32), dev(q2[[0, 1, 3, 4, 5]], torch.float32)
+        got = hip.knn_kth(q3, b3, 50).cpu().numpy()
+        assert rel_err(got, oracle.knn_kth_score(bank2[:m3], q2[[0, 1, 3, 4, 5]], 50, normalize=False)) < 1e-5, m3
+        big = hip.knn_kth(dev(np.tile(q2[[0, 1, 3, 4, 5]], (5, 1)), torch.float32), b3, 50).cpu().numpy()  # 25 rows: the tile kernels
+        assert np.array_equal(big[:5], got), m3
 
 
 @pytest.mark.parametrize("d,c", [(2048, 10), (300, 16), (512, 3)])

@@ -24,7 +24,7 @@ pp = _hip.pack_weights(prec); cm = torch.randn(C, D, device=dev); mu_p = (cm.dou
 # LaREM from latents (cfg2 shapes): folded weights 512 -> 256
 m = torch.randn(512, 256, dtype=torch.float64, device=dev).contiguous() * 0.05; cvec = torch.randn(256, dtype=torch.float64, device=dev)
 pm = _hip.pack_weights(m)
-for n in (1, 8, 64, 128, 512):
+for n in (1, 2, 4, 8, 12, 16, 64, 128, 512):
     q = torch.nn.functional.normalize(torch.randn(n, 2048, device=dev), dim=1)
     f = torch.randn(n, D, device=dev)
     lg = torch.randn(n, 1000, device=dev)
