@@ -649,7 +649,7 @@ def main():
                            f"passes of this command ({rec.get('profile', 'see profiles/README.md')}); not measured in this run")
             if "valu_insts_per_launch" in rec:
                 # VALU-issue floor: instructions x 4 issue cycles / 1024 SIMDs / the clock the kernel holds (measured:
-                # GRBM_GUI_ACTIVE / 8 over the launches' durations, profiles/r4_cfg2_pmc_summary.json; 2.4 GHz if not recorded)
+                # GRBM_GUI_ACTIVE / 8 over the launches' durations, profiles/r5b_driver_pmc_summary.json; 2.4 GHz if not recorded)
                 clock_ghz = float(rec.get("clock_ghz_held", 2.4))
                 floor_ms = rec["valu_insts_per_launch"] * imgs_per_launch / rec.get("images_per_launch", 10000) * 4 / 1024 / (clock_ghz * 1e9) * 1e3
                 # ... and at what K1's own instruction mix costs on gfx950 when every instruction reads three different
