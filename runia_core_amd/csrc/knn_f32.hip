@@ -153,10 +153,16 @@ __device__ __forceinline__ float exact_sqdist_wave(const float* __restrict__ qr,
 constexpr int kOneQ = 2;
 __global__ __launch_bounds__(64 * kRowWaves) void knn_one_dist_kernel(const float* __restrict__ q,
                                                                         const float* __restrict__ bank,
-                                                                        float* __restrict__ dist,
+                                                                        float* __restrict__ dist, float* __restrict__ qn,
                                                                         unsigned* __restrict__ bn_max_bits, int Q, int64_t M,
                                                                         int64_t D) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  if (blockIdx.x == 0 && wave < Q) {  // |q|^2 of the selection's range bound (was a launch of its own in front of this one)
+    float sq = 0.f;
+    for (int64_t i = lane; i < D; i += 64) sq = fmaf(q[(int64_t)wave * D + i], q[(int64_t)wave * D + i], sq);
+    sq = wave_sum_f32(sq);
+    if (lane == 0) qn[wave] = sq;
+  }
   for (int64_t m = (int64_t)blockIdx.x * kRowWaves + wave; m < M; m += (int64_t)gridDim.x * kRowWaves) {
     const float* br = bank + m * D;
     float acc[kOneQ], bsq = 0.f;
@@ -219,7 +225,7 @@ constexpr int kSmallWaves = 16;  // waves per workgroup
 constexpr int64_t kSmallLdsBytes = 144 * 1024;
 __global__ __launch_bounds__(64 * kSmallWaves) void knn_small_dist_kernel(const float* __restrict__ q,
                                                                           const float* __restrict__ bank,
-                                                                          float* __restrict__ dist,
+                                                                          float* __restrict__ dist, float* __restrict__ qn,
                                                                           unsigned* __restrict__ bn_max_bits, int Q, int64_t M,
                                                                           int64_t D) {
   extern __shared__ float q_lds[];  // [Q][D]
@@ -234,6 +240,12 @@ __global__ __launch_bounds__(64 * kSmallWaves) void knn_small_dist_kernel(const 
     }
   }
   __syncthreads();
+  if (blockIdx.x == 0 && wave < Q) {  // |q|^2 of the selection's range bound (was a launch of its own in front of this one)
+    float sq = 0.f;
+    for (int64_t i = lane; i < D; i += 64) sq = fmaf(q_lds[(int64_t)wave * D + i], q_lds[(int64_t)wave * D + i], sq);
+    sq = wave_sum_f32(sq);
+    if (lane == 0) qn[wave] = sq;
+  }
   for (int64_t m0 = ((int64_t)blockIdx.x * kSmallWaves + wave) * kSmallRows; m0 < M; m0 += (int64_t)gridDim.x * kSmallWaves * kSmallRows) {
     const float* br[kSmallRows];
 #pragma unroll
@@ -890,7 +902,6 @@ static int knn_scan(const float* q, const float* bank, float* score, float* dist
 
 static int knn_small_path(const float* q, const float* bank, float* score, float* dist, float* qn, unsigned* bn_max,
                           int64_t N, int64_t M, int64_t D, int k, hipStream_t s) {
-  row_sqnorm_kernel<<<runia_rows_grid(N), 64 * kRowWaves, 0, s>>>(q, qn, N, D, nullptr);
   const int lds = (int)(N * D * 4);
   static std::atomic<uint64_t> lds_ok{0};
   if (int rc = runia_allow_dynamic_lds(reinterpret_cast<const void*>(knn_small_dist_kernel), (int)kSmallLdsBytes, lds_ok)) return rc;
@@ -898,8 +909,8 @@ static int knn_small_path(const float* q, const float* bank, float* score, float
   int64_t grid = runia_cu_count();
   const int64_t trips = (M + kSmallWaves * kSmallRows - 1) / (kSmallWaves * kSmallRows);
   if (grid > trips) grid = trips;
-  if (N <= kOneQ) knn_one_dist_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(q, bank, dist, bn_max, (int)N, M, D);
-  else knn_small_dist_kernel<<<(unsigned)grid, 64 * kSmallWaves, lds, s>>>(q, bank, dist, bn_max, (int)N, M, D);
+  if (N <= kOneQ) knn_one_dist_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(q, bank, dist, qn, bn_max, (int)N, M, D);
+  else knn_small_dist_kernel<<<(unsigned)grid, 64 * kSmallWaves, lds, s>>>(q, bank, dist, qn, bn_max, (int)N, M, D);
   kth_select_range_kernel<<<(unsigned)N, 256, 0, s>>>(dist, q, bank, qn, bn_max, score, N, M, D, k, kRefineRel,
                                                       knn_perm_identity(), nullptr, nullptr, 0);
   return runia_check_launch();
