@@ -329,27 +329,18 @@ __device__ __forceinline__ void roi_load_map(float (&u)[HT * WT], const RoiSourc
   for (int p = 0; p < HT * WT; ++p) u[p] = acc[p] / count;
 }
 
-template <int HT, int WT, int NP, int K, bool FULL, bool ENTROPY = true, int ROI_G = 0>
-#ifdef K1_WAVES
-__attribute__((amdgpu_waves_per_eu(K1_WAVES, 8)))
+#ifndef K1_IMGS
+#define K1_IMGS 1  // images per workgroup, one after the other (timing experiments: fewer, longer waves)
 #endif
-__global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __restrict__ x,
-                                                          const float* __restrict__ table,
-                                                          double* __restrict__ h, float* __restrict__ z_out,
-                                                          double* __restrict__ zero_fill, int64_t N, int C,
-                                                          int n_mc_rt, double min_dist, double const_term,
-                                                          double inv_n) {
+template <int HT, int WT, int NP, int K, bool FULL, bool ENTROPY, int ROI_G>
+__device__ __forceinline__ void mc_entropy_item(const float* __restrict__ x, const float* __restrict__ table,
+                                                double* __restrict__ h, float* __restrict__ z_out,
+                                                double* __restrict__ zero_fill, int64_t N, int C, int n_mc_rt,
+                                                double min_dist, double const_term, double inv_n, int64_t img, int c) {
   constexpr int HW = HT * WT;
   constexpr bool PAIRS = (HT % 2 == 0);
   const int n_mc = FULL ? NP : n_mc_rt;
-  // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
-  // channel blocks of one image are given ids that are congruent mod 8 - the image's keep-flag table is then
-  // fetched into ONE L2 (with the plain (block, image) grid up to 4 XCDs fetched it: +35 MB per 10 000 images).
-  const unsigned chunks = (unsigned)(C + kK1Block - 1) / kK1Block;
-  const unsigned slot = blockIdx.x >> 3;
-  const int64_t img = (int64_t)(slot / chunks) * 8 + (blockIdx.x & 7);
   if (img >= N) return;
-  const int c = (int)(slot % chunks) * kK1Block + threadIdx.x;
   if (zero_fill && c == 0) zero_fill[img] = 0.0;  // the accumulator of the score launch that follows (optional)
   if (c >= C) return;
   const float* mk = table + img * (int64_t)(n_mc * (HW + 2));  // wave-uniform
@@ -515,6 +506,30 @@ __global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __res
     double res = const_term + inv_n * column_log_sum<NP, K, FULL>(z, n_mc, min_dist);
     if (bad) res = NAN;
     h[img * C + c] = res;
+  }
+}
+
+template <int HT, int WT, int NP, int K, bool FULL, bool ENTROPY = true, int ROI_G = 0>
+#ifdef K1_WAVES
+__attribute__((amdgpu_waves_per_eu(K1_WAVES, 8)))
+#endif
+__global__ __launch_bounds__(kK1Block) void mc_entropy_kernel(const float* __restrict__ x,
+                                                          const float* __restrict__ table,
+                                                          double* __restrict__ h, float* __restrict__ z_out,
+                                                          double* __restrict__ zero_fill, int64_t N, int C,
+                                                          int n_mc_rt, double min_dist, double const_term,
+                                                          double inv_n) {
+  // XCD-aware order: consecutive workgroup ids go round-robin over the 8 XCDs (each with its own L2), so the
+  // channel blocks of one image are given ids that are congruent mod 8 - the image's keep-flag table is then
+  // fetched into ONE L2 (with the plain (block, image) grid up to 4 XCDs fetched it: +35 MB per 10 000 images).
+  const unsigned chunks = (unsigned)(C + kK1Block - 1) / kK1Block;
+  const unsigned slot = blockIdx.x >> 3;
+  const int c = (int)(slot % chunks) * kK1Block + threadIdx.x;
+#pragma unroll 1
+  for (int rep = 0; rep < K1_IMGS; ++rep) {
+    const int64_t img = ((int64_t)(slot / chunks) * K1_IMGS + rep) * 8 + (blockIdx.x & 7);
+    mc_entropy_item<HT, WT, NP, K, FULL, ENTROPY, ROI_G>(x, table, h, z_out, zero_fill, N, C, n_mc_rt, min_dist, const_term,
+                                                        inv_n, img, c);
   }
 }
 
@@ -1018,7 +1033,7 @@ extern "C" int runia_mc_stack_table_f32(const float* x, const float* rnd, int64_
                              block_size, 0, stream))
     return rc;
   const float* table = reinterpret_cast<const float*>(workspace);
-  const unsigned grid = (unsigned)(((N + 7) / 8) * 8 * ((C + kK1Block - 1) / kK1Block));
+  const unsigned grid = (unsigned)((((N + 7) / 8 + K1_IMGS - 1) / K1_IMGS) * 8 * ((C + kK1Block - 1) / kK1Block));
   hipStream_t s = as_stream(stream);
 #define RUNIA_MCE(HH, WW, NPP, KK)                                                                          \
   if (H == HH && W == WW && n_mc <= NPP && n_mc > NPP / 2) {                                                \
@@ -1048,7 +1063,7 @@ extern "C" int runia_mc_entropy_from_table_f32(const float* x, const void* works
   if (!runia_mc_entropy_supported(H, W, n_mc, k)) return RUNIA_E_INVALID;  // callers: mc_stack + kl_entropy_per_dim
   const float* table = reinterpret_cast<const float*>(workspace);
   const double ct = digamma_diff(n_mc, k), inv_n = 1.0 / (double)n_mc;
-  const unsigned grid = (unsigned)(((N + 7) / 8) * 8 * ((C + kK1Block - 1) / kK1Block));
+  const unsigned grid = (unsigned)((((N + 7) / 8 + K1_IMGS - 1) / K1_IMGS) * 8 * ((C + kK1Block - 1) / kK1Block));
   hipStream_t s = as_stream(stream);
   const bool x16 = ((((uintptr_t)x) & 15) == 0);
 #define RUNIA_MCE(HH, WW, NPP, KK)                                                                          \
@@ -1137,7 +1152,7 @@ extern "C" int runia_roi_mc_entropy_f32(const float* feat_nhwc, const float* box
   const float* table = reinterpret_cast<const float*>(workspace);
   const float* src = reinterpret_cast<const float*>(tab);  // the RoiSource at the head of the sample table
   const double ct = digamma_diff(n_mc, k), inv_n = 1.0 / (double)n_mc;
-  const unsigned grid = (unsigned)(((K + 7) / 8) * 8 * ((C + kK1Block - 1) / kK1Block));
+  const unsigned grid = (unsigned)((((K + 7) / 8 + K1_IMGS - 1) / K1_IMGS) * 8 * ((C + kK1Block - 1) / kK1Block));
 #define RUNIA_ROI_MCE(HH, WW, NPP, KK, GG)                                                                         \
   if (PH == HH && PW == WW && n_mc <= NPP && n_mc > NPP / 2 && k == KK && sampling_ratio == GG) {                  \
     if (n_mc == NPP)                                                                                               \
