@@ -12,7 +12,9 @@ finds its inputs in a cache.
 `python bench.py --gpus N` with N > 1 and no WORLD_SIZE starts its own N ranks (torch.distributed.run as a child
 process, before this process makes any GPU call) and exits with the child's code.
 
-Prints ONE JSON line (rank 0) with the driver's contract plus
+Prints ONE JSON line of < 4 KB (rank 0; contract_line below) with the driver's contract plus `roofline`, `cpu_baseline`,
+`parity` and `stages` as {leg: [ms, frac]} pairs.  The full record (everything listed below, per-step lists, notes, the harness
+table) goes to stderr and to bench_detail.json next to this file (and under gpurun_out/ when that directory exists):
   `roofline`      dominant kernel (K1, sampler + entropy), timed inside the timed region with HIP events attached to its
                   dispatch on its launch stream (the kernel's own start / end timestamps, as rocprofv3's kernel trace
                   reports them; runia_time_next_launch); `achieved` uses BASELINE.md section 4's algorithmic 33 800 B/image;
@@ -44,6 +46,111 @@ HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s 
 ALGO_BYTES_PER_IMAGE = C * H * W * 4 + N_MC * H * W * 4 + 8
 # what K1 itself moves per image: latent map + keep-flag table of the image (n_mc*(H*W+2) floats) + C entropies in f64
 K1_BOUNDARY_BYTES_PER_IMAGE = C * H * W * 4 + N_MC * (H * W + 2) * 4 + C * 8
+
+
+CONTRACT_MAX_BYTES = 4096  # the driver keeps ~8 KB of stdout: the contract line stays well inside it
+DETAIL_FILE = "bench_detail.json"
+_TOP_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+             "vs_baseline", "dtype", "data")
+_ROOFLINE_KEYS = ("bound", "binding_limit", "kernel", "achieved", "peak", "unit", "frac", "traffic",
+                  "algorithmic_bytes_per_launch", "avg_launch_ms", "launches_per_step", "launches_timed")
+_CPU_KEYS = ("value", "unit", "cores", "kind", "sample")
+_CONFIG_MAX_SCALARS = 8
+
+
+def _clip(v, n):
+    return v if not isinstance(v, str) or len(v) <= n else v[: n - 3] + "..."
+
+
+def _num(v, digits=4):
+    """Numbers on the contract line carry at most `digits` significant decimals (floats only; ints pass through)."""
+    if isinstance(v, bool) or not isinstance(v, float):
+        return v
+    if v != v or v in (float("inf"), float("-inf")):
+        return None
+    return float(f"{v:.{digits + 2}g}") if abs(v) < 1 else round(v, digits)
+
+
+def stage_pairs(stages, prefix=""):
+    """`stages` of the detail record -> {"leg": [ms, frac]} (frac None where the leg has no roofline): every dict that
+    carries an "ms" entry is a leg; nested legs are named parent.child."""
+    out = {}
+    if not isinstance(stages, dict):
+        return out
+    for k, v in stages.items():
+        if not isinstance(v, dict):
+            continue
+        name = f"{prefix}{k}"
+        ms = v.get("ms")
+        if ms is None and isinstance(v.get("seconds_device_resident"), (int, float)):
+            ms = 1e3 * v["seconds_device_resident"]  # the harness sweep reports seconds
+        if isinstance(ms, (int, float)):
+            frac = v.get("frac")
+            out[name] = [_num(float(ms)), _num(float(frac)) if isinstance(frac, (int, float)) else None]
+        out.update(stage_pairs(v, name + "."))
+    return out
+
+
+def contract_line(full) -> str:
+    """The ONE line bench.py writes to stdout: the driver's contract keys + `roofline` + `cpu_baseline` + `parity` +
+    `stages` as {leg: [ms, frac]} pairs, at most CONTRACT_MAX_BYTES bytes.  Everything else of `full` (per-step lists,
+    notes, spreads, the harness table, api_level, ...) goes to stderr and to DETAIL_FILE (emit_record below)."""
+    line = {k: (_clip(full.get(k), 160) if k in ("metric", "dtype") else _num(full.get(k), 4)) for k in _TOP_KEYS}
+    cfg = full.get("config") or {}
+    slim = {"workload": _clip(str(cfg.get("workload", "")), 200)}
+    for k, v in cfg.items():
+        if k == "workload":
+            continue
+        if len(slim) > _CONFIG_MAX_SCALARS:
+            break
+        if isinstance(v, (bool, int, float)) or (isinstance(v, str) and len(v) <= 48):
+            slim[k] = _num(v)
+    line["config"] = slim
+    roof = full.get("roofline")
+    line["roofline"] = None if not isinstance(roof, dict) else {
+        k: (_clip(roof.get(k), 96) if isinstance(roof.get(k), str) else _num(roof.get(k))) for k in _ROOFLINE_KEYS}
+    cpu = full.get("cpu_baseline")
+    if isinstance(cpu, dict):
+        line["cpu_baseline"] = {k: (_clip(cpu.get(k), 120) if isinstance(cpu.get(k), str) else _num(cpu.get(k))) for k in _CPU_KEYS}
+    par = full.get("parity")
+    if isinstance(par, dict):
+        errs = [v for k, v in par.items() if k.startswith("max_rel_err") and isinstance(v, (int, float))]
+        line["parity"] = {"max_rel_err": (float(f"{max(errs):.3g}") if errs else None),
+                          "auroc_gpu": par.get("auroc_gpu"), "auroc_oracle": par.get("auroc_oracle")}
+    line["detail"] = DETAIL_FILE
+    pairs = stage_pairs(full.get("stages"))
+    if isinstance(full.get("stages"), dict) and "error" in full["stages"]:
+        line["stages_error"] = _clip(str(full["stages"]["error"]), 160)
+    if pairs:
+        line["stages"] = pairs
+    text = json.dumps(line, separators=(",", ":"))
+    while len(text.encode()) >= CONTRACT_MAX_BYTES and line.get("stages"):
+        line["stages"].popitem()  # legs dropped from the end; all of them stay in DETAIL_FILE
+        line["stages_truncated"] = True
+        text = json.dumps(line, separators=(",", ":"))
+    if len(text.encode()) >= CONTRACT_MAX_BYTES:
+        raise AssertionError(f"contract line is {len(text.encode())} bytes (limit {CONTRACT_MAX_BYTES})")
+    return text
+
+
+def emit_record(full, saved_stdout=None):
+    """Detail record -> stderr + DETAIL_FILE (next to bench.py, and under gpurun_out/ when that directory exists, so that it comes
+    back from a GPU box); then the contract line, alone, as the LAST line of stdout."""
+    detail = json.dumps(full)
+    for d in (ROOT, os.path.join(ROOT, "gpurun_out")):
+        try:
+            if os.path.isdir(d):
+                with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                    f.write(detail + "\n")
+        except OSError as e:
+            print(f"bench.py: could not write {DETAIL_FILE} under {d}: {e}", file=sys.stderr)
+    print("bench detail: " + detail, file=sys.stderr, flush=True)
+    text = contract_line(full)
+    sys.stdout.flush()
+    if saved_stdout is not None:
+        os.dup2(saved_stdout, 1)
+    print(text, flush=True)
+    return text
 
 
 def parse_args():
@@ -256,9 +363,7 @@ def main_cfg3(args, device, rank, world, dist, saved_stdout):
     for k in ("cpu_baseline", "parity"):
         if k in rec:
             out[k] = rec[k]
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    print(json.dumps(out), flush=True)
+    emit_record(out, saved_stdout)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -294,9 +399,7 @@ def main_larex(args, device, rank, world, dist, saved_stdout):
         out["cpu_baseline"] = {"value": None, "unit": "s (bounded subset, see sample)", "cores": rec["cpu_baseline"]["cores"], "kind": "port",
                                "sample": rec["cpu_baseline"]["sample"], "seconds": rec["cpu_baseline"]["seconds"],
                                "device_seconds_same_subset": rec["cpu_baseline"]["device_seconds_same_subset"]}
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    print(json.dumps(out), flush=True)
+    emit_record(out, saved_stdout)
     if dist is not None:
         dist.destroy_process_group()
 
@@ -854,9 +957,7 @@ def main():
             out["stages"] = stages
         except Exception as e:  # a reported extra; its failure must not lose the headline measurement
             out["stages"] = {"error": repr(e)[:300]}
-    sys.stdout.flush()
-    os.dup2(saved_stdout, 1)
-    print(json.dumps(out), flush=True)
+    emit_record(out, saved_stdout)
     if use_dist:
         dist.destroy_process_group()
 
