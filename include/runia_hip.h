@@ -454,6 +454,20 @@ int runia_ash_s_rows_f32(const float* x, float* y, float* pruned, int64_t N, int
  *   upper triangle of inv is zero).  Setup of the class-wise Gaussians of GMMLatentSpace / DDU (inference/postprocessors.py:
  *   426-492, 694-786; torch.distributions.MultivariateNormal keeps scale_tril): the precision of a class is inv^T inv. */
 int runia_tril_inverse_f64(const double* tril, double* inv, int64_t batch, int64_t D, runia_stream_t stream);
+/* runia_gmm_log_prob_f32: class-wise Gaussian log densities, all classes in one pass - replaces gmm.log_prob(x[:, None, :]) of
+ *   the torch MultivariateNormal that gmm_fit builds (inference/funcs.py:265-344), as called by GMMLatentSpace.postprocess and
+ *   DDU.postprocess (inference/postprocessors.py:490-491, 778-779), and the scipy logsumexp that follows it.
+ *   x [N, D] f32; means [C, D] f32; w_tril [C, D, D] f32 row-major = L_c^-1, the inverse of torch's scale_tril, LOWER TRIANGULAR
+ *   with exact zeros above the diagonal; consts [C] f64 = -D/2 log(2 pi) - sum log diag L_c.
+ *   log_prob [N, C] f32 (optional) = consts[c] - 0.5 || w_c (x_n - means_c) ||^2, the difference formed in f32 as torch forms it,
+ *   the products on the f32 matrix cores with only the k <= column half of w_c multiplied (D^2 flop per (row, class));
+ *   lse [N] f32 (optional) = logsumexp over the classes of the f32 log_prob values (NaN in -> NaN).  At least one output.
+ *   workspace: runia_gmm_log_prob_workspace_bytes(N, D, C) bytes, 8-byte aligned (per-column-tile sums of squares, f64); a smaller
+ *   one is accepted as long as it holds 128 rows (the rows are then scored in chunks). */
+size_t runia_gmm_log_prob_workspace_bytes(int64_t N, int64_t D, int C);
+int runia_gmm_log_prob_f32(const float* x, const float* means, const float* w_tril, const double* consts, float* log_prob,
+                           float* lse, void* workspace, size_t workspace_bytes, int64_t N, int64_t D, int C,
+                           runia_stream_t stream);
 /* runia_proj_norm_*: ViM residual norm || (x - u) @ NS ||_2 per row (inference/postprocessors.py:1106):
  *   x [N, D], u [D] (same dtype as x; f32 - f32 is rounded to f32 first, as NumPy), packed_ns = pack(NS [D, n]),
  *   norm [N] f64. */

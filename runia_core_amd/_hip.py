@@ -118,6 +118,9 @@ _SIGNATURES = {
         [c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int,
          c_int, c_double, c_int, c_int, c_double, c_int, c_void_p],
     ),
+    "runia_gmm_log_prob_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
+    "runia_gmm_log_prob_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64,
+                                       c_int64, c_int, c_void_p]),
     "runia_ood_metrics_workspace_bytes": (c_size_t, [c_int64]),
     "runia_ood_metrics_f64": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
     "runia_ood_metrics_f32": (c_int, [c_void_p, c_int64, c_void_p, c_int64, c_void_p, c_void_p, c_size_t, c_void_p]),
@@ -1340,3 +1343,32 @@ def tril_inverse(tril: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(tril)
     _check(lib.runia_tril_inverse_f64(tril.data_ptr(), out.data_ptr(), tril.shape[0], tril.shape[1], _stream()), "runia_tril_inverse_f64")
     return out
+
+
+_GMM_WORKSPACE_CAP = 1 << 30  # bytes of per-tile sums kept at once (262 144 rows x 2048 x 10 classes: 336 MB)
+
+
+@_device_guard()
+def gmm_log_prob(x: torch.Tensor, means: torch.Tensor, w_tril: torch.Tensor, consts: torch.Tensor, want_log_prob: bool = True,
+                 want_lse: bool = False):
+    """Class-wise Gaussian log densities with the inverse Cholesky factors (``runia_gmm_log_prob_f32``): x [N, D] f32, means [C, D] f32,
+    w_tril [C, D, D] f32 lower triangular (= L_c^-1), consts [C] f64 -> ``(log_prob [N, C] f32 or None, lse [N] f32 or None)``."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2
+    assert means.dtype == torch.float32 and w_tril.dtype == torch.float32 and consts.dtype == torch.float64
+    n, d = x.shape
+    c = means.shape[0]
+    assert tuple(means.shape) == (c, d) and tuple(w_tril.shape) == (c, d, d) and tuple(consts.shape) == (c,)
+    assert want_log_prob or want_lse
+    x, means, w_tril, consts = x.contiguous(), means.contiguous(), w_tril.contiguous(), consts.contiguous()
+    lp = torch.empty((n, c), dtype=torch.float32, device=x.device) if want_log_prob else None
+    lse = torch.empty((n,), dtype=torch.float32, device=x.device) if want_lse else None
+    if n == 0:
+        return lp, lse
+    need = int(lib.runia_gmm_log_prob_workspace_bytes(n, d, c))
+    ws_bytes = min(need, max(_GMM_WORKSPACE_CAP, need // max(1, n) * 128))  # the entry point scores the rows in chunks that fit
+    ws = torch.empty(((ws_bytes + 7) // 8,), dtype=torch.float64, device=x.device)
+    _check(lib.runia_gmm_log_prob_f32(x.data_ptr(), means.data_ptr(), w_tril.data_ptr(), consts.data_ptr(), _ptr(lp), _ptr(lse),
+                                      ws.data_ptr(), ws.numel() * 8, n, d, c, _stream()), "runia_gmm_log_prob_f32")
+    return lp, lse

@@ -46,16 +46,21 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 
 // 32 per-lane values -> their totals over the 32 lanes that share lane bit 5: lane ends with the total of slot (lane & 31).
 // Halving exchange: at distance d the lanes with bit d clear keep the lower half of the slots and receive their partner's.
-__device__ __forceinline__ double halve32(double (&v)[32], int lane) {
+template <int D_, int N_>
+__device__ __forceinline__ void halve_step(double (&v)[32], int lane) {
+  const bool up = (lane & D_) != 0;
 #pragma unroll
-  for (int d = 16, n = 16; d >= 1; d >>= 1, n >>= 1) {
-    const bool up = (lane & d) != 0;
-#pragma unroll
-    for (int u = 0; u < n; ++u) {
-      const double send = up ? v[u] : v[u + n], keep = up ? v[u + n] : v[u];
-      v[u] = keep + shfl_xor_f64(send, d);
-    }
+  for (int u = 0; u < N_; ++u) {
+    const double send = up ? v[u] : v[u + N_], keep = up ? v[u + N_] : v[u];
+    v[u] = keep + shfl_xor_f64(send, D_);
   }
+}
+__device__ __forceinline__ double halve32(double (&v)[32], int lane) {
+  halve_step<16, 16>(v, lane);
+  halve_step<8, 8>(v, lane);
+  halve_step<4, 4>(v, lane);
+  halve_step<2, 2>(v, lane);
+  halve_step<1, 1>(v, lane);
   return v[0];
 }
 

@@ -1,7 +1,7 @@
 // Library-level entry points of librunia_hip.so.
 #include "common.hpp"
 
-extern "C" int runia_abi_version(void) { return 5; }
+extern "C" int runia_abi_version(void) { return 6; }
 
 extern "C" const char* runia_error_string(int code) {
   switch (code) {

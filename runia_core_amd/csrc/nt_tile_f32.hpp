@@ -1,6 +1,7 @@
 // 128 x 128 NT tile engine on the f32 matrix cores (v_mfma_f32_32x32x2_f32, exact-f32 fma chains), shared by the kNN distance
 // kernel (knn_f32.hip: d2[q, m] = |q|^2 + |b_m|^2 - 2 q.b_m) and the final linear layer of the logits / features postprocessors
-// (linear.hip: out[q, m] = min(x_q, clip).w_m + bias_m).  Included by exactly those two translation units.
+// (linear.hip: out[q, m] = min(x_q, clip).w_m + bias_m); the triangular whitening kernel of the class-wise Gaussians (gmm_tril.hip)
+// uses its staging helpers and tile order.  Included by exactly those three translation units.
 //
 // A workgroup owns a 128-row x 128-row tile of two K-contiguous operands (4 waves x 64x64, i.e. 2x2 MFMA tiles of 32x32 per
 // wave), staged 32 k at a time into LDS with a 34-float pitch (conflict-free ds_read_b64: one 8-byte read feeds two MFMA

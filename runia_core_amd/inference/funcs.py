@@ -162,27 +162,36 @@ def gmm_fit(embeddings: torch.Tensor, labels: torch.Tensor, num_classes: int):
 
 
 class GmmState:
-    """Device-resident form of a fitted class-wise ``MultivariateNormal``: for every component the precision
-    ``(L L^T)^-1`` (float32 ``scale_tril`` widened exactly, inverted in f64, packed for the MFMA kernel), the mean and
-    ``-0.5 * D * log(2 pi) - sum(log diag L)``.  ``log_prob`` = ``gmm.log_prob(x[:, None, :])`` -> ``(N, C)`` f32."""
+    """Device-resident form of a fitted class-wise ``MultivariateNormal``: for every component the inverse ``W = L^-1`` of its float32
+    ``scale_tril`` (widened exactly, inverted in f64 by ``runia_tril_inverse_f64``, rounded to f32: lower triangular), the mean and
+    ``-0.5 * D * log(2 pi) - sum(log diag L)``.  ``log_prob`` = ``gmm.log_prob(x[:, None, :])`` -> ``(N, C)`` f32 from ONE launch over
+    all components (``runia_gmm_log_prob_f32``: ``|| W (x - mu) ||^2`` on the f32 matrix cores - torch's own arithmetic, a triangular
+    solve in f32 - with the zero half of ``W`` skipped).
 
-    def __init__(self, gmm):
+    ``dense=True`` keeps rounds 4-5's form instead (the f64 precision ``W^T W`` packed for ``runia_md_score_f32``, one launch per
+    component, 2 D^2 multiply-adds per row and component): the comparison leg of the tests and of ``tools/ablate/run_gmm.py``."""
+
+    def __init__(self, gmm, dense: bool = False):
         loc = gmm.loc.detach().cpu()
         tril = gmm.scale_tril.detach().cpu()
         self.n_comp, self.dim = loc.shape
-        self.means = [_hip.to_device(loc[c].numpy(), torch.float32) for c in range(self.n_comp)]
-        # precision of a class = (L L^T)^-1 = W^T W with W = L^-1: the triangular inverses of all classes in one launch
-        # (runia_tril_inverse_f64) and one f64 product each - torch.cholesky_inverse on the host took 0.8 s of a 4.4 s harness sweep
-        w = _hip.tril_inverse(_hip.to_device(tril.double().numpy(), torch.float64))
-        self.packed = []
-        for c in range(self.n_comp):
-            prec = _hip.matmul_f64(w[c].t().contiguous(), w[c])
-            self.packed.append(_hip.pack_weights(prec))
+        self.dense = bool(dense)
+        w = _hip.tril_inverse(_hip.to_device(tril.double().numpy(), torch.float64))   # all classes in one launch
         half_log_det = tril.diagonal(dim1=-2, dim2=-1).log().sum(-1)  # f32, as torch
-        self.const = (-0.5 * self.dim * float(np.log(2 * np.pi)) - half_log_det.double()).tolist()
+        const = -0.5 * self.dim * float(np.log(2 * np.pi)) - half_log_det.double()
+        self.const = const.tolist()
+        if self.dense:
+            self.means = [_hip.to_device(loc[c].numpy(), torch.float32) for c in range(self.n_comp)]
+            self.packed = [_hip.pack_weights(_hip.matmul_f64(w[c].t().contiguous(), w[c])) for c in range(self.n_comp)]
+        else:
+            self.means_dev = _hip.to_device(np.ascontiguousarray(loc.numpy()), torch.float32)
+            self.w_tril = w.to(torch.float32).contiguous()
+            self.const_dev = _hip.to_device(const.numpy(), torch.float64)
 
     def log_prob_device(self, x: torch.Tensor) -> torch.Tensor:
         x = x.to(torch.float32).contiguous()
+        if not self.dense:
+            return _hip.gmm_log_prob(x, self.means_dev, self.w_tril, self.const_dev, True, False)[0]
         cols = []
         for c in range(self.n_comp):
             neg_m = _hip.md_score(x, self.means[c], self.packed[c])  # -(x-mu)^T P (x-mu), diff in f32 like torch
@@ -190,6 +199,8 @@ class GmmState:
         return torch.stack(cols, dim=1).contiguous()
 
     def energy_device(self, x: torch.Tensor) -> torch.Tensor:
+        if not self.dense:  # logsumexp over the components inside the same call: no (N, C) table
+            return _hip.gmm_log_prob(x.to(torch.float32).contiguous(), self.means_dev, self.w_tril, self.const_dev, False, True)[1]
         lse, _ = _hip.row_lse_msp(self.log_prob_device(x), True, False)
         return lse
 

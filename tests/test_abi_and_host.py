@@ -49,7 +49,7 @@ def test_library_exports_every_header_symbol():
     out = subprocess.run(["nm", "-D", "--defined-only", _hip.library_path()], capture_output=True, text=True).stdout
     exported = set(re.findall(r"\bT (runia_[a-z0-9_]+)", out))
     assert set(syms) <= exported
-    assert lib.runia_abi_version() == 5
+    assert lib.runia_abi_version() == 6
     assert lib.runia_error_string(-1).decode().startswith("invalid argument")
     # K padded to a multiple of 32 plus four zero k-step pairs (32 rows), n to a multiple of 256
     assert lib.runia_packed_weights_bytes(512, 256) == (512 + 32) * 256 * 8

@@ -1267,3 +1267,68 @@ def test_md_few_rows_column_split_scores_the_bits_of_the_one_launch(hip, n_feat)
         xo, mo = x.astype(np.float32).astype(np.float64), mean
         assert rel_err(got.cpu().numpy(), -np.einsum("ij,jk,ik->i", xo - mo, prec, xo - mo)) < 1e-9
     assert lib.runia_md_score_workspace_bytes(100000, n_feat) == 0 and lib.runia_md_score_workspace_bytes(64, 200) == 0
+
+
+def _gmm_case(rng, n, d, c, cond=0.05):
+    """Class means, Cholesky factors (f32, as torch's MultivariateNormal keeps them) and test rows of a class-wise Gaussian."""
+    loc = (rng.standard_normal((c, d)) * 0.7).astype(np.float32)
+    a = rng.standard_normal((c, d, 2 * d + 3))
+    cov = a @ a.transpose(0, 2, 1) / (2 * d + 3) + cond * np.eye(d)
+    tril = np.linalg.cholesky(cov).astype(np.float32)
+    x = (loc[rng.integers(0, c, n)] + rng.standard_normal((n, d))).astype(np.float32)
+    return loc, tril, x
+
+
+@pytest.mark.parametrize("n,d,c", [(1, 1, 1), (5, 3, 2), (130, 37, 3), (257, 128, 4), (300, 129, 2), (128, 256, 10), (1000, 300, 6),
+                                   (513, 1024, 3), (96, 2048, 2)])
+def test_gmm_log_prob_triangular_kernel_vs_torch(hip, n, d, c):
+    """runia_gmm_log_prob_f32 (round 6): all class-wise Gaussian log densities from one launch, || L^-1 (x - mu) ||^2 on the f32
+    matrix cores with the zero half of L^-1 skipped, against torch's own MultivariateNormal.log_prob (the reference's call,
+    inference/postprocessors.py:490, 778) and scipy's logsumexp; the dense f64 form of rounds 4-5 beside it; ragged D (column
+    tiles that end inside a 128 block), a NaN row, an infinite row; a workspace of one row tile gives the same bits."""
+    from runia_core_amd.inference.funcs import GmmState
+
+    rng = np.random.default_rng(100 * d + c)
+    loc, tril, x = _gmm_case(rng, n, d, c)
+    gmm = torch.distributions.MultivariateNormal(loc=torch.from_numpy(loc), scale_tril=torch.from_numpy(tril))
+    want = gmm.log_prob(torch.from_numpy(x)[:, None, :]).numpy()
+    want64 = torch.distributions.MultivariateNormal(loc=torch.from_numpy(loc).double(), scale_tril=torch.from_numpy(tril).double()
+                                                    ).log_prob(torch.from_numpy(x).double()[:, None, :]).numpy()
+    st = GmmState(gmm)
+    xd = dev(x, torch.float32)
+    got = st.log_prob_device(xd).cpu().numpy()
+    assert got.dtype == np.float32 and got.shape == (n, c)
+    assert rel_err(got, want) < TOL
+    # no further from the exact (f64) densities than torch's own f32 evaluation is, up to a factor and a floor of f32 rounding
+    assert rel_err(got, want64) <= 4 * rel_err(want, want64) + 2e-6
+    lse = st.energy_device(xd).cpu().numpy()
+    assert lse.dtype == np.float32 and rel_err(lse, oracle.gmm_energy(gmm, x)) < TOL
+    dense = GmmState(gmm, dense=True)
+    assert rel_err(got, dense.log_prob_device(xd).cpu().numpy()) < TOL
+    # same bits whatever the chunking of the rows (workspace of one row tile) and with both outputs from one call
+    lib = hip.load_library()
+    lp2 = torch.empty((n, c), dtype=torch.float32, device="cuda")
+    lse2 = torch.empty((n,), dtype=torch.float32, device="cuda")
+    one_tile = int(lib.runia_gmm_log_prob_workspace_bytes(128, d, c))
+    ws = torch.empty(one_tile // 8, dtype=torch.float64, device="cuda")
+    rc = lib.runia_gmm_log_prob_f32(xd.data_ptr(), st.means_dev.data_ptr(), st.w_tril.data_ptr(), st.const_dev.data_ptr(), lp2.data_ptr(),
+                                    lse2.data_ptr(), ws.data_ptr(), one_tile, n, d, c, None)
+    assert rc == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(lp2.cpu().numpy(), got) and np.array_equal(lse2.cpu().numpy(), lse)
+    # too small a workspace / no output / bad sizes are refused
+    assert lib.runia_gmm_log_prob_f32(xd.data_ptr(), st.means_dev.data_ptr(), st.w_tril.data_ptr(), st.const_dev.data_ptr(), lp2.data_ptr(),
+                                      None, ws.data_ptr(), 8, n + 200, d, c, None) < 0
+    assert lib.runia_gmm_log_prob_f32(xd.data_ptr(), st.means_dev.data_ptr(), st.w_tril.data_ptr(), st.const_dev.data_ptr(), None,
+                                      None, ws.data_ptr(), one_tile, n, d, c, None) < 0
+    if n >= 5:
+        xb = x.copy()
+        xb[1, d // 2] = np.nan
+        xb[3, 0] = np.inf
+        gb = st.log_prob_device(dev(xb, torch.float32)).cpu().numpy()
+        lb = st.energy_device(dev(xb, torch.float32)).cpu().numpy()
+        assert np.isnan(gb[1]).all() and np.isnan(lb[1])
+        assert not np.isfinite(gb[3]).any()   # torch: -inf or nan for an infinite coordinate
+        keep = np.ones(n, bool)
+        keep[[1, 3]] = False
+        assert np.array_equal(gb[keep], got[keep]) and np.array_equal(lb[keep], lse[keep])  # other rows untouched

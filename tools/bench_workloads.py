@@ -729,18 +729,23 @@ def run_f4_legs(device, feats, logits, w, b, centres, cpu_legs: bool = True) -> 
     n_g = min(n, 262_144)
     xg = feats[:n_g]
     ms, sp, s_gmm = _timed(lambda: state.energy_device(xg), reps=2)
-    rec["gmm_ddu"] = _leg(ms, sp, n_g, "mfma_f64", N_CLASSES * (2.0 * d * d + 2 * d), F64_MFMA_TF, "TFLOP/s",
-                          shape=f"{n_g} x {d} f32, {N_CLASSES} full-covariance components", fit_s=round(t_fit, 2), jitter=float(jitter))
+    # round 6: || L_c^-1 (x - mu_c) ||^2 with the triangular inverse factor on the f32 matrix cores (torch's own arithmetic), all
+    # components in one launch: D^2 flop per (row, component) - the zero half of L_c^-1 is not multiplied (rounds 4-5: dense f64
+    # x P_c x^T per component, 2 D^2 multiply-adds, 353 ms)
+    rec["gmm_ddu"] = _leg(ms, sp, n_g, "mfma_f32", N_CLASSES * (1.0 * d * d), F32_MFMA_TF, "TFLOP/s",
+                          shape=f"{n_g} x {d} f32, {N_CLASSES} full-covariance components, triangular L^-1 in f32 (D^2 flop per row and component)",
+                          fit_s=round(t_fit, 2), jitter=float(jitter))
     # bytes past the L2 from the PMC passes of the driver's command (profiles/pmc_traffic.json), scaled by rows
     try:
         import json as _json
 
         pmc = _json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "pmc_traffic.json")))["stages"]
         for leg, key in (("vim", "f4_vim"), ("react", "f4_react"), ("dice", "f4_react"), ("ash_s", "f4_ash_s"), ("gen", "f4_gen"), ("pred_h_mi", "f4_pred_h_mi"),
-                         ("gmm_ddu", "f4_gmm_component")):
+                         ("gmm_ddu", "f4_gmm_whiten")):
+            if key not in pmc:
+                continue
             e = pmc[key]
-            mult = N_CLASSES if leg == "gmm_ddu" else 1
-            rec[leg]["traffic"] = int(mult * e["bytes_per_launch"] * rec[leg]["rows"] / e["rows_per_launch"])
+            rec[leg]["traffic"] = int(e["bytes_per_launch"] * rec[leg]["rows"] / e["rows_per_launch"])
             rec[leg]["traffic_source"] = f"profiles/pmc_traffic.json stages.{key} ({e['kernel']}): 2 x FETCH_SIZE + WRITE_SIZE per launch, scaled by rows; not measured in this run"
             for extra in ("matrix_pipe_busy_share", "clock_ghz_held"):
                 if extra in e:
