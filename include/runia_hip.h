@@ -454,6 +454,13 @@ int runia_ash_s_rows_f32(const float* x, float* y, float* pruned, int64_t N, int
  *   upper triangle of inv is zero).  Setup of the class-wise Gaussians of GMMLatentSpace / DDU (inference/postprocessors.py:
  *   426-492, 694-786; torch.distributions.MultivariateNormal keeps scale_tril): the precision of a class is inv^T inv. */
 int runia_tril_inverse_f64(const double* tril, double* inv, int64_t batch, int64_t D, runia_stream_t stream);
+/* runia_cholesky_*: a [batch, D, D] row-major, in place: the lower triangle of every matrix is replaced by its Cholesky factor L
+ *   (a + jitter I = L L^T), the strict upper triangle by zeros; info[b] = 0, or j + 1 when the pivot of column j was not positive
+ *   (LAPACK potrf's convention; the matrix is then partly overwritten).  f32: the factorisation inside torch's
+ *   MultivariateNormal(covariance_matrix=...) that gmm_fit's jitter ladder retries (inference/funcs.py:310-342); f64: the factor
+ *   of a precision matrix for runia_md_score_tril_*.  One fixed summation order: same bits from run to run. */
+int runia_cholesky_f32(float* a, int* info, int64_t batch, int64_t D, double jitter, runia_stream_t stream);
+int runia_cholesky_f64(double* a, int* info, int64_t batch, int64_t D, double jitter, runia_stream_t stream);
 /* runia_gmm_log_prob_f32: class-wise Gaussian log densities, all classes in one pass - replaces gmm.log_prob(x[:, None, :]) of
  *   the torch MultivariateNormal that gmm_fit builds (inference/funcs.py:265-344), as called by GMMLatentSpace.postprocess and
  *   DDU.postprocess (inference/postprocessors.py:490-491, 778-779), and the scipy logsumexp that follows it.

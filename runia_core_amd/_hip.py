@@ -118,6 +118,8 @@ _SIGNATURES = {
         [c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int,
          c_int, c_double, c_int, c_int, c_double, c_int, c_void_p],
     ),
+    "runia_cholesky_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
+    "runia_cholesky_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
     "runia_gmm_log_prob_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
     "runia_gmm_log_prob_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64,
                                        c_int64, c_int, c_void_p]),
@@ -275,18 +277,42 @@ def _cuda_tensors(value):
 def resolve_device(args, kwargs, exempt=()):
     """The one device a wrapper call runs on: that of its CUDA tensor arguments (``exempt``: names the wrapper moves to
     the first tensor's device itself).  Tensors on different devices raise ``RuniaHipError`` - a kernel launched with
-    pointers of two GPUs would fault or, worse, read peer memory silently.  No CUDA tensor -> None (the current device)."""
+    pointers of two GPUs would fault or, worse, read peer memory silently.  No CUDA tensor -> None (the current device).
+    (On the path of every wrapper call - 1 500 per harness sweep: plain loops, no intermediate lists.)"""
     dev, first = None, None
-    for name, value in list(enumerate(args)) + list(kwargs.items()):
-        if name in exempt:
+    i = -1
+    for value in args:
+        i += 1
+        if value is None or i in exempt:
+            continue
+        if type(value) is torch.Tensor:
+            if not value.is_cuda:
+                continue
+            d = value.device
+            if dev is None:
+                dev, first = d, i
+            elif d != dev:
+                _raise_two_devices(dev, first, d, i)
+        elif isinstance(value, (tuple, list, torch.Tensor)):
+            for t in _cuda_tensors(value):
+                if dev is None:
+                    dev, first = t.device, i
+                elif t.device != dev:
+                    _raise_two_devices(dev, first, t.device, i)
+    for name, value in kwargs.items():
+        if value is None or name in exempt:
             continue
         for t in _cuda_tensors(value):
             if dev is None:
                 dev, first = t.device, name
             elif t.device != dev:
-                raise RuniaHipError(f"tensor arguments sit on different devices ({dev} for argument {first!r}, {t.device} for "
-                                    f"argument {name!r}): move them to one GPU before the call")
+                _raise_two_devices(dev, first, t.device, name)
     return dev
+
+
+def _raise_two_devices(dev, first, other, name):
+    raise RuniaHipError(f"tensor arguments sit on different devices ({dev} for argument {first!r}, {other} for "
+                        f"argument {name!r}): move them to one GPU before the call")
 
 
 def _device_guard(*exempt):
@@ -313,7 +339,14 @@ def _device_guard(*exempt):
     return wrap
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def _stream() -> int:
+    """The current device's current stream as the C ABI's ``runia_stream_t`` (torch's raw-stream query where this build has it:
+    no ``torch.cuda.Stream`` object per wrapper call - 2 400 of them per harness sweep)."""
+    if _raw_stream is not None:
+        return _raw_stream(torch.cuda.current_device())
     return torch.cuda.current_stream().cuda_stream
 
 
@@ -751,27 +784,45 @@ def kde_score(train: torch.Tensor, x: torch.Tensor, bandwidth: float = 1.0) -> t
     return s
 
 
-_TIMED_EVENT_POOL: list = []
+_TIMED_EVENT_POOL: dict = {}  # device index -> event pairs created (recorded once) on that device
 
 
 def reserve_timed_events(n: int) -> None:
-    """Create ``n`` event pairs for :func:`_timed_launch_events` now (an event exists only once it has been recorded: two
-    marker packets on the stream per pair), so that a bracketed launch inside a timed region costs no record of its own."""
+    """Create ``n`` event pairs for :func:`_timed_launch_events` now, on the current device (an event exists only once it has
+    been recorded: two marker packets on the stream per pair), so that a bracketed launch inside a timed region costs no record of
+    its own.  The pool is kept per device: an event belongs to the device it was first recorded on."""
+    pool = _TIMED_EVENT_POOL.setdefault(torch.cuda.current_device(), [])
     for _ in range(int(n)):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         e1.record()
-        _TIMED_EVENT_POOL.append((e0, e1))
+        pool.append((e0, e1))
 
 
 def _timed_launch_events():
     """An event pair attached to the NEXT timed launch site (``runia_time_next_launch``): the events then hold the kernel's
     own start / end timestamps (what rocprofv3's kernel trace reports).  A pair recorded around the launch on the stream also
-    counts the dispatch gap behind the previous kernel: K1 read 117.3 us that way against 109.5 us in the trace of the same run."""
-    if not _TIMED_EVENT_POOL:
+    counts the dispatch gap behind the previous kernel: K1 read 117.3 us that way against 109.5 us in the trace of the same run.
+    Use :func:`_timed_call` around the entry point: it disarms the pair if the call returns before its launch site."""
+    pool = _TIMED_EVENT_POOL.setdefault(torch.cuda.current_device(), [])
+    if not pool:
         reserve_timed_events(1)
-    e0, e1 = _TIMED_EVENT_POOL.pop()
+    e0, e1 = pool.pop()
     _check(load_library().runia_time_next_launch(e0.cuda_event, e1.cuda_event), "runia_time_next_launch")
+    return e0, e1
+
+
+def _timed_call(fn, what: str):
+    """Arm an event pair, run the entry point ``fn()`` (-> return code), and ALWAYS disarm afterwards: an entry point that
+    returns before its timed launch site (unsupported shape, short workspace) must not leave the pair to the thread's next,
+    unrelated launch.  Returns the pair; raises as ``_check`` does (the pair of a failed call never received timestamps and is
+    dropped)."""
+    e0, e1 = _timed_launch_events()
+    try:
+        rc = fn()
+    finally:
+        load_library().runia_time_next_launch(None, None)
+    _check(rc, what)
     return e0, e1
 
 
@@ -837,13 +888,12 @@ def mc_entropy(x: torch.Tensor, rand: Union[torch.Tensor, CounterDraws, None], n
         assert table.is_cuda and table.numel() >= ws_bytes and n <= 65535
         if zero_fill is not None:
             assert zero_fill.is_cuda and zero_fill.dtype == torch.float64 and zero_fill.shape == (n,) and zero_fill.is_contiguous()
+        call = lambda: lib.runia_mc_entropy_from_table_f32(x.data_ptr(), table.data_ptr(), ws_bytes, h.data_ptr(), _ptr(z),  # noqa: E731
+                                                           _ptr(zero_fill), n, c, hh, ww, n_mc, int(k), float(min_dist), _stream())
         if kernel_events is not None:
-            e0, e1 = _timed_launch_events()
-        _check(lib.runia_mc_entropy_from_table_f32(x.data_ptr(), table.data_ptr(), ws_bytes, h.data_ptr(), _ptr(z),
-                                                   _ptr(zero_fill), n, c, hh, ww, n_mc, int(k), float(min_dist), _stream()),
-               "runia_mc_entropy_from_table_f32")
-        if kernel_events is not None:
-            kernel_events.append((e0, e1))
+            kernel_events.append(_timed_call(call, "runia_mc_entropy_from_table_f32"))
+        else:
+            _check(call(), "runia_mc_entropy_from_table_f32")
         return (h, z) if want_samples else h
     stride = 0
     counter = rand if isinstance(rand, CounterDraws) else None
@@ -903,14 +953,11 @@ def mc_entropy(x: torch.Tensor, rand: Union[torch.Tensor, CounterDraws, None], n
                                                 int(block_size), _stream()),
                     "runia_mc_mask_table_f32",
                 )
-            e0, e1 = _timed_launch_events()
-            _check(
-                lib.runia_mc_entropy_from_table_f32(x.data_ptr() + done * c * hh * ww * 4, ws.data_ptr(), ws_bytes,
-                                                    h.data_ptr() + done * c * 8, zp, zf, m, c, hh, ww, n_mc, int(k),
-                                                    float(min_dist), _stream()),
-                "runia_mc_entropy_from_table_f32",
-            )
-            kernel_events.append((e0, e1))
+            kernel_events.append(_timed_call(
+                lambda: lib.runia_mc_entropy_from_table_f32(x.data_ptr() + done * c * hh * ww * 4, ws.data_ptr(), ws_bytes,
+                                                            h.data_ptr() + done * c * 8, zp, zf, m, c, hh, ww, n_mc, int(k),
+                                                            float(min_dist), _stream()),
+                "runia_mc_entropy_from_table_f32"))
         done += m
     return (h, z) if want_samples else h
 
@@ -1318,9 +1365,10 @@ def clock_probe(chain: int = 8192, device: Optional[torch.device] = None) -> tor
     """Queue one clock probe (``runia_clock_probe``) on the current stream -> device tensor [4] int64
     (shader-clock ticks, 100 MHz ticks, FMAs in the chain, 0).  Read it with :func:`clock_ghz` after a synchronisation."""
     lib = load_library()
-    dev = require_gpu() if device is None else device
-    out = torch.zeros(4, dtype=torch.int64, device=dev)
-    _check(lib.runia_clock_probe(out.data_ptr(), int(chain), _stream()), "runia_clock_probe")
+    dev = require_gpu() if device is None else torch.device(device)
+    with torch.cuda.device(dev):  # the probe runs on `dev`'s stream and reads `dev`'s clock, whatever device is current
+        out = torch.zeros(4, dtype=torch.int64, device=dev)
+        _check(lib.runia_clock_probe(out.data_ptr(), int(chain), _stream()), "runia_clock_probe")
     return out
 
 
@@ -1372,3 +1420,18 @@ def gmm_log_prob(x: torch.Tensor, means: torch.Tensor, w_tril: torch.Tensor, con
     _check(lib.runia_gmm_log_prob_f32(x.data_ptr(), means.data_ptr(), w_tril.data_ptr(), consts.data_ptr(), _ptr(lp), _ptr(lse),
                                       ws.data_ptr(), ws.numel() * 8, n, d, c, _stream()), "runia_gmm_log_prob_f32")
     return lp, lse
+
+
+@_device_guard()
+def cholesky(a: torch.Tensor, jitter: float = 0.0):
+    """a [B, D, D] (or [D, D]) f32 / f64 symmetric on the device -> ``(L, info)``: the lower Cholesky factors of ``a + jitter * I``
+    (a new tensor; zeros above the diagonal) and ``info`` [B] int32 on the device - 0, or j + 1 where column j's pivot was not
+    positive (``runia_cholesky_*``)."""
+    lib = load_library()
+    require_gpu()
+    assert a.is_cuda and a.dtype in (torch.float32, torch.float64) and a.dim() in (2, 3) and a.shape[-1] == a.shape[-2]
+    m = a.reshape(-1, a.shape[-1], a.shape[-1]).contiguous().clone()
+    info = torch.empty((m.shape[0],), dtype=torch.int32, device=a.device)
+    fn = lib.runia_cholesky_f32 if a.dtype == torch.float32 else lib.runia_cholesky_f64
+    _check(fn(m.data_ptr(), info.data_ptr(), m.shape[0], m.shape[1], float(jitter), _stream()), "runia_cholesky")
+    return m.reshape(a.shape), info

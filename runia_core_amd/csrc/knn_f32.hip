@@ -209,7 +209,7 @@ __global__ __launch_bounds__(64 * kRowWaves) void knn_one_dist_kernel(const floa
     bsq = wave_sum_f32(bsq);
     if (lane == 0 && bsq < INFINITY) {  // NaN / inf rows do not set the range (as row_sqnorm_kernel)
       const unsigned b = __float_as_uint(bsq);
-      if (b > __atomic_load_n(bn_max_bits, __ATOMIC_RELAXED)) atomicMax(bn_max_bits, b);
+      if (bn_max_bits && b > __atomic_load_n(bn_max_bits, __ATOMIC_RELAXED)) atomicMax(bn_max_bits, b);  // (null: a prepared bank state already holds it)
     }
   }
 }
@@ -318,7 +318,7 @@ __global__ __launch_bounds__(64 * kSmallWaves) void knn_small_dist_kernel(const 
       const float bs = wave_sum_f32(bsq[r]);
       if (lane == 0 && m0 + r < M && bs < INFINITY) {  // NaN / inf rows do not set the range (as row_sqnorm_kernel)
         const unsigned b = __float_as_uint(bs);
-        if (b > __atomic_load_n(bn_max_bits, __ATOMIC_RELAXED)) atomicMax(bn_max_bits, b);
+        if (bn_max_bits && b > __atomic_load_n(bn_max_bits, __ATOMIC_RELAXED)) atomicMax(bn_max_bits, b);  // (null: a prepared bank state already holds it)
       }
     }
   }
@@ -836,7 +836,7 @@ struct Knn16Run {            // (use16 only)
   Knn16Filter f;
 };
 static int knn_scan(const float* q, const float* bank, float* score, float* dist, float* qn, const float* bn,
-                    unsigned* bn_max, const Knn16Run* r16, int64_t qc, int64_t N, int64_t M, int64_t D, int k,
+                    const unsigned* bn_max, const Knn16Run* r16, int64_t qc, int64_t N, int64_t M, int64_t D, int k,
                     hipStream_t s, int64_t min_rows16 = 256) {
   const KnnPerm pm = r16 ? knn_perm_for(M) : knn_perm_identity();
   const int64_t Mpad = runia_knn16_padded_rows(M), qpad = runia_knn16_padded_rows(qc);
@@ -900,17 +900,21 @@ static int knn_scan(const float* q, const float* bank, float* score, float* dist
   return RUNIA_OK;
 }
 
-static int knn_small_path(const float* q, const float* bank, float* score, float* dist, float* qn, unsigned* bn_max,
-                          int64_t N, int64_t M, int64_t D, int k, hipStream_t s) {
+// bn_max_w: where the distance kernels leave max |b|^2 (a plain call's workspace word, cleared by the caller), or null when
+// bn_max already holds it (a prepared bank state: read-only, shareable between concurrent scoring calls).
+// Returns 1 when the few-query kernel's LDS limit cannot be raised: the caller then takes the scan.
+static int knn_small_path(const float* q, const float* bank, float* score, float* dist, float* qn, const unsigned* bn_max,
+                          unsigned* bn_max_w, int64_t N, int64_t M, int64_t D, int k, hipStream_t s) {
   const int lds = (int)(N * D * 4);
   static std::atomic<uint64_t> lds_ok{0};
-  if (int rc = runia_allow_dynamic_lds(reinterpret_cast<const void*>(knn_small_dist_kernel), (int)kSmallLdsBytes, lds_ok)) return rc;
+  if (N > kOneQ && runia_allow_dynamic_lds(reinterpret_cast<const void*>(knn_small_dist_kernel), (int)kSmallLdsBytes, lds_ok) != RUNIA_OK)
+    return 1;
   // one workgroup per compute unit (92 registers x 16 waves), each walking its share of the bank: the queries are staged CUs times
   int64_t grid = runia_cu_count();
   const int64_t trips = (M + kSmallWaves * kSmallRows - 1) / (kSmallWaves * kSmallRows);
   if (grid > trips) grid = trips;
-  if (N <= kOneQ) knn_one_dist_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(q, bank, dist, qn, bn_max, (int)N, M, D);
-  else knn_small_dist_kernel<<<(unsigned)grid, 64 * kSmallWaves, lds, s>>>(q, bank, dist, qn, bn_max, (int)N, M, D);
+  if (N <= kOneQ) knn_one_dist_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(q, bank, dist, qn, bn_max_w, (int)N, M, D);
+  else knn_small_dist_kernel<<<(unsigned)grid, 64 * kSmallWaves, lds, s>>>(q, bank, dist, qn, bn_max_w, (int)N, M, D);
   kth_select_range_kernel<<<(unsigned)N, 256, 0, s>>>(dist, q, bank, qn, bn_max, score, N, M, D, k, kRefineRel,
                                                       knn_perm_identity(), nullptr, nullptr, 0);
   return runia_check_launch();
@@ -954,8 +958,10 @@ extern "C" int runia_knn_kth_f32(const float* q, const float* bank, float* score
   unsigned* bn_max = reinterpret_cast<unsigned*>(bn + M);
   if (use16) qn = reinterpret_cast<float*>(r16.ws + r16.f.qn);
   if (hipMemsetAsync(bn_max, 0, sizeof(unsigned), s) != hipSuccess) return RUNIA_E_LAUNCH;
-  if (knn_small_fits(N, M, D) && qc >= N)  // a handful of queries: one pass over the bank, exact distances
-    return knn_small_path(q, bank, score, dist, qn, bn_max, N, M, D, k, s);
+  if (knn_small_fits(N, M, D) && qc >= N) {  // a handful of queries: one pass over the bank, exact distances
+    const int rc_small = knn_small_path(q, bank, score, dist, qn, bn_max, bn_max, N, M, D, k, s);
+    if (rc_small <= 0) return rc_small;
+  }
   row_sqnorm_kernel<<<runia_rows_grid(M), 64 * kRowWaves, 0, s>>>(bank, bn, M, D, bn_max);
   int rc = runia_check_launch();
   if (rc != RUNIA_OK) return rc;
@@ -1027,7 +1033,7 @@ extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, con
   }
   if (!workspace || workspace_bytes < (size_t)(M + 1) * sizeof(float)) return RUNIA_E_WORKSPACE;
   const float* bn = reinterpret_cast<const float*>(state);
-  unsigned* bn_max = const_cast<unsigned*>(reinterpret_cast<const unsigned*>(bn + M));  // (only ever re-written with its own value)
+  const unsigned* bn_max = reinterpret_cast<const unsigned*>(bn + M);  // max |b|^2 of the prepared bank: never written by a scoring call
   // the bf16 kernel when the state holds the pieces and the workspace is the one asked for; else the f32 kernel with as
   // many query rows per pass as the workspace holds
   const bool use16 = knn16_prepared_wanted(N, M, D) && state_bytes >= runia_knn_bank_state_bytes(M, D) &&
@@ -1039,8 +1045,10 @@ extern "C" int runia_knn_kth_prepared_f32(const float* q, const float* bank, con
   if (!use16 && qc > kQueryChunk) qc = kQueryChunk;
   float* dist = reinterpret_cast<float*>(workspace);
   float* qn = dist + qc * M;
-  if (knn_small_fits(N, M, D) && qc >= N)  // a handful of queries: one pass over the bank, exact distances
-    return knn_small_path(q, bank, score, dist, qn, bn_max, N, M, D, k, s);
+  if (knn_small_fits(N, M, D) && qc >= N) {  // a handful of queries: one pass over the bank, exact distances
+    const int rc_small = knn_small_path(q, bank, score, dist, qn, bn_max, nullptr, N, M, D, k, s);
+    if (rc_small <= 0) return rc_small;
+  }
   Knn16Run r16{};
   if (use16) {
     const char* st = reinterpret_cast<const char*>(state);

@@ -13,6 +13,10 @@
   ``svd_solver="randomized"`` = sklearn's randomized range finder carried out in covariance space with the SAME random
   test matrix (drawn from NumPy's global generator exactly as sklearn draws it), see ``pca_fit_randomized_device``.
 
+* round 6: ``gmm_fit`` (class means, class covariances, float32 Cholesky factors under the reference's jitter ladder,
+  ``inference/funcs.py:265-344``): rows grouped by label on the device, one ``runia_covariance_f32in`` per class, all classes'
+  factorisations in one ``runia_cholesky_f32`` launch per ladder step (``gmm_fit_device``).
+
 No vendor solver is involved.  The default (False) keeps the reference's own host calls, so fitted state is
 bit-identical to the reference.
 """
@@ -23,7 +27,7 @@ import torch
 
 from . import _hip
 
-__all__ = ["empirical_precision_device", "pinvh_device", "pca_fit_device", "pca_fit_randomized_device", "FittedPCA"]
+__all__ = ["empirical_precision_device", "pinvh_device", "pca_fit_device", "pca_fit_randomized_device", "FittedPCA", "gmm_fit_device"]
 
 
 def pinvh_device(cov: torch.Tensor) -> torch.Tensor:
@@ -156,3 +160,49 @@ def pca_fit_randomized_device(samples, n_components: int, whiten: bool = True, n
     scale = np.full(n_components, 1.0 / (n - 1.0)) if whiten else 1.0 / np.maximum(_hip.to_host(sing[:n_components]), 1e-300) ** 2
     fitted._train_projection = (_hip.to_host(proj.T.contiguous()), scale)
     return fitted
+
+
+_GMM_JITTERS = (0.0,) + tuple(10.0 ** e for e in range(-20, 0))
+
+
+def gmm_fit_device(embeddings, labels, num_classes: int):
+    """``gmm_fit`` on the device -> ``(loc [C', D] f32, scale_tril [C', D, D] f32, jitter)`` as DEVICE tensors, classes without
+    samples left out (``C'`` present classes in label order).
+
+    The reference (``inference/funcs.py:265-344``) takes, in float32 torch on the host: the class means, the covariance of every
+    class's centred rows over ``max(n_c, 2) - 1``, and the smallest jitter of ``0, 1e-20, ..., 1e-1`` for which
+    ``MultivariateNormal(covariance_matrix=cov + jitter I)`` can be built, i.e. for which every class has a float32 Cholesky
+    factor.  Here: rows grouped by label with one gather, mean and covariance of a class from ``runia_covariance_f32in``
+    (accumulated in f64 on the matrix cores, then rounded to f32 - closer to the exact moments than a float32 accumulation), and
+    the ladder walked with ``runia_cholesky_f32`` on all classes at once: float32 arithmetic like torch's LAPACK call, so a
+    covariance that is indefinite to float32 rounding fails here as it does there (the summation order inside a dot product
+    differs: a pivot within rounding of zero can fall the other way; ``tests/test_api_gpu.py`` compares jitter and factors with the
+    host fit on the reference-run fixtures)."""
+    x = embeddings.detach().cpu().numpy() if isinstance(embeddings, torch.Tensor) else np.asarray(embeddings)
+    lab = labels.detach().cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
+    lab = lab.reshape(-1).astype(np.int64)
+    valid = (lab >= 0) & (lab < num_classes)
+    counts = np.bincount(lab[valid], minlength=num_classes)
+    order = np.argsort(np.where(valid, lab, num_classes), kind="stable")[: int(valid.sum())]
+    xd = _hip.to_device(np.ascontiguousarray(x, dtype=np.float32), torch.float32)
+    xs = xd.index_select(0, _hip.to_device(order, torch.int64))  # rows grouped by class (a gather, no arithmetic)
+    del xd
+    means, covs, start = [], [], 0
+    for c in range(num_classes):
+        n_c = int(counts[c])
+        if n_c == 0:
+            continue
+        mean, cov = _hip.covariance(xs[start: start + n_c])           # f64, cov = sum / n_c
+        means.append(mean.to(torch.float32))
+        covs.append((cov * (n_c / (max(n_c, 2) - 1.0))).to(torch.float32))
+        start += n_c
+    loc, cov = torch.stack(means), torch.stack(covs)
+    chosen, factor = _GMM_JITTERS[-1], None
+    for jitter in _GMM_JITTERS:
+        tril, info = _hip.cholesky(cov, jitter)
+        if int(info.abs().max()) == 0 and bool(torch.isfinite(tril).all()):
+            chosen, factor = jitter, tril
+            break
+    if factor is None:  # nothing on the ladder is positive definite: the reference's last attempt raises as well
+        raise RuntimeError("gmm_fit: no jitter of the ladder makes every class covariance positive definite (cholesky failed)")
+    return loc, factor, (0 if chosen == 0.0 else chosen)

@@ -13,6 +13,7 @@ BLAS / OpenMP pools NumPy and SciPy use) at that number for the duration; a proc
 import contextlib
 import math
 import os
+import threading
 
 __all__ = ["usable_cpus", "host_compute"]
 
@@ -45,27 +46,45 @@ def usable_cpus() -> int:
     return max(1, min(n, quota) if quota else n)
 
 
+_LOCK = threading.RLock()
+_DEPTH = 0          # nested / concurrent host_compute() contexts in this process
+_BEFORE = None      # torch's intra-op thread count seen by the FIRST context to enter
+_LIMITER = None     # threadpoolctl limiter set by the first context
+
+
 @contextlib.contextmanager
 def host_compute():
+    """Cap the process-global pools for the duration.  The effect is GLOBAL (torch's intra-op pool and the BLAS / OpenMP pools
+    belong to the process, not to a thread): the cap is set by the first context to enter and lifted by the last one to leave
+    (depth counter under a lock), so overlapping contexts on several threads cannot restore each other's 'before' value out of
+    order.  Other CPU torch work of the process sees the cap while any context is open.  Keep device calls outside of it."""
     import torch
 
+    global _DEPTH, _BEFORE, _LIMITER
     cap = usable_cpus()
-    before = torch.get_num_threads()
-    limiter = None
-    if before > cap:
-        torch.set_num_threads(cap)
-    try:
-        try:
-            from threadpoolctl import threadpool_info, threadpool_limits
+    with _LOCK:
+        _DEPTH += 1
+        if _DEPTH == 1:
+            _BEFORE = torch.get_num_threads()
+            if _BEFORE > cap:
+                torch.set_num_threads(cap)
+            try:
+                from threadpoolctl import threadpool_info, threadpool_limits
 
-            # only the pools that are larger than the quota (a pool the user already made smaller stays as it is)
-            over = {lib["user_api"]: cap for lib in threadpool_info() if lib.get("num_threads", 0) > cap}
-            limiter = threadpool_limits(limits=over) if over else None
-        except Exception:  # threadpoolctl absent or a pool it cannot drive: torch's pool is capped anyway
-            limiter = None
+                # only the pools that are larger than the quota (a pool the user already made smaller stays as it is)
+                over = {lib["user_api"]: cap for lib in threadpool_info() if lib.get("num_threads", 0) > cap}
+                _LIMITER = threadpool_limits(limits=over) if over else None
+            except Exception:  # threadpoolctl absent or a pool it cannot drive: torch's pool is capped anyway
+                _LIMITER = None
+    try:
         yield cap
     finally:
-        if limiter is not None:
-            limiter.restore_original_limits()
-        if torch.get_num_threads() != before:
-            torch.set_num_threads(before)
+        with _LOCK:
+            _DEPTH -= 1
+            if _DEPTH == 0:
+                if _LIMITER is not None:
+                    _LIMITER.restore_original_limits()
+                    _LIMITER = None
+                if _BEFORE is not None and torch.get_num_threads() != _BEFORE:
+                    torch.set_num_threads(_BEFORE)
+                _BEFORE = None

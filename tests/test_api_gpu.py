@@ -766,7 +766,11 @@ def test_device_metrics_vs_oracle(case):
     (the end buckets); 1 + 1 scores."""
     from runia_core_amd.evaluation.metrics import auroc_fpr95_aupr_device
 
-    rng = np.random.default_rng(abs(hash(case)) % 1000)
+    # a fixed seed per case (hash(str) is salted per process: a red case could not have been reproduced)
+    seeds = {"f64_far": 101, "f64_unit": 102, "f32": 103, "ties": 104, "saturated": 105, "tiny": 106, "big": 107, "clustered": 108,
+             "clustered_unit": 109, "constant": 110, "infinite": 111, "two": 112, "larem_like": 113, "energy_like_f32": 114,
+             "ties_big": 115, "infinite_big": 116}
+    rng = np.random.default_rng(seeds[case])
     if case == "f64_far":
         ind, ood = rng.standard_normal(5000) * 3 + 1, rng.standard_normal(3000) * 3 - 1
     elif case == "f64_unit":
@@ -1607,3 +1611,50 @@ def test_detector_kde_other_kernels_vs_sklearn(kernel):
             assert np.all(got[gone] == -np.inf) and np.all(ref[gone] < -25.0)
     with pytest.raises(ValueError):
         DetectorKDE(train, kernel="triangular")
+
+
+def test_gmm_fit_on_the_device_equals_the_host_fit():
+    """Round 6: gmm_fit's moments and float32 factorisations on the device (device_fit.gmm_fit_device: runia_covariance_f32in per
+    class + runia_cholesky_f32 under the reference's jitter ladder) against the host fit in float32 torch (the reference's own
+    arithmetic, inference/funcs.py:265-344): same present classes, means and factors at 1e-6 / 1e-5, same jitter - on the
+    reference-run fixture, on 512-d rows with an empty class and a single-row class, and on rank-deficient class covariances
+    (the ladder has to move: the jitter chosen may differ by one step where a pivot is within rounding of zero)."""
+    from runia_core_amd import config
+    from runia_core_amd.inference import GMMLatentSpace, gmm_fit
+
+    g = load_npz("ref_f4.npz")
+    rng = np.random.default_rng(5)
+    big = (rng.standard_normal((6000, 512)) * (0.5 + rng.random(512))).astype(np.float32)
+    big_lab = rng.integers(0, 9, 6000)
+    big_lab[big_lab == 4] = 3            # class 4 is empty
+    big_lab[0] = 9                       # class 9 has a single row: zero covariance -> the ladder moves
+    cases = [(g["gmm_train"], g["gmm_labels"], 10, True), (big[:, :40], rng.integers(0, 5, 6000), 5, True), (big, big_lab, 10, False)]
+    low = (rng.standard_normal((300, 4)) @ rng.standard_normal((4, 48))).astype(np.float32)   # rank 4 in 48 dims
+    cases.append((low, rng.integers(0, 3, 300), 3, False))
+    before = config.device_fit
+    try:
+        for x, lab, c, same_jitter in cases:
+            config.device_fit = False
+            gh, jh = gmm_fit(torch.from_numpy(x), torch.from_numpy(np.asarray(lab)), c)
+            config.device_fit = True
+            gd, jd = gmm_fit(torch.from_numpy(x), torch.from_numpy(np.asarray(lab)), c)
+            assert hasattr(gd, "_runia_device_params") and not hasattr(gh, "_runia_device_params")
+            assert gd.loc.shape == gh.loc.shape and gd.scale_tril.shape == gh.scale_tril.shape
+            assert np.allclose(gd.loc.numpy(), gh.loc.numpy(), atol=1e-6 * max(1.0, float(gh.loc.abs().max())))
+            if same_jitter:
+                assert jd == jh
+                assert np.allclose(gd.scale_tril.numpy(), gh.scale_tril.numpy(), atol=1e-5 * max(1.0, float(gh.scale_tril.abs().max())))
+            else:
+                ladder = [0.0] + [10.0 ** e for e in range(-20, 0)]
+                assert abs(ladder.index(float(jd)) - ladder.index(float(jh))) <= 1
+            # both fits give a usable distribution: finite densities on the training rows
+            for gm in (gd, gh):
+                assert bool(torch.isfinite(gm.log_prob(torch.from_numpy(x[:50])[:, None, :])).all())
+        # the postprocessor scores through the device fit equal the reference-run fixture (also covered under both fits by
+        # test_gmm_and_ddu_fixtures)
+        config.device_fit = True
+        p = GMMLatentSpace()
+        p.setup(g["gmm_train"], ind_train_labels=g["gmm_labels"])
+        assert rel_err(p.postprocess(g["gmm_test"]), g["gmm_scores"]) < 1e-5
+    finally:
+        config.device_fit = before

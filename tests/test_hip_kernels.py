@@ -1332,3 +1332,38 @@ def test_gmm_log_prob_triangular_kernel_vs_torch(hip, n, d, c):
         keep = np.ones(n, bool)
         keep[[1, 3]] = False
         assert np.array_equal(gb[keep], got[keep]) and np.array_equal(lb[keep], lse[keep])  # other rows untouched
+
+
+@pytest.mark.parametrize("dtype", [np.float32, np.float64])
+@pytest.mark.parametrize("d,batch", [(1, 3), (2, 2), (63, 2), (64, 1), (200, 10), (513, 2), (1024, 1)])
+def test_cholesky_kernel_vs_lapack(hip, d, batch, dtype):
+    """runia_cholesky_* (round 6; gmm_fit's jitter ladder on the device, the triangular factor of MD's precision): L L^T = a + jitter I
+    against LAPACK's factor, zeros above the diagonal, info = j + 1 at the first pivot that is not positive (an indefinite and a NaN
+    matrix in the same batch as good ones), same bits from run to run."""
+    rng = np.random.default_rng(7 * d + batch)
+    a = rng.standard_normal((batch, d, 3 * d + 5))
+    cov = (a @ a.transpose(0, 2, 1) / (3 * d + 5) + 0.01 * np.eye(d)).astype(dtype)
+    tt = torch.float32 if dtype == np.float32 else torch.float64
+    L, info = hip.cholesky(dev(cov, tt), 0.0)
+    L2, _ = hip.cholesky(dev(cov, tt), 0.0)
+    assert torch.equal(L, L2) and int(info.abs().max()) == 0
+    L = L.cpu().numpy()
+    assert L.dtype == dtype and np.array_equal(np.triu(L, 1), np.zeros_like(L))
+    ref = np.linalg.cholesky(cov.astype(np.float64))
+    tol = 2e-4 if dtype == np.float32 else 1e-11
+    assert np.max(np.abs(L - ref)) <= tol * max(1.0, np.abs(ref).max())
+    eps = np.finfo(dtype).eps
+    assert np.max(np.abs(L.astype(np.float64) @ L.astype(np.float64).transpose(0, 2, 1) - cov)) <= 8 * d * eps * np.abs(cov).max()
+    # jitter enters the diagonal
+    Lj, infoj = hip.cholesky(dev(cov, tt), 0.5)
+    assert int(infoj.abs().max()) == 0
+    assert np.max(np.abs(Lj.cpu().numpy() - np.linalg.cholesky(cov.astype(np.float64) + 0.5 * np.eye(d)))) <= tol * max(1.0, np.abs(ref).max())
+    if d >= 2 and batch >= 2:
+        bad = cov.copy()
+        bad[0] = -np.eye(d, dtype=dtype)                     # first pivot negative
+        bad[1][d - 1, d - 1] = -1.0                          # last pivot negative
+        _, info_b = hip.cholesky(dev(bad, tt), 0.0)
+        info_b = info_b.cpu().numpy()
+        assert info_b[0] == 1 and info_b[1] == d and (info_b[2:] == 0).all()
+        bad[0][0, 0] = np.nan
+        assert hip.cholesky(dev(bad, tt), 0.0)[1].cpu().numpy()[0] == 1
