@@ -74,11 +74,12 @@ def pca_fit_device(samples, n_components: int, whiten: bool = True) -> FittedPCA
     """sklearn ``PCA(n_components, svd_solver="covariance_eigh").fit`` on the GPU (sklearn ``_pca.py::_fit_full``):
     covariance with ``ddof = 1``, symmetric eigen-decomposition, eigenvalues descending and clamped at 0, components =
     eigenvectors with the sign that makes the largest-magnitude entry of every component positive."""
-    x = np.asarray(samples)
+    on_dev = isinstance(samples, torch.Tensor) and samples.is_cuda
+    x = samples if on_dev else np.asarray(samples)
     n, d = x.shape
     if not 0 < n_components <= min(n, d):
         raise ValueError(f"n_components={n_components} must be between 0 and min(n_samples, n_features)={min(n, d)}")
-    xd = _hip.to_device(x, torch.float32 if x.dtype == np.float32 else torch.float64)
+    xd = x if on_dev else _hip.to_device(x, torch.float32 if x.dtype == np.float32 else torch.float64)
     mean, cov = _hip.covariance(xd)                  # bias = 1 (divided by n)
     cov = cov * (n / (n - 1.0))
     w, v = _hip.eigh(cov)
@@ -121,7 +122,8 @@ def pca_fit_randomized_device(samples, n_components: int, whiten: bool = True, n
         Vt = diag(1/s) U^T T^(-1/2) (S Z)^T.
     Agreement with sklearn: components to ~1e-11 on the test spectra (tests/test_api_gpu.py).  Data with fewer samples than
     features (sklearn transposes the problem and draws a different matrix) is not covered: the caller falls back to sklearn."""
-    x = np.asarray(samples)
+    on_dev = isinstance(samples, torch.Tensor) and samples.is_cuda   # rows already in HBM (the harness's device-resident sweep)
+    x = samples if on_dev else np.asarray(samples)
     n, d = x.shape
     if not 0 < n_components <= min(n, d):
         raise ValueError(f"n_components={n_components} must be between 0 and min(n_samples, n_features)={min(n, d)}")
@@ -130,7 +132,7 @@ def pca_fit_randomized_device(samples, n_components: int, whiten: bool = True, n
     size = min(n_components + n_oversamples, d)
     omega = np.random.normal(size=(d, n_components + n_oversamples))[:, :size]  # the draw sklearn makes (random_state=None)
     n_iter = 7 if n_components < 0.1 * min(n, d) else 4
-    xd = _hip.to_device(x, torch.float32 if x.dtype == np.float32 else torch.float64)
+    xd = x if on_dev else _hip.to_device(x, torch.float32 if x.dtype == np.float32 else torch.float64)
     mean, cov = _hip.covariance(xd)           # bias = 1
     s_mat = (cov * float(n)).contiguous()     # S = M^T M of the centred rows
     z = _hip.to_device(omega, torch.float64)
@@ -178,14 +180,16 @@ def gmm_fit_device(embeddings, labels, num_classes: int):
     covariance that is indefinite to float32 rounding fails here as it does there (the summation order inside a dot product
     differs: a pivot within rounding of zero can fall the other way; ``tests/test_api_gpu.py`` compares jitter and factors with the
     host fit on the reference-run fixtures)."""
-    x = embeddings.detach().cpu().numpy() if isinstance(embeddings, torch.Tensor) else np.asarray(embeddings)
+    on_dev = isinstance(embeddings, torch.Tensor) and embeddings.is_cuda
+    if not on_dev:
+        x = embeddings.detach().cpu().numpy() if isinstance(embeddings, torch.Tensor) else np.asarray(embeddings)
     lab = labels.detach().cpu().numpy() if isinstance(labels, torch.Tensor) else np.asarray(labels)
     lab = lab.reshape(-1).astype(np.int64)
     valid = (lab >= 0) & (lab < num_classes)
     counts = np.bincount(lab[valid], minlength=num_classes)
     order = np.argsort(np.where(valid, lab, num_classes), kind="stable")[: int(valid.sum())]
-    xd = _hip.to_device(np.ascontiguousarray(x, dtype=np.float32), torch.float32)
-    xs = xd.index_select(0, _hip.to_device(order, torch.int64))  # rows grouped by class (a gather, no arithmetic)
+    xd = embeddings.detach().to(torch.float32) if on_dev else _hip.to_device(np.ascontiguousarray(x, dtype=np.float32), torch.float32)
+    xs = xd.index_select(0, _hip.to_device(order, torch.int64).to(xd.device))  # rows grouped by class (a gather, no arithmetic)
     del xd
     means, covs, start = [], [], 0
     for c in range(num_classes):

@@ -115,7 +115,8 @@ def apply_pca_ds_split(samples: np.ndarray, nro_components: int = 16, svd_solver
     if config.use_device_fit() and isinstance(nro_components, int):
         from .device_fit import pca_fit_device, pca_fit_randomized_device
 
-        shape = np.shape(samples)
+        on_dev = isinstance(samples, torch.Tensor) and samples.is_cuda  # additive: rows already in HBM -> reduced rows stay there
+        shape = tuple(samples.shape) if on_dev else np.shape(samples)
         fitted = None
         if svd_solver in ("covariance_eigh", "full"):
             fitted = pca_fit_device(samples, nro_components, whiten)
@@ -125,8 +126,11 @@ def apply_pca_ds_split(samples: np.ndarray, nro_components: int = 16, svd_solver
             if getattr(fitted, "_train_projection", None) is not None:
                 # randomized solver: sklearn's fit_transform is U * sqrt(n - 1) (or U * S), see pca_fit_randomized_device
                 proj, var = fitted._train_projection
-                return apply_pca_transform(samples, DevicePCA(proj, fitted.mean_, var, True)), fitted
-            return apply_pca_transform(samples, fitted), fitted
+                dp = DevicePCA(proj, fitted.mean_, var, True)
+                return (dp.transform_device(samples) if on_dev else apply_pca_transform(samples, dp)), fitted
+            return (device_pca_for(fitted).transform_device(samples) if on_dev else apply_pca_transform(samples, fitted)), fitted
+    if isinstance(samples, torch.Tensor):
+        samples = samples.detach().cpu().numpy()
     from sklearn.decomposition import PCA
 
     from .host_threads import host_compute

@@ -59,28 +59,48 @@ def _get_best_postprocessors_metrics(baselines_names, overall_metrics_df, postpr
     return best
 
 
-def _get_best_post_processor_thresholds(postprocessors_names, best_postprocessors_dict, cfg, ind_data, ood_data):
+def _get_best_post_processor_thresholds(postprocessors_names, best_postprocessors_dict, cfg, ind_data, ood_data, ind_dev=None,
+                                        ood_dev=None):
     """Reference :521-605 without the histograms: refit every postprocessor at its best PCA size, threshold = mean - 1.645 std
-    of its InD valid scores; the OoD scores of that configuration are attached to ``ood_data`` under ``f"{ood} {best}"``."""
+    of its InD valid scores; the OoD scores of that configuration are attached to ``ood_data`` under ``f"{ood} {best}"``.
+    ``ind_dev`` / ``ood_dev`` (device-resident sweep): the same splits as device tensors - fits and scores then run from HBM
+    (``setup_device`` / ``postprocess_device``), only the score vectors come back."""
     from ..inference.postprocessors import postprocessors_dict
 
+    on_dev = ind_dev is not None
     thresholds = {}
     for name in postprocessors_names:
-        train_data = np.asarray(ind_data["train latent_space_means"]).copy()
-        valid_data = np.asarray(ind_data["valid latent_space_means"]).copy()
+        # (the reference copies the splits here; nothing below writes to them)
+        train_data = ind_dev["train latent_space_means"] if on_dev else np.asarray(ind_data["train latent_space_means"])
+        valid_data = ind_dev["valid latent_space_means"] if on_dev else np.asarray(ind_data["valid latent_space_means"])
         pca_transformation = None
         pp = postprocessors_dict[name](cfg=cfg)
         pp._setup_flag = False
         best_postp = best_postprocessors_dict[name]["best_comp"]
+        dev_path = on_dev and hasattr(pp, "setup_device") and hasattr(pp, "postprocess_device")
+        if not dev_path and on_dev:
+            train_data, valid_data = np.asarray(ind_data["train latent_space_means"]), np.asarray(ind_data["valid latent_space_means"])
         if "PCA" in best_postp:
             train_data, pca_transformation = apply_pca_ds_split(samples=train_data, nro_components=int(best_postp.split("PCA")[1]))
-        pp.setup(train_data, ind_train_labels=ind_data["train labels"])
-        if "PCA" in best_postp:
-            valid_data = apply_pca_transform(valid_data, pca_transformation)
-        ind_valid = pp.postprocess(valid_data, pred_labels=ind_data["valid labels"])
+        if dev_path:
+            pp.setup_device(train_data, ind_train_labels=ind_data["train labels"])
+            dp = device_pca_for(pca_transformation) if "PCA" in best_postp else None
+            if dp is not None:
+                valid_data = dp.transform_device(valid_data)
+            ind_valid = _hip.to_host(pp.postprocess_device(valid_data))
+        else:
+            pp.setup(train_data, ind_train_labels=ind_data["train labels"])
+            if "PCA" in best_postp:
+                valid_data = apply_pca_transform(valid_data, pca_transformation)
+            ind_valid = pp.postprocess(valid_data, pred_labels=ind_data["valid labels"])
         thresholds[best_postp] = np.mean(ind_valid) - (1.645 * np.std(ind_valid))
         for ood_dataset_name in _cfg_get(cfg, "ood_datasets"):
-            ood_dataset = np.asarray(ood_data[f"{ood_dataset_name} latent_space_means"]).copy()
+            if dev_path:
+                rows = ood_dev[f"{ood_dataset_name} latent_space_means"]
+                rows = dp.transform_device(rows) if dp is not None else rows
+                ood_data[f"{ood_dataset_name} {best_postp}"] = _hip.to_host(pp.postprocess_device(rows))
+                continue
+            ood_dataset = np.asarray(ood_data[f"{ood_dataset_name} latent_space_means"])
             if "PCA" in best_postp:
                 ood_dataset = apply_pca_transform(ood_dataset, pca_transformation)
             ood_data[f"{ood_dataset_name} {best_postp}"] = pp.postprocess(ood_dataset, pred_labels=ood_data[f"{ood_dataset_name} labels"])
@@ -114,7 +134,12 @@ def log_evaluate_larex(cfg, baselines_names: List[str], ood_baselines_scores: Di
         return _hip.to_device(a, torch.float32 if a.dtype == np.float32 else torch.float64)
 
     ind_eval, ood_eval = dict(ind_data_dict), dict(ood_data_dict)
+    train_rows = ind_data_dict["train latent_space_means"]
     if device_resident:
+        # ONE upload of every split, the training rows included (round 6): fits (setup_device, the PCA refits) and scores run
+        # from HBM; before, every postprocessor's setup and every PCA refit uploaded the training split again (17 x 205 MB) and
+        # formed its host-side statistics with NumPy / CPU torch
+        train_rows = ind_eval["train latent_space_means"] = on_device(ind_data_dict["train latent_space_means"])
         ind_eval["valid latent_space_means"] = on_device(ind_data_dict["valid latent_space_means"])
         for name in ood_datasets:
             ood_eval[f"{name} latent_space_means"] = on_device(ood_data_dict[f"{name} latent_space_means"])
@@ -124,8 +149,7 @@ def log_evaluate_larex(cfg, baselines_names: List[str], ood_baselines_scores: Di
     frames.append(res["results_df"])
     # PCA-reduced vectors
     for n_components in n_pca_components:
-        pca_ind_train, pca_transformation = apply_pca_ds_split(samples=ind_data_dict["train latent_space_means"],
-                                                               nro_components=n_components)
+        pca_ind_train, pca_transformation = apply_pca_ds_split(samples=train_rows, nro_components=n_components)
         ind_dict_pca = {"train latent_space_means": pca_ind_train}
         ood_dict_pca = {}
         if device_resident:
@@ -154,6 +178,7 @@ def log_evaluate_larex(cfg, baselines_names: List[str], ood_baselines_scores: Di
     best = _get_best_postprocessors_metrics(baselines_names, overall_metrics_df, postprocessors, n_pca_components, ood_datasets)
     if not thresholds:
         return overall_metrics_df, best, {}, ood_data_dict
-    postprocessor_thresholds, ood_data_dict = _get_best_post_processor_thresholds(postprocessors, best, cfg, ind_data_dict,
-                                                                                 ood_data_dict)
+    postprocessor_thresholds, ood_data_dict = _get_best_post_processor_thresholds(
+        postprocessors, best, cfg, ind_data_dict, ood_data_dict, ind_eval if device_resident else None,
+        ood_eval if device_resident else None)
     return overall_metrics_df, best, postprocessor_thresholds, ood_data_dict

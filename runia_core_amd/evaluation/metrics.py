@@ -148,7 +148,12 @@ def log_evaluate_postprocessors(ind_dict, ood_dict, ood_datasets_names, experime
     for postprocessor in postprocessors:
         postp_instance = postprocessors_dict[postprocessor](cfg=cfg)
         postp_instance._setup_flag = False
-        postp_instance.setup(host(ind_dict["train latent_space_means"]), ind_train_labels=host(ind_dict["train labels"]))
+        train_rows = ind_dict["train latent_space_means"]
+        if isinstance(train_rows, torch.Tensor) and train_rows.is_cuda and hasattr(postp_instance, "setup_device"):
+            # additive: training rows already in HBM (log_evaluate_larex(device_resident=True)) - same fitted state, no host pass
+            postp_instance.setup_device(train_rows, ind_train_labels=host(ind_dict["train labels"]))
+        else:
+            postp_instance.setup(host(train_rows), ind_train_labels=host(ind_dict["train labels"]))
         ind_scores_dict[postprocessor] = score(postp_instance, ind_dict["valid latent_space_means"], ind_dict["valid labels"])
         ood_scores_dict[postprocessor] = {}
         for ood_dataset_name in ood_datasets_names:

@@ -81,11 +81,18 @@ class DetectorKDE:
         return self
 
     def __getstate__(self):
-        return {**self.__dict__, "_train_dev": None, "_packed": None}  # device copies are rebuilt on first use
+        state = {**self.__dict__, "_train_dev": None, "_packed": None}  # device copies are rebuilt on first use
+        if isinstance(state.get("train_embeddings"), Tensor):
+            state["train_embeddings"] = _hip.to_host(state["train_embeddings"])
+        return state
 
     def _train(self) -> Tensor:
         if self._train_dev is None:
-            self._train_dev = _hip.to_device(np.asarray(self.train_embeddings), torch.float64)
+            t = self.train_embeddings
+            if isinstance(t, Tensor) and t.is_cuda:   # setup_device: the training rows are in HBM already
+                self._train_dev = t.detach().to(torch.float64).contiguous()
+            else:
+                self._train_dev = _hip.to_device(np.asarray(t), torch.float64)
         return self._train_dev
 
     def score_samples_device(self, x: Tensor) -> Tensor:
@@ -125,6 +132,18 @@ class KDELatentSpace(Postprocessor):
         else:
             warnings.warn("KDEPostprocessor already trained")
 
+    def setup_device(self, ind_train_data: Tensor, **kwargs) -> None:
+        """``setup`` on training rows that already sit in HBM (additive; the harness's device-resident sweep): same fitted
+        state, no host copy of the rows (``detector.train_embeddings`` is then the device tensor)."""
+        if not config.use_device_fit():  # config.device_fit = False: the reference's own host fits, from a host copy of the rows
+            return self.setup(_hip.to_host(ind_train_data), **kwargs)
+        assert ind_train_data.ndim == 2, "ind_feats must be 2 dimensional"
+        if not self._setup_flag:
+            self.detector = DetectorKDE(train_embeddings=ind_train_data)
+            self._setup_flag = True
+        else:
+            warnings.warn("KDEPostprocessor already trained")
+
     def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:
         assert test_data.ndim == 2, "ood_feats must be 2 dimensional"
         return self.detector.get_density_scores(test_data)
@@ -141,8 +160,45 @@ class MDLatentSpace(Postprocessor):
         super().__init__(cfg)
         self.feats_mean = None
         self.precision = None
-        self.centered_data = None
+        self._centered = None
+        self._train_rows_dev = None
         self._dev = None
+
+    @property
+    def centered_data(self):
+        """``ind_train_data - feats_mean`` (a public attribute of the reference).  After ``setup_device`` it is formed on first
+        access from the device rows (the sweep never reads it: 200 MB of host arithmetic per fit otherwise)."""
+        if self._centered is None and self._train_rows_dev is not None:
+            self._centered = _hip.to_host(self._train_rows_dev) - self.feats_mean
+        return self._centered
+
+    @centered_data.setter
+    def centered_data(self, value):
+        self._centered = value
+
+    def __getstate__(self):
+        # device copies are rebuilt on first use; a device-side setup's rows travel as the host attribute the reference exposes
+        return {**self.__dict__, "_dev": None, "_train_rows_dev": None, "_centered": self.centered_data}
+
+    def setup_device(self, ind_train_data: Tensor, **kwargs) -> None:
+        """``setup`` on training rows that already sit in HBM (additive): mean and covariance in ONE pass of the covariance kernel,
+        ``pinvh`` on the device; ``feats_mean`` / ``precision`` come back as the host arrays the reference exposes."""
+        if not config.use_device_fit():  # config.device_fit = False: the reference's own host fits, from a host copy of the rows
+            return self.setup(_hip.to_host(ind_train_data), **kwargs)
+        assert ind_train_data.ndim == 2, "ind_feats must be 2 dimensional"
+        if not self._setup_flag:
+            from ..device_fit import pinvh_device
+
+            mean, cov = _hip.covariance(ind_train_data)
+            self.feats_mean = _hip.to_host(mean).reshape(1, -1)
+            if ind_train_data.dtype == torch.float32:
+                self.feats_mean = self.feats_mean.astype(np.float32)  # np.mean of float32 rows is float32
+            self.precision = _hip.to_host(pinvh_device(cov))
+            self._centered, self._train_rows_dev = None, ind_train_data
+            self._dev = None
+            self._setup_flag = True
+        else:
+            warnings.warn("MDPostprocessor already trained")
 
     def setup(self, ind_train_data: np.ndarray, **kwargs) -> None:
         assert ind_train_data.ndim == 2, "ind_feats must be 2 dimensional"
@@ -243,6 +299,46 @@ class cMDLatentSpace(Postprocessor):
         else:
             warnings.warn("cMDPostprocessor already trained")
 
+    def setup_device(self, ind_train_data: Tensor, **kwargs) -> None:
+        """``setup`` on training rows that already sit in HBM (additive).  The reference works in float32 torch: class means, rows
+        centred on their class mean, ``EmpiricalCovariance`` of the pooled centred rows, ``pinvh``.  Here: the rows as float32,
+        grouped by label with one gather, mean and covariance of every class from the covariance kernel (f64 accumulation), the
+        pooled covariance as their count-weighted sum (the pooled mean of class-centred rows is zero), ``pinvh`` on the device."""
+        if not config.use_device_fit():  # config.device_fit = False: the reference's own host fits, from a host copy of the rows
+            return self.setup(_hip.to_host(ind_train_data), **kwargs)
+        try:
+            labels = kwargs["ind_train_labels"]
+        except KeyError:
+            raise ValueError("id_labels not provided. Pass ID train labels as 'ind_train_labels' argument.")
+        assert ind_train_data.ndim == 2, "ind_feats must be 2 dimensional"
+        if not self._setup_flag:
+            from ..device_fit import pinvh_device
+
+            lab = labels.detach().cpu().numpy() if isinstance(labels, Tensor) else np.asarray(labels)
+            lab = lab.reshape(-1).astype(np.int64)
+            n, d = ind_train_data.shape
+            x32 = ind_train_data.detach().to(torch.float32)
+            order = np.argsort(lab, kind="stable")
+            xs = x32.index_select(0, _hip.to_device(order, torch.int64).to(x32.device))
+            sorted_lab = lab[order]
+            means, pooled, total = [], torch.zeros((d, d), dtype=torch.float64, device=x32.device), 0
+            for c in range(self.num_classes):
+                lo, hi = int(np.searchsorted(sorted_lab, c, "left")), int(np.searchsorted(sorted_lab, c, "right"))
+                if hi == lo:
+                    warnings.warn(f"No examples for class {c} to build class-wise Mahalanobis Distance score")
+                    means.append(torch.full((d,), float("nan"), dtype=torch.float32))
+                    continue
+                mean, cov = _hip.covariance(xs[lo:hi])
+                means.append(mean.to(torch.float32).cpu())
+                pooled += cov * float(hi - lo)
+                total += hi - lo
+            self.class_mean = torch.stack(means)
+            self.precision = pinvh_device(pooled / float(max(total, 1))).to(torch.float32).cpu()
+            self._state = None
+            self._setup_flag = True
+        else:
+            warnings.warn("cMDPostprocessor already trained")
+
     def postprocess_device(self, test_data: Tensor) -> Tensor:
         if self._state is None:
             # the f32 precision the reference multiplies with, widened exactly; the quadratic form itself runs in f64
@@ -270,8 +366,42 @@ class KNNLatentSpace(Postprocessor):
             self.K = cfg.k_neighbors
         except AttributeError:
             self.K = 50
-        self.activation_log = None
+        self._activation_log = None
+        self._activation_log_dev = None
         self.index = None
+
+    @property
+    def activation_log(self):
+        """The normalised training rows (a public attribute of the reference); after ``setup_device`` read back on first access."""
+        if self._activation_log is None and self._activation_log_dev is not None:
+            self._activation_log = _hip.to_host(self._activation_log_dev)
+        return self._activation_log
+
+    @activation_log.setter
+    def activation_log(self, value):
+        self._activation_log = value
+
+    def __getstate__(self):
+        return {**self.__dict__, "_activation_log_dev": None, "_activation_log": self.activation_log}
+
+    def setup_device(self, ind_train_data: Tensor, **kwargs) -> None:
+        """``setup`` on training rows that already sit in HBM (additive): ``x / (||x||_2 + 1e-10)`` in the rows' own dtype (the
+        squared norms from ``runia_row_sqnorm_f64`` for float64 rows), rounded to the float32 bank faiss holds."""
+        if not config.use_device_fit():  # config.device_fit = False: the reference's own host fits, from a host copy of the rows
+            return self.setup(_hip.to_host(ind_train_data), **kwargs)
+        assert ind_train_data.ndim == 2, "ind_train_feats must be 2 dimensional"
+        if not self._setup_flag:
+            x = ind_train_data.detach()
+            if x.dtype == torch.float64:
+                normed = x / (torch.sqrt(_hip.row_sqnorm(x)).unsqueeze(1) + 1e-10)   # NumPy's dtype rules: float64 rows stay float64
+            else:
+                normed = _hip.l2_normalize(x.to(torch.float32))
+            self._activation_log, self._activation_log_dev = None, normed
+            self.index = FlatL2Bank(ind_train_data.shape[1])
+            self.index.add_device(normed.to(torch.float32).contiguous())
+            self._setup_flag = True
+        else:
+            warnings.warn("KNNPostprocessor already trained")
 
     def setup(self, ind_train_data: np.ndarray, **kwargs) -> None:
         assert ind_train_data.ndim == 2, "ind_train_feats must be 2 dimensional"
@@ -313,13 +443,29 @@ class FlatL2Bank:
     def add(self, x: np.ndarray) -> None:
         x = np.ascontiguousarray(np.asarray(x).astype(np.float32))
         assert x.ndim == 2 and x.shape[1] == self.d
-        self._host = np.concatenate([self._host, x]) if self.ntotal else x
+        self._host = np.concatenate([self._host_rows(), x]) if self.ntotal else x
         self.ntotal = self._host.shape[0]
         self._dev = None
         self._state = None
 
+    def add_device(self, x: Tensor) -> None:
+        """``add`` for rows that already sit in HBM (f32, contiguous): the bank IS that tensor; the host copy (pickling, a later
+        ``add``) is read back only when asked for."""
+        assert x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.shape[1] == self.d
+        if self.ntotal:
+            return self.add(_hip.to_host(x))
+        self._host = None
+        self.ntotal = int(x.shape[0])
+        self._dev = x.contiguous()
+        self._state = None
+
+    def _host_rows(self) -> np.ndarray:
+        if self._host is None:
+            self._host = _hip.to_host(self._dev)
+        return self._host
+
     def __getstate__(self):
-        return {**self.__dict__, "_dev": None, "_state": None}  # the device copies are rebuilt on first use
+        return {**self.__dict__, "_host": self._host_rows(), "_dev": None, "_state": None}  # the device copies are rebuilt on first use
 
     def _bank(self) -> Tensor:
         if self._dev is None:
@@ -368,6 +514,22 @@ class GMMLatentSpace(Postprocessor):
             except KeyError:
                 raise ValueError("id_labels not provided")
             self.gmm, _ = gmm_fit(embeddings=Tensor(ind_train_data), labels=labels, num_classes=self.num_classes)
+            self._state = None
+            self._setup_flag = True
+        else:
+            warnings.warn("GMMPostprocessor already trained")
+
+    def setup_device(self, ind_train_data: Tensor, **kwargs) -> None:
+        """``setup`` on training rows that already sit in HBM (additive): ``gmm_fit`` without the host copy of the rows."""
+        if not config.use_device_fit():  # config.device_fit = False: the reference's own host fits, from a host copy of the rows
+            return self.setup(_hip.to_host(ind_train_data), **kwargs)
+        assert ind_train_data.ndim == 2, "ind_train_feats must be 2 dimensional"
+        if not self._setup_flag:
+            try:
+                labels = kwargs["ind_train_labels"]
+            except KeyError:
+                raise ValueError("id_labels not provided")
+            self.gmm, _ = gmm_fit(embeddings=ind_train_data, labels=labels, num_classes=self.num_classes)
             self._state = None
             self._setup_flag = True
         else:
