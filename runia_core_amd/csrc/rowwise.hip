@@ -224,11 +224,12 @@ constexpr int kth_slots(int NV) { return NV >= 8 ? NV / 4 : 0; }  // registers p
 // through `buf` (64 * NV/4 words of the wave's own LDS) - until at most 64 are left, then one register per lane.  With
 // all 32 steps on all registers the scalar unit was the limit (two scalar instructions per register and step: GEN
 // 1 M x 1000 3.3 ms, ASH-S 1 M x 2048 5.5 ms).
+// `prefix` / `bit` / `lo0` (optional): bits above `bit` that every candidate shares, found by the caller (GEN: the wave's largest
+// and smallest key agree in them) - the steps that would only confirm them are skipped; lo0 = number of keys >= prefix.
 template <int NV>
-__device__ __forceinline__ unsigned kth_largest_key(const unsigned (&key)[NV], int k, unsigned* buf, int lane) {
+__device__ __forceinline__ unsigned kth_largest_key(const unsigned (&key)[NV], int k, unsigned* buf, int lane,
+                                                    unsigned prefix = 0u, int bit = 31, int lo0 = 64 * NV) {
   constexpr int R1 = kth_slots(NV);
-  unsigned prefix = 0u;
-  int bit = 31;
   if constexpr (R1 == 0) {
 #pragma unroll 1
     for (; bit >= 0; --bit) {
@@ -237,7 +238,7 @@ __device__ __forceinline__ unsigned kth_largest_key(const unsigned (&key)[NV], i
     }
     return prefix;
   } else {
-    int lo = 64 * NV, hi = 0;  // keys >= prefix, keys >= the range's upper end
+    int lo = lo0, hi = 0;  // keys >= prefix, keys >= the range's upper end
 #pragma unroll 1
     for (; bit >= 0 && lo - hi > 64 * R1; --bit) {
       const unsigned cand = prefix | (1u << bit);
@@ -365,77 +366,114 @@ __global__ __launch_bounds__(256) void gen_tiny_kernel(const float* __restrict__
   }
 }
 
-template <int NV>
+// Round 6 (1 M x 1000, M = 100: 1.84 -> see profiles/README.md; the kernel is bound by vector-instruction issue - 834 per row):
+//   * the M largest are selected on the softmax NUMERATORS e = exp(v - max) (the quotient e / s is monotone in e, and rows that tie
+//     in p contribute the same term whichever of them is taken), so only the ~M selected values are divided, not all C;
+//   * 16-byte loads when the rows allow it (VEC: lane holds 4 consecutive classes per 256-class stripe; the selection does not
+//     care which lane holds what);
+//   * the bit search starts below the bits the row's largest and smallest key share (numerators of a row span a few binades: the
+//     sign and most exponent bits cost a full-width count each just to be confirmed).
+template <int NV, bool VEC>
 __global__ __launch_bounds__(64 * kRowWaves) void gen_kernel(const float* __restrict__ logits, float* __restrict__ score,
                                                    int64_t N, int C, int M, float gamma, int from_probs) {
   constexpr int kBufWords = (64 * kth_slots(NV) > kGenCompact) ? 64 * kth_slots(NV) : kGenCompact;
-  __shared__ unsigned gen_sel[kRowWaves][kBufWords];  // the selection's packed keys, then the selected probabilities (as bits)
+  __shared__ unsigned gen_sel[kRowWaves][kBufWords];  // the selection's packed keys, then the selected numerators (as bits)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n4 = C >> 2;
   for (int64_t row = (int64_t)blockIdx.x * kRowWaves + wave; row < N; row += (int64_t)gridDim.x * kRowWaves) {
     const float* p = logits + row * C;
     float v[NV];
-    float m = -INFINITY;
+    bool ok[NV];  // element t of this lane is a class of the row (compile-time pattern per chunk under VEC)
+    if constexpr (VEC) {
+      const float4* p4 = reinterpret_cast<const float4*>(p);
 #pragma unroll
-    for (int t = 0; t < NV; ++t) {
-      const int j = lane + 64 * t;
-      v[t] = (j < C) ? p[j] : -INFINITY;
-      m = fmaxf(m, v[t]);
+      for (int c = 0; c < NV / 4; ++c) {
+        const bool in = lane + 64 * c < n4;
+        const float4 t = in ? p4[lane + 64 * c] : make_float4(-INFINITY, -INFINITY, -INFINITY, -INFINITY);
+        v[4 * c] = t.x; v[4 * c + 1] = t.y; v[4 * c + 2] = t.z; v[4 * c + 3] = t.w;
+        ok[4 * c] = ok[4 * c + 1] = ok[4 * c + 2] = ok[4 * c + 3] = in;
+      }
+    } else {
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        ok[t] = lane + 64 * t < C;
+        v[t] = ok[t] ? p[lane + 64 * t] : -INFINITY;
+      }
     }
-    m = wave_max_f32(m);
     float s = 1.f;
-    if (!from_probs) {  // (uniform) the rows are logits: softmax first
+    if (!from_probs) {  // (uniform) the rows are logits: softmax numerators first
+      float m = -INFINITY;
+#pragma unroll
+      for (int t = 0; t < NV; ++t) m = fmaxf(m, v[t]);
+      m = wave_max_f32(m);
       s = 0.f;
 #pragma unroll
       for (int t = 0; t < NV; ++t) {
+        // (one v_exp_f32 of d * log2(e) with the product's low part - 3 instructions for exp_nonpos's 9 - measured 1.487 -> 1.416 ms
+        // and lost the 1e-5 contract on narrow heads, tests/test_hip_kernels.py::test_gen_score_widths_and_m: not kept)
         v[t] = exp_nonpos(v[t] - m);  // padding -> 0
         s += v[t];
       }
       s = wave_sum_f32(s);
     }
     const float rs = 1.0f / s;
-    unsigned key[NV];
-#pragma unroll
-    for (int t = 0; t < NV; ++t) {
-      v[t] = from_probs ? ((lane + 64 * t < C) ? v[t] : 0.f) : div_by_rcp(v[t], s, rs);  // (softmax) probability
-      key[t] = (lane + 64 * t < C) ? (__float_as_uint(v[t]) | 0x80000000u) : 0u;  // p >= 0
-    }
+    auto prob = [&](float e) { return from_probs ? e : div_by_rcp(e, s, rs); };  // the (softmax) probability of a numerator
     float acc = 0.f;
     if (M >= C) {
 #pragma unroll
       for (int t = 0; t < NV; ++t)
-        if (lane + 64 * t < C) acc += gen_term(v[t], gamma);
+        if (ok[t]) acc += gen_term(prob(v[t]), gamma);
       acc = wave_sum_f32(acc);
     } else {
-      const unsigned thr = kth_largest_key<NV>(key, M, gen_sel[wave], lane);
+      unsigned key[NV];  // numerators / probabilities are >= 0: their bit patterns order them; padding = 0 sorts last
+      unsigned kmax = 0u, kmin = 0xffffffffu;
+#pragma unroll
+      for (int t = 0; t < NV; ++t) {
+        key[t] = ok[t] ? __float_as_uint(v[t]) : 0u;
+        kmax = key[t] > kmax ? key[t] : kmax;
+        const unsigned lowk = ok[t] ? key[t] : 0xffffffffu;
+        kmin = lowk < kmin ? lowk : kmin;
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) {
+        const unsigned a = (unsigned)__shfl_xor((int)kmax, o, 64), b = (unsigned)__shfl_xor((int)kmin, o, 64);
+        kmax = a > kmax ? a : kmax;
+        kmin = b < kmin ? b : kmin;
+      }
+      const unsigned diff = kmax ^ kmin;  // wave-uniform
+      unsigned thr;
+      if (diff == 0u) {
+        thr = kmax;  // every class has the same numerator
+      } else {
+        const int top = 31 - __builtin_clz(diff);
+        const unsigned prefix0 = (top == 31) ? 0u : (kmax & ~((2u << top) - 1u));
+        thr = kth_largest_key<NV>(key, M, gen_sel[wave], lane, prefix0, top, C);
+      }
       int gt = 0;  // wave-uniform: elements above the threshold
       if (M <= kGenCompact) {
-        // The selected probabilities (< M of the row's C) are packed into LDS first, so that the transcendentals of a term are
-        // evaluated for M/64 elements per lane instead of all NV under a mask (C = 1000, M = 100: 2 instead of 16).
+        // The selected numerators (< M of the row's C) are packed into LDS first, so that the division and the transcendentals of a
+        // term are evaluated for M/64 elements per lane instead of all NV under a mask (C = 1000, M = 100: 2 instead of 16).
         unsigned* sel = gen_sel[wave];
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
           const bool take = key[t] > thr;
           const unsigned long long mk = __ballot(take);
-          if (take) sel[gt + __popcll(mk & ((1ull << lane) - 1ull))] = __float_as_uint(v[t]);
+          if (take) sel[gt + __popcll(mk & ((1ull << lane) - 1ull))] = key[t];
           gt += __popcll(mk);
         }
         __builtin_amdgcn_wave_barrier();
-        for (int i = lane; i < gt; i += 64) {
-          const float pv = __uint_as_float(sel[i]);
-          acc += gen_term(pv, gamma);
-        }
+        for (int i = lane; i < gt; i += 64) acc += gen_term(prob(__uint_as_float(sel[i])), gamma);
         __builtin_amdgcn_wave_barrier();  // sel is reused by this wave's next row
       } else {
 #pragma unroll
         for (int t = 0; t < NV; ++t) {
           const bool take = key[t] > thr;
-          if (take) acc += gen_term(v[t], gamma);
+          if (take) acc += gen_term(prob(v[t]), gamma);
           gt += __popcll(__ballot(take));
         }
       }
       acc = wave_sum_f32(acc);
-      const float pt = __uint_as_float(thr & 0x7fffffffu);
-      acc += (float)(M - gt) * (gen_term(pt, gamma));
+      acc += (float)(M - gt) * (gen_term(prob(__uint_as_float(thr)), gamma));
     }
     if (lane == 0) score[row] = -acc;
   }
@@ -541,10 +579,14 @@ static int gen_rows(const float* logits, float* score, int64_t N, int64_t C, int
 #undef RUNIA_GEN_TINY
     return runia_check_launch();
   }
-  if (C <= 64) gen_kernel<1><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
-  else if (C <= 256) gen_kernel<4><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
-  else if (C <= 1024) gen_kernel<16><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
-  else gen_kernel<64><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
+  const bool vec = (C & 3) == 0 && (((uintptr_t)logits) & 15) == 0;  // rows of whole, aligned 16-byte groups
+  if (C <= 64) gen_kernel<1, false><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
+  else if (C <= 256 && vec) gen_kernel<4, true><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
+  else if (C <= 256) gen_kernel<4, false><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
+  else if (C <= 1024 && vec) gen_kernel<16, true><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
+  else if (C <= 1024) gen_kernel<16, false><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
+  else if (vec) gen_kernel<64, true><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
+  else gen_kernel<64, false><<<grid, kT, 0, s>>>(logits, score, N, (int)C, M, g, from_probs);
   return runia_check_launch();
 }
 
