@@ -128,6 +128,19 @@ int runia_md_score_f32(const float* x, const float* mean, const double* packed_p
                        int64_t N, int64_t n, runia_stream_t stream);
 int runia_md_score_f32x_f64mean(const float* x, const double* mean, const double* packed_p,
                                 double* score, int64_t N, int64_t n, runia_stream_t stream);
+/* runia_md_score_tril_*: the same score from the TRIANGULAR factor of the precision (round 6): precision = W^T W with W lower
+ *   triangular (e.g. the reversed Cholesky factor, see runia_cholesky_f64), packed_wt = runia_pack_weights_f64 of W^T [n, n]:
+ *   score = -|| W (x - mean) ||^2 = -(x - mean) precision (x - mean)^T (inference/postprocessors.py:241-242) with only the
+ *   k <= column part of every 256-column block multiplied - n^2 + 256 n multiply-adds per row instead of 2 n^2.  Same dtype
+ *   combinations and centring rules as runia_md_score_*.  The caller keeps runia_md_score_* for a precision that has no such
+ *   factor (rank-deficient pinvh).  workspace (optional): runia_md_score_workspace_bytes(N, n) bytes, as runia_md_score_ws_*
+ *   (few rows of wide features: column blocks on separate workgroups + a replay launch, same bits). */
+int runia_md_score_tril_f64(const double* x, const double* mean, const double* packed_wt, double* score, void* workspace,
+                            size_t workspace_bytes, int64_t N, int64_t n, runia_stream_t stream);
+int runia_md_score_tril_f32(const float* x, const float* mean, const double* packed_wt, double* score, void* workspace,
+                            size_t workspace_bytes, int64_t N, int64_t n, runia_stream_t stream);
+int runia_md_score_tril_f32x_f64mean(const float* x, const double* mean, const double* packed_wt, double* score,
+                                     void* workspace, size_t workspace_bytes, int64_t N, int64_t n, runia_stream_t stream);
 /* The same scores (bit for bit) with a workspace (round 4): for few rows of wide features - MD on un-reduced 2048-d features,
  * one image at a time - the 256-column blocks of a 16-row tile go to separate workgroups and a second launch adds their
  * products in the one-launch kernel's order (0.9 -> 0.1 ms at <= 512 rows x 2048).  runia_md_score_workspace_bytes returns

@@ -52,6 +52,9 @@ _SIGNATURES = {
     "runia_md_score_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "runia_md_score_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
     "runia_md_score_f32x_f64mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int64, c_void_p]),
+    "runia_md_score_tril_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
+    "runia_md_score_tril_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
+    "runia_md_score_tril_f32x_f64mean": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
     "runia_md_score_workspace_bytes": (c_size_t, [c_int64, c_int64]),
     "runia_md_score_ws_f64": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
     "runia_md_score_ws_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int64, c_void_p]),
@@ -620,6 +623,32 @@ def md_score(x: torch.Tensor, mean: torch.Tensor, packed_p: torch.Tensor) -> tor
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
     _check(fn(x.data_ptr(), mean.data_ptr(), packed_p.data_ptr(), s.data_ptr(), _ptr(ws), ws_bytes, nrow, n, _stream()),
            "runia_md_score_ws")
+    return s
+
+
+@_device_guard()
+def md_score_tril(x: torch.Tensor, mean: torch.Tensor, packed_wt: torch.Tensor) -> torch.Tensor:
+    """``md_score`` from the triangular factor of the precision (``runia_md_score_tril_*``): precision = W^T W with W lower
+    triangular, ``packed_wt = pack_weights(W^T)``; score [N] f64 = -|| W (x - mean) ||^2, same centring rules as ``md_score``."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dim() == 2 and x.dtype in (torch.float32, torch.float64)
+    x = x.contiguous()
+    nrow, n = x.shape
+    if x.dtype == torch.float64:
+        mean = mean.to(torch.float64)
+        fn = lib.runia_md_score_tril_f64
+    elif mean.dtype == torch.float32:
+        fn = lib.runia_md_score_tril_f32
+    else:
+        mean = mean.to(torch.float64)
+        fn = lib.runia_md_score_tril_f32x_f64mean
+    mean = mean.contiguous()
+    s = torch.empty((nrow,), dtype=torch.float64, device=x.device)
+    ws_bytes = int(lib.runia_md_score_workspace_bytes(nrow, n))  # few rows of wide features: column blocks + replay (same bits)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=x.device) if ws_bytes else None
+    _check(fn(x.data_ptr(), mean.data_ptr(), packed_wt.data_ptr(), s.data_ptr(), _ptr(ws), ws_bytes, nrow, n, _stream()),
+           "runia_md_score_tril")
     return s
 
 

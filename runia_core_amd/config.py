@@ -30,3 +30,9 @@ knn_bf16_candidates = True
 # calls (scipy.special.softmax / logsumexp, inference/postprocessors.py:549, 606).  Ignored where a GPU is present
 # (the HIP kernels always run there); every other postprocessor still raises without one.
 host_logits_without_gpu = False
+
+# MDLatentSpace on wide (un-reduced) features, n >= 512: score = -|| W (x - mu) ||^2 with the lower-triangular factor W of the
+# precision (precision = W^T W, device Cholesky) instead of -(x - mu) P (x - mu)^T - about half the multiply-adds (the kernel
+# skips the zero half of W).  Falls back to the P form by itself when the precision has no such factor (rank-deficient pinvh,
+# not symmetric, badly conditioned).  The choice depends on the fitted state alone, never on the batch.  False: always the P form.
+md_triangular = True

@@ -58,6 +58,10 @@ struct GemmArgs {
   double* md_vals;
   // outputs
   double* out;          // EPI_PCA / EPI_STORE: [N, n] (ld = n); EPI_ROWDOT / EPI_ROWNORM / EPI_KDE: [N]
+  // EPI_ROWNORM with a TRIANGULAR right-hand matrix (round 6, runia_md_score_tril_*): B = W^T with W lower triangular, i.e.
+  // B[k][col] = 0 for k > col - the 256-column block cb only multiplies its first (cb + 1) * 256 k values (the chunk loop ends at
+  // the diagonal block: about half the products of a wide matrix), and neg_sq writes -sum of squares instead of the norm
+  int tri, neg_sq;
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const double* __restrict__ B, int64_t ldb,
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   const int64_t NT = n_pad / 16;
   const int64_t nchunks = k_padded(g.K) / KC;
   int64_t tile_id = blockIdx.x, cb_begin = 0, cb_end = n_pad / BN;
-  if constexpr (EPI == EPI_MAHA || EPI == EPI_KDE || EPI == EPI_ROWDOT) {
+  if constexpr (EPI == EPI_MAHA || EPI == EPI_KDE || EPI == EPI_ROWDOT || EPI == EPI_ROWNORM) {
     if ((EPI == EPI_MAHA) ? (g.maha_part != nullptr) : (EPI == EPI_KDE) ? (g.kde_vals != nullptr) : (g.md_vals != nullptr)) {  // column-split launch (uniform)
       const int64_t nb = n_pad / BN;
       if constexpr (EPI == EPI_MAHA) {
@@ -322,7 +326,11 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
 
     if (cb == cb_begin) load_a_regs<TA, TS, RT, SUB>(g, r0, 0, tid, areg);
     int buf = 0;
-    for (int64_t ch = 0; ch < nchunks; ++ch) {
+    int64_t nch = nchunks;  // chunks of this column block
+    if constexpr (EPI == EPI_ROWNORM) {
+      if (g.tri && (cb + 1) * (BN / KC) < nchunks) nch = (cb + 1) * (BN / KC);  // (uniform) nothing below the diagonal block
+    }
+    for (int64_t ch = 0; ch < nch; ++ch) {
       {
         constexpr int PER = 2 * RT, TPR = KC / PER;
         const int row = tid / TPR, kk = (tid % TPR) * PER;
@@ -333,7 +341,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
       // the next chunk's rows are requested before this chunk's products; behind the last chunk that is the FIRST chunk of
       // the next 256-column block (the same rows again), so its latency passes under the products and the epilogue instead
       // of in front of every block (KDE at K = 256: 8 chunks per block)
-      if (ch + 1 < nchunks) load_a_regs<TA, TS, RT, SUB>(g, r0, (ch + 1) * KC, tid, areg);
+      if (ch + 1 < nch) load_a_regs<TA, TS, RT, SUB>(g, r0, (ch + 1) * KC, tid, areg);
       else if (cb + 1 < cb_end) load_a_regs<TA, TS, RT, SUB>(g, r0, 0, tid, areg);
       if constexpr (RING) mfma_chunk_ring<RT, NCT>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, bring);
       else mfma_chunk<RT, NCT>(acc, &lds_a[buf][0][0], APITCH, li, lg, bp + ch * 4 * NT * 64, NT * 64, b0);
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
             kde_online_update<NCT>(val, rowmax[a][r], rowdot[a][r]);
           }
         }
-    } else if (EPI == EPI_ROWDOT && g.md_vals) {  // column-split launch: the products go to memory, md_replay_kernel adds them
+    } else if ((EPI == EPI_ROWDOT || EPI == EPI_ROWNORM) && g.md_vals) {  // column-split launch: the products go to memory, md_replay_kernel adds them
       const TA* x = reinterpret_cast<const TA*>(g.x);
 #pragma unroll
       for (int a = 0; a < RT; ++a)
@@ -440,9 +448,13 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
             const int64_t row = r0 + 16 * a + lg + 4 * r;
             double prod = 0.0;  // (a term the unsplit kernel skips: adding +0.0 leaves its running sum as it is)
             if (row < g.N && col < g.n) {
-              const TA xv = x[row * g.ldx + col];
-              const double d = g.sub ? sub_promote<TA, TS>(xv, reinterpret_cast<const TS*>(g.sub)[col]) : (double)xv;
-              prod = acc[a][c][r] * d;
+              if constexpr (EPI == EPI_ROWNORM) {
+                prod = acc[a][c][r] * acc[a][c][r];
+              } else {
+                const TA xv = x[row * g.ldx + col];
+                const double d = g.sub ? sub_promote<TA, TS>(xv, reinterpret_cast<const TS*>(g.sub)[col]) : (double)xv;
+                prod = acc[a][c][r] * d;
+              }
             }
             g.md_vals[(((tile_id * (n_pad / BN) + cb) * 256 + tid) * (RT * 4) + (a * 4 + r)) * NCT + c] = prod;
           }
@@ -511,7 +523,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     kde_merge_store<RT>(rowdot, rowmax, lds_part, lds_part2, wave, li, lg, tid, r0, g.N, g.addc, g.out);
   }
   if constexpr (EPI == EPI_ROWDOT || EPI == EPI_ROWNORM) {
-    if (EPI == EPI_ROWDOT && g.md_vals) return;
+    if ((EPI == EPI_ROWDOT || EPI == EPI_ROWNORM) && g.md_vals) return;
 #pragma unroll
     for (int a = 0; a < RT; ++a)
 #pragma unroll
@@ -528,7 +540,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
       const int64_t row = r0 + tid;
       if (row < g.N) {
         const double t = ((lds_part[0][tid] + lds_part[1][tid]) + lds_part[2][tid]) + lds_part[3][tid];
-        g.out[row] = (EPI == EPI_ROWNORM) ? sqrt(t) : -t;
+        g.out[row] = (EPI == EPI_ROWNORM && !g.neg_sq) ? sqrt(t) : -t;
       }
     }
   }
@@ -892,6 +904,41 @@ extern "C" int runia_md_score_ws_f32x_f64mean(const float* x, const double* mean
                                               void* workspace, size_t workspace_bytes, int64_t N, int64_t n,
                                               runia_stream_t stream) {
   return md_ws_impl<float, double>(x, mean, packed_p, score, workspace, workspace_bytes, N, n, stream);
+}
+
+// MD / LaREM score with the triangular factor of the precision (round 6): P = W^T W, W lower triangular ->
+// -(x - mean) P (x - mean)^T = -|| W (x - mean) ||^2 with packed_wt = pack(W^T): the zero half of W is not multiplied.  Few rows
+// of wide features take the column-split launch + replay of runia_md_score_ws_* (same workspace size, same bits as the one launch).
+template <typename TA, typename TS>
+static int md_tril_impl(const TA* x, const TS* mean, const double* packed_wt, double* score, void* workspace,
+                        size_t workspace_bytes, int64_t N, int64_t n, runia_stream_t stream) {
+  if (N < 0 || n <= 0) return RUNIA_E_INVALID;
+  if (N == 0) return RUNIA_OK;
+  if (!x || !packed_wt || !score) return RUNIA_E_INVALID;
+  GemmArgs g{};
+  g.x = x; g.ldx = n; g.packed = packed_wt; g.N = N; g.K = n; g.n = n;
+  g.sub = mean; g.out = score; g.tri = 1; g.neg_sq = 1;
+  hipStream_t s = as_stream(stream);
+  const size_t need = runia_md_score_workspace_bytes(N, n);
+  if (need == 0 || !workspace || workspace_bytes < need) return launch_gemm<TA, EPI_ROWNORM, TS>(g, s);
+  g.md_vals = reinterpret_cast<double*>(workspace);
+  const int64_t tiles = (N + 15) / 16, nb = n_padded(n) / BN;
+  gemm_rows_kernel<TA, TS, EPI_ROWNORM, 1, 4><<<(unsigned)(tiles * nb), 256, 0, s>>>(g);
+  md_replay_kernel<<<(unsigned)tiles, 256, 0, s>>>(g.md_vals, score, N, nb);
+  return runia_check_launch();
+}
+extern "C" int runia_md_score_tril_f64(const double* x, const double* mean, const double* packed_wt, double* score,
+                                       void* workspace, size_t workspace_bytes, int64_t N, int64_t n, runia_stream_t stream) {
+  return md_tril_impl<double, double>(x, mean, packed_wt, score, workspace, workspace_bytes, N, n, stream);
+}
+extern "C" int runia_md_score_tril_f32(const float* x, const float* mean, const double* packed_wt, double* score, void* workspace,
+                                       size_t workspace_bytes, int64_t N, int64_t n, runia_stream_t stream) {
+  return md_tril_impl<float, float>(x, mean, packed_wt, score, workspace, workspace_bytes, N, n, stream);
+}
+extern "C" int runia_md_score_tril_f32x_f64mean(const float* x, const double* mean, const double* packed_wt, double* score,
+                                                void* workspace, size_t workspace_bytes, int64_t N, int64_t n,
+                                                runia_stream_t stream) {
+  return md_tril_impl<float, double>(x, mean, packed_wt, score, workspace, workspace_bytes, N, n, stream);
 }
 
 // ViM residual: || (x - u) @ NS ||_2 per row (reference inference/postprocessors.py:1106): x - u follows NumPy's

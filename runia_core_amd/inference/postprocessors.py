@@ -225,9 +225,31 @@ class MDLatentSpace(Postprocessor):
         # rebuilt when precision / feats_mean are reassigned after first use (the reference reads the live attributes)
         fp = (_hip.array_fingerprint(self.precision), _hip.array_fingerprint(self.feats_mean))
         if self._dev is None or self._dev.get("fp") != fp:
-            packed = _hip.pack_weights(_hip.to_device(np.asarray(self.precision, dtype=np.float64), torch.float64))
-            self._dev = {"packed_p": packed, "mean": {}, "fp": fp}
+            prec = _hip.to_device(np.asarray(self.precision, dtype=np.float64), torch.float64)
+            self._dev = {"packed_p": _hip.pack_weights(prec), "packed_wt": self._triangular_factor(prec), "mean": {}, "fp": fp}
         return self._dev
+
+    _TRI_MIN_WIDTH = 512   # two 256-column blocks: below that the triangular kernel multiplies what the dense one does
+
+    @staticmethod
+    def _triangular_factor(prec: Tensor):
+        """pack(W^T) with precision = W^T W, W lower triangular - or None when the P form stays (narrow, not symmetric, no Cholesky
+        factor: a pinvh that dropped directions is singular; or a factor whose pivots span more than ~1e6).  W^T = U is the
+        upper-triangular factor precision = U U^T: the Cholesky factor of the precision with rows and columns reversed, reversed
+        back (``runia_cholesky_f64``; flips are data movement)."""
+        n = prec.shape[0]
+        if not config.md_triangular or n < MDLatentSpace._TRI_MIN_WIDTH or prec.shape[0] != prec.shape[1]:
+            return None
+        top = float(prec.abs().max())
+        if not np.isfinite(top) or top == 0.0 or float((prec - prec.t()).abs().max()) > 1e-12 * top:
+            return None
+        g, info = _hip.cholesky(torch.flip(prec, dims=(0, 1)).contiguous())
+        if int(info.item()) != 0:
+            return None
+        diag = torch.diagonal(g)
+        if not bool(torch.isfinite(g).all()) or float(diag.min()) < 1e-6 * float(diag.max()):
+            return None
+        return _hip.pack_weights(torch.flip(g, dims=(0, 1)).contiguous())
 
     def _mean(self, dtype: torch.dtype) -> Tensor:
         st = self._device_state()
@@ -239,6 +261,8 @@ class MDLatentSpace(Postprocessor):
         """Device rows ``(N, D)`` f64/f32 -> device scores ``(N,)`` f64."""
         st = self._device_state()
         mean_dtype = torch.float32 if np.asarray(self.feats_mean).dtype == np.float32 else torch.float64
+        if st.get("packed_wt") is not None:   # wide features with a triangular factor: half the products (config.md_triangular)
+            return _hip.md_score_tril(test_data, self._mean(mean_dtype), st["packed_wt"])
         return _hip.md_score(test_data, self._mean(mean_dtype), st["packed_p"])
 
     def postprocess(self, test_data: np.ndarray, **kwargs) -> np.ndarray:

@@ -185,3 +185,50 @@ def test_array_lifting_pickler_moves_large_arrays_out_of_band():
     assert len(buf.getvalue()) < 4096  # the 512 KB array is not in the byte stream
     back = _ArrayPlacingUnpickler(io.BytesIO(buf.getvalue()), [p.arrays[0].numpy()]).load()
     assert back["a"] is back["b"][0] and np.array_equal(back["a"], big) and back["c"][1] == "v"
+
+
+def _worker_big_state(rank, world, port, out_dir):
+    import resource
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from runia_core_amd.inference.postprocessors import FlatL2Bank
+
+        m, d = 50_000, 2048   # cfg3: kNN bank 50 000 x 2048 f32 = 410 MB, Mahalanobis precision 2048 x 2048 f64 = 33.5 MB
+        state = None
+        if rank == 0:
+            bank = FlatL2Bank(d)
+            rows = np.empty((m, d), dtype=np.float32)
+            rows[:] = np.arange(d, dtype=np.float32)[None, :] * 1e-3
+            rows[:, 0] = np.arange(m, dtype=np.float32)
+            bank.add(rows)
+            del rows
+            prec = np.zeros((d, d), dtype=np.float64)
+            prec[np.arange(d), np.arange(d)] = np.arange(1, d + 1, dtype=np.float64)
+            state = {"bank": bank, "precision": prec, "class_mean": np.ones((10, d), dtype=np.float32)}
+        state_bytes = m * d * 4 + d * d * 8
+        dist.barrier()
+        before = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024
+        got = broadcast_fitted(state)
+        after = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss * 1024
+        host = got["bank"]._host
+        ok = (host.shape == (m, d) and host.dtype == np.float32 and float(host[12345, 0]) == 12345.0 and host[777, 2047] == np.float32(2047) * np.float32(1e-3)
+              and got["bank"].ntotal == m and float(got["precision"][2047, 2047]) == 2048.0 and got["class_mean"].shape == (10, d))
+        np.savez(os.path.join(out_dir, f"b{rank}.npz"), grew=after - before, state_bytes=state_bytes, ok=ok)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_broadcast_fitted_of_a_cfg3_sized_state_makes_no_second_copy(tmp_path):
+    """broadcast_fitted on the fitted state of BASELINE.json configs[2] (410 MB kNN bank + 33.5 MB precision) under gloo, world 2:
+    the arrays travel out of band, so the sender's peak memory does not grow by another copy of the state and the receiver's
+    grows by about one copy (not by pickle stream + unpickled arrays)."""
+    world = 2
+    mp.spawn(_worker_big_state, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    g0, g1 = np.load(tmp_path / "b0.npz"), np.load(tmp_path / "b1.npz")
+    assert bool(g0["ok"]) and bool(g1["ok"])
+    size = int(g0["state_bytes"])
+    assert int(g0["grew"]) < 0.5 * size, (int(g0["grew"]), size)    # rank 0: no pickled copy of the 444 MB
+    assert int(g1["grew"]) < 1.6 * size, (int(g1["grew"]), size)    # receiver: the arrays once (+ allocator slack)

@@ -1367,3 +1367,60 @@ def test_cholesky_kernel_vs_lapack(hip, d, batch, dtype):
         assert info_b[0] == 1 and info_b[1] == d and (info_b[2:] == 0).all()
         bad[0][0, 0] = np.nan
         assert hip.cholesky(dev(bad, tt), 0.0)[1].cpu().numpy()[0] == 1
+
+
+@pytest.mark.parametrize("n,rows,xdt,mdt", [(512, 300, np.float64, np.float64), (640, 70, np.float32, np.float32), (1024, 1000, np.float32, np.float64),
+                                            (2048, 9000, np.float32, np.float32), (100, 50, np.float64, np.float64), (777, 33, np.float64, np.float64)])
+def test_md_score_from_the_triangular_factor(hip, n, rows, xdt, mdt):
+    """runia_md_score_tril_* (round 6): -|| W (x - mean) ||^2 with precision = W^T W, W lower triangular, the zero half of W
+    skipped by the kernel - against the oracle's -(x - mean) P (x - mean)^T and the dense kernel; the factor comes from
+    runia_cholesky_f64 of the reversed precision (MDLatentSpace._triangular_factor)."""
+    from runia_core_amd import config
+    from runia_core_amd.inference import MDLatentSpace
+
+    rng = np.random.default_rng(n + rows)
+    a = rng.standard_normal((n, 2 * n + 7))
+    cov = a @ a.T / (2 * n + 7) + 0.05 * np.eye(n)
+    prec = np.linalg.inv(cov)
+    prec = 0.5 * (prec + prec.T)
+    mean = rng.standard_normal(n).astype(mdt)
+    x = (rng.standard_normal((rows, n)) * 1.5 + 0.2).astype(xdt)
+    tt = lambda d: torch.float32 if d == np.float32 else torch.float64  # noqa: E731
+    # the factor, by hand: U upper triangular with P = U U^T
+    g, info = hip.cholesky(torch.flip(dev(prec, torch.float64), dims=(0, 1)).contiguous())
+    assert int(info.item()) == 0
+    u = torch.flip(g, dims=(0, 1)).contiguous()
+    assert np.allclose(np.tril(u.cpu().numpy(), -1), 0.0) and np.allclose((u @ u.t()).cpu().numpy(), prec, atol=1e-10 * np.abs(prec).max())
+    got = hip.md_score_tril(dev(x, tt(xdt)), dev(mean, tt(mdt)), hip.pack_weights(u)).cpu().numpy()
+    diff = (x - mean) if (xdt == np.float32 and mdt == np.float32) else (x.astype(np.float64) - mean.astype(np.float64))
+    exp = -np.einsum("ij,jk,ik->i", diff.astype(np.float64), prec, diff.astype(np.float64))
+    assert got.dtype == np.float64 and rel_err(got, exp) < 1e-11
+    dense = hip.md_score(dev(x, tt(xdt)), dev(mean, tt(mdt)), hip.pack_weights(dev(prec, torch.float64))).cpu().numpy()
+    assert rel_err(got, dense) < 1e-11
+    # a row's bits do not depend on the batch it arrives in
+    one = hip.md_score_tril(dev(x[:1], tt(xdt)), dev(mean, tt(mdt)), hip.pack_weights(u)).cpu().numpy()
+    assert one[0] == got[0]
+    # the postprocessor takes the factor from n = 512 upward, the P form below, and on request / for a singular precision
+    md = MDLatentSpace()
+    md.feats_mean, md.precision, md._setup_flag = mean.reshape(1, -1), prec, True
+    s = md.postprocess(x)
+    assert (md._device_state()["packed_wt"] is not None) == (n >= 512)
+    assert rel_err(s, exp) < 1e-11
+    if n >= 512:
+        before = config.md_triangular
+        try:
+            config.md_triangular = False
+            md2 = MDLatentSpace()
+            md2.feats_mean, md2.precision, md2._setup_flag = mean.reshape(1, -1), prec, True
+            assert md2._device_state()["packed_wt"] is None and rel_err(md2.postprocess(x), exp) < 1e-11
+        finally:
+            config.md_triangular = before
+        sing = prec.copy()
+        w, v = np.linalg.eigh(sing)
+        w[:5] = 0.0                                   # a pinvh that dropped five directions
+        sing = (v * w) @ v.T
+        md3 = MDLatentSpace()
+        md3.feats_mean, md3.precision, md3._setup_flag = mean.reshape(1, -1), 0.5 * (sing + sing.T), True
+        s3 = md3.postprocess(x)
+        assert md3._device_state()["packed_wt"] is None
+        assert rel_err(s3, -np.einsum("ij,jk,ik->i", diff.astype(np.float64), md3.precision, diff.astype(np.float64))) < 1e-10
