@@ -296,7 +296,7 @@ def resolve_device(args, kwargs, exempt=()):
                 dev, first = d, i
             elif d != dev:
                 _raise_two_devices(dev, first, d, i)
-        elif isinstance(value, (tuple, list, torch.Tensor)):
+        elif isinstance(value, (tuple, list)) or getattr(value, "is_cuda", False) is True:  # packed states, tensor subclasses
             for t in _cuda_tensors(value):
                 if dev is None:
                     dev, first = t.device, i

@@ -109,6 +109,21 @@ def clock_bracket():
     return done
 
 
+def stage_clocks(stages) -> dict:
+    """One more (untimed) pass of a chain with a clock probe queued directly behind every stage: {stage: GHz}.  ``stages`` = list
+    of (name, fn(previous result) -> result).  The same launch reads a different fraction of its roofline behind a bandwidth-bound
+    kernel than behind an instruction-bound one (cfg4's PCA: 0.67 in one leg, 0.78 in the other, round 5) - the clock each stage
+    STARTS at is the previous stage's reading here, the one it holds is its own."""
+    from runia_core_amd import _hip
+
+    probes, prev = [], None
+    for name, fn in stages:
+        prev = fn(prev)
+        probes.append((name, _hip.clock_probe()))
+    torch.cuda.synchronize()
+    return {name: _hip.clock_ghz(pr)["ghz"] for name, pr in probes}
+
+
 def _rel(a, b):
     a, b = np.asarray(a, np.float64), np.asarray(b, np.float64)
     return float(np.max(np.abs(a - b) / np.maximum(1.0, np.abs(b)))) if a.size else 0.0
@@ -370,6 +385,8 @@ def run_cfg4_lared(device, n_props: int = 100_000, n_train: int = 4000, n_mc: in
         s = chain(ev)
     clocks = clocks()  # the probe directly behind the last rep (~30 us of one wave), then the synchronisation
     wall = (time.perf_counter() - t0) / reps
+    by_stage = stage_clocks([("entropy", lambda _: _hip.kl_entropy_per_dim(z, n_mc, 5)), ("pca", dp.transform_device),
+                             ("kde", kde.postprocess_device)])
     per = [[m[i].elapsed_time(m[i + 1]) for m in ev] for i in range(3)]
     ms = [float(np.median(p)) for p in per]   # median of the reps (min / max beside it)
     ent_gbs = (n_mc * d * 4 + d * 8) * n_props / (ms[0] * 1e-3) / 1e9
@@ -377,6 +394,7 @@ def run_cfg4_lared(device, n_props: int = 100_000, n_train: int = 4000, n_mc: in
     kde_tf = 2.0 * n_train * n_pca * n_props / (ms[2] * 1e-3) / 1e12
     rec = {"shape": f"{n_props} proposals x {n_mc} MC x {d} f32 -> entropy -> PCA-{n_pca} -> KDE on {n_train} train rows",
            "rows": n_props, "ms": round(1e3 * wall, 4), "rows_per_s": round(n_props / wall, 1), "clock_ghz_observed": clocks,
+           "clock_ghz_behind_stage": by_stage,
            "timing": "0.3 s of the same chain untimed, then the median of %d reps per stage (HIP events)" % reps,
            "entropy": {"ms": round(ms[0], 4), "ms_spread": spread(per[0]), "bound": "hbm", "achieved": round(ent_gbs, 1), "peak": HBM_PEAK_GBS,
                        "unit": "GB/s", "frac": round(ent_gbs / HBM_PEAK_GBS, 4)},
@@ -482,6 +500,8 @@ def run_cfg4_from_maps(device, n_img: int = 100, per_img: int = 1000, c: int = 1
         s, h = chain(ev_roi, ev)
     clocks = clocks()  # the probe directly behind the last rep (~30 us of one wave), then the synchronisation
     wall = (time.perf_counter() - t0) / reps
+    by_stage = stage_clocks([("roi_sampler_entropy", lambda _: rois_entropy(0, k)), ("pca", dp.transform_device),
+                             ("kde", kde.postprocess_device)])
     per = [[m[i].elapsed_time(m[i + 1]) for m in ev] for i in range(3)]
     ms = [float(np.median(p)) for p in per]
     # the ROI leg takes one launch group per slice of 65 535 proposals: sum the slices of a rep, then the median over reps
@@ -494,6 +514,7 @@ def run_cfg4_from_maps(device, n_img: int = 100, per_img: int = 1000, c: int = 1
     rec = {"shape": f"{n_img} maps x {c} ch x {fh}x{fw} f32 + {per_img} boxes each -> roi_align 7x7/2 -> {n_mc} MC DropBlock -> entropy "
                     f"-> PCA-{n_pca} -> KDE on {n_train} train rows",
            "rows": k, "ms": round(1e3 * wall, 3), "rows_per_s": round(k / wall, 1), "clock_ghz_observed": clocks,
+           "clock_ghz_behind_stage": by_stage,
            "timing": "0.3 s of the same chain untimed, then the median of %d reps per stage (HIP events)" % reps,
            "channels_last_copy": {"ms": round(ms_t, 4), "ms_spread": spread(per_t), "bound": "hbm", "achieved": round(2 * fm.numel() * 4 / (ms_t * 1e-3) / 1e9, 1),
                                   "peak": HBM_PEAK_GBS, "unit": "GB/s"},
@@ -540,9 +561,14 @@ def _timed(fn, reps: int = 3, warm: float = 0.3):
     for i in range(reps):
         out = fn()
         marks[i + 1].record()
+    from runia_core_amd import _hip
+
+    probe = _hip.clock_probe()  # directly behind the last rep: the clock THIS leg's kernels left the GPU at
     torch.cuda.synchronize()
     per = [marks[i].elapsed_time(marks[i + 1]) for i in range(reps)]
-    return float(np.median(per)), spread(per), out
+    sp = spread(per)
+    sp["clock_ghz"] = _hip.clock_ghz(probe)["ghz"]
+    return float(np.median(per)), sp, out
 
 
 def _leg(ms, sp, rows, bound, per_row, peak, unit, **extra):
