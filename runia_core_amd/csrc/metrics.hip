@@ -491,10 +491,14 @@ struct MsdState {
   ProbeRec recs[kProbeBlocks];    // the probe's workgroups
   unsigned lin[kMsdBuckets];      // round 5: scores per bin of the raw range (msd_lin_hist_kernel), the sketch the buckets are equalised with
   unsigned hist[kMsdBuckets];
-  unsigned cursor[kMsdBuckets];
   unsigned start[kMsdBuckets + 1];
   unsigned done_blocks;           // curve_terms: the last block to finish writes the three scalars
   unsigned done_group[8 * 32];    // ... counted per residue of the workgroup id mod 8 first (one 128-byte line each)
+  // the scatter's slot cursor of a bucket (low half) and - round 6, for the fused sort + curve launch - the bucket's positives
+  // (in-distribution scores; high half): ONE returning atomic per non-empty (tile, bucket) serves both
+  unsigned long long cursor64[kMsdBuckets];
+  // ---- not cleared by the probe (written before read) ----
+  unsigned long long split[kMsdBuckets];  // round 6: splitter keys of the equalised buckets (msd_split_kernel)
 };
 
 template <typename T>
@@ -507,12 +511,10 @@ template <typename T>
 __global__ __launch_bounds__(256) void msd_probe_kernel(const T* __restrict__ ind, int64_t n_ind, const T* __restrict__ ood,
                                                         int64_t n_ood, MsdState* st) {
   __shared__ unsigned long long smin[4], smax[4];
-  {  // the words later launches add to
-    constexpr unsigned kClear = 3 * kMsdBuckets + 1 + 8 * 32;
-    static_assert(offsetof(MsdState, done_group) + sizeof(unsigned) * 8 * 32 - offsetof(MsdState, lin) == (kClear + kMsdBuckets + 1) * 4,
-                  "lin, hist, cursor, start, done_blocks, done_group are contiguous");
+  {  // the words later launches add to: everything from `lin` up to the splitters
+    constexpr unsigned kClearWords = (unsigned)((offsetof(MsdState, split) - offsetof(MsdState, lin)) / 4);
     unsigned* z = st->lin;
-    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < kClear + kMsdBuckets + 1; i += gridDim.x * 256) z[i] = 0u;
+    for (unsigned i = blockIdx.x * 256 + threadIdx.x; i < kClearWords; i += gridDim.x * 256) z[i] = 0u;
   }
   bool bad = false;
   unsigned long long mn = ~0ull, mx = 0ull;  // key range of the raw, finite scores (no exp here: see MsdRange)
@@ -650,6 +652,76 @@ __device__ __forceinline__ unsigned msd_bucket(double raw, uint64_t key, const M
 // scores still puts ~120 into an average bin; the launch is a pass over the scores with LDS atomics, 19 us -> ~7 at 2 M)
 constexpr int kSketchStride = 4;
 constexpr int64_t kSketchAll = 1 << 17;  // up to here every score is counted
+// Splitter e (1 .. nb - 1) of the bucket function: the key of the raw score at which the bucket index steps from e - 1 to e -
+// squashed like every other key - made non-decreasing by a running maximum over e (so that "number of splitters <= key" is a
+// monotone function of the key whatever the rounding of the lines below).  cum / cnt: the sketch (exclusive scan of the bin
+// counts, bin counts) or null for raw-linear buckets; out[0] = 0.  One workgroup of 256 threads; nb a power of two <= kMsdBuckets.
+template <typename T>
+__device__ __forceinline__ void msd_make_splitters(const MsdRange& rg, bool squash, const unsigned* __restrict__ cum,
+                                                   const unsigned* __restrict__ cnt, double buckets_per_key, int nb,
+                                                   unsigned long long* __restrict__ out) {
+  __shared__ unsigned long long wmax_s[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int per = (nb + 255) / 256;  // consecutive entries per thread (<= 16)
+  uint64_t run = 0ull, mine[kMsdBuckets / 256];
+#pragma unroll
+  for (int j0 = 0; j0 < kMsdBuckets / 256; j0 += 4) {
+    // four entries at a time: their binary searches over the sketch are four independent chains of LDS reads (one chain per
+    // entry left the sketch launch's last workgroup 22 us behind the others at 2 M scores)
+    double xs[4];
+    int bs[4];
+    double ts[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int e = tid * per + j0 + q;
+      xs[q] = (double)e;  // raw-linear bins: the boundary is the bin edge
+      ts[q] = cum ? (double)e / buckets_per_key : 0.0;  // the rank at which bucket e starts
+      bs[q] = 0;
+    }
+    if (cum) {  // (uniform)
+#pragma unroll 1
+      for (int step = kMsdBuckets / 2; step > 0; step >>= 1) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+          if ((double)cum[bs[q] + step] <= ts[q]) bs[q] += step;  // largest bin with cum[b] <= t
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const double c = (double)cnt[bs[q]];
+        double frac = c > 0.0 ? (ts[q] - (double)cum[bs[q]]) / c : 0.0;
+        frac = frac < 0.0 ? 0.0 : (frac > 1.0 ? 1.0 : frac);
+        xs[q] = (double)bs[q] + frac;
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int j = j0 + q, e = tid * per + j;
+      uint64_t sk = 0ull;
+      if (j < per && e >= 1 && e < nb)  // no finite range (rg.scale == 0): no key reaches a splitter - everything is bucket 0
+        sk = (rg.scale > 0.0) ? score_key<T>((T)(rg.hi - xs[q] / rg.scale), squash) : ~0ull;
+      run = sk > run ? sk : run;
+      mine[j] = run;
+    }
+  }
+  uint64_t x = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t y = ((uint64_t)(unsigned)__shfl_up((int)(unsigned)(x >> 32), o, 64) << 32) | (unsigned)__shfl_up((int)(unsigned)x, o, 64);
+    if (lane >= o) x = y > x ? y : x;
+  }
+  uint64_t before = ((uint64_t)(unsigned)__shfl_up((int)(unsigned)(x >> 32), 1, 64) << 32) | (unsigned)__shfl_up((int)(unsigned)x, 1, 64);
+  if (lane == 0) before = 0ull;
+  __syncthreads();  // (wmax_s may still be read by a previous caller's threads)
+  if (lane == 63) wmax_s[wave] = x;
+  __syncthreads();
+  for (int w = 0; w < wave; ++w) before = wmax_s[w] > before ? wmax_s[w] : before;
+#pragma unroll
+  for (int j = 0; j < kMsdBuckets / 256; ++j) {
+    const int e = tid * per + j;
+    if (j < per && e < nb) out[e] = (e == 0) ? 0ull : (mine[j] > before ? mine[j] : before);
+  }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void msd_lin_hist_kernel(const T* __restrict__ ind, int64_t n_ind, const T* __restrict__ ood,
                                                            int64_t n_ood, unsigned* __restrict__ any_outside, MsdState* st,
@@ -676,6 +748,62 @@ __global__ __launch_bounds__(256) void msd_lin_hist_kernel(const T* __restrict__
     const unsigned c = lh[b];
     if (c) atomicAdd(&st->lin[b], c);
   }
+}
+
+// round 6: the finished sketch -> the splitter keys of the equalised buckets, 256 per workgroup (16 workgroups), one per thread.
+// (As the tail of the sketch launch - its last workgroup to arrive derived all 4 095 - the one workgroup worked 17 us while the
+// chip waited; as a prologue of every key-launch workgroup, 60 us of that launch.)  The running maximum that makes them
+// non-decreasing is taken by the key launch as it loads them.
+template <typename T>
+__global__ __launch_bounds__(256) void msd_split_kernel(unsigned* __restrict__ any_outside, MsdState* st, unsigned n_probe_recs) {
+  __shared__ unsigned cum_s[kMsdBuckets], cnt_s[kMsdBuckets];
+  __shared__ unsigned wsum_s[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const ProbeResult pr = msd_reduce_probe(st, n_probe_recs, any_outside);
+  const MsdRange rg = msd_range_of(pr.nkmin, pr.kmax);
+  constexpr int PER = kMsdBuckets / 256;
+  unsigned v[PER], tot = 0u;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) { v[j] = st->lin[tid * PER + j]; tot += v[j]; }
+  unsigned x = tot;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  if (lane == 63) wsum_s[wave] = x;
+  __syncthreads();
+  unsigned off = x - tot;
+  for (int w = 0; w < wave; ++w) off += wsum_s[w];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    cum_s[tid * PER + j] = off;
+    cnt_s[tid * PER + j] = v[j];
+    off += v[j];
+  }
+  const unsigned finite_total = wsum_s[0] + wsum_s[1] + wsum_s[2] + wsum_s[3];
+  __syncthreads();
+  const int e = (int)blockIdx.x * 256 + tid;
+  uint64_t sk = 0ull;
+  if (e >= 1 && e < kMsdBuckets) {
+    sk = ~0ull;  // no finite range: no key reaches a splitter - everything is bucket 0
+    if (rg.scale > 0.0) {
+      double xs = (double)e;
+      if (finite_total) {
+        const double t = (double)e * ((double)finite_total / (double)kMsdBuckets);  // the rank at which bucket e starts
+        int b = 0;  // largest bin with cum[b] <= t
+#pragma unroll 1
+        for (int step = kMsdBuckets / 2; step > 0; step >>= 1)
+          if ((double)cum_s[b + step] <= t) b += step;
+        const double c = (double)cnt_s[b];
+        double frac = c > 0.0 ? (t - (double)cum_s[b]) / c : 0.0;
+        frac = frac < 0.0 ? 0.0 : (frac > 1.0 ? 1.0 : frac);
+        xs = (double)b + frac;
+      }
+      sk = score_key<T>((T)(rg.hi - xs / rg.scale), pr.squash);
+    }
+  }
+  if (e < kMsdBuckets) st->split[e] = sk;
 }
 
 template <typename T>
@@ -740,14 +868,15 @@ __global__ __launch_bounds__(256) void msd_keys_kernel(const T* __restrict__ ind
 }
 
 constexpr int kScatItems = METRICS_SCAT_ITEMS, kScatTile = 256 * kScatItems;  // 8 192 keys per workgroup: ~2 per (tile, bucket)
-template <typename T>
+template <typename T, int ITEMS = kScatItems>  // small sets: 8 keys per thread (20 000 scores: 10 workgroups instead of 3)
 __global__ __launch_bounds__(256) void msd_scatter_kernel(const uint64_t* __restrict__ keys_in, const uint8_t* __restrict__ lab_in,
                                                           uint64_t* __restrict__ keys_out, uint8_t* __restrict__ lab_out, int64_t n,
                                                           const uint16_t* __restrict__ bucket_of, MsdState* st) {
   __shared__ unsigned cnt[kMsdBuckets];   // keys of this tile per bucket, then the tile's first slot in the bucket
   __shared__ unsigned first[kMsdBuckets]; // keys in the buckets before b
+  __shared__ unsigned lpos[kMsdBuckets];  // positives of this tile per bucket (round 6: the fused sort + curve launch starts from them)
   __shared__ unsigned wsum[4];
-  for (int b = threadIdx.x; b < kMsdBuckets; b += 256) cnt[b] = 0u;
+  for (int b = threadIdx.x; b < kMsdBuckets; b += 256) { cnt[b] = 0u; lpos[b] = 0u; }
   {
     // the exclusive scan of the bucket counts, by every workgroup for itself (16 KB of counts from L2) instead of by one
     // workgroup in a launch of its own in front of this one; workgroup 0 leaves it in st->start for the sort
@@ -775,30 +904,36 @@ __global__ __launch_bounds__(256) void msd_scatter_kernel(const uint64_t* __rest
     if (blockIdx.x == 0 && tid == 255) st->start[kMsdBuckets] = off;
   }
   __syncthreads();
-  const int64_t t0 = (int64_t)blockIdx.x * kScatTile;
-  uint64_t key[kScatItems];
-  unsigned slot[kScatItems];  // bucket << 16 | rank of the key among the tile's keys of that bucket (< 16 384)
+  const int64_t t0 = (int64_t)blockIdx.x * (256 * ITEMS);
+  uint64_t key[ITEMS];
+  unsigned slot[ITEMS];  // bucket << 16 | rank of the key among the tile's keys of that bucket (< 16 384)
+  unsigned labbits = 0u;      // label of item c in bit c
   static_assert(kScatTile <= 65536 && kMsdBits <= 16, "bucket and rank share a word; a bucket index fits the 16-bit array");
+  static_assert(ITEMS <= 32, "one label bit per item");
 #pragma unroll
-  for (int c = 0; c < kScatItems; ++c) {
+  for (int c = 0; c < ITEMS; ++c) {
     const int64_t i = t0 + c * 256 + threadIdx.x;
     key[c] = (i < n) ? keys_in[i] : 0ull;
     const unsigned b = (i < n) ? (unsigned)bucket_of[i] : 0u;
+    const unsigned lab = (i < n) ? (unsigned)lab_in[i] : 0u;
+    labbits |= (lab & 1u) << c;
     slot[c] = (b << 16) | ((i < n) ? atomicAdd(&cnt[b], 1u) : 0u);
+    if (lab) atomicAdd(&lpos[b], 1u);
   }
   __syncthreads();
   for (int b = threadIdx.x; b < kMsdBuckets; b += 256) {
     const unsigned c = cnt[b];
-    cnt[b] = c ? first[b] + atomicAdd(&st->cursor[b], c) : 0u;  // ONE global atomic per non-empty (tile, bucket)
+    // ONE global atomic per non-empty (tile, bucket): the tile's slots in the bucket (low half) + its positives (high half)
+    cnt[b] = c ? first[b] + (unsigned)atomicAdd(&st->cursor64[b], (unsigned long long)c | ((unsigned long long)lpos[b] << 32)) : 0u;
   }
   __syncthreads();
 #pragma unroll
-  for (int c = 0; c < kScatItems; ++c) {
+  for (int c = 0; c < ITEMS; ++c) {
     const int64_t i = t0 + c * 256 + threadIdx.x;
     if (i < n) {
       const unsigned pos = cnt[slot[c] >> 16] + (slot[c] & 0xffffu);
       keys_out[pos] = key[c];
-      lab_out[pos] = lab_in[i];
+      lab_out[pos] = (uint8_t)((labbits >> c) & 1u);
     }
   }
 }
@@ -820,19 +955,9 @@ constexpr int kMsdWaveCap = 1024;
 // stage waiting for the last - took 97 us per 2 M keys (4 096 buckets of ~490).  Equal keys never swap (their order does
 // not matter to the curve: a run is one point), so both lanes of a pair decide alike.
 template <int PER>
-__device__ __forceinline__ void wave_sort_in_registers(uint64_t* __restrict__ keys, uint8_t* __restrict__ labs, unsigned lo,
-                                                       unsigned nb, int lane) {
+__device__ __forceinline__ void wave_sort_network(uint64_t (&k)[PER], unsigned (&l)[PER], int lane) {
   constexpr int LOG_PER = (PER == 1) ? 0 : (PER == 2) ? 1 : (PER == 4) ? 2 : (PER == 8) ? 3 : 4, LOG_M = LOG_PER + 6;
   static_assert((1 << LOG_PER) == PER, "PER is a power of two up to 16");
-  uint64_t k[PER];
-  unsigned l[PER];
-  // (which unsorted key starts in which register does not matter: consecutive lanes read consecutive keys)
-#pragma unroll
-  for (int r = 0; r < PER; ++r) {
-    const unsigned e = (unsigned)r * 64u + (unsigned)lane;
-    k[r] = (e < nb) ? keys[lo + e] : ~0ull;  // padding: the largest key, behind every real one
-    l[r] = (e < nb) ? labs[lo + e] : 0u;
-  }
 #pragma unroll
   for (int lk = 1; lk <= LOG_M; ++lk) {
 #pragma unroll
@@ -867,6 +992,26 @@ __device__ __forceinline__ void wave_sort_in_registers(uint64_t* __restrict__ ke
       }
     }
   }
+}
+// the bucket's keys and labels into registers; (which unsorted key starts in which register does not matter: consecutive lanes
+// read consecutive keys).  Padding: the largest key, behind every real one.
+template <int PER>
+__device__ __forceinline__ void wave_sort_load(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ labs, unsigned lo,
+                                               unsigned nb, int lane, uint64_t (&k)[PER], unsigned (&l)[PER]) {
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const unsigned e = (unsigned)r * 64u + (unsigned)lane;
+    k[r] = (e < nb) ? keys[lo + e] : ~0ull;
+    l[r] = (e < nb) ? labs[lo + e] : 0u;
+  }
+}
+template <int PER>
+__device__ __forceinline__ void wave_sort_in_registers(uint64_t* __restrict__ keys, uint8_t* __restrict__ labs, unsigned lo,
+                                                       unsigned nb, int lane) {
+  uint64_t k[PER];
+  unsigned l[PER];
+  wave_sort_load<PER>(keys, labs, lo, nb, lane, k, l);
+  wave_sort_network<PER>(k, l, lane);
   // (stores straight from the registers, PER consecutive keys per lane; through the wave's LDS slice for consecutive lanes to
   // write consecutive keys: 183 registers + 42 KB of LDS per workgroup, 211 -> 233 us per 2 M scores)
 #pragma unroll
@@ -1082,6 +1227,450 @@ __global__ __launch_bounds__(256) void curve_terms_finalize_kernel(const uint64_
   }
 }
 
+// ---- round 6: six launches instead of eight (four instead of seven for sets without a sketch, <= 262 144 scores) --------------------------------------------------------
+// probe | [sketch | splitters] | keys | scatter | sort + curve + finalise.  Two changes make the back half ONE launch:
+//   * the key launch assigns a key to its bucket by comparing the KEY with 4 095 splitter keys (the keys of the raw-score values
+//     at which the equalised bucket function steps, squashed like every other key, made non-decreasing by a running maximum):
+//     bucket = number of splitters <= key.  Equal keys can no longer lie in two buckets - squashing merges raw scores that the raw
+//     bins keep apart: float32 energies, saturated LaREM scores - so the last key of a bucket always ends a run, and the
+//     cumulative counts in front of a bucket are the sums of the counts / positives of the buckets before it.  (It also makes the
+//     bucket order the key order BY CONSTRUCTION: the round-5 form derived the bucket from the raw score and relied on
+//     1 / (1 + exp(-v)) being monotone - ADVICE r5.)  The arithmetic bucket of round 5 stays as the first guess (two LDS reads
+//     confirm it); a binary search over the splitters only runs when the guess is off.
+//   * the sort launch keeps a bucket's sorted keys in the wave's registers and forms the curve terms there - label prefix, run ends,
+//     the previous run end of every run end as a running maximum of (index, positives) - instead of storing the keys for three
+//     more passes (tile summary, tile prefix, curve terms: 55 us of kernels + the tps / prev_end arrays at 2 M scores).  Buckets
+//     beyond a wave's 1 024 keys: a bucket of equal keys is one run end (its counts are known: nothing is read); anything else
+//     is sorted by the workgroup as before and walked in chunks of 1 024 with carries.
+// The three scalars come from per-workgroup records added in index order by the last workgroup (same bits from run to run).
+struct FusedPart { double roc, pr; unsigned long long first_idx; unsigned first_fp, pad; };
+
+template <typename T, int ITEMS = kItems>  // ITEMS keys per thread: small sets take 4 (20 000 scores: 20 workgroups instead of 5)
+__global__ __launch_bounds__(256) void msd_keys_split_kernel(const T* __restrict__ ind, int64_t n_ind, const T* __restrict__ ood,
+                                                             int64_t n_ood, unsigned* __restrict__ any_outside, MsdState* st,
+                                                             unsigned n_probe_recs, uint64_t* __restrict__ keys,
+                                                             uint8_t* __restrict__ labels, uint16_t* __restrict__ bucket_of, int equalise,
+                                                             int nbk) {
+  __shared__ unsigned long long split[kMsdBuckets];  // split[e], e = 1 .. nbk - 1: bucket of a key = number of splitters <= key
+  __shared__ unsigned lh[kMsdBuckets];               // this tile's keys per bucket
+  const int tid = threadIdx.x;
+  const ProbeResult pr = msd_reduce_probe(st, n_probe_recs, any_outside);
+  const bool squash = pr.squash;
+  for (int b = tid; b < kMsdBuckets; b += 256) lh[b] = 0u;
+  if (equalise) {  // (uniform) the splitters of the equalised buckets (msd_split_kernel), made non-decreasing by a running maximum
+    __shared__ unsigned long long wmax_l[4];
+    const int lane = tid & 63, wave = tid >> 6;
+    constexpr int PER = kMsdBuckets / 256;
+    uint64_t mine[PER], run = 0ull;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const uint64_t v = st->split[tid * PER + j];
+      run = v > run ? v : run;
+      mine[j] = run;
+    }
+    uint64_t x = run;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const uint64_t y = ((uint64_t)(unsigned)__shfl_up((int)(unsigned)(x >> 32), o, 64) << 32) | (unsigned)__shfl_up((int)(unsigned)x, o, 64);
+      if (lane >= o) x = y > x ? y : x;
+    }
+    uint64_t before = ((uint64_t)(unsigned)__shfl_up((int)(unsigned)(x >> 32), 1, 64) << 32) | (unsigned)__shfl_up((int)(unsigned)x, 1, 64);
+    if (lane == 0) before = 0ull;
+    if (lane == 63) wmax_l[wave] = x;
+    __syncthreads();
+    for (int w = 0; w < wave; ++w) before = wmax_l[w] > before ? wmax_l[w] : before;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) split[tid * PER + j] = mine[j] > before ? mine[j] : before;
+  } else {         // raw-linear buckets, nbk of them over the range of the finite scores
+    MsdRange rg = msd_range_of(pr.nkmin, pr.kmax);
+    rg.scale *= (double)nbk / (double)kMsdBuckets;
+    msd_make_splitters<T>(rg, squash, nullptr, nullptr, 0.0, nbk, split);
+  }
+  __syncthreads();
+  const int64_t n = n_ind + n_ood;
+  const int64_t t0 = (int64_t)blockIdx.x * (256 * ITEMS);
+  constexpr int W = (ITEMS % 8 == 0) ? 8 : 4;  // independent searches per trip: their LDS reads overlap
+  static_assert(ITEMS % W == 0, "whole trips");
+  for (int c0 = 0; c0 < ITEMS; c0 += W) {
+    uint64_t key[W];
+    unsigned b[W];
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int64_t i = t0 + (c0 + j) * 256 + tid;
+      const T v = (i < n) ? ((i < n_ind) ? ind[i] : ood[i - n_ind]) : (T)0;
+      key[j] = score_key<T>(v, squash);
+      b[j] = 0u;
+    }
+    for (unsigned step = (unsigned)nbk >> 1; step > 0u; step >>= 1) {
+#pragma unroll
+      for (int j = 0; j < W; ++j)
+        if (split[b[j] + step] <= key[j]) b[j] += step;
+    }
+#pragma unroll
+    for (int j = 0; j < W; ++j) {
+      const int64_t i = t0 + (c0 + j) * 256 + tid;
+      if (i < n) {
+        keys[i] = key[j];
+        labels[i] = (i < n_ind) ? 1 : 0;
+        bucket_of[i] = (uint16_t)b[j];
+        atomicAdd(&lh[b[j]], 1u);
+      }
+    }
+  }
+  __syncthreads();
+  for (int b = tid; b < nbk; b += 256) {
+    const unsigned c = lh[b];
+    if (c) atomicAdd(&st->hist[b], c);
+  }
+}
+
+// one curve term pair (ROC trapezoid, PR trapezoid) of the run end with cumulative (tp, fp), previous run end (tp0, fp0);
+// has_prev = false: the first run end pairs with torchmetrics' (precision 1, recall 0) end point.  float32 arithmetic as in
+// curve_terms_body.
+struct CurveAcc { double roc, pr; unsigned long long first_idx; unsigned first_fp; };
+__device__ __forceinline__ void curve_term(CurveAcc& a, unsigned long long idx, unsigned tpu, unsigned tp0u, unsigned fp0u, bool has_prev,
+                                           float P, float Nn) {
+  const float tp = (float)tpu, fp = (float)((unsigned)(idx + 1ull) - tpu);
+  const float tp0 = has_prev ? (float)tp0u : 0.f, fp0 = has_prev ? (float)fp0u : 0.f;
+  // x / P and x / Nn as x * (1 / den) corrected by its remainder: the correctly rounded quotient (counts and totals are integers
+  // below 2^31, their float32 images finite and non-zero) in 3 instructions instead of the ~10 of an IEEE division, four per term
+  const float rP = 1.0f / P, rN = 1.0f / Nn;
+  auto quot = [](float a, float den, float r) { const float q = a * r; return fmaf(fmaf(-q, den, a), r, q); };
+  const float tpr = quot(tp, P, rP), fpr = quot(fp, Nn, rN), tpr0 = quot(tp0, P, rP), fpr0 = quot(fp0, Nn, rN);
+  a.roc += (double)((fpr - fpr0) * (tpr + tpr0));
+  if (tpr >= 0.95f && idx < a.first_idx) { a.first_idx = idx; a.first_fp = (unsigned)(idx + 1ull) - tpu; }
+  const float prec = tp / (tp + fp), rec = tpr;
+  const float prec0 = has_prev ? tp0 / (tp0 + fp0) : 1.0f, rec0 = has_prev ? tpr0 : 0.0f;
+  a.pr += (double)((rec0 - rec) * (prec0 + prec));
+}
+
+// a bucket of up to 64 * PER keys: sorted in the wave's registers, its curve terms formed there.  base_cnt / base_pos: keys /
+// positives in the buckets before it (the bucket before it ended with a run end: see the head of this section).
+template <int PER>
+__device__ __forceinline__ void wave_bucket_curve(const uint64_t* __restrict__ keys, const uint8_t* __restrict__ labs, unsigned lo,
+                                                  unsigned nb, unsigned base_pos, int lane, float P, float Nn, CurveAcc& acc) {
+  uint64_t k[PER];
+  unsigned l[PER];
+  wave_sort_load<PER>(keys, labs, lo, nb, lane, k, l);
+  // the network leaves element e = lane * PER + r in register r of lane `lane`; the load put element r * 64 + lane there - any
+  // assignment of the unsorted keys to the slots will do
+  wave_sort_network<PER>(k, l, lane);
+  // inclusive label prefix
+  unsigned tp[PER], s = 0u;
+#pragma unroll
+  for (int r = 0; r < PER; ++r) { s += l[r]; tp[r] = s; }
+  unsigned x = s;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const unsigned y = __shfl_up(x, o, 64);
+    if (lane >= o) x += y;
+  }
+  const unsigned off = x - s;
+  // run ends: the key differs from the next one; the bucket's last key always ends a run
+  const uint64_t next0 = ((uint64_t)(unsigned)__shfl_down((int)(unsigned)(k[0] >> 32), 1, 64) << 32) | (unsigned)__shfl_down((int)(unsigned)k[0], 1, 64);
+  bool end[PER];
+  uint64_t pm[PER], run = 0ull;  // (element + 1) << 32 | positives at it, of the last run end before element r of this lane
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    const unsigned e = (unsigned)lane * PER + r;
+    const uint64_t kn = (r + 1 < PER) ? k[(r + 1 < PER) ? r + 1 : r] : next0;
+    end[r] = e < nb && (e + 1u == nb || k[r] != kn);
+    pm[r] = run;
+    const uint64_t packed = ((uint64_t)(e + 1u) << 32) | (uint64_t)(off + tp[r]);
+    run = end[r] ? packed : run;  // indices rise with r: the latest run end is the maximum
+  }
+  uint64_t m = run;
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+    const uint64_t y = ((uint64_t)(unsigned)__shfl_up((int)(unsigned)(m >> 32), o, 64) << 32) | (unsigned)__shfl_up((int)(unsigned)m, o, 64);
+    if (lane >= o) m = y > m ? y : m;
+  }
+  uint64_t carry = ((uint64_t)(unsigned)__shfl_up((int)(unsigned)(m >> 32), 1, 64) << 32) | (unsigned)__shfl_up((int)(unsigned)m, 1, 64);
+  if (lane == 0) carry = 0ull;
+#pragma unroll
+  for (int r = 0; r < PER; ++r) {
+    if (!end[r]) continue;
+    const unsigned e = (unsigned)lane * PER + r;
+    const uint64_t prev = pm[r] > carry ? pm[r] : carry;
+    const unsigned tpu = base_pos + off + tp[r];
+    if (prev != 0ull) {
+      const unsigned pe = (unsigned)(prev >> 32) - 1u, ptp = base_pos + (unsigned)prev;
+      curve_term(acc, (unsigned long long)lo + e, tpu, ptp, (lo + pe + 1u) - ptp, true, P, Nn);
+    } else {  // the bucket's first run end: the one before it is the end of the keys in front of the bucket (none: the curve's start)
+      curve_term(acc, (unsigned long long)lo + e, tpu, base_pos, lo - base_pos, lo != 0u, P, Nn);
+    }
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void msd_sort_curve_kernel(uint64_t* __restrict__ keys, uint8_t* __restrict__ labs,
+                                                             uint64_t* __restrict__ alt_keys, uint8_t* __restrict__ alt_labs,
+                                                             MsdState* st, FusedPart* __restrict__ parts, float P, float Nn,
+                                                             double* __restrict__ out) {
+  __shared__ unsigned base[256];
+  __shared__ unsigned wcnt[4][256];
+  __shared__ unsigned dsum[4];
+  __shared__ unsigned psum[4];
+  __shared__ double sroc[4], spr[4];
+  __shared__ unsigned long long sidx[4];
+  __shared__ unsigned sfp[4];
+  __shared__ unsigned long long diff_s;
+  __shared__ unsigned carry_tp_s;
+  __shared__ unsigned long long carry_prev_s;
+  __shared__ unsigned long long wprev[4];
+  __shared__ int last;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int b0 = 4 * blockIdx.x;
+  // positives in the buckets before this workgroup's first one
+  unsigned before_pos;
+  {
+    unsigned q = 0u;
+    for (int c = tid; c < b0; c += 256) q += (unsigned)(st->cursor64[c] >> 32);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o, 64);
+    if (lane == 0) psum[wave] = q;
+    __syncthreads();
+    before_pos = psum[0] + psum[1] + psum[2] + psum[3];
+  }
+  CurveAcc acc{0.0, 0.0, ~0ull, 0u};
+  {
+    const int b = b0 + wave;
+    const unsigned lo = st->start[b], nb = st->start[b + 1] - lo;
+    unsigned base_pos = before_pos;
+    for (int c = b0; c < b; ++c) base_pos += (unsigned)(st->cursor64[c] >> 32);
+    if (nb >= 1u && nb <= (unsigned)kMsdWaveCap) {  // (wave-uniform)
+      if (nb <= 64u) wave_bucket_curve<1>(keys, labs, lo, nb, base_pos, lane, P, Nn, acc);
+      else if (nb <= 128u) wave_bucket_curve<2>(keys, labs, lo, nb, base_pos, lane, P, Nn, acc);
+      else if (nb <= 256u) wave_bucket_curve<4>(keys, labs, lo, nb, base_pos, lane, P, Nn, acc);
+      else if (nb <= 512u) wave_bucket_curve<8>(keys, labs, lo, nb, base_pos, lane, P, Nn, acc);
+      else wave_bucket_curve<16>(keys, labs, lo, nb, base_pos, lane, P, Nn, acc);
+    }
+  }
+  for (int b = b0; b < b0 + 4; ++b) {
+    const unsigned lo = st->start[b], nb = st->start[b + 1] - lo;
+    if (nb <= (unsigned)kMsdWaveCap) continue;  // (uniform)
+    unsigned base_pos = before_pos;
+    for (int c = b0; c < b; ++c) base_pos += (unsigned)(st->cursor64[c] >> 32);
+    // the bits in which the bucket's keys differ at all: OR of key ^ first key over the bucket
+    __syncthreads();
+    if (tid == 0) diff_s = 0ull;
+    __syncthreads();
+    {
+      const uint64_t k0 = keys[lo];
+      unsigned long long d = 0ull;
+      for (unsigned i = tid; i < nb; i += 256) d |= keys[lo + i] ^ k0;
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1)
+        d |= ((unsigned long long)__shfl_xor((unsigned)(d >> 32), o, 64) << 32) | __shfl_xor((unsigned)d, o, 64);
+      if (lane == 0 && d) atomicOr(&diff_s, d);
+    }
+    __syncthreads();
+    const unsigned long long diff = diff_s;
+    if (diff == 0ull) {  // one run: its end carries the bucket's counts (nothing else of it is read)
+      if (tid == 0)
+        curve_term(acc, (unsigned long long)lo + nb - 1u, base_pos + (unsigned)(st->cursor64[b] >> 32), base_pos, lo - base_pos, lo != 0u, P, Nn);
+      continue;
+    }
+    const int low_bits = 64 - __builtin_clzll(diff);
+    const int first_bit = __builtin_ctzll(diff) & ~7;
+    uint64_t* src_k = keys + lo;
+    uint8_t* src_l = labs + lo;
+    uint64_t* dst_k = alt_keys + lo;
+    uint8_t* dst_l = alt_labs + lo;
+    const uint64_t lt_mask = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int shift = first_bit; shift < low_bits; shift += 8) {  // stable 8-bit radix passes, as msd_bucket_sort_kernel
+      __syncthreads();
+      base[tid] = 0u;
+      __syncthreads();
+      for (unsigned i = tid; i < nb; i += 256) atomicAdd(&base[(unsigned)(src_k[i] >> shift) & 255u], 1u);
+      __syncthreads();
+      {
+        const unsigned v = base[tid];
+        unsigned x = v;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const unsigned y = __shfl_up(x, o, 64);
+          if (lane >= o) x += y;
+        }
+        if (lane == 63) dsum[wave] = x;
+        __syncthreads();
+        unsigned woff = 0u;
+        for (int w = 0; w < wave; ++w) woff += dsum[w];
+        base[tid] = woff + x - v;
+      }
+#pragma unroll
+      for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0u;
+      __syncthreads();
+      for (unsigned i0 = 0; i0 < nb; i0 += 256) {  // chunks in order: the pass is stable
+        const unsigned i = i0 + tid;
+        const bool valid = i < nb;
+        const uint64_t key = valid ? src_k[i] : 0ull;
+        const unsigned d = (unsigned)(key >> shift) & 255u;
+        uint64_t same = __ballot(valid);
+#pragma unroll
+        for (int bb = 0; bb < 8; ++bb) {
+          const uint64_t bal = __ballot((d >> bb) & 1u);
+          same &= ((d >> bb) & 1u) ? bal : ~bal;
+        }
+        const unsigned rank_in_wave = (unsigned)__popcll(same & lt_mask);
+        if (valid && rank_in_wave == 0u) wcnt[wave][d] = (unsigned)__popcll(same);
+        __syncthreads();
+        if (valid) {
+          unsigned o2 = base[d] + rank_in_wave;
+          for (int w = 0; w < wave; ++w) o2 += wcnt[w][d];
+          dst_k[o2] = key;
+          dst_l[o2] = src_l[i];
+        }
+        __syncthreads();
+        base[tid] += wcnt[0][tid] + wcnt[1][tid] + wcnt[2][tid] + wcnt[3][tid];
+#pragma unroll
+        for (int w = 0; w < 4; ++w) wcnt[w][tid] = 0u;
+        __syncthreads();
+      }
+      __threadfence_block();
+      uint64_t* tk = src_k; src_k = dst_k; dst_k = tk;
+      uint8_t* tl = src_l; src_l = dst_l; dst_l = tl;
+    }
+    __syncthreads();
+    // the sorted bucket lies at src_k / src_l: chunks of 1 024 (four consecutive keys per thread) with carries
+    if (tid == 0) { carry_tp_s = 0u; carry_prev_s = 0ull; }
+    __syncthreads();
+    for (unsigned c0 = 0; c0 < nb; c0 += 1024u) {
+      const unsigned e0 = c0 + 4u * (unsigned)tid;
+      uint64_t kk[5];
+      unsigned ll[4];
+#pragma unroll
+      for (int j = 0; j < 5; ++j) kk[j] = (e0 + j < nb) ? src_k[e0 + j] : ~0ull;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) ll[j] = (e0 + j < nb) ? (unsigned)src_l[e0 + j] : 0u;
+      unsigned tpj[4], ssum = 0u;
+      bool endj[4];
+      uint64_t pmj[4], run = 0ull;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { ssum += ll[j]; tpj[j] = ssum; }
+      unsigned x = ssum;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const unsigned y = __shfl_up(x, o, 64);
+        if (lane >= o) x += y;
+      }
+      if (lane == 63) dsum[wave] = x;
+      __syncthreads();
+      unsigned off = x - ssum + carry_tp_s;
+      for (int w = 0; w < wave; ++w) off += dsum[w];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const unsigned e = e0 + j;
+        endj[j] = e < nb && (e + 1u == nb || kk[j] != kk[j + 1]);
+        pmj[j] = run;
+        run = endj[j] ? (((uint64_t)(e + 1u) << 32) | (uint64_t)(off + tpj[j])) : run;
+      }
+      uint64_t m = run;
+#pragma unroll
+      for (int o = 1; o < 64; o <<= 1) {
+        const uint64_t y = ((uint64_t)(unsigned)__shfl_up((int)(unsigned)(m >> 32), o, 64) << 32) | (unsigned)__shfl_up((int)(unsigned)m, o, 64);
+        if (lane >= o) m = y > m ? y : m;
+      }
+      uint64_t carry = ((uint64_t)(unsigned)__shfl_up((int)(unsigned)(m >> 32), 1, 64) << 32) | (unsigned)__shfl_up((int)(unsigned)m, 1, 64);
+      if (lane == 0) carry = 0ull;
+      if (lane == 63) wprev[wave] = m;
+      __syncthreads();
+      carry = carry > carry_prev_s ? carry : carry_prev_s;
+      for (int w = 0; w < wave; ++w) carry = wprev[w] > carry ? wprev[w] : carry;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        if (!endj[j]) continue;
+        const unsigned e = e0 + j;
+        const uint64_t prev = pmj[j] > carry ? pmj[j] : carry;
+        const unsigned tpu = base_pos + off + tpj[j];
+        if (prev != 0ull) {
+          const unsigned pe = (unsigned)(prev >> 32) - 1u, ptp = base_pos + (unsigned)prev;
+          curve_term(acc, (unsigned long long)lo + e, tpu, ptp, (lo + pe + 1u) - ptp, true, P, Nn);
+        } else {
+          curve_term(acc, (unsigned long long)lo + e, tpu, base_pos, lo - base_pos, lo != 0u, P, Nn);
+        }
+      }
+      __syncthreads();
+      if (tid == 255) {
+        carry_tp_s = off + ssum;
+        const uint64_t mm = m > carry ? m : carry;
+        carry_prev_s = mm;
+      }
+      __syncthreads();
+    }
+  }
+  // the workgroup's record
+  {
+    double roc = acc.roc, prs = acc.pr;
+    unsigned long long fi = acc.first_idx;
+    unsigned ffp = acc.first_fp;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+      roc += shfl_xor_f64(roc, o);
+      prs += shfl_xor_f64(prs, o);
+      const unsigned long long oi = ((unsigned long long)__shfl_xor((unsigned)(fi >> 32), o, 64) << 32) | __shfl_xor((unsigned)fi, o, 64);
+      const unsigned of = __shfl_xor(ffp, o, 64);
+      if (oi < fi) { fi = oi; ffp = of; }
+    }
+    __syncthreads();
+    if (lane == 0) { sroc[wave] = roc; spr[wave] = prs; sidx[wave] = fi; sfp[wave] = ffp; }
+    __syncthreads();
+  }
+  if (tid == 0) {
+    FusedPart r;
+    r.roc = ((sroc[0] + sroc[1]) + sroc[2]) + sroc[3];
+    r.pr = ((spr[0] + spr[1]) + spr[2]) + spr[3];
+    r.first_idx = sidx[0]; r.first_fp = sfp[0]; r.pad = 0u;
+    for (int w = 1; w < 4; ++w)
+      if (sidx[w] < r.first_idx) { r.first_idx = sidx[w]; r.first_fp = sfp[w]; }
+    parts[blockIdx.x] = r;
+    // "last one out", as curve_terms_finalize_kernel: eight counters on lines of their own, then the common one
+    const unsigned grp = blockIdx.x & 7u, groups = gridDim.x < 8u ? gridDim.x : 8u;
+    const unsigned in_grp = (gridDim.x + 7u - grp) / 8u;
+    int l = 0;
+    __threadfence();
+    if (atomicAdd(&st->done_group[grp * 32], 1u) + 1u == in_grp) {
+      __threadfence();
+      l = (atomicAdd(&st->done_blocks, 1u) + 1u == groups) ? 1 : 0;
+    }
+    last = l;
+  }
+  __syncthreads();
+  if (!last) return;
+  __threadfence();
+  // the last workgroup: the records in index order (thread t: records t, t + 256, ... - then the fixed tree below)
+  double roc = 0.0, prs = 0.0;
+  unsigned long long fi = ~0ull;
+  unsigned ffp = 0u;
+  for (unsigned g = tid; g < gridDim.x; g += 256) {
+    roc += __hip_atomic_load(&parts[g].roc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    prs += __hip_atomic_load(&parts[g].pr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long oi = __hip_atomic_load(&parts[g].first_idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned of = __hip_atomic_load(&parts[g].first_fp, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (oi < fi) { fi = oi; ffp = of; }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    roc += shfl_xor_f64(roc, o);
+    prs += shfl_xor_f64(prs, o);
+    const unsigned long long oi = ((unsigned long long)__shfl_xor((unsigned)(fi >> 32), o, 64) << 32) | __shfl_xor((unsigned)fi, o, 64);
+    const unsigned of = __shfl_xor(ffp, o, 64);
+    if (oi < fi) { fi = oi; ffp = of; }
+  }
+  if (lane == 0) { sroc[wave] = roc; spr[wave] = prs; sidx[wave] = fi; sfp[wave] = ffp; }
+  __syncthreads();
+  if (tid == 0) {
+    const double r = ((sroc[0] + sroc[1]) + sroc[2]) + sroc[3], q = ((spr[0] + spr[1]) + spr[2]) + spr[3];
+    unsigned long long f = sidx[0];
+    unsigned fp = sfp[0];
+    for (int w = 1; w < 4; ++w)
+      if (sidx[w] < f) { f = sidx[w]; fp = sfp[w]; }
+    out[0] = (double)(float)(r * 0.5);                 // trapz(tpr, fpr), reported as float32 like torchmetrics
+    out[1] = (f == ~0ull) ? NAN : (double)((float)fp / Nn);
+    out[2] = (double)(float)(-(q * 0.5));              // see finalize_body
+  }
+}
+
 // ---- why the step stays a chain of launches (round 4) ------------------------------------------------------------------
 // The whole step was written as ONE persistent launch - every workgroup resident, the phases above behind grid-wide
 // barriers, a radix pass as one phase with a decoupled look-back over (aggregate | inclusive) words - and measured
@@ -1095,7 +1684,7 @@ __global__ __launch_bounds__(256) void curve_terms_finalize_kernel(const uint64_
 size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 struct Layout {
-  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, dtot, tile_sum, tile_end, tile_cnt, accum, flag, msd, parts, bucket_of, total;
+  size_t keys_a, keys_b, lab_a, lab_b, tps, prev_end, table, dtot, tile_sum, tile_end, tile_cnt, accum, flag, msd, parts, bucket_of, parts2, total;
   unsigned nblocks;
 };
 
@@ -1119,6 +1708,7 @@ Layout make_layout(int64_t n) {
   L.msd = o; o += align256(sizeof(MsdState));  // (accum, flag and msd are contiguous: one memset clears them)
   L.parts = o; o += align256(kCurveBlocks * sizeof(MetricsAccum));  // per-workgroup records of the curve-term launch (written before read)
   L.bucket_of = o; o += align256((size_t)n * 2);                     // bucket of every key (key launch -> scatter)
+  L.parts2 = o; o += align256((size_t)(kMsdBuckets / 4) * sizeof(FusedPart));  // per-workgroup records of the fused sort + curve launch
   L.total = o;
   return L;
 }
@@ -1151,6 +1741,9 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
 #ifndef METRICS_MSD
 #define METRICS_MSD 1
 #endif
+#ifndef METRICS_FUSED
+#define METRICS_FUSED 1
+#endif
   if (METRICS_MSD) {
     MsdState* st = reinterpret_cast<MsdState*>(w + L.msd);
     // eight launches, nothing cleared beforehand (MsdState)
@@ -1163,8 +1756,29 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
     if (equalise) {
       const int64_t sketch_n = (n > kSketchAll) ? (n + kSketchStride - 1) / kSketchStride : n;
       msd_lin_hist_kernel<T><<<(unsigned)((sketch_n + kScatTileHist - 1) / kScatTileHist), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid);
+      if (METRICS_FUSED && !tps_out) msd_split_kernel<T><<<kMsdBuckets / 256, 256, 0, s>>>(flag, st, pgrid);
     }
     uint16_t* bucket_of = reinterpret_cast<uint16_t*>(w + L.bucket_of);
+    if (METRICS_FUSED && !tps_out) {  // the three scalars alone (round 6): six launches, four without the sketch
+      // buckets: 4 096 (equalised by the sketch) for large sets; for small ones raw-linear bins, ~64 keys each - every (tile,
+      // bucket) pair costs the scatter an atomic and every four buckets the last launch a workgroup (20 000 scores in 4 096
+      // buckets: 28 + 28 us for those two launches)
+      int nbk = kMsdBuckets;
+      if (!equalise) {
+        nbk = 64;
+        while (nbk < kMsdBuckets && (int64_t)nbk * 64 < n) nbk <<= 1;
+      }
+      if (n <= 65536) {  // small sets: smaller tiles, more workgroups (the two launches are latency-bound there)
+        msd_keys_split_kernel<T, 4><<<(unsigned)((n + 1023) / 1024), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise, nbk);
+        msd_scatter_kernel<T, 8><<<(unsigned)((n + 2047) / 2048), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
+      } else {
+        msd_keys_split_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise, nbk);
+        msd_scatter_kernel<T><<<(unsigned)((n + kScatTile - 1) / kScatTile), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
+      }
+      msd_sort_curve_kernel<T><<<(unsigned)(nbk / 4), 256, 0, s>>>(keys[1], labs[1], keys[0], labs[0], st,
+                                                                   reinterpret_cast<FusedPart*>(w + L.parts2), (float)n_ind, (float)n_ood, out3);
+      return runia_check_launch();
+    }
     msd_keys_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise);
     msd_scatter_kernel<T><<<(unsigned)((n + kScatTile - 1) / kScatTile), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
     msd_bucket_sort_kernel<T><<<kMsdBuckets / 4, 256, 0, s>>>(keys[1], labs[1], keys[0], labs[0], flag, st);  // (four buckets per workgroup)

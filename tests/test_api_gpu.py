@@ -1709,3 +1709,30 @@ def test_setup_device_equals_setup_for_the_latent_space_family():
         postprocessors_dict["cMD"](cfg=Cfg()).setup_device(tr_d)
     with pytest.raises(ValueError, match="id_labels not provided"):
         postprocessors_dict["GMM"](cfg=Cfg()).setup_device(tr_d)
+
+
+@pytest.mark.parametrize("n_ind,n_ood", [(1, 1), (31, 33), (40, 25), (600, 424), (2100, 1996), (30_000, 35_536), (30_000, 35_537),
+                                         (131_072, 131_072), (131_073, 131_072), (300_000, 200_000)])
+@pytest.mark.parametrize("kind", ["normal", "squashed_ties", "unit_ties"])
+def test_fused_metrics_launches_equal_the_curve_chain(n_ind, n_ood, kind):
+    """Round 6: the three scalars come from six launches (four without the sketch) - buckets by splitter KEYS, bucket sort and
+    curve terms in one launch - while the curve API keeps the eight-launch chain (it needs every run's counts in memory).  Both
+    against each other and the oracle across the sizes where the new path changes shape: bucket counts 64 ... 4 096, the small-tile
+    launches up to 65 536 scores, the sketch + splitter launches beyond 262 144; float32 scores whose sigmoids tie across many
+    buckets (the squash merges raw scores the raw bins keep apart) and scores inside [0, 1] with ties."""
+    from runia_core_amd import _hip
+
+    rng = np.random.default_rng(n_ind + 7 * n_ood)
+    if kind == "normal":
+        ind, ood = rng.standard_normal(n_ind) * 2 + 0.5, rng.standard_normal(n_ood) * 2 - 0.5
+    elif kind == "squashed_ties":   # float32 energies around 9: sigmoids within 1e-4 of 1
+        ind, ood = (rng.standard_normal(n_ind) * 2 + 9).astype(np.float32), (rng.standard_normal(n_ood) * 2 + 7).astype(np.float32)
+    else:
+        ind, ood = rng.integers(0, 50, n_ind) / 49.0, rng.integers(0, 40, n_ood) / 49.0
+    a, b = torch.from_numpy(np.ascontiguousarray(ind)).cuda(), torch.from_numpy(np.ascontiguousarray(ood)).cuda()
+    fused = _hip.ood_metrics(a, b).cpu().numpy()
+    chain = _hip.ood_clf_curve(a, b)[0].cpu().numpy()
+    assert fused == pytest.approx(chain, abs=2e-7, nan_ok=True), (fused, chain)
+    exp = oracle.auroc_fpr95_aupr(ind, ood)
+    assert tuple(fused) == pytest.approx(exp, abs=2e-6, nan_ok=True)
+    assert np.array_equal(_hip.ood_metrics(a, b).cpu().numpy(), fused, equal_nan=True)   # same bits from run to run
