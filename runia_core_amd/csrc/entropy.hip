@@ -458,6 +458,154 @@ __global__ __launch_bounds__(256) void entropy_joint_reg_kernel(const float* __r
   }
 }
 
+// ---- joint entropy, pair-group form (round 6; 9 <= n <= 16 samples, rows of whole aligned pairs of dims) ------------------------
+// The register form above gives every thread ALL 120 sample pairs of its own dims and reduces sixteen pair maxima at a time over
+// the wave (no room for 120 f64 accumulators per lane): at 16 samples x 512 dims the reductions are 1 040 of the 4 140 vector
+// instructions an image costs (two waves), and the f64 subtract + maximum per (pair, dim) are 1 920.  Here ONE wave takes an
+// image and its two halves of 32 lanes split the PAIRS: every lane keeps 60 accumulators over all passes of the row and the
+// cross-lane reduction happens once per image.  Both halves run the same instructions on the same register numbers, so the split
+// is a property of the DATA: the 60 register pairs are the edges of a self-complementary graph on 16 vertices (four blocks of
+// four registers A B C D; edges: inside A, inside D, A-B, B-C, C-D), the lower half loads sample i into register i, the upper half
+// sample sigma(i) with sigma: A -> B -> D -> C -> A blockwise - the image of the graph under sigma is its complement, so the two
+// halves together visit each of the 120 sample pairs exactly once.  Distances are maxima of exact f64 differences: the same bits
+// as the other two forms whatever the order.  10 000 x 16 x 512: 0.1325 -> 0.114 ms.  (With the per-dimension entropies of
+// get_dl_h_z formed in the same pass - the single-read kernel, entropy_joint_reg_kernel<16, 5> - this form measured 0.236 ms
+// against 0.174: 60 accumulators + a 16-input sort do not fit 256 registers; the single-read call keeps the register form.)
+__device__ __forceinline__ int pair16_sigma(int i) { return i < 4 ? i + 4 : (i < 8 ? i + 8 : (i < 12 ? i - 8 : i - 4)); }
+__device__ const unsigned char kPair16A[64] = {0, 0, 0, 1, 1, 2, 12, 12, 12, 13, 13, 14, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3,
+                                               4, 4, 4, 4, 5, 5, 5, 5, 6, 6, 6, 6, 7, 7, 7, 7, 8, 8, 8, 8, 9, 9, 9, 9, 10, 10, 10, 10,
+                                               11, 11, 11, 11, 0, 0, 0, 0};
+__device__ const unsigned char kPair16B[64] = {1, 2, 3, 2, 3, 3, 13, 14, 15, 14, 15, 15, 4, 5, 6, 7, 4, 5, 6, 7, 4, 5, 6, 7, 4, 5, 6, 7,
+                                               8, 9, 10, 11, 8, 9, 10, 11, 8, 9, 10, 11, 8, 9, 10, 11, 12, 13, 14, 15, 12, 13, 14, 15,
+                                               12, 13, 14, 15, 12, 13, 14, 15, 0, 0, 0, 0};
+// 16 per-lane values -> their maxima over the 32 lanes that share lane bit 5; lane L ends with slot
+// 8 * bit4(L) + 4 * bit3(L) + 2 * bit2(L) + bit1(L) (both lanes of a pair L, L ^ 1)
+__device__ __forceinline__ double half_max16(double (&v)[16], int lane) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) halve16(v[j], v[j + 8]);
+  const bool u8 = (lane & 8) != 0, u4 = (lane & 4) != 0, u2 = (lane & 2) != 0;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {  // lanes i, i ^ 8
+    const double send = u8 ? v[j] : v[j + 4], keep = u8 ? v[j + 4] : v[j];
+    v[j] = max_f64(keep, dpp_f64<kDppRowRor8>(send, send));
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {  // lanes i, i ^ 4
+    const double send = u4 ? v[j] : v[j + 2], keep = u4 ? v[j + 2] : v[j];
+    double recv = dpp_f64<kDppRowRor4, 0xA>(send, send);
+    recv = dpp_f64<kDppRowRor12, 0x5>(recv, send);
+    v[j] = max_f64(keep, recv);
+  }
+  {  // lanes i, i ^ 2
+    const double send = u2 ? v[0] : v[1], keep = u2 ? v[1] : v[0];
+    v[0] = max_f64(keep, dpp_f64<kDppQuadXor2>(send, send));
+  }
+  return max_f64(v[0], dpp_f64<kDppQuadXor1>(v[0], v[0]));
+}
+
+__global__ __launch_bounds__(64) void entropy_joint_pair16_kernel(const float* __restrict__ z, double* __restrict__ h_mvn, int64_t N,
+                                                                  int n, int64_t D, int k, double min_dist, double const_term,
+                                                                  double d_over_n) {
+  constexpr int NP = 16, DP = NP + 1;
+  __shared__ double dist[NP * DP];
+  const int lane = threadIdx.x, grp = lane >> 5, l = lane & 31;
+  // register i of this lane holds sample src(i) (clamped to the last real sample: pairs with a slot >= n are never read back)
+  unsigned roff[NP];
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int src = grp ? pair16_sigma(i) : i;
+    roff[i] = (unsigned)((src < n ? src : n - 1) * D);
+  }
+  for (int64_t img = blockIdx.x; img < N; img += gridDim.x) {
+    const float* base = z + img * n * D;
+    for (int i = lane; i < NP * DP; i += 64) dist[i] = 0.0;
+    double acc[64];
+#pragma unroll
+    for (int p = 0; p < 64; ++p) acc[p] = 0.0;
+    bool my_nan = false;
+    int pass = 0;
+    for (int64_t d0 = 0; d0 < D; d0 += 64, ++pass) {
+      const int64_t dd = d0 + 2 * l;
+      const int64_t d = (dd < D) ? dd : 0;  // (a lane past the end of the row re-reads dims 0, 1: maxima are idempotent)
+      float2 raw[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) raw[i] = *reinterpret_cast<const float2*>(base + roff[i] + d);
+      double x[NP][2];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        my_nan = my_nan || (raw[i].x != raw[i].x) || (raw[i].y != raw[i].y);
+        x[i][0] = (double)raw[i].x;
+        x[i][1] = (double)raw[i].y;
+      }
+      // the 60 register pairs (edges of the self-complementary graph), compile-time indices
+      int p = 0;
+#define RUNIA_PAIR(a, b)                                                                         \
+  acc[p] = max_f64(acc[p], max_abs2_f64(x[a][0] - x[b][0], x[a][1] - x[b][1]));                 \
+  ++p;
+#pragma unroll
+      for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 4; ++b) { RUNIA_PAIR(a, b) }
+#pragma unroll
+      for (int a = 12; a < 15; ++a)
+#pragma unroll
+        for (int b = a + 1; b < 16; ++b) { RUNIA_PAIR(a, b) }
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 4; b < 8; ++b) { RUNIA_PAIR(a, b) }
+#pragma unroll
+      for (int a = 4; a < 8; ++a)
+#pragma unroll
+        for (int b = 8; b < 12; ++b) { RUNIA_PAIR(a, b) }
+#pragma unroll
+      for (int a = 8; a < 12; ++a)
+#pragma unroll
+        for (int b = 12; b < 16; ++b) { RUNIA_PAIR(a, b) }
+#undef RUNIA_PAIR
+    }
+    // once per image: the accumulators over the 32 lanes of the half, sixteen slots at a time
+    const int slot_in_group = ((lane >> 4) & 1) * 8 + ((lane >> 3) & 1) * 4 + ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();  // dist is zeroed
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      double v[16];
+#pragma unroll
+      for (int j = 0; j < 16; ++j) v[j] = acc[16 * g + j];
+      const double m = half_max16(v, lane);
+      const int pidx = 16 * g + slot_in_group;
+      if (pidx < 60 && (lane & 1) == 0) {
+        const int ia = kPair16A[pidx], ib = kPair16B[pidx];
+        const int a = grp ? pair16_sigma(ia) : ia, b = grp ? pair16_sigma(ib) : ib;
+        if (a < n && b < n) {
+          dist[a * DP + b] = m;
+          dist[b * DP + a] = m;
+        }
+      }
+    }
+    const bool any_nan = __ballot(my_nan) != 0ull;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+    double logsum = 0.0;
+    if (lane < NP) {  // sample slot i: its row of distances into registers, sorted there; the k-th smallest is entry k-1
+      double r[NP];
+#pragma unroll
+      for (int c = 0; c < NP; ++c) r[c] = (c < n && c != lane) ? dist[lane * DP + c] : kInf;
+      sort_asc<NP>(r);
+      double kth = r[0];
+#pragma unroll
+      for (int c = 1; c < NP - 1; ++c) kth = (c == k - 1) ? r[c] : kth;
+      if (lane < n) logsum = log(2.0 * fmax(kth, min_dist));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) logsum += shfl_xor_f64(logsum, o);
+    if (lane == 0) h_mvn[img] = any_nan ? NAN : const_term + d_over_n * logsum;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+    __builtin_amdgcn_wave_barrier();  // dist is rewritten by the next image
+  }
+}
+
 int next_pow2(int n) {
   int p = 4;
   while (p < n) p <<= 1;
@@ -520,6 +668,13 @@ extern "C" int runia_kl_entropy_joint_f32(const float* z, double* h_mvn, int64_t
   const double ct = digamma_diff(n_mc, k);
   const double d_over_n = (double)D / (double)n_mc;
   hipStream_t s = as_stream(stream);
+#ifndef JOINT_PAIR16
+#define JOINT_PAIR16 1
+#endif
+  if (JOINT_PAIR16 && n_mc > 8 && n_mc <= 16 && (D & 1) == 0 && (((uintptr_t)z) & 7) == 0) {  // pair-group form (round 6)
+    entropy_joint_pair16_kernel<<<(unsigned)(N < 0x7fffffffll ? N : 0x7fffffffll), 64, 0, s>>>(z, h_mvn, N, n_mc, D, k, min_dist, ct, d_over_n);
+    return runia_check_launch();
+  }
   {
     // register form: rows of whole, aligned vectors (the LDS form below takes everything else)
     const int vec = n_mc <= 8 ? 4 : (n_mc <= 16 ? JOINT_VEC16 : 2);
