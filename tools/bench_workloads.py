@@ -668,8 +668,9 @@ def run_metrics_leg(device, n_each: int = 1_000_000, cpu_legs: bool = True) -> d
                 recs[tag]["max_abs_err"] = float(max(abs(x - y) for x, y in zip(out.cpu().tolist(), exp)))
                 recs[tag]["cpu_ms"] = round(1e3 * t_cpu, 2)
     recs["cpu_form"] = "NumPy argsort + cumulative sums + float32 trapezoids (torchmetrics' definitions), 1 core"
-    recs["note"] = ("round 5: buckets from the raw score, equalised with a sketch histogram - before, 2 M LaREM scores took 81.7 ms and "
-                    "20 000 took 0.75 ms (value-linear buckets of the SIGMOID crowd into one bucket), profiles/r5_metrics_timing.txt")
+    recs["note"] = ("round 6: six launches (four without the sketch) - buckets by splitter KEYS (order by construction), bucket sort + curve terms in "
+                    "one launch; round 5: 0.234 / 0.082 ms per 2 M / 20 000 scores in eight / seven launches; DESIGN.md 4.18, "
+                    "profiles/r6_metrics_2m_kernel_stats.csv, r6_metrics_20k_kernel_stats.csv")
     return recs
 
 
