@@ -91,8 +91,21 @@ __global__ __launch_bounds__(256) void gmm_whiten_kernel(const float* __restrict
     if (bt >= nbt || qt >= nqt) return;
     q0 = qt * TQ;
   }
+#ifndef GMM_ORDER
+#define GMM_ORDER 1
+#endif
+  // which (component, column tile) the tile index stands for.  GMM_ORDER 1: the component runs fastest and the column tiles come
+  // longest first - the eight tiles a super-tile puts side by side on an XCD are the SAME column tile of eight components: they
+  // share the row slices, run the same number of chunks (they sweep K in step, so a slice is fetched into that L2 once), and the
+  // launch ends on its shortest tiles.  0: component-major (eight consecutive column tiles of one component: K ranges 1 : 8).
+#if GMM_ORDER
+  const int c = (int)(bt % C);
+  const int64_t jt = nct - 1 - bt / C;
+#else
   const int c = (int)(bt / nct);
-  const int64_t m0 = (bt - (int64_t)c * nct) * TB;       // first column (= row of W_c) of the tile
+  const int64_t jt = bt - (int64_t)c * nct;
+#endif
+  const int64_t m0 = jt * TB;                             // first column (= row of W_c) of the tile
   const int64_t kend = (m0 + TB < D) ? m0 + TB : D;      // W_c[m, k] = 0 for k > m: nothing right of the diagonal block
   const float* wc = w + (int64_t)c * D * D;
   const float* muc = mu + (int64_t)c * D;
@@ -149,7 +162,7 @@ __global__ __launch_bounds__(256) void gmm_whiten_kernel(const float* __restrict
   const int slot_row = wq * 64 + (li >> 4) * 32 + (li & 3) + 8 * ((li & 15) >> 2) + 4 * lh;
   red[wb * TQ + slot_row] = tot;
   __syncthreads();
-  if (tid < TQ && q0 + tid < N) partial[bt * N + q0 + tid] = red[tid] + red[TQ + tid];
+  if (tid < TQ && q0 + tid < N) partial[((int64_t)c * nct + jt) * N + q0 + tid] = red[tid] + red[TQ + tid];
 }
 
 // log_prob[n, c] = consts[c] - 0.5 sum_j partial[c nct + j][n]; lse[n] = logsumexp_c of the f32 log_probs

@@ -4,6 +4,8 @@ import sys, os, gc
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np, torch
 from runia_core_amd import _hip
+if os.environ.get('RUNIA_LIB'):
+    _hip._LIB_PATH = os.environ['RUNIA_LIB']
 from runia_core_amd.inference.funcs import GmmState
 gc.disable()
 N, D, C = [int(v) for v in sys.argv[1:4]] if len(sys.argv) >= 4 else (262144, 2048, 10)
