@@ -1771,6 +1771,9 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
       if (n <= 65536) {  // small sets: smaller tiles, more workgroups (the two launches are latency-bound there)
         msd_keys_split_kernel<T, 4><<<(unsigned)((n + 1023) / 1024), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise, nbk);
         msd_scatter_kernel<T, 8><<<(unsigned)((n + 2047) / 2048), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
+      } else if (n <= 524288) {  // mid-sized sets: 16 keys per thread in the scatter (200 000 scores: 85 -> 73 us; 2 M: 230 -> 240)
+        msd_keys_split_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise, nbk);
+        msd_scatter_kernel<T, 16><<<(unsigned)((n + 4095) / 4096), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
       } else {
         msd_keys_split_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise, nbk);
         msd_scatter_kernel<T><<<(unsigned)((n + kScatTile - 1) / kScatTile), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
