@@ -61,7 +61,12 @@ struct GemmArgs {
   // EPI_ROWNORM with a TRIANGULAR right-hand matrix (round 6, runia_md_score_tril_*): B = W^T with W lower triangular, i.e.
   // B[k][col] = 0 for k > col - the 256-column block cb only multiplies its first (cb + 1) * 256 k values (the chunk loop ends at
   // the diagonal block: about half the products of a wide matrix), and neg_sq writes -sum of squares instead of the norm
-  int tri, neg_sq;
+  int tri, neg_sq;      // neg_sq: 0 = sqrt(sum), 1 = -sum, 2 = the sum itself (a first launch whose columns a second one completes)
+  // EPI_ROWNORM over a column RANGE of the packed matrix (round 6, ViM: 1 048 columns = four full 256-column blocks + 24): the
+  // blocks [cb0, cb1) (cb1 = 0: all of them) with the launch's first column tile at ct0; acc_in (optional) = sums of squares of
+  // the columns another launch took, added before the final sqrt / sign
+  int64_t cb0, cb1, ct0;
+  const double* acc_in;
 };
 
 __global__ __launch_bounds__(256) void pack_weights_kernel(const double* __restrict__ B, int64_t ldb,
@@ -251,7 +256,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
   const int64_t n_pad = n_padded(g.n);
   const int64_t NT = n_pad / 16;
   const int64_t nchunks = k_padded(g.K) / KC;
-  int64_t tile_id = blockIdx.x, cb_begin = 0, cb_end = n_pad / BN;
+  int64_t tile_id = blockIdx.x, cb_begin = g.cb0, cb_end = g.cb1 ? g.cb1 : n_pad / BN;
   if constexpr (EPI == EPI_MAHA || EPI == EPI_KDE || EPI == EPI_ROWDOT || EPI == EPI_ROWNORM) {
     if ((EPI == EPI_MAHA) ? (g.maha_part != nullptr) : (EPI == EPI_KDE) ? (g.kde_vals != nullptr) : (g.md_vals != nullptr)) {  // column-split launch (uniform)
       const int64_t nb = n_pad / BN;
@@ -307,7 +312,7 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     }
   };
   for (int64_t cb = cb_begin; cb < cb_end; ++cb) {
-    const int64_t ctbase = cb * 16 + wave * NCT;
+    const int64_t ctbase = g.ct0 + cb * 16 + wave * NCT;
     double cn[(EPI == EPI_KDE) ? NCT : 1];
     if constexpr (EPI == EPI_KDE) {
 #pragma unroll
@@ -539,8 +544,13 @@ __global__ __launch_bounds__(256) void gemm_rows_kernel(GemmArgs g) {
     if (tid < BM) {
       const int64_t row = r0 + tid;
       if (row < g.N) {
-        const double t = ((lds_part[0][tid] + lds_part[1][tid]) + lds_part[2][tid]) + lds_part[3][tid];
-        g.out[row] = (EPI == EPI_ROWNORM && !g.neg_sq) ? sqrt(t) : -t;
+        double t = ((lds_part[0][tid] + lds_part[1][tid]) + lds_part[2][tid]) + lds_part[3][tid];
+        if constexpr (EPI == EPI_ROWNORM) {
+          if (g.acc_in) t += g.acc_in[row];
+          g.out[row] = (g.neg_sq == 0) ? sqrt(t) : (g.neg_sq == 1 ? -t : t);
+        } else {
+          g.out[row] = -t;
+        }
       }
     }
   }
@@ -590,6 +600,7 @@ static GemmArgs gemm_rows_from(const GemmArgs& g, int64_t first, int64_t out_ld)
   t.x = reinterpret_cast<const TA*>(g.x) + first * g.ldx;
   t.N = g.N - first;
   if (g.rown) t.rown = g.rown + first;
+  if (g.acc_in) t.acc_in = g.acc_in + first;
   t.out = g.out + first * out_ld;
   return t;
 }
@@ -952,6 +963,21 @@ static int proj_norm_impl(const TA* x, const TS* u, const double* packed_ns, dou
   GemmArgs g{};
   g.x = x; g.ldx = D; g.packed = packed_ns; g.N = N; g.K = D; g.n = n;
   g.sub = u; g.bias = nullptr; g.scale = nullptr; g.out = norm;
+  // A ragged last block: n = 1 048 (ViM at D = 2048, DIM = 1000) pads to 1 280 columns and the fifth 256-column block multiplies
+  // 24 real ones (92 ms per 1 M rows, 0.59 of the matrix peak per useful product).  Two launches instead: the whole blocks leave
+  // their sums of squares in `norm`, then the tail - one 64- or 128-column pass of the narrow-tile kernel over the same packed
+  // matrix, started at its column tile - adds its own and takes the root.
+  const int64_t whole = n / BN, tail = n - whole * BN;
+  if (whole >= 1 && tail > 0 && tail <= 128) {
+    hipStream_t s = as_stream(stream);
+    GemmArgs a = g;
+    a.cb0 = 0; a.cb1 = whole; a.neg_sq = 2;
+    int rc = launch_gemm_nct<TA, EPI_ROWNORM, TS, 4>(a, s);
+    if (rc != RUNIA_OK) return rc;
+    GemmArgs b = g;
+    b.cb0 = 0; b.cb1 = 1; b.ct0 = whole * (BN / 16); b.acc_in = norm; b.neg_sq = 0;
+    return tail <= 64 ? launch_gemm_nct<TA, EPI_ROWNORM, TS, 1>(b, s) : launch_gemm_nct<TA, EPI_ROWNORM, TS, 2>(b, s);
+  }
   return launch_gemm<TA, EPI_ROWNORM, TS>(g, as_stream(stream));
 }
 extern "C" int runia_proj_norm_f32(const float* x, const float* u, const double* packed_ns, double* norm, int64_t N,

@@ -1424,3 +1424,24 @@ def test_md_score_from_the_triangular_factor(hip, n, rows, xdt, mdt):
         s3 = md3.postprocess(x)
         assert md3._device_state()["packed_wt"] is None
         assert rel_err(s3, -np.einsum("ij,jk,ik->i", diff.astype(np.float64), md3.precision, diff.astype(np.float64))) < 1e-10
+
+
+@pytest.mark.parametrize("d,n,rows", [(700, 300, 5), (700, 300, 3000), (512, 380, 2100), (2048, 1048, 9000), (1024, 536, 40000), (300, 257, 33),
+                                      (640, 384, 1000)])
+@pytest.mark.parametrize("dt", [np.float32, np.float64])
+def test_proj_norm_with_a_ragged_last_column_block(hip, d, n, rows, dt):
+    """runia_proj_norm_* (ViM's residual norm, reference inference/postprocessors.py:1106) when the 256-column blocks do not divide n:
+    round 6 takes the whole blocks in one launch and the last <= 128 columns in a second, narrow-tile launch over the same packed
+    matrix (ViM at D = 2048: 1 048 columns, four blocks + 24).  Against NumPy; a row's bits do not depend on the batch."""
+    rng = np.random.default_rng(d + n + rows)
+    ns = np.linalg.qr(rng.standard_normal((d, n)))[0]
+    u = (rng.standard_normal(d) * 0.1).astype(dt)
+    x = (rng.standard_normal((rows, d)) + 0.3).astype(dt)
+    tt = torch.float32 if dt == np.float32 else torch.float64
+    packed = hip.pack_weights(dev(ns, torch.float64))
+    got = hip.proj_norm(dev(x, tt), dev(u, tt), packed, n).cpu().numpy()
+    diff = (x - u) if dt == np.float32 else (x.astype(np.float64) - u.astype(np.float64))
+    exp = np.linalg.norm(diff.astype(np.float64) @ ns, axis=-1)
+    assert got.dtype == np.float64 and rel_err(got, exp) < 1e-12
+    one = hip.proj_norm(dev(x[:1], tt), dev(u, tt), packed, n).cpu().numpy()
+    assert one[0] == got[0]
