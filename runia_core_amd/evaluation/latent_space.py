@@ -60,7 +60,7 @@ def _get_best_postprocessors_metrics(baselines_names, overall_metrics_df, postpr
 
 
 def _get_best_post_processor_thresholds(postprocessors_names, best_postprocessors_dict, cfg, ind_data, ood_data, ind_dev=None,
-                                        ood_dev=None):
+                                        ood_dev=None, train_dev=None):
     """Reference :521-605 without the histograms: refit every postprocessor at its best PCA size, threshold = mean - 1.645 std
     of its InD valid scores; the OoD scores of that configuration are attached to ``ood_data`` under ``f"{ood} {best}"``.
     ``ind_dev`` / ``ood_dev`` (device-resident sweep): the same splits as device tensors - fits and scores then run from HBM
@@ -80,9 +80,17 @@ def _get_best_post_processor_thresholds(postprocessors_names, best_postprocessor
         dev_path = on_dev and hasattr(pp, "setup_device") and hasattr(pp, "postprocess_device")
         if not dev_path and on_dev:
             train_data, valid_data = np.asarray(ind_data["train latent_space_means"]), np.asarray(ind_data["valid latent_space_means"])
+        fit_dev = (not dev_path) and train_dev is not None and hasattr(pp, "setup_device")  # host-array mode: the FIT still runs from HBM
+        if fit_dev:
+            train_data = train_dev
         if "PCA" in best_postp:
             train_data, pca_transformation = apply_pca_ds_split(samples=train_data, nro_components=int(best_postp.split("PCA")[1]))
-        if dev_path:
+        if fit_dev:
+            pp.setup_device(train_data, ind_train_labels=ind_data["train labels"])
+            if "PCA" in best_postp:
+                valid_data = apply_pca_transform(valid_data, pca_transformation)
+            ind_valid = pp.postprocess(valid_data, pred_labels=ind_data["valid labels"])
+        elif dev_path:
             pp.setup_device(train_data, ind_train_labels=ind_data["train labels"])
             dp = device_pca_for(pca_transformation) if "PCA" in best_postp else None
             if dp is not None:
@@ -133,13 +141,18 @@ def log_evaluate_larex(cfg, baselines_names: List[str], ood_baselines_scores: Di
         a = np.asarray(a)
         return _hip.to_device(a, torch.float32 if a.dtype == np.float32 else torch.float64)
 
+    from .. import config as _config
+
     ind_eval, ood_eval = dict(ind_data_dict), dict(ood_data_dict)
     train_rows = ind_data_dict["train latent_space_means"]
-    if device_resident:
-        # ONE upload of every split, the training rows included (round 6): fits (setup_device, the PCA refits) and scores run
-        # from HBM; before, every postprocessor's setup and every PCA refit uploaded the training split again (17 x 205 MB) and
-        # formed its host-side statistics with NumPy / CPU torch
+    train_on_device = device_resident or (_config.use_device_fit() and isinstance(train_rows, np.ndarray))
+    if train_on_device:
+        # ONE upload of the training rows (round 6), in BOTH modes: every postprocessor's fit (setup_device) and every PCA refit run
+        # from HBM; before, every setup and every refit uploaded the training split again (17 x 205 MB) and formed its host-side
+        # statistics with NumPy / CPU torch.  The fitted objects live inside this function only; the host-array mode still scores
+        # host arrays through postprocess() and builds the ROC curves, as the reference does.
         train_rows = ind_eval["train latent_space_means"] = on_device(ind_data_dict["train latent_space_means"])
+    if device_resident:
         ind_eval["valid latent_space_means"] = on_device(ind_data_dict["valid latent_space_means"])
         for name in ood_datasets:
             ood_eval[f"{name} latent_space_means"] = on_device(ood_data_dict[f"{name} latent_space_means"])
@@ -180,5 +193,5 @@ def log_evaluate_larex(cfg, baselines_names: List[str], ood_baselines_scores: Di
         return overall_metrics_df, best, {}, ood_data_dict
     postprocessor_thresholds, ood_data_dict = _get_best_post_processor_thresholds(
         postprocessors, best, cfg, ind_data_dict, ood_data_dict, ind_eval if device_resident else None,
-        ood_eval if device_resident else None)
+        ood_eval if device_resident else None, train_dev=train_rows if train_on_device else None)
     return overall_metrics_df, best, postprocessor_thresholds, ood_data_dict
