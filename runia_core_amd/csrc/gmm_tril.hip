@@ -39,11 +39,6 @@ __device__ __forceinline__ void store_diff(const float (&v)[16], const float (&m
     *reinterpret_cast<float2*>(&dst[row][half * 16 + 2 * j]) = make_float2(v[2 * j] - m[2 * j], v[2 * j + 1] - m[2 * j + 1]);
 }
 
-__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
-  const int lo = __shfl_xor(__double2loint(v), mask, 64), hi = __shfl_xor(__double2hiint(v), mask, 64);
-  return __hiloint2double(hi, lo);
-}
-
 // 32 per-lane values -> their totals over the 32 lanes that share lane bit 5: lane ends with the total of slot (lane & 31).
 // Halving exchange: at distance d the lanes with bit d clear keep the lower half of the slots and receive their partner's.
 template <int D_, int N_>

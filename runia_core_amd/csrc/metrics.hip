@@ -4,7 +4,9 @@
 // _binary_clf_curve: descending sort, one curve point per run of equal scores, cumulative true / false positives).
 // Everything stays on the device: the sort of the 64-bit keys (round 4: one split into 4 096 buckets that are linear in the
 // score + a sort per bucket, 10 launches; the stable LSD radix sort of rounds 2-3, 8 passes of 8 bits and ~31 launches, is
-// kept behind -DMETRICS_MSD=0), a scan of the labels and of the run ends, and the trapezoid sums.
+// kept behind -DMETRICS_MSD=0), a scan of the labels and of the run ends, and the trapezoid sums.  Round 6: the three scalars
+// alone take six launches (four without the sketch) - buckets by splitter keys, bucket sort and curve terms in one launch
+// (msd_keys_split_kernel, msd_sort_curve_kernel below); the curve API keeps the eight-launch chain.
 //
 // Reference behaviour that is reproduced on purpose (the oracle pins it with the reference's goldens):
 //   * if any score lies outside [0, 1] (or is NaN) every score goes through a sigmoid first - in the dtype of the
