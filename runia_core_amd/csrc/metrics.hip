@@ -628,28 +628,11 @@ __device__ __forceinline__ double msd_lin_pos(double raw, const MsdRange& r) {
   constexpr double kTop = (double)kMsdBuckets * (1.0 - 0x1p-52);  // the largest position inside the last bin
   return (x >= kTop) ? kTop : (x > 0.0 ? x : 0.0);
 }
-// Equalised bucket (round 5).  Raw-linear bins of a bell-shaped score set hold 0 ... 4 x the mean, and a bin beyond the wave
-// sort's 1 024 keys takes the slow workgroup path (2 M N(0, 1) scores: 0.36 ms).  With the bin counts known (`lin`, one
-// histogram launch over the scores), the cumulative count at a score - linear inside its bin - is its approximate RANK; the
-// bucket is that rank cut into kMsdBuckets equal parts.  Monotone in the score (cum[b] + f * cnt[b] <= cum[b + 1] for f < 1;
-// products with positive constants and truncations keep order), so the buckets still follow the key order, and their sizes
-// follow the mean as closely as the density is flat inside one bin.  cum / cnt: this workgroup's LDS copy of the sketch.
-__device__ __forceinline__ unsigned msd_bucket(double raw, uint64_t key, const MsdRange& r, const unsigned* __restrict__ cum,
-                                               const unsigned* __restrict__ cnt, double buckets_per_key) {
-  if (!(raw - raw == 0.0)) {
-    // +inf (its sigmoid is 1.0: the largest key) -> the first bucket, -inf (0.0) -> the last; a NaN keeps the end of the
-    // key space its (squashed) key lies at - NaN keys sort before +inf or behind -inf by their sign bit
-    if (raw == raw) return raw > 0.0 ? 0u : (unsigned)(kMsdBuckets - 1);
-    return (key >> 63) ? (unsigned)(kMsdBuckets - 1) : 0u;
-  }
-  const double x = msd_lin_pos(raw, r);
-  const int b = (int)x;
-  if (buckets_per_key == 0.0) return (unsigned)b;  // (uniform) no sketch: the raw-linear bin itself
-  const double rank = (double)cum[b] + (x - (double)b) * (double)cnt[b];
-  const int e = (int)(rank * buckets_per_key);
-  return (unsigned)(e >= kMsdBuckets ? kMsdBuckets - 1 : e);
-}
-
+// Equalised buckets (round 5; by splitter keys since round 6).  Raw-linear bins of a bell-shaped score set hold 0 ... 4 x the mean, and
+// a bin beyond the wave sort's 1 024 keys takes the slow workgroup path (2 M N(0, 1) scores: 0.36 ms).  With the bin counts known
+// (`lin`, one histogram launch over the scores), the cumulative count at a score - linear inside its bin - is its approximate RANK;
+// bucket e starts at the raw score whose rank is e / 4 096 of the total (msd_split_kernel inverts that, msd_keys_split_kernel compares
+// KEYS with the keys of those scores).
 // the sketch: finite raw scores per linear bin - of every kSketchStride-th score once the set is large (a quarter of 2 M
 // scores still puts ~120 into an average bin; the launch is a pass over the scores with LDS atomics, 19 us -> ~7 at 2 M)
 constexpr int kSketchStride = 4;
@@ -806,67 +789,6 @@ __global__ __launch_bounds__(256) void msd_split_kernel(unsigned* __restrict__ a
     }
   }
   if (e < kMsdBuckets) st->split[e] = sk;
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void msd_keys_kernel(const T* __restrict__ ind, int64_t n_ind, const T* __restrict__ ood,
-                                                       int64_t n_ood, unsigned* __restrict__ any_outside, MsdState* st,
-                                                       unsigned n_probe_recs, uint64_t* __restrict__ keys,
-                                                       uint8_t* __restrict__ labels, uint16_t* __restrict__ bucket_of, int equalise) {
-  __shared__ unsigned lh[kMsdBuckets];
-  __shared__ unsigned cum[kMsdBuckets], cnt[kMsdBuckets];  // the sketch: finite scores in the bins before b, in bin b
-  __shared__ unsigned wsum_k[4];
-  const ProbeResult pr = msd_reduce_probe(st, n_probe_recs, any_outside);
-  const bool squash = pr.squash;
-  const MsdRange rg = msd_range_of(pr.nkmin, pr.kmax);
-  for (int b = threadIdx.x; b < kMsdBuckets; b += 256) lh[b] = 0u;
-  unsigned finite_total = 0u;
-  if (equalise) {  // (uniform) exclusive scan of the bin counts, every workgroup for itself (16 KB from L2)
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    constexpr int PER = kMsdBuckets / 256;
-    unsigned v[PER], tot = 0u;
-#pragma unroll
-    for (int j = 0; j < PER; ++j) { v[j] = st->lin[tid * PER + j]; tot += v[j]; }
-    unsigned x = tot;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const unsigned y = __shfl_up(x, o, 64);
-      if (lane >= o) x += y;
-    }
-    if (lane == 63) wsum_k[wave] = x;
-    __syncthreads();
-    unsigned off = x - tot;
-    for (int w = 0; w < wave; ++w) off += wsum_k[w];
-#pragma unroll
-    for (int j = 0; j < PER; ++j) {
-      cum[tid * PER + j] = off;
-      cnt[tid * PER + j] = v[j];
-      off += v[j];
-    }
-    finite_total = wsum_k[0] + wsum_k[1] + wsum_k[2] + wsum_k[3];
-  }
-  const double buckets_per_key = finite_total ? (double)kMsdBuckets / (double)finite_total : 0.0;
-  __syncthreads();
-  const int64_t n = n_ind + n_ood;
-  const int64_t t0 = (int64_t)blockIdx.x * kTile;
-#pragma unroll 4
-  for (int c = 0; c < kItems; ++c) {
-    const int64_t i = t0 + c * 256 + threadIdx.x;
-    if (i < n) {
-      const T v = (i < n_ind) ? ind[i] : ood[i - n_ind];
-      const uint64_t key = score_key<T>(v, squash);
-      keys[i] = key;
-      labels[i] = (i < n_ind) ? 1 : 0;
-      const unsigned b = msd_bucket((double)v + 0.0, key, rg, cum, cnt, buckets_per_key);
-      bucket_of[i] = (uint16_t)b;
-      atomicAdd(&lh[b], 1u);
-    }
-  }
-  __syncthreads();
-  for (int b = threadIdx.x; b < kMsdBuckets; b += 256) {
-    const unsigned c = lh[b];
-    if (c) atomicAdd(&st->hist[b], c);
-  }
 }
 
 constexpr int kScatItems = METRICS_SCAT_ITEMS, kScatTile = 256 * kScatItems;  // 8 192 keys per workgroup: ~2 per (tile, bucket)
@@ -1758,34 +1680,33 @@ int ood_metrics(const T* ind, int64_t n_ind, const T* ood, int64_t n_ood, double
     if (equalise) {
       const int64_t sketch_n = (n > kSketchAll) ? (n + kSketchStride - 1) / kSketchStride : n;
       msd_lin_hist_kernel<T><<<(unsigned)((sketch_n + kScatTileHist - 1) / kScatTileHist), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid);
-      if (METRICS_FUSED && !tps_out) msd_split_kernel<T><<<kMsdBuckets / 256, 256, 0, s>>>(flag, st, pgrid);
+      msd_split_kernel<T><<<kMsdBuckets / 256, 256, 0, s>>>(flag, st, pgrid);
     }
     uint16_t* bucket_of = reinterpret_cast<uint16_t*>(w + L.bucket_of);
-    if (METRICS_FUSED && !tps_out) {  // the three scalars alone (round 6): six launches, four without the sketch
-      // buckets: 4 096 (equalised by the sketch) for large sets; for small ones raw-linear bins, ~64 keys each - every (tile,
-      // bucket) pair costs the scatter an atomic and every four buckets the last launch a workgroup (20 000 scores in 4 096
-      // buckets: 28 + 28 us for those two launches)
-      int nbk = kMsdBuckets;
-      if (!equalise) {
-        nbk = 64;
-        while (nbk < kMsdBuckets && (int64_t)nbk * 64 < n) nbk <<= 1;
-      }
-      if (n <= 65536) {  // small sets: smaller tiles, more workgroups (the two launches are latency-bound there)
-        msd_keys_split_kernel<T, 4><<<(unsigned)((n + 1023) / 1024), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise, nbk);
-        msd_scatter_kernel<T, 8><<<(unsigned)((n + 2047) / 2048), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
-      } else if (n <= 524288) {  // mid-sized sets: 16 keys per thread in the scatter (200 000 scores: 85 -> 73 us; 2 M: 230 -> 240)
-        msd_keys_split_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise, nbk);
-        msd_scatter_kernel<T, 16><<<(unsigned)((n + 4095) / 4096), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
-      } else {
-        msd_keys_split_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise, nbk);
-        msd_scatter_kernel<T><<<(unsigned)((n + kScatTile - 1) / kScatTile), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
-      }
+    // Front half of both forms (round 6): keys + buckets by splitter keys, scatter.  Buckets: 4 096 (equalised by the sketch) for
+    // large sets; for small ones raw-linear bins, ~64 keys each - every (tile, bucket) pair costs the scatter an atomic and every
+    // four buckets the sort launch a workgroup (20 000 scores in 4 096 buckets: 28 + 28 us for those two launches)
+    int nbk = kMsdBuckets;
+    if (!equalise) {
+      nbk = 64;
+      while (nbk < kMsdBuckets && (int64_t)nbk * 64 < n) nbk <<= 1;
+    }
+    if (n <= 65536) {  // small sets: smaller tiles, more workgroups (the two launches are latency-bound there)
+      msd_keys_split_kernel<T, 4><<<(unsigned)((n + 1023) / 1024), 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise, nbk);
+      msd_scatter_kernel<T, 8><<<(unsigned)((n + 2047) / 2048), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
+    } else if (n <= 524288) {  // mid-sized sets: 16 keys per thread in the scatter (200 000 scores: 85 -> 73 us; 2 M: 230 -> 240)
+      msd_keys_split_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise, nbk);
+      msd_scatter_kernel<T, 16><<<(unsigned)((n + 4095) / 4096), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
+    } else {
+      msd_keys_split_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise, nbk);
+      msd_scatter_kernel<T><<<(unsigned)((n + kScatTile - 1) / kScatTile), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
+    }
+    if (METRICS_FUSED && !tps_out) {  // the three scalars alone: bucket sort + curve terms + finalise in ONE launch (six launches, four without the sketch)
       msd_sort_curve_kernel<T><<<(unsigned)(nbk / 4), 256, 0, s>>>(keys[1], labs[1], keys[0], labs[0], st,
                                                                    reinterpret_cast<FusedPart*>(w + L.parts2), (float)n_ind, (float)n_ood, out3);
       return runia_check_launch();
     }
-    msd_keys_kernel<T><<<L.nblocks, 256, 0, s>>>(ind, n_ind, ood, n_ood, flag, st, pgrid, keys[0], labs[0], bucket_of, equalise);
-    msd_scatter_kernel<T><<<(unsigned)((n + kScatTile - 1) / kScatTile), 256, 0, s>>>(keys[0], labs[0], keys[1], labs[1], n, bucket_of, st);
+    // the curve API: every run's cumulative counts have to land in memory - bucket sort, tile summary, tile prefix, terms
     msd_bucket_sort_kernel<T><<<kMsdBuckets / 4, 256, 0, s>>>(keys[1], labs[1], keys[0], labs[0], flag, st);  // (four buckets per workgroup)
     tile_summary_kernel<<<L.nblocks, 256, 0, s>>>(keys[1], labs[1], n, tile_sum, tile_end, tile_cnt);
     tile_prefix_raw_kernel<<<L.nblocks, 256, 0, s>>>(keys[1], labs[1], n, tile_sum, tile_end, tile_cnt, tps, prev_end, tps_out,
