@@ -345,11 +345,28 @@ __global__ __launch_bounds__(256) void gen_tiny_kernel(const float* __restrict__
     }
     float s = 1.f;
     if (!from_probs) {  // (uniform) the rows are logits: softmax first
-      s = 0.f;
 #pragma unroll
-      for (int j = 0; j < CT; ++j) {
-        v[j] = exp_nonpos(v[j] - m);
-        s += v[j];
+      for (int j = 0; j < CT; ++j) v[j] = exp_nonpos(v[j] - m);
+      // the row sum in NumPy's order (scipy.special.softmax: np.sum over the contiguous axis = pairwise_sum: below 8 terms one
+      // chain; up to 128: eight interleaved partial sums r[j] += a[8 i + j], ((r0+r1)+(r2+r3))+((r4+r5)+(r6+r7)), the remainder
+      // behind).  On a confident row 1 - p cancels in float32 and (1 - p)^gamma moves 2.5 % per ulp of p: with the sum added in
+      // another order a row could land 2e-5 from the reference's own float32 value (tools/fuzz_kernels.py, seed 99).
+      if constexpr (CT < 8) {
+        s = 0.f;
+#pragma unroll
+        for (int j = 0; j < CT; ++j) s += v[j];
+      } else {
+        float r[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) r[j] = v[j];
+        constexpr int kWhole = CT - CT % 8;
+#pragma unroll
+        for (int i = 8; i < kWhole; i += 8)
+#pragma unroll
+          for (int j = 0; j < 8; ++j) r[j] += v[i + j];
+        s = ((r[0] + r[1]) + (r[2] + r[3])) + ((r[4] + r[5]) + (r[6] + r[7]));
+#pragma unroll
+        for (int i = kWhole; i < CT; ++i) s += v[i];
       }
     }
     const float rs = 1.0f / s;
