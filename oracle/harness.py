@@ -19,6 +19,10 @@ vectors, then one PCA refit + transform per entry of ``n_pca_components``) and `
   (``oracle.knn_kth_score``'s), the bank rows to measure picked by float64 BLAS distances first;
 * GMM: ``gmm_fit`` restated in upstream's form (inference/funcs.py:285-344: per-class mean, ``x^T x / (max(n, 2) - 1)``, the
   jitter ladder through exceptions) + ``oracle.gmm_energy``.
+
+``all_baselines`` follows ``calculate_all_baselines`` (/root/reference/runia_core/evaluation/baselines.py:713-854), the loop of
+the features / logits postprocessors; pinned by the ten means of /root/reference/tests/unit_test_baselines.py:255-268
+(tests/test_baselines_harness.py).
 """
 from __future__ import annotations
 
@@ -180,3 +184,59 @@ def larex_eval_sweep(ind: Dict[str, np.ndarray], ood: Dict[str, np.ndarray], ood
         seconds["pca"] = seconds.get("pca", 0.0) + time.perf_counter() - t0
         one_config(train_red, valid_red, oods_red, f" PCA {n_comp}")
     return table, seconds
+
+
+BASELINES = ("vim", "msp", "raw", "knn", "energy", "ash", "gen", "react", "dice", "dice_react", "mdist", "ddu")
+
+
+def all_baselines(names: Iterable[str], ind: Dict[str, np.ndarray], ood: Dict[str, np.ndarray], ood_names: Sequence[str], w, b,
+                  num_classes: int, k_neighbors: int, ash_percentile: int, react_percentile: int, dice_percentile: int,
+                  gen_gamma: float, seconds: Dict[str, float] | None = None) -> Dict[str, Dict[str, np.ndarray]]:
+    """CPU form of ``calculate_all_baselines`` (/root/reference/runia_core/evaluation/baselines.py:713-854): every baseline fit
+    on the training split and scored on ``"valid"`` + every OoD set -> ``{baseline: {"valid": scores, ood_name: scores}}``.  The
+    labels of ``mdist`` / ``ddu`` are the argmax of the TRAIN LOGITS (``get_labels_from_logits``, :614-683, run before them); the
+    postprocessors are the oracle's restatements (``hotpath.py``), the Gaussians of ``ddu`` upstream's ``gmm_fit`` (above).
+    ``ind`` / ``ood`` are read only."""
+    seconds = {} if seconds is None else seconds
+    feats = {"valid": ind["valid features"], **{n: ood[f"{n} features"] for n in ood_names}}
+    logits = {"valid": ind["valid logits"], **{n: ood[f"{n} logits"] for n in ood_names}}
+    tr_f, tr_l = ind["train features"], ind["train logits"]
+    labels = np.argmax(tr_l[:, :-1] if tr_l.shape[1] in (21, 11) else tr_l, axis=-1)
+    out: Dict[str, Dict[str, np.ndarray]] = {}
+    for name in names:
+        t0 = time.perf_counter()
+        if name == "vim":
+            u, ns, alpha = H.vim_setup(tr_f, tr_l, w, b)
+            out[name] = {s: H.vim_score(feats[s], logits[s], u, ns, alpha) for s in feats}
+        elif name in ("msp", "raw"):
+            out[name] = {s: H.msp_score(v) for s, v in logits.items()}
+        elif name == "energy":
+            out[name] = {s: H.energy_score(v) for s, v in logits.items()}
+        elif name == "gen":
+            out[name] = {s: H.gen_score(v, gen_gamma, num_classes) for s, v in logits.items()}
+        elif name == "knn":
+            bank = np.ascontiguousarray(H.normalizer(tr_f).astype(np.float32))
+            out[name] = {s: knn_kth_blas(bank, v, k_neighbors) for s, v in feats.items()}
+        elif name == "ash":
+            out[name] = {s: H.linear_energy(H.ash_s_defined(np.array(v, copy=True), ash_percentile), w, b) for s, v in feats.items()}
+        elif name == "react":
+            thr = H.react_threshold(tr_f, react_percentile)
+            out[name] = {s: H.react_score(v, w, b, thr) for s, v in feats.items()}
+        elif name in ("dice", "dice_react"):
+            mw = H.dice_masked_weight(tr_f, w, dice_percentile)
+            clip = np.float32(H.react_threshold(tr_f, react_percentile)) if name == "dice_react" else None
+            out[name] = {s: logsumexp(H.dice_logits(v if clip is None else v.clip(max=clip), mw, b), axis=1) for s, v in feats.items()}
+        elif name == "mdist":
+            import warnings
+
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")  # (a class without samples warns, as upstream)
+                cm, prec = H.mahalanobis_setup(tr_f, labels, num_classes)
+            out[name] = {s: H.mahalanobis_score(v, cm, prec, num_classes) for s, v in feats.items()}
+        elif name == "ddu":
+            gmm, _ = gmm_fit(tr_f, labels, num_classes)
+            out[name] = {s: H.gmm_energy(gmm, np.asarray(v, dtype=np.float32)) for s, v in feats.items()}
+        else:
+            raise KeyError(name)
+        seconds[name] = seconds.get(name, 0.0) + time.perf_counter() - t0
+    return out

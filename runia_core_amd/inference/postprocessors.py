@@ -923,7 +923,10 @@ class ViM(OodPostprocessor):
         if dt not in self._dev["u"]:
             self._dev["u"][dt] = _hip.to_device(np.asarray(self.u), dt)
         x = _hip.to_device(feats, dt)
-        return _hip.to_host(_hip.proj_norm(x, self._dev["u"][dt], self._dev["packed"], np.asarray(self.NS).shape[1]))
+        vlogit = _hip.to_host(_hip.proj_norm(x, self._dev["u"][dt], self._dev["packed"], np.asarray(self.NS).shape[1]))
+        # NumPy's result type of norm(matmul(feats - u, NS)): float32 rows against a float32 fit stay float32 upstream (and with
+        # them alpha and the scores: tests/golden/ref_baselines.npz); the f64 accumulation here is rounded once
+        return vlogit.astype(np.float32) if f32 and np.asarray(self.NS).dtype == np.float32 else vlogit
 
     @staticmethod
     def _energy(logits) -> np.ndarray:

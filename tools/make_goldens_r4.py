@@ -118,7 +118,7 @@ def main():
 
     names = {}
     for rel in ("inference/funcs.py", "inference/postprocessors.py", "inference/abstract_classes.py", "inference/image_level.py",
-                "inference/__init__.py", "evaluation/entropy.py", "evaluation/metrics.py", "evaluation/latent_space.py",
+                "inference/__init__.py", "evaluation/entropy.py", "evaluation/metrics.py", "evaluation/latent_space.py", "evaluation/baselines.py",
                 "dimensionality_reduction.py",
                 "feature_extraction/abstract_classes.py", "feature_extraction/utils.py", "feature_extraction/image_level.py",
                 "feature_extraction/object_level.py", "feature_extraction/__init__.py", "llm_uncertainty/scores.py"):
