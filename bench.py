@@ -158,12 +158,14 @@ def emit_record(full, saved_stdout=None):
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--workload", choices=["cfg2", "cfg3", "larex_eval"], default="cfg2",
+    ap.add_argument("--workload", choices=["cfg2", "cfg3", "larex_eval", "baselines_eval"], default="cfg2",
                     help="cfg2 (default, the headline metric): LaREM-16MC/PCA-256 from latents, weak scaling.  cfg3: "
                          "BASELINE.json configs[2] - synthetic 1M x 2048 rows through Mahalanobis + Energy + kNN(k=50), "
                          "the rows sharded over the ranks (strong scaling), one all_gather per postprocessor.  larex_eval: the "
                          "reference's evaluation harness loop (log_evaluate_larex: PCA refit sweep x five latent-space postprocessors x "
-                         "two OoD sets -> AUROC table), one wall clock for the whole sweep; N > 1 runs independent replicas")
+                         "two OoD sets -> AUROC table), one wall clock for the whole sweep; N > 1 runs independent replicas.  baselines_eval: the "
+                         "reference's baselines loop (calculate_all_baselines: twelve features / logits postprocessors fitted and scored on "
+                         "cfg3-synth splits), one wall clock for the loop; N > 1 runs independent replicas")
     ap.add_argument("--steps", type=int, default=None, help="timed steps (default: 200 for cfg2, 3 for cfg3)")
     ap.add_argument("--warmup", type=int, default=None, help="untimed warm-up steps (default: 10 for cfg2, 1 for cfg3)")
     ap.add_argument("--rows", type=int, default=1_000_000, help="cfg3: rows of the synthetic test set (all ranks together)")
@@ -207,9 +209,9 @@ def parse_args():
                          "stream (runia_core_amd.distributed.OneShotGather)")
     args = ap.parse_args()
     if args.steps is None:
-        args.steps = {"cfg2": 200, "cfg3": 3, "larex_eval": 1}[args.workload]
+        args.steps = {"cfg2": 200, "cfg3": 3, "larex_eval": 1, "baselines_eval": 1}[args.workload]
     if args.warmup is None:
-        args.warmup = {"cfg2": 10, "cfg3": 1, "larex_eval": 1}[args.workload]
+        args.warmup = {"cfg2": 10, "cfg3": 1, "larex_eval": 1, "baselines_eval": 1}[args.workload]
     return args
 
 
@@ -407,6 +409,44 @@ def main_larex(args, device, rank, world, dist, saved_stdout):
         dist.destroy_process_group()
 
 
+def main_baselines(args, device, rank, world, dist, saved_stdout):
+    """--workload baselines_eval: a step = one full pass of the reference's baselines loop (evaluation/baselines.py:713-854) over
+    train 50 000 / valid 10 000 / two OoD sets of 10 000 x 2048 features + 10-class logits.  The loop does not shard (every fit
+    needs the whole training split): N > 1 runs N independent replicas ("replicas only")."""
+    import torch
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import bench_workloads as bw
+
+    log = (lambda m: print(m, file=sys.stderr, flush=True)) if rank == 0 else None
+    rec = bw.run_baselines_eval(device, cpu_legs=(rank == 0 and not args.no_cpu_baseline), log=log)
+    if dist is not None:
+        t = torch.tensor([rec["seconds_device_resident"]], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        rec["seconds_device_resident"] = float(t.item())
+    if rank != 0:
+        if dist is not None:
+            dist.destroy_process_group()
+        return
+    sec = rec["seconds_device_resident"]
+    out = {"metric": "OOD scores/sec through the baselines harness loop (calculate_all_baselines: 12 features / logits postprocessors x (valid + 2 OoD sets))",
+           "value": round(world * rec["rows_scored"] / sec, 1), "unit": "rows scored/s", "n_gpus": world, "steps": 1, "warmup": 1,
+           "ms_per_step": round(1e3 * sec, 1), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+           "dtype": "f32 (f64 Mahalanobis), as the reference's postprocessors return", "data": "synthetic",
+           "config": {"workload": "calculate_all_baselines on cfg3-synth splits: " + rec["shape"],
+                      "multi_gpu": "replicas only (the loop's fits need the whole training split)"},
+           "roofline": None, "baselines_eval": rec}
+    if "cpu_baseline" in rec:
+        out["cpu_baseline"] = {"value": None, "unit": "s (bounded subset, see sample)", "cores": rec["cpu_baseline"]["cores"], "kind": "port",
+                               "sample": rec["cpu_baseline"]["sample"], "seconds": rec["cpu_baseline"]["seconds"],
+                               "device_seconds_same_subset": rec["cpu_baseline"]["device_seconds_same_subset"]}
+        errs = rec["parity_on_subset"]["max_rel_err_per_baseline"]
+        out["parity"] = {"max_rel_err": max(errs.values()), **{f"max_rel_err_{k}": v for k, v in errs.items()}}
+    emit_record(out, saved_stdout)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "--cpu-pool-child":
         return cpu_pool_child(sys.argv[2], int(sys.argv[3]), int(sys.argv[4]), float(sys.argv[5]), int(sys.argv[6]))
@@ -456,6 +496,8 @@ def main():
         return main_cfg3(args, device, rank, world, dist if use_dist else None, saved_stdout)
     if args.workload == "larex_eval":
         return main_larex(args, device, rank, world, dist if use_dist else None, saved_stdout)
+    if args.workload == "baselines_eval":
+        return main_baselines(args, device, rank, world, dist if use_dist else None, saved_stdout)
 
     # ---------------- setup (untimed): fit PCA-256 + LaREM on in-distribution entropies ----------
     probe = LaREMPipeline(None, None, N_MC, DROP_PROB, BLOCK)
@@ -956,6 +998,10 @@ def main():
             stages["entropy_joint"] = bw.run_entropy_joint_leg(device, cpu_legs=cpu)
             torch.cuda.empty_cache()
             stages["larex_eval"] = bw.run_larex_eval(device, cpu_legs=cpu)
+            torch.cuda.empty_cache()
+            # (without ViM here: its float32 np.linalg.eig of a 2048 x 2048 covariance is seconds of host time per fit, as upstream;
+            # `--workload baselines_eval` runs all twelve)
+            stages["baselines_eval"] = bw.run_baselines_eval(device, names=tuple(n for n in bw.BASELINES_ALL if n != "vim"), cpu_legs=cpu)
             stages["seconds"] = round(time.perf_counter() - t_s, 1)
             out["stages"] = stages
         except Exception as e:  # a reported extra; its failure must not lose the headline measurement

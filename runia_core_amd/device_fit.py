@@ -27,7 +27,8 @@ import torch
 
 from . import _hip
 
-__all__ = ["empirical_precision_device", "pinvh_device", "pca_fit_device", "pca_fit_randomized_device", "FittedPCA", "gmm_fit_device"]
+__all__ = ["empirical_precision_device", "pinvh_device", "pca_fit_device", "pca_fit_randomized_device", "FittedPCA", "gmm_fit_device",
+           "vim_null_space_device"]
 
 
 def pinvh_device(cov: torch.Tensor) -> torch.Tensor:
@@ -162,6 +163,24 @@ def pca_fit_randomized_device(samples, n_components: int, whiten: bool = True, n
     scale = np.full(n_components, 1.0 / (n - 1.0)) if whiten else 1.0 / np.maximum(_hip.to_host(sing[:n_components]), 1e-300) ** 2
     fitted._train_projection = (_hip.to_host(proj.T.contiguous()), scale)
     return fitted
+
+
+def vim_null_space_device(train, u: np.ndarray, dim: int) -> np.ndarray:
+    """ViM's residual space (reference ``inference/postprocessors.py:1051-1058``): eigenvectors of the second moment of
+    ``train - u`` (sklearn ``EmpiricalCovariance(assume_centered=True)``) beyond the ``dim`` largest eigenvalues, columns in
+    descending eigenvalue order -> ``(D, D - dim)`` host array in the features' dtype (float32 rows give a float32 basis, as
+    NumPy's ``eig`` of a float32 matrix does upstream).  The moment about ``u`` is ``cov + (mean - u)(mean - u)^T`` with the
+    bias-1 covariance and the column means of ``runia_covariance_*`` (f64 accumulation on the matrix cores); the decomposition is
+    the symmetric Jacobi solver, so the basis is orthonormal and real by construction (upstream's general solver can return a
+    complex one)."""
+    f32 = getattr(train, "dtype", None) in (np.float32, torch.float32)
+    xd = _hip.to_device(train, torch.float32 if f32 else torch.float64)
+    mean, cov = _hip.covariance(xd)
+    delta = mean - _hip.to_device(np.asarray(u, dtype=np.float64).reshape(-1), torch.float64)
+    vals, vecs = _hip.eigh(cov + torch.outer(delta, delta))          # ascending
+    order = torch.argsort(vals, descending=True, stable=True)[dim:]
+    ns = _hip.to_host(vecs.index_select(1, order).contiguous())
+    return np.ascontiguousarray(ns.astype(np.float32) if f32 else ns)
 
 
 _GMM_JITTERS = (0.0,) + tuple(10.0 ** e for e in range(-20, 0))

@@ -950,15 +950,19 @@ class ViM(OodPostprocessor):
         self.u = -np.matmul(np.linalg.pinv(w), b)
         d = ind_train_data.shape[-1]
         self.DIM = 1000 if d >= 2048 else (512 if d >= 768 else d // 2)
-        # This fit stays on the host whatever config.device_fit says: for float32 features the reference runs the
-        # covariance and np.linalg.eig in float32, and its scores carry that solver's rounding - a float64 Jacobi
-        # decomposition of the same matrix (covariance kernel + runia_eigh) moves them by 1.5e-5 on the reference-run
-        # fixture (tests/golden/ref_f4.npz), beyond the 1e-5 contract.  GMM / DDU (gmm_fit: float32 torch on the host,
-        # a jitter ladder decided by float32 round-off) stay there for the same reason.
-        ec = EmpiricalCovariance(assume_centered=True)
-        ec.fit(ind_train_data - self.u)
-        eig_vals, eigen_vectors = np.linalg.eig(ec.covariance_)
-        self.NS = np.ascontiguousarray((eigen_vectors.T[np.argsort(eig_vals * -1)[self.DIM:]]).T)
+        # This fit stays on the host whatever config.device_fit says (config.vim_device_fit is its own opt-in): for float32
+        # features the reference runs the covariance and np.linalg.eig in float32, and its scores carry that solver's
+        # rounding - a float64 Jacobi decomposition of the same matrix (covariance kernel + runia_eigh) moves them by 1.5e-5
+        # on the reference-run fixture (tests/golden/ref_f4.npz), beyond the 1e-5 contract.
+        if config.vim_device_fit:  # explicit opt-in (config.py): exact covariance + Jacobi solver on the device
+            from ..device_fit import vim_null_space_device
+
+            self.NS = vim_null_space_device(ind_train_data, self.u, self.DIM)
+        else:
+            ec = EmpiricalCovariance(assume_centered=True)
+            ec.fit(ind_train_data - self.u)
+            eig_vals, eigen_vectors = np.linalg.eig(ec.covariance_)
+            self.NS = np.ascontiguousarray((eigen_vectors.T[np.argsort(eig_vals * -1)[self.DIM:]]).T)
         self._dev = None
         vlogit_id_train = self._residual_norm(ind_train_data)
         self.alpha = kwargs["train_logits"].max(axis=-1).mean() / vlogit_id_train.mean()

@@ -469,6 +469,41 @@ def test_vim_fixture_and_contract(fit_on):
     assert rel_err(nrm, exp) < 1e-12
 
 
+def test_vim_device_fit_opt_in():
+    """config.vim_device_fit: the residual space from the exact second moment + the Jacobi solver.  Orthonormal, real, in the
+    features' dtype; scores within 5e-5 of the reference-run fixture (the reference's float32 eig sits 1.5e-5 from the exact
+    null space: INTEGRATION.md 'Known divergences'); the default stays the reference's host call."""
+    from runia_core_amd import config
+    from runia_core_amd.inference import ViM
+
+    g = load_npz("ref_f4.npz")
+    fc = {"weight": g["w"], "bias": g["b"]}
+    kw = dict(final_linear_layer_params=fc, train_logits=g["logits_train"], valid_feats=g["valid"], valid_logits=g["logits_valid"])
+    assert config.vim_device_fit is False
+    config.vim_device_fit = True
+    try:
+        p = ViM(flip_sign=False)
+        p.setup(g["train"], **kw)
+        s = p.postprocess(g["test"], logits=g["logits_test"])
+    finally:
+        config.vim_device_fit = False
+    assert p.NS.shape == (300, 150) and p.NS.dtype == np.float32 and not np.iscomplexobj(p.NS)
+    gram = p.NS.astype(np.float64).T @ p.NS.astype(np.float64)
+    assert np.max(np.abs(gram - np.eye(150))) < 1e-6
+    assert s.dtype == g["vim_scores"].dtype and rel_err(s, g["vim_scores"]) < 5e-5
+    assert abs(p.alpha - float(g["vim_alpha"])) < 5e-5 * abs(p.alpha)
+    # the same subspace as the exact decomposition of the same moment (NumPy f64 eigh): projector difference at round-off
+    x = g["train"].astype(np.float64) - np.asarray(p.u, dtype=np.float64)
+    w_, v_ = np.linalg.eigh(x.T @ x / x.shape[0])
+    ns = v_[:, np.argsort(-w_)[150:]]
+    y = g["test"].astype(np.float64) - np.asarray(p.u, dtype=np.float64)
+    a, b = np.linalg.norm(y @ ns, axis=-1), np.linalg.norm(y @ p.NS.astype(np.float64), axis=-1)
+    assert np.max(np.abs(a - b) / a) < 2e-6  # (the basis is rounded to float32)
+    h = ViM(flip_sign=False)
+    h.setup(g["train"], **kw)
+    assert rel_err(h.postprocess(g["test"], logits=g["logits_test"]), g["vim_scores"]) < 1e-5
+
+
 def test_gmm_and_ddu_fixtures(fit_on):
     """GMM (LaREG) and DDU against the reference run by path on well-conditioned data (float32 arithmetic there)."""
     from runia_core_amd.inference import DDU, GMMLatentSpace, gmm_fit

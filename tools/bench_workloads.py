@@ -958,3 +958,130 @@ def run_larex_eval(device, n_train: int = 50_000, n_valid: int = 10_000, n_ood: 
         worst[pp] = max(worst.get(pp, 0.0), abs(float(g["auroc"]) - au), abs(float(g["fpr@95"]) - fp), abs(float(g["aupr"]) - ap))
     rec["parity"]["max_abs_diff_with_host_fits"] = {k: float(v) for k, v in worst.items()}
     return rec
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the baselines harness (round 6): calculate_all_baselines over cfg3-synth features / logits
+# ---------------------------------------------------------------------------------------------------------------------
+BASELINES_ALL = ("vim", "msp", "raw", "knn", "energy", "ash", "gen", "react", "dice", "dice_react", "mdist", "ddu")
+
+
+def run_baselines_eval(device, n_train: int = 50_000, n_valid: int = 10_000, n_ood: int = 10_000, names=BASELINES_ALL,
+                       cpu_sample=(4000, 256, 256), cpu_legs: bool = True, log=None) -> dict:
+    """One wall clock for the reference's baselines loop (evaluation/baselines.py:713-854) on cfg3-synth rows: features
+    ReLU(mu_class + N(0, I)) of width 2048, logits of the 10-class slice of the synthetic head (``gen`` refuses more than 21
+    classes upstream), two OoD sets (shifted by +0.5 and -0.5).  Timed twice through
+    runia_core_amd.evaluation.calculate_all_baselines: host arrays as upstream (every postprocess uploads its rows), and
+    device_resident=True (each split uploaded once).  The oracle's CPU form of the loop runs on a bounded subset: parity of the
+    device scores on that subset, and the CPU figure."""
+    from runia_core_amd.evaluation import calculate_all_baselines
+
+    say = log or (lambda *_: None)
+    centres = class_centres(device)
+    w_all, b_all = linear_head(device)
+    w, b = w_all[:N_CLASSES].contiguous(), b_all[:N_CLASSES].contiguous()
+    ood_names = ["ood_up", "ood_down"]
+    t0 = time.perf_counter()
+
+    def split(n, which, shift):
+        f, _ = feature_rows(0, n, which, device, centres)
+        if shift:
+            f = torch.relu(f + shift)
+        return f.cpu().numpy(), logits_of(f, w, b).cpu().numpy()
+
+    trf, trl = split(n_train, 1, 0.0)
+    vaf, val = split(n_valid, 0, 0.0)
+    ind = {"train features": trf, "train logits": trl, "valid features": vaf, "valid logits": val}
+    ood = {}
+    for i, name in enumerate(ood_names):
+        f, _ = feature_rows(n_valid + i * n_ood, n_valid + (i + 1) * n_ood, 0, device, centres)
+        f = torch.relu(f + (0.5 if i == 0 else -0.5))
+        ood[f"{name} features"], ood[f"{name} logits"] = f.cpu().numpy(), logits_of(f, w, b).cpu().numpy()
+    fc = {"weight": w.cpu().numpy(), "bias": b.cpu().numpy()}
+    cfg = {"ood_datasets": ood_names, "ash_percentile": 90, "react_percentile": 90, "dice_percentile": 90, "gen_gamma": 0.1,
+           "k_neighbors": K_NN}
+    t_data = time.perf_counter() - t0
+    say(f"baselines_eval: {n_train} + {n_valid} + 2 x {n_ood} rows x {D_FEAT} in {t_data:.1f} s")
+
+    def loop(ind_d, ood_d, resident, which=names):
+        import contextlib
+        import io
+        import warnings
+
+        torch.cuda.synchronize()
+        t = time.perf_counter()
+        with warnings.catch_warnings(), contextlib.redirect_stdout(io.StringIO()):  # (the loop prints one line per baseline, as upstream)
+            warnings.simplefilter("ignore")
+            i2, _, sc = calculate_all_baselines(list(which), dict(ind_d), dict(ood_d), fc, cfg, N_CLASSES, device_resident=resident)
+        torch.cuda.synchronize()
+        return i2, sc, time.perf_counter() - t
+
+    loop(ind, ood, True)  # warm-up
+    i_d, s_d, t_dev = loop(ind, ood, True)
+    i_h, s_h, t_host = loop(ind, ood, False)
+    same = max([float(np.max(np.abs(s_d[k].astype(np.float64) - s_h[k].astype(np.float64)))) for k in s_d] +
+               [float(np.max(np.abs(i_d[n].astype(np.float64) - i_h[n].astype(np.float64)))) for n in names])
+    scored = (n_valid + len(ood_names) * n_ood) * len(names)
+    # per-baseline seconds of the device-resident mode (one more pass, one baseline at a time)
+    per = {}
+    for n in names:
+        _, _, per[n] = loop(ind, ood, True, which=(n,))
+    vim_opt = None
+    if "vim" in names:  # the opt-in device fit of ViM's residual space (config.vim_device_fit): seconds and distance to the default's scores
+        from runia_core_amd import config as _config
+
+        _config.vim_device_fit = True
+        try:
+            loop(ind, ood, True, which=("vim",))
+            i_v, s_v, t_v = loop(ind, ood, True, which=("vim",))
+        finally:
+            _config.vim_device_fit = False
+        vim_opt = {"seconds": round(t_v, 3), "seconds_default_host_eig": round(per["vim"], 3),
+                   "max_rel_diff_to_default_scores": max(_rel(s_v[f"{o} vim"], s_d[f"{o} vim"]) for o in ood_names),
+                   "loop_seconds_with_it": round(t_dev - per["vim"] + t_v, 3)}
+    rec = {"shape": f"train {n_train} / valid {n_valid} / {len(ood_names)} OoD sets of {n_ood} x {D_FEAT} f32 features + {N_CLASSES}-class logits; "
+                    f"baselines {list(names)}",
+           "seconds_device_resident": round(t_dev, 3), "seconds_host_arrays_api": round(t_host, 3), "rows_scored": scored,
+           "rows_scored_per_s": round(scored / t_dev, 1), "max_abs_diff_between_the_two_modes": same,
+           "seconds_per_baseline": {k: round(v, 3) for k, v in per.items()}, "data_generation_s": round(t_data, 2)}
+    if vim_opt:
+        rec["vim_device_fit_opt_in"] = vim_opt
+    if not cpu_legs:
+        return rec
+    from oracle import harness  # checker / CPU baseline only
+    from runia_core_amd.host_threads import host_compute, usable_cpus
+
+    a, v, c = cpu_sample
+    ind_s = {"train features": trf[:a], "train logits": trl[:a], "valid features": vaf[:v], "valid logits": val[:v]}
+    ood_s = {f"{n} {kind}": ood[f"{n} {kind}"][:c] for n in ood_names for kind in ("features", "logits")}
+    # ddu fits on the WHOLE training split in both legs: ten Gaussians in 2048 dimensions from 400 rows each are singular
+    # matrices behind a jitter - their log-densities are the factorisation's round-off, not something to compare (INTEGRATION.md)
+    ind_full = dict(ind_s, **{"train features": trf, "train logits": trl})
+    rest = tuple(n for n in names if n != "ddu")
+    i_s, s_s, t_dev_s = loop(ind_s, ood_s, True, which=rest)
+    if "ddu" in names:
+        i_s2, s_s2, t2 = loop(ind_full, ood_s, True, which=("ddu",))
+        i_s["ddu"] = i_s2["ddu"]
+        s_s.update(s_s2)
+        t_dev_s += t2
+    secs = {}
+    import warnings
+
+    with host_compute(), warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        t = time.perf_counter()
+        exp = harness.all_baselines(rest, ind_s, ood_s, ood_names, fc["weight"], fc["bias"], N_CLASSES, K_NN, 90, 90, 90, 0.1, secs)
+        if "ddu" in names:
+            exp.update(harness.all_baselines(("ddu",), ind_full, ood_s, ood_names, fc["weight"], fc["bias"], N_CLASSES, K_NN, 90, 90, 90,
+                                             0.1, secs))
+        t_cpu = time.perf_counter() - t
+    err = {}
+    for n in names:
+        e = [_rel(i_s[n], exp[n]["valid"])] + [_rel(s_s[f"{o} {n}"], exp[n][o]) for o in ood_names]
+        err[n] = float(max(e))
+    rec["parity_on_subset"] = {"max_rel_err_per_baseline": {k: float(f"{v:.3g}") for k, v in err.items()},
+                               "note": "ash: the oracle's defined op (upstream's scatter permutes kept values in some rows)"}
+    rec["cpu_baseline"] = {"seconds": round(t_cpu, 2), "cores": usable_cpus(), "kind": "port",
+                           "sample": f"train {a} (ddu: all {n_train}) / valid {v} / 2 x {c} rows of the same splits, oracle.harness.all_baselines (NumPy / SciPy / CPU torch)",
+                           "seconds_per_baseline": {k: round(x, 2) for k, x in secs.items()}, "device_seconds_same_subset": round(t_dev_s, 3)}
+    return rec
