@@ -72,12 +72,123 @@ __global__ __launch_bounds__(64 * kCholWaves) void cholesky_kernel(T* __restrict
   }
 }
 
+// ---- wide matrices (D >= kCholBlockedFrom): the same left-looking factorisation in panels of kCholPanel columns.  The one-workgroup
+// kernel above reads D^3 / 3 elements through one compute unit and meets 3 barriers per column with dot products of up to D terms
+// between them (ten 2048 x 2048 float32 matrices: 173 ms, and a jitter ladder calls it several times).  Per panel [j0, j1):
+//   chol_update_kernel  rows >= j0, columns of the panel: A[i][c] = (A[i][c] + jitter on the diagonal) - sum_{k < j0} L[i][k] L[c][k]
+//                       as 64 x 64 tiles on the whole chip (one fma chain over k per element, k ascending);
+//   chol_panel_kernel   one workgroup per matrix, column by column inside the panel: the dot products are now over k in [j0, j)
+//                       (< kCholPanel terms, one chain per row), pivot test, scaling.
+// A failed pivot writes info = j + 1 (LAPACK's convention) and every later launch of that matrix returns at its first instruction.
+// Every sum has one fixed order: same bits from run to run and on every rank (not the bits of the one-workgroup kernel: the
+// sums are grouped by panel).
+constexpr int kCholPanel = 64;
+constexpr int64_t kCholBlockedFrom = 768;
+
+template <typename T>
+__global__ __launch_bounds__(256) void chol_update_kernel(T* __restrict__ a, int64_t D, int64_t j0, int64_t j1, T jitter,
+                                                           const int* __restrict__ info) {
+  const int64_t b = blockIdx.y;
+  if (info[b] != 0) return;  // (uniform)
+  T* m = a + b * D * D;
+  const int64_t r0 = j0 + (int64_t)blockIdx.x * 64;
+  __shared__ T As[64][33], Bs[64][33];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  T acc[4][4];
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) acc[r][c] = (T)0;
+  for (int64_t k0 = 0; k0 < j0; k0 += 32) {
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int idx = tid + 256 * e, row = idx >> 5, kk = idx & 31;
+      const int64_t k = k0 + kk, ia = r0 + row, ib = j0 + row;
+      As[row][kk] = (ia < D && k < j0) ? m[ia * D + k] : (T)0;
+      Bs[row][kk] = (ib < j1 && k < j0) ? m[ib * D + k] : (T)0;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int kk = 0; kk < 32; ++kk) {
+      T av[4], bv[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) av[r] = As[ty * 4 + r][kk];
+#pragma unroll
+      for (int c = 0; c < 4; ++c) bv[c] = Bs[tx * 4 + c][kk];
+#pragma unroll
+      for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) acc[r][c] = fma(av[r], bv[c], acc[r][c]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int r = 0; r < 4; ++r)
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+      const int64_t i = r0 + ty * 4 + r, cc = j0 + tx * 4 + c;
+      if (i < D && cc < j1 && cc <= i) m[i * D + cc] = (m[i * D + cc] + ((i == cc) ? jitter : (T)0)) - acc[r][c];
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(1024) void chol_panel_kernel(T* __restrict__ a, int64_t D, int64_t j0, int64_t j1, int* __restrict__ info) {
+  const int64_t b = blockIdx.x;
+  if (info[b] != 0) return;  // (uniform)
+  T* m = a + b * D * D;
+  const int tid = threadIdx.x;
+  __shared__ T rowj[kCholPanel];
+  for (int64_t j = j0; j < j1; ++j) {
+    if (tid < j - j0) rowj[tid] = m[j * D + j0 + tid];  // row j of the panel: final since the steps before
+    __syncthreads();
+    const int len = (int)(j - j0);
+    for (int64_t i = j + tid; i < D; i += 1024) {
+      const T* ri = m + i * D + j0;
+      T acc = (T)0;
+      for (int k = 0; k < len; ++k) acc = fma(ri[k], rowj[k], acc);
+      m[i * D + j] -= acc;
+    }
+    __syncthreads();
+    const T p = m[j * D + j];
+    if (!(p > (T)0)) {  // not positive, or NaN: the leading minor of order j + 1 is not positive definite
+      if (tid == 0) info[b] = (int)(j + 1);
+      return;  // uniform: every thread read the same pivot
+    }
+    const T d = sqrt(p);
+    __syncthreads();  // every thread has read the pivot before it is overwritten
+    for (int64_t i = j + tid; i < D; i += 1024) m[i * D + j] = (i == j) ? d : m[i * D + j] / d;
+    __syncthreads();
+  }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void chol_zero_upper_kernel(T* __restrict__ a, int64_t D) {
+  T* m = a + (int64_t)blockIdx.y * D * D;
+  for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < D * D; e += (int64_t)gridDim.x * 256) {
+    const int64_t i = e / D, c = e - i * D;
+    if (c > i) m[e] = (T)0;
+  }
+}
+
 template <typename T>
 int launch_cholesky(T* a, int* info, int64_t batch, int64_t D, double jitter, runia_stream_t stream) {
   if (batch < 0 || D <= 0 || D > 16384 || batch > 65535) return RUNIA_E_INVALID;
   if (batch == 0) return RUNIA_OK;
   if (!a || !info) return RUNIA_E_INVALID;
-  cholesky_kernel<T><<<(unsigned)batch, 64 * kCholWaves, 0, as_stream(stream)>>>(a, D, (T)jitter, info);
+  hipStream_t s = as_stream(stream);
+  if (D < kCholBlockedFrom) {
+    cholesky_kernel<T><<<(unsigned)batch, 64 * kCholWaves, 0, s>>>(a, D, (T)jitter, info);
+    return runia_check_launch();
+  }
+  if (hipMemsetAsync(info, 0, (size_t)batch * sizeof(int), s) != hipSuccess) return RUNIA_E_LAUNCH;
+  for (int64_t j0 = 0; j0 < D; j0 += kCholPanel) {
+    const int64_t j1 = (j0 + kCholPanel < D) ? j0 + kCholPanel : D;
+    const dim3 grid((unsigned)((D - j0 + 63) / 64), (unsigned)batch);
+    chol_update_kernel<T><<<grid, 256, 0, s>>>(a, D, j0, j1, (T)jitter, info);
+    chol_panel_kernel<T><<<(unsigned)batch, 1024, 0, s>>>(a, D, j0, j1, info);
+  }
+  const dim3 zgrid((unsigned)runia_stream_grid(D * D, 256) < 1024u ? (unsigned)runia_stream_grid(D * D, 256) : 1024u, (unsigned)batch);
+  chol_zero_upper_kernel<T><<<zgrid, 256, 0, s>>>(a, D);
   return runia_check_launch();
 }
 
