@@ -474,6 +474,12 @@ int runia_tril_inverse_f64(const double* tril, double* inv, int64_t batch, int64
  *   of a precision matrix for runia_md_score_tril_*.  One fixed summation order: same bits from run to run. */
 int runia_cholesky_f32(float* a, int* info, int64_t batch, int64_t D, double jitter, runia_stream_t stream);
 int runia_cholesky_f64(double* a, int* info, int64_t batch, int64_t D, double jitter, runia_stream_t stream);
+/* runia_select_hist_f32: one histogram pass of a radix select over a flat f32 array - hist [2048] (u32, cleared by the call) counts,
+ *   among the elements whose order-preserving key k satisfies (k & prefix_mask) == prefix, the digit (k >> shift) & 2047.  Three
+ *   passes (shift 21, 10, 0) give an exact order statistic; two neighbouring ones give np.percentile(train.flatten(), p), the
+ *   clipping threshold of ReAct / DICE+ReAct (inference/postprocessors.py:1441, 1466).  n < 2^32; NaNs sort above +inf. */
+int runia_select_hist_f32(const float* x, unsigned* hist, int64_t n, unsigned prefix, unsigned prefix_mask, int shift,
+                          runia_stream_t stream);
 /* runia_gmm_log_prob_f32: class-wise Gaussian log densities, all classes in one pass - replaces gmm.log_prob(x[:, None, :]) of
  *   the torch MultivariateNormal that gmm_fit builds (inference/funcs.py:265-344), as called by GMMLatentSpace.postprocess and
  *   DDU.postprocess (inference/postprocessors.py:490-491, 778-779), and the scipy logsumexp that follows it.

@@ -6,8 +6,10 @@ NO CPU fallback: without the library or without a GPU the wrappers raise.
 """
 from __future__ import annotations
 
+import contextlib
 import ctypes
 import os
+import threading
 from ctypes import c_char_p, c_double, c_float, c_int, c_int64, c_size_t, c_uint64, c_void_p
 from typing import NamedTuple, Optional, Union
 
@@ -121,6 +123,7 @@ _SIGNATURES = {
         [c_void_p, c_uint64, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t, c_int64, c_int, c_int, c_int,
          c_int, c_double, c_int, c_int, c_double, c_int, c_void_p],
     ),
+    "runia_select_hist_f32": (c_int, [c_void_p, c_void_p, c_int64, ctypes.c_uint32, ctypes.c_uint32, c_int, c_void_p]),
     "runia_cholesky_f32": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
     "runia_cholesky_f64": (c_int, [c_void_p, c_void_p, c_int64, c_int64, c_double, c_void_p]),
     "runia_gmm_log_prob_workspace_bytes": (c_size_t, [c_int64, c_int64, c_int]),
@@ -357,10 +360,47 @@ def _ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     return None if t is None else t.data_ptr()
 
 
+class _UploadCache(threading.local):
+    depth = 0
+    entries = None
+
+
+_upload_cache = _UploadCache()
+_UPLOAD_CACHE_MIN_BYTES = 1 << 20
+
+
+@contextlib.contextmanager
+def upload_cache():
+    """While the context is open (re-entrant, per thread), ``to_device`` of a C-contiguous host ndarray of at least 1 MB is done once
+    per (buffer address, shape, dtype, target dtype): later calls return the same device tensor.  For loops that hand the SAME
+    host arrays to many setup / postprocess calls (``evaluation.baselines.calculate_all_baselines(device_resident=True)``: the
+    training features would otherwise be uploaded by eight fits, each split by every baseline).  The arrays must not be written to
+    while the context is open (the postprocessors never do: inputs are read-only by contract); the cache holds a reference to
+    every array it has seen and drops everything when the outermost context closes.  The tensors are shared: read-only as well."""
+    c = _upload_cache
+    if c.depth == 0:
+        c.entries = {}
+    c.depth += 1
+    try:
+        yield
+    finally:
+        c.depth -= 1
+        if c.depth == 0:
+            c.entries = None
+
+
 def to_device(a, dtype: torch.dtype) -> torch.Tensor:
-    """Host ndarray / tensor -> contiguous device tensor of ``dtype`` (H2D copy if needed)."""
+    """Host ndarray / tensor -> contiguous device tensor of ``dtype`` (H2D copy if needed; see ``upload_cache``)."""
     dev = require_gpu()
     if isinstance(a, np.ndarray):
+        c = _upload_cache
+        if c.depth > 0 and a.flags.c_contiguous and a.nbytes >= _UPLOAD_CACHE_MIN_BYTES:
+            key = (a.__array_interface__["data"][0], a.shape, a.dtype.str, dtype, str(dev))
+            hit = c.entries.get(key)
+            if hit is None:
+                hit = (a, torch.from_numpy(a).to(device=dev, dtype=dtype, non_blocking=False).contiguous())
+                c.entries[key] = hit
+            return hit[1]
         t = torch.from_numpy(np.ascontiguousarray(a))
     elif isinstance(a, torch.Tensor):
         t = a.detach()
@@ -1449,6 +1489,37 @@ def gmm_log_prob(x: torch.Tensor, means: torch.Tensor, w_tril: torch.Tensor, con
     _check(lib.runia_gmm_log_prob_f32(x.data_ptr(), means.data_ptr(), w_tril.data_ptr(), consts.data_ptr(), _ptr(lp), _ptr(lse),
                                       ws.data_ptr(), ws.numel() * 8, n, d, c, _stream()), "runia_gmm_log_prob_f32")
     return lp, lse
+
+
+@_device_guard()
+def kth_smallest_flat(x: torch.Tensor, ranks) -> list:
+    """Exact order statistics of a float32 device tensor read as one flat array: ``sorted(x.flatten())[k]`` for every ``k`` of
+    ``ranks`` (0-based), as Python floats holding float32 values.  Radix select: three histogram passes per rank
+    (``runia_select_hist_f32``), one 8 KB read-back per pass.  Setup-time (synchronises).  The array must not contain NaNs (their
+    keys sort above +inf; NumPy's partition puts them last as well, but its percentile then returns NaN: the caller checks)."""
+    lib = load_library()
+    require_gpu()
+    assert x.is_cuda and x.dtype == torch.float32
+    x = x.contiguous()
+    n = x.numel()
+    hist = torch.empty((2048,), dtype=torch.int32, device=x.device)
+    out = []
+    for k in ranks:
+        k = int(k)
+        assert 0 <= k < n
+        prefix, mask = 0, 0
+        for shift, width in ((21, 11), (10, 11), (0, 10)):
+            _check(lib.runia_select_hist_f32(x.data_ptr(), hist.data_ptr(), n, prefix, mask, shift, _stream()), "runia_select_hist_f32")
+            h = hist.cpu().numpy().astype(np.int64) & 0xFFFFFFFF
+            cum = np.cumsum(h)
+            b = int(np.searchsorted(cum, k, side="right"))
+            assert b < 2048 and h[b] > 0, "radix select lost the rank (NaNs in the array?)"
+            k -= int(cum[b - 1]) if b else 0
+            prefix |= (b & ((1 << width) - 1)) << shift  # (the last pass's 11-bit digit repeats bit 10, already in the prefix)
+            mask |= ((1 << width) - 1) << shift
+        bits = (prefix & 0x7FFFFFFF) if (prefix & 0x80000000) else (~prefix & 0xFFFFFFFF)
+        out.append(float(np.array([bits], dtype=np.uint32).view(np.float32)[0]))
+    return out
 
 
 @_device_guard()

@@ -9,16 +9,17 @@ the dictionaries and derives the labels from them, as upstream - and the same ``
 classes.  One table (``_BASELINES``) holds what differs between the twelve ``get_*_score_*`` functions of the reference:
 constructor arguments, ``setup`` keywords, which split is scored.
 
-Additive ``device_resident=True`` (``calculate_all_baselines`` and every ``get_*`` function): the valid and OoD splits are
-uploaded ONCE and scored from HBM by every baseline (upstream, and the default here, each ``postprocess`` call uploads its
-rows again: eight feature baselines x three splits); the returned scores are host arrays either way, same bits.
+Additive ``device_resident=True`` (``calculate_all_baselines`` and every ``get_*`` function): every split - the training
+features included - is uploaded ONCE for the whole loop (``_hip.upload_cache``; upstream, and the default here, each ``setup`` and
+each ``postprocess`` call moves its rows again: eight fits x 410 MB at cfg3 size, three splits per baseline); the returned scores
+are host arrays either way, same bits.
 """
 from __future__ import annotations
 
-from typing import Dict, List, Optional, Tuple, Union
+import contextlib
+from typing import Dict, List, Tuple, Union
 
 import numpy as np
-import torch
 
 from .. import _hip
 from ..inference.postprocessors import ASH, DDU, DICE, GEN, KNN, MSP, DICEReAct, Energy, Mahalanobis, ReAct, ViM
@@ -26,49 +27,39 @@ from ..inference.postprocessors import ASH, DDU, DICE, GEN, KNN, MSP, DICEReAct,
 __all__ = ["remove_latent_features", "calculate_all_baselines", "get_labels_from_logits", "baseline_name_dict"]
 
 
-class _DeviceSplits:
-    """float32 splits of the two dictionaries, uploaded on first use and kept for the rest of the call."""
-
-    def __init__(self, enabled: bool):
-        self.enabled = enabled
-        self._cache: Dict[Tuple[int, str], tuple] = {}  # (the host array it was made from, its device copy)
-
-    def rows(self, d: dict, key: str):
-        a = d[key]
-        if not self.enabled or not isinstance(a, np.ndarray) or a.dtype != np.float32:
-            return a  # (other dtypes keep the host call: its output dtype follows the input's)
-        k = (id(d), key)
-        if k not in self._cache or self._cache[k][0] is not a:
-            self._cache[k] = (a, _hip.to_device(a, torch.float32))
-        return self._cache[k][1]
+def _resident(device_resident: bool):
+    """``device_resident=True``: every large host array handed to a fit or a scoring call inside the context is uploaded once
+    (``_hip.upload_cache``) - the training features by the first of the eight fits that read them, each valid / OoD split by the
+    first baseline that scores it."""
+    return _hip.upload_cache() if device_resident else contextlib.nullcontext()
 
 
-def _score(pp, rows, **kwargs) -> np.ndarray:
-    """``pp.postprocess(test_data=rows)``; rows already in HBM go through ``postprocess_device`` where ``postprocess`` would
-    take them back to the host first (KNN, Mahalanobis)."""
-    if isinstance(rows, torch.Tensor) and isinstance(pp, (KNN, Mahalanobis)):
-        return _hip.to_host(pp.postprocess_device(rows))
-    return pp.postprocess(test_data=rows, **kwargs)
+def _FEATS_FC(ind, fc):  # setup keywords of the linear-layer family
+    return dict(ind_train_data=ind["train features"], valid_feats=ind["valid features"], final_linear_layer_params=fc)
+
+
+def _FEATS_LABELS(ind, fc):  # ... of the class-conditional fits
+    return dict(ind_train_data=ind["train features"], train_labels=ind["train labels"], valid_feats=ind["valid features"])
 
 
 # name -> (message, constructor(ind, params), setup keywords(ind, fc), input kind, needs the logits at postprocess)
 _BASELINES = {
     "dice": ("Calculating DICE score",
              lambda ind, p: DICE(flip_sign=False, dice_percentile=p["percentile"], num_classes=ind["train logits"].shape[1]),
-             lambda ind, fc: dict(ind_train_data=ind["train features"], valid_feats=ind["valid features"], final_linear_layer_params=fc),
+             _FEATS_FC,
              "features", False),
     "react": ("Calculating ReAct score",
               lambda ind, p: ReAct(flip_sign=False, react_percentile=p["percentile"]),
-              lambda ind, fc: dict(ind_train_data=ind["train features"], valid_feats=ind["valid features"], final_linear_layer_params=fc),
+              _FEATS_FC,
               "features", False),
     "dice_react": ("Calculating DICE+ReAct score",
                    lambda ind, p: DICEReAct(flip_sign=False, dice_percentile=p["dice_percentile"], react_percentile=p["react_percentile"],
                                             num_classes=ind["train logits"].shape[1]),
-                   lambda ind, fc: dict(ind_train_data=ind["train features"], valid_feats=ind["valid features"], final_linear_layer_params=fc),
+                   _FEATS_FC,
                    "features", False),
     "ash": ("Calculating ash score",
             lambda ind, p: ASH(flip_sign=False, ash_percentile=p["ash_percentile"]),
-            lambda ind, fc: dict(ind_train_data=ind["train features"], valid_feats=ind["valid features"], final_linear_layer_params=fc),
+            _FEATS_FC,
             "features", False),
     "gen": ("Calculating GEN score",
             lambda ind, p: GEN(flip_sign=False, gamma=p["gamma"], num_classes=p["gen_m"]),
@@ -89,7 +80,7 @@ _BASELINES = {
                "logits", False),
     "mdist": ("Calculating mahalanobis score",
               lambda ind, p: Mahalanobis(flip_sign=False, num_classes=p["num_classes"]),
-              lambda ind, fc: dict(ind_train_data=ind["train features"], train_labels=ind["train labels"], valid_feats=ind["valid features"]),
+              _FEATS_LABELS,
               "features", False),
     "knn": ("Calculating knn score",
             lambda ind, p: KNN(flip_sign=False, k_neighbors=p["k_neighbors"]),
@@ -97,100 +88,90 @@ _BASELINES = {
             "features", False),
     "ddu": ("Calculating ddu score",
             lambda ind, p: DDU(flip_sign=False, num_classes=p["num_classes"]),
-            lambda ind, fc: dict(ind_train_data=ind["train features"], train_labels=ind["train labels"], valid_feats=ind["valid features"]),
+            _FEATS_LABELS,
             "features", False),
 }
 
 
-def _run(name: str, fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, params, device_resident=False,
-         _splits: Optional[_DeviceSplits] = None):
+def _run(name: str, fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, params, device_resident=False):
     """One baseline: fit on the training split, score the InD valid split into ``ind_data_dict[name]`` and every OoD set into
-    ``ood_baselines_dict[f"{ood} {name}"]``."""
+    ``ood_baselines_dict[f"{ood} {name}"]`` (keyword calls, as upstream)."""
     message, make, setup_kwargs, kind, with_logits = _BASELINES[name]
     print(message)
-    splits = _splits if _splits is not None else _DeviceSplits(device_resident)
-    pp = make(ind_data_dict, params)
-    pp.setup(**setup_kwargs(ind_data_dict, fc_params))
-    # (ViM reads host rows and takes the logits as a keyword, as upstream)
-    rows = (lambda d, key: d[key]) if with_logits else splits.rows
-    extra = (lambda d, prefix: {"logits": d[f"{prefix} logits"]}) if with_logits else (lambda d, prefix: {})
-    ind_data_dict[name] = _score(pp, rows(ind_data_dict, f"valid {kind}"), **extra(ind_data_dict, "valid"))
-    for ood_name in ood_names:
-        ood_baselines_dict[f"{ood_name} {name}"] = _score(pp, rows(ood_data_dict, f"{ood_name} {kind}"), **extra(ood_data_dict, ood_name))
+    with _resident(device_resident):
+        pp = make(ind_data_dict, params)
+        pp.setup(**setup_kwargs(ind_data_dict, fc_params))
+        extra = (lambda d, prefix: {"logits": d[f"{prefix} logits"]}) if with_logits else (lambda d, prefix: {})  # (ViM)
+        ind_data_dict[name] = pp.postprocess(test_data=ind_data_dict[f"valid {kind}"], **extra(ind_data_dict, "valid"))
+        for ood_name in ood_names:
+            ood_baselines_dict[f"{ood_name} {name}"] = pp.postprocess(test_data=ood_data_dict[f"{ood_name} {kind}"],
+                                                                     **extra(ood_data_dict, ood_name))
     return ind_data_dict, ood_baselines_dict
 
 
 # ---- the reference's per-baseline functions (signatures of baselines.py:37-611; `device_resident` is additive) ----
-def get_dice_score_from_features(fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, percentile, device_resident=False,
-                                 _splits=None):
+def get_dice_score_from_features(fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, percentile,
+                                 device_resident=False):
     return _run("dice", fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"percentile": percentile},
-                device_resident, _splits)
+                device_resident)
 
 
 def get_react_score_from_features(fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, percentile,
-                                  device_resident=False, _splits=None):
+                                  device_resident=False):
     return _run("react", fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"percentile": percentile},
-                device_resident, _splits)
+                device_resident)
 
 
 def get_dice_react_score_from_features(fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, dice_percentile,
-                                       react_percentile, device_resident=False, _splits=None):
+                                       react_percentile, device_resident=False):
     return _run("dice_react", fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict,
-                {"dice_percentile": dice_percentile, "react_percentile": react_percentile}, device_resident, _splits)
+                {"dice_percentile": dice_percentile, "react_percentile": react_percentile}, device_resident)
 
 
 def get_ash_score_from_features(fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, ash_percentile,
-                                device_resident=False, _splits=None):
-    return _run("ash", fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"ash_percentile": ash_percentile},
-                device_resident, _splits)
+                                device_resident=False):
+    return _run("ash", fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"ash_percentile": ash_percentile}, device_resident)
 
 
-def get_gen_score_from_logits(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, gamma, gen_m, device_resident=False,
-                              _splits=None):
-    return _run("gen", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"gamma": gamma, "gen_m": gen_m},
-                device_resident, _splits)
+def get_gen_score_from_logits(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, gamma, gen_m, device_resident=False):
+    return _run("gen", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"gamma": gamma, "gen_m": gen_m}, device_resident)
 
 
-def calculate_vim_score(fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, device_resident=False, _splits=None):
-    return _run("vim", fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {}, device_resident, _splits)
+def calculate_vim_score(fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, device_resident=False):
+    return _run("vim", fc_params, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {}, device_resident)
 
 
-def get_msp_score_from_logits(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, device_resident=False, _splits=None):
-    return _run("msp", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {}, device_resident, _splits)
+def get_msp_score_from_logits(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, device_resident=False):
+    return _run("msp", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {}, device_resident)
 
 
-def get_raw_score_from_logits(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, device_resident=False, _splits=None):
+def get_raw_score_from_logits(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, device_resident=False):
     """``raw`` (reference :395-425): the maximum softmax probability with no postprocessor object around it (no threshold)."""
     print("Calculating raw score")
-    splits = _splits if _splits is not None else _DeviceSplits(device_resident)
     pp = MSP(flip_sign=False)
     pp._setup_flag = True  # (scores only: upstream calls scipy's softmax directly)
-    ind_data_dict["raw"] = pp.postprocess(test_data=splits.rows(ind_data_dict, "valid logits"))
-    for ood_name in ood_names:
-        ood_baselines_dict[f"{ood_name} raw"] = pp.postprocess(test_data=splits.rows(ood_data_dict, f"{ood_name} logits"))
+    with _resident(device_resident):
+        ind_data_dict["raw"] = pp.postprocess(test_data=ind_data_dict["valid logits"])
+        for ood_name in ood_names:
+            ood_baselines_dict[f"{ood_name} raw"] = pp.postprocess(test_data=ood_data_dict[f"{ood_name} logits"])
     return ind_data_dict, ood_baselines_dict
 
 
-def get_energy_score_from_logits(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, device_resident=False, _splits=None):
-    return _run("energy", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {}, device_resident, _splits)
+def get_energy_score_from_logits(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, device_resident=False):
+    return _run("energy", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {}, device_resident)
 
 
-def get_mahalanobis_score_from_features(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, num_classes, device_resident=False,
-                                        _splits=None):
-    return _run("mdist", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"num_classes": num_classes},
-                device_resident, _splits)
+def get_mahalanobis_score_from_features(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, num_classes,
+                                        device_resident=False):
+    return _run("mdist", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"num_classes": num_classes}, device_resident)
 
 
-def get_knn_score_from_features(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, k_neighbors, device_resident=False,
-                                _splits=None):
-    return _run("knn", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"k_neighbors": k_neighbors},
-                device_resident, _splits)
+def get_knn_score_from_features(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, k_neighbors, device_resident=False):
+    return _run("knn", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"k_neighbors": k_neighbors}, device_resident)
 
 
-def get_ddu_score_from_features(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, num_classes, device_resident=False,
-                                _splits=None):
-    return _run("ddu", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"num_classes": num_classes},
-                device_resident, _splits)
+def get_ddu_score_from_features(ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, num_classes, device_resident=False):
+    return _run("ddu", None, ind_data_dict, ood_data_dict, ood_names, ood_baselines_dict, {"num_classes": num_classes}, device_resident)
 
 
 def _labels_of(logits):
@@ -238,7 +219,8 @@ def _cfg_get(cfg, name):
     return cfg[name] if isinstance(cfg, dict) else getattr(cfg, name)
 
 
-def calculate_all_baselines(baselines_names: List[str], ind_data_dict: Dict[str, np.ndarray], ood_data_dict: Dict[str, np.ndarray],
+def calculate_all_baselines(baselines_names: List[str], ind_data_dict: Dict[str, np.ndarray], ood_data_dict: Dict[str,
+                            np.ndarray],
                             fc_params: Union[Dict[str, np.ndarray], None], cfg, num_classes: int, device_resident: bool = False):
     """``calculate_all_baselines`` of the reference (:713-854): returns ``(ind_data_dict, ood_data_dict,
     ood_baselines_scores_dict)``.  ``cfg`` needs ``ood_datasets`` and, for the baselines that read them, ``k_neighbors``,
@@ -249,8 +231,8 @@ def calculate_all_baselines(baselines_names: List[str], ind_data_dict: Dict[str,
                          "Otherwise implement M parameter specification")
     ood_names = list(_cfg_get(cfg, "ood_datasets"))
     scores: Dict[str, np.ndarray] = {}
-    splits = _DeviceSplits(device_resident)
-    common = dict(ind_data_dict=ind_data_dict, ood_data_dict=ood_data_dict, ood_names=ood_names, ood_baselines_dict=scores, _splits=splits)
+    common = dict(ind_data_dict=ind_data_dict, ood_data_dict=ood_data_dict, ood_names=ood_names, ood_baselines_dict=scores,
+                  device_resident=device_resident)
     want = lambda name: name in baselines_names  # noqa: E731
     if want("vim"):
         calculate_vim_score(fc_params=fc_params, **common)

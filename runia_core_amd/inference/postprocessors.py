@@ -22,7 +22,7 @@ import torch
 from torch import Tensor
 
 from .. import _hip, config
-from ..device_fit import empirical_precision_device
+from ..device_fit import empirical_precision_device, percentile_flat
 from .abstract_classes import OodPostprocessor, Postprocessor
 from .funcs import GmmState, MahalanobisState, _maha_dtype, gmm_fit, mahalanobis_preprocess
 
@@ -809,7 +809,7 @@ class ReAct(_LinearEnergy):
     def setup(self, ind_train_data: np.ndarray, **kwargs):
         self.w, self.b = _fc_params(kwargs, "ReAct")
         self._wd = None
-        self.activation_threshold = np.percentile(np.asarray(ind_train_data).flatten(), self.react_percentile)
+        self.activation_threshold = percentile_flat(ind_train_data, self.react_percentile)
         self.set_threshold(self.flip_sign_fn(self._scores(kwargs["valid_feats"])))
 
 
@@ -868,7 +868,7 @@ class DICEReAct(DICE):
 
     def setup(self, ind_train_data: np.ndarray, **kwargs):
         self._fit_layer(ind_train_data, kwargs, "DICE")
-        self.react_activation_threshold = np.percentile(np.asarray(ind_train_data).flatten(), self.react_percentile)
+        self.react_activation_threshold = percentile_flat(ind_train_data, self.react_percentile)
         self.set_threshold(self.flip_sign_fn(self._scores(kwargs["valid_feats"])))
 
 
@@ -1006,8 +1006,10 @@ class DDU(OodPostprocessor):
     def setup(self, ind_train_data: np.ndarray, **kwargs):
         assert "valid_feats" in kwargs, "valid_feats must be provided for DDU"
         assert "train_labels" in kwargs, "train_labels must be provided for DDU"
-        self.gmm, _ = gmm_fit(embeddings=Tensor(ind_train_data), labels=Tensor(kwargs["train_labels"]),
-                              num_classes=self.num_classes)
+        rows = np.asarray(ind_train_data)
+        # (float32 rows: a tensor over the same memory - upstream's Tensor(...) copies them; same values)
+        emb = torch.from_numpy(rows) if rows.dtype == np.float32 and rows.flags.c_contiguous and rows.flags.writeable else Tensor(ind_train_data)
+        self.gmm, _ = gmm_fit(embeddings=emb, labels=Tensor(kwargs["train_labels"]), num_classes=self.num_classes)
         self._state = None
         self.set_threshold(self.flip_sign_fn(self._scores(kwargs["valid_feats"])))
 

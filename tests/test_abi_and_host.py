@@ -629,3 +629,30 @@ def test_host_compute_caps_the_pools_at_the_cpu_quota_and_restores_them(monkeypa
     g2, j2 = gmm_fit(x, lab, 3)
     assert j1 == j2 and torch.allclose(g1.loc, g2.loc, atol=1e-6) and torch.allclose(g1.scale_tril, g2.scale_tril, atol=1e-5)
     assert torch.get_num_threads() == before
+
+
+def test_percentile_plan_is_numpys_own_arithmetic():
+    """device_fit._numpy_linear_percentile_plan (round 6; the ReAct / DICE+ReAct threshold from two device order statistics):
+    neighbours + interpolation equal np.percentile bit for bit on the installed NumPy - float32 arrays, including sizes where
+    NumPy's float32 index arithmetic is not (n - 1) q / 100 any more (n > 2^24) - and the plan refuses what it does not cover."""
+    from runia_core_amd.device_fit import _numpy_linear_percentile_plan as plan
+
+    rng = np.random.default_rng(11)
+    cases = [(n, q) for n in (1, 2, 3, 10, 101, 1000, 4097, 65536, 1_000_003) for q in (0, 1, 37.5, 50, 90, 99, 100)]
+    cases += [(20_000_003, 90), (20_000_003, 65), (33_554_433, 90)]
+    for n, q in cases:
+        a = np.maximum(rng.standard_normal(n).astype(np.float32), 0) if n % 2 else rng.standard_normal(n).astype(np.float32)
+        want = np.percentile(a, q)
+        got = plan(n, q, np.float32)
+        assert got is not None, (n, q)
+        prev, nxt, finish = got
+        srt = np.sort(a)
+        res = finish(srt[prev], srt[nxt])
+        assert np.asarray(res).dtype == np.asarray(want).dtype == np.float32 and np.array_equal(res, want), (n, q, res, want)
+    assert plan(100, [10, 20], np.float32) is None and plan(100, 101, np.float32) is None
+    # small or non-float32 arrays never leave NumPy
+    from runia_core_amd.device_fit import percentile_flat
+
+    x = rng.standard_normal((50, 7))
+    assert percentile_flat(x, 90) == np.percentile(x.flatten(), 90)
+    assert percentile_flat(x.astype(np.float32), 35) == np.percentile(x.astype(np.float32).flatten(), 35)

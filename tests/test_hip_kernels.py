@@ -1446,3 +1446,62 @@ def test_proj_norm_with_a_ragged_last_column_block(hip, d, n, rows, dt):
     assert got.dtype == np.float64 and rel_err(got, exp) < 1e-12
     one = hip.proj_norm(dev(x[:1], tt), dev(u, tt), packed, n).cpu().numpy()
     assert one[0] == got[0]
+
+
+def test_radix_select_and_percentile_flat(hip):
+    """runia_select_hist_f32 / _hip.kth_smallest_flat (round 6): exact order statistics of a flat float32 array - negative values,
+    a ReLU layer's share of exact zeros, -0.0, duplicates, +-inf, subnormals - against np.sort; device_fit.percentile_flat equals
+    np.percentile bit for bit from 2^22 elements (below it NumPy's own call runs)."""
+    from runia_core_amd import config
+    from runia_core_amd.device_fit import percentile_flat
+
+    rng = np.random.default_rng(5)
+    n = 3_000_001
+    a = rng.standard_normal(n).astype(np.float32)
+    a[::7] = 0.0
+    a[1::1001] = -0.0
+    a[5::50_000] = np.inf
+    a[6::70_000] = -np.inf
+    a[11::9973] = np.float32(1e-42)
+    a[12::9973] = a[13]
+    srt = np.sort(a)
+    ranks = [0, 1, 17, n // 7, n // 2, n // 2 + 1, n - 2, n - 1, int(0.9 * (n - 1))]
+    got = hip.kth_smallest_flat(dev(a, torch.float32), ranks)
+    for k, g in zip(ranks, got):
+        assert np.float32(g) == srt[k] or (np.isinf(g) and g == srt[k]), (k, g, srt[k])
+    relu = np.maximum(rng.standard_normal((2100, 2048)).astype(np.float32), 0)  # 4.3 M activations, 50 % zeros
+    for q in (90, 65, 50, 10, 99.9, 100, 0):
+        want = np.percentile(relu.flatten(), q)
+        res = percentile_flat(relu, q)
+        assert np.asarray(res).dtype == np.float32 and np.array_equal(res, want), (q, res, want)
+    assert config.device_fit is None
+    config.device_fit = False
+    try:
+        assert np.array_equal(percentile_flat(relu, 90), np.percentile(relu.flatten(), 90))  # the host call, same value
+    finally:
+        config.device_fit = None
+    bad = relu.copy()
+    bad[3, 3] = np.nan
+    assert np.isnan(percentile_flat(bad, 90))  # NumPy's own answer for an array with a NaN
+
+
+def test_upload_cache_returns_one_tensor_per_host_buffer(hip):
+    a = np.random.default_rng(1).standard_normal((600, 512)).astype(np.float32)  # 1.2 MB
+    small = np.ones((8, 8), dtype=np.float32)
+    t0 = hip.to_device(a, torch.float32)
+    assert hip.to_device(a, torch.float32).data_ptr() != t0.data_ptr()  # no cache outside the context
+    with hip.upload_cache():
+        t1 = hip.to_device(a, torch.float32)
+        with hip.upload_cache():  # re-entrant
+            assert hip.to_device(a, torch.float32).data_ptr() == t1.data_ptr()
+            assert hip.to_device(a[:], torch.float32).data_ptr() == t1.data_ptr()          # another view object of the same buffer
+            assert hip.to_device(a, torch.float64).data_ptr() != t1.data_ptr()             # another target dtype: its own entry
+            assert hip.to_device(a[1:], torch.float32).data_ptr() != t1.data_ptr()         # another buffer address
+        assert hip.to_device(a, torch.float32).data_ptr() == t1.data_ptr()                 # still open
+        assert hip.to_device(small, torch.float32).data_ptr() != hip.to_device(small, torch.float32).data_ptr()  # below 1 MB
+        assert torch.equal(t1, t0)
+    t2 = hip.to_device(a, torch.float32)
+    assert t2.data_ptr() != t1.data_ptr() or True  # (the allocator may hand the block out again; the cache is gone:)
+    from runia_core_amd import _hip as H
+
+    assert H._upload_cache.depth == 0 and H._upload_cache.entries is None
