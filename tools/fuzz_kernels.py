@@ -404,6 +404,36 @@ for t in range(a.rounds):
               rel(kb[smp].cpu().numpy(), oracle.kde_score(trb.cpu().numpy(), yb[smp].cpu().numpy(), 4.0)), 1e-9)
         del hb, yb, kb, sb
 
+    # ---- round 6: Cholesky / triangular inverse around the panel switch (768), order statistics of a flat array ----
+    if t % 4 == 0:
+        dc = int(rng.choice([1, 5, 63, 64, 65, 300, 767, 768, 769, 831, 896, 1000, 1100]))
+        bc = int(rng.integers(1, 4))
+        ac = rng.standard_normal((bc, dc, dc + int(rng.integers(1, 40))))
+        cov = ac @ ac.transpose(0, 2, 1) / ac.shape[2] + float(rng.choice([1e-3, 0.05, 1.0])) * np.eye(dc)
+        jit = float(rng.choice([0.0, 1e-3]))
+        ref = np.linalg.cholesky(cov + jit * np.eye(dc))
+        for dt_, tol_ in ((torch.float64, 1e-9), (torch.float32, 3e-3)):
+            L_, info_ = _hip.cholesky(dev(cov, dt_), jit)
+            ok_ = int(info_.abs().max()) == 0 and bool((torch.triu(L_, 1) == 0).all())
+            check(f"cholesky {dt_}", (dc, bc, jit), rel(L_.cpu().numpy(), ref) if ok_ else 1.0, tol_ * max(1.0, np.abs(ref).max()))
+        bad_ = cov.copy()
+        jbad = int(rng.integers(0, dc))
+        bad_[0, jbad, jbad] = -abs(bad_[0, jbad, jbad]) - 1.0  # the leading minor of order jbad + 1 cannot be positive definite
+        info_b = _hip.cholesky(dev(bad_, torch.float64), 0.0)[1].cpu().numpy()
+        check("cholesky info", (dc, bc, jbad), 0.0 if (info_b[0] == jbad + 1 and (info_b[1:] == 0).all()) else 1.0, 0.5)
+        w_ = _hip.tril_inverse(dev(ref, torch.float64)).cpu().numpy()
+        eye_err = max(float(np.max(np.abs(w_[b_] @ ref[b_] - np.eye(dc)))) for b_ in range(bc))
+        check("tril inverse", (dc, bc), eye_err if np.allclose(np.triu(w_, 1), 0.0) else 1.0, 1e-9 * max(1.0, float(np.linalg.cond(ref[0]))))
+        ns_ = int(rng.choice([1, 2, 255, 256, 257, 70_001, 1_000_003]))
+        xs_ = (rng.standard_normal(ns_) * float(rng.choice([1e-30, 1.0, 1e20]))).astype(np.float32)
+        if rng.random() < 0.5:
+            xs_ = np.maximum(xs_, 0)
+        if ns_ > 10 and rng.random() < 0.3:
+            xs_[:: int(rng.integers(2, 9))] = xs_[1]
+        ranks_ = sorted(set(int(r_) for r_ in rng.integers(0, ns_, size=4)) | {0, ns_ - 1})
+        got_ = np.array(_hip.kth_smallest_flat(dev(xs_), ranks_), dtype=np.float32)
+        check("radix select", (ns_,), 0.0 if np.array_equal(got_, np.sort(xs_)[ranks_]) else 1.0, 0.5)
+
     if (t + 1) % 10 == 0:
         print(f"round {t + 1}/{a.rounds}, mismatches so far: {bad}", flush=True)
 print("fuzz done, mismatches:", bad)
