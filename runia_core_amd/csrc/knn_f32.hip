@@ -725,8 +725,11 @@ static bool knn16_bank_ok(int64_t M, int64_t D) {
 // (round 4, with the candidate filter the feature width no longer has to pay for a distance matrix: 65 536 x 50 000 at
 // D = 8 / 16 / 32 / 64 / 128: 5.6 / 5.6 / 5.7 / 6.0 / 6.7 ms against 9.1 / 9.0 / 9.0 / 10.2 / 13.1 for the f32 kernel, same
 // bits, tools/ablate/run_knn_low_d.py; the limit was 256 while the bf16 kernel wrote the matrix too)
+// (round 6: from D = 1 - a call of >= 2^27 pairs on 2 ... 7 features, e.g. KNNLatentSpace behind a PCA to 2 or 4 components in the
+// harness sweep, wrote and re-read its whole chunk x bank matrix through the f32 kernel: 10 000 x 50 000 at D = 4 / 3 / 2:
+// 1.52 / 1.48 / 1.62 -> 1.01 / 1.02 / 1.36 ms, 65 536 x 50 000 at D = 4: 8.79 -> 5.62 ms, same bits)
 #ifndef KNN16_MIN_D
-#define KNN16_MIN_D 8
+#define KNN16_MIN_D 1
 #endif
   return KNN_BF16 && M >= 4096 && D >= KNN16_MIN_D && D <= runia_knn16_max_width() && runia_knn16_fits(M, D) &&
          runia_knn16_fits(kQueryChunk, D) && 4 * M * 256 <= ((int64_t)1 << 31);  // (chunks of >= 256 queries: whole tiles)
@@ -734,8 +737,12 @@ static bool knn16_bank_ok(int64_t M, int64_t D) {
 // Worth the two split passes and the 256 x 256 tiles: a bank of some thousand rows, wide features, a batch of queries, 2^31
 // multiply-adds, 512 queries (tools/ablate/run_knn_paths.py: 1 024 x 4 096 x 256 is 8 % slower on the bf16 kernel, 1 024 x 4 096 x 2048
 // 1.46 x faster, 8 192 x 50 000 x 2048 2.67 x)
+#ifndef KNN16_WORK_MIN_D
+#define KNN16_WORK_MIN_D 16  // width the work threshold counts at least: narrow rows cost the f32 kernel its distance matrix, not
+#endif                       // multiply-adds (4 096 x 20 000 at D = 2 stays there: 0.36 against 0.39 ms; 10 000 x 50 000 does not)
 static bool knn16_wanted(int64_t N, int64_t M, int64_t D) {
-  return knn16_bank_ok(M, D) && N >= KNN16_MIN_ROWS && N * M >= ((int64_t)1 << 31) / D;
+  const int64_t dw = D < KNN16_WORK_MIN_D ? KNN16_WORK_MIN_D : D;
+  return knn16_bank_ok(M, D) && N >= KNN16_MIN_ROWS && N * M >= ((int64_t)1 << 31) / dw;
 }
 int runia_knn16_terms();
 extern "C" int runia_knn_piece_products(int64_t N, int64_t M, int64_t D) { return knn16_wanted(N, M, D) ? runia_knn16_terms() : 0; }

@@ -965,7 +965,15 @@ class ViM(OodPostprocessor):
                 ec = EmpiricalCovariance(assume_centered=True, store_precision=False)  # (covariance_ is all that is read: no pinvh)
                 ec.fit(ind_train_data - self.u)
                 eig_vals, eigen_vectors = np.linalg.eig(ec.covariance_)
-            self.NS = np.ascontiguousarray((eigen_vectors.T[np.argsort(eig_vals * -1)[self.DIM:]]).T)
+            if np.iscomplexobj(eigen_vectors):
+                # LAPACK's general solver returned complex pairs for a matrix that is symmetric up to rounding (upstream then scores
+                # with complex numbers): the symmetric solver on the device has no such outcome
+                from ..device_fit import vim_null_space_device
+
+                warnings.warn("ViM: np.linalg.eig returned complex eigenvectors; residual space taken from the symmetric solver")
+                self.NS = vim_null_space_device(ind_train_data, self.u, self.DIM)
+            else:
+                self.NS = np.ascontiguousarray((eigen_vectors.T[np.argsort(eig_vals * -1)[self.DIM:]]).T)
         self._dev = None
         vlogit_id_train = self._residual_norm(ind_train_data)
         self.alpha = kwargs["train_logits"].max(axis=-1).mean() / vlogit_id_train.mean()

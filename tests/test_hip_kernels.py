@@ -508,7 +508,8 @@ def test_knn_sampled_threshold_path_and_its_fallbacks(hip, m):
 
 
 @pytest.mark.parametrize("n,m,d", [(2048, 8192, 512), (1500, 8200, 300), (1024, 4096, 2048), (8192, 8300, 64), (4100, 8192, 100),
-                                   (8192, 4096, 128), (16400, 8200, 16), (32768, 8192, 9)])
+                                   (8192, 4096, 128), (16400, 8200, 16), (32768, 8192, 9), (16400, 8200, 4), (32768, 8192, 2),
+                                   (20000, 8192, 3), (33000, 8192, 1)])  # (round 6: from one feature)
 def test_knn_bf16_candidate_distances_equal_the_f32_path(hip, n, m, d):
     """Large problems take their candidate distances from bf16 piece products (csrc/knn_bf16.hip) when the caller's
     workspace holds the planes (runia_knn_workspace_bytes asks for them); with an f32-sized workspace the same entry
@@ -545,11 +546,11 @@ def test_knn_bf16_candidate_distances_equal_the_f32_path(hip, n, m, d):
     # (2) un-normalised rows over six orders of magnitude, a block of copied bank rows, NaN / infinite rows
     bank2 = (rng.standard_normal((m, d)) * 10.0 ** rng.uniform(-3, 3, size=(m, 1))).astype(np.float32)
     bank2[1000:1700] = bank2[17]
-    bank2[5, 3] = np.nan
+    bank2[5, min(3, d - 1)] = np.nan
     bank2[6, 0] = np.inf
     q2 = (rng.standard_normal((n, d)) * 10.0 ** rng.uniform(-3, 3, size=(n, 1))).astype(np.float32)
     q2[3] = bank2[17]
-    q2[7, 1] = np.nan
+    q2[7, min(1, d - 1)] = np.nan
     q2[8, :] = np.inf
     a, b = run(q2, bank2, True), run(q2, bank2, False)
     assert not (a == 123.0).any() and np.array_equal(a, b)

@@ -7,7 +7,8 @@ if os.environ.get('RUNIA_LIB'):
 lib = _hip.load_library()
 torch.manual_seed(0)
 k = 50
-for (n, m, d) in ((65536, 50000, 8), (65536, 50000, 16), (16384, 20000, 16), (65536, 50000, 32), (65536, 50000, 64), (65536, 50000, 128), (65536, 50000, 256), (8192, 20000, 64), (8192, 20000, 128), (2048, 8192, 128)):
+SIZES = [tuple(int(v) for v in a.split(",")) for a in sys.argv[1:]] or None
+for (n, m, d) in SIZES or ((65536, 50000, 8), (65536, 50000, 16), (16384, 20000, 16), (65536, 50000, 32), (65536, 50000, 64), (65536, 50000, 128), (65536, 50000, 256), (8192, 20000, 64), (8192, 20000, 128), (2048, 8192, 128)):
     q = torch.nn.functional.normalize(torch.randn(n, d, device="cuda"), dim=1)
     b = torch.nn.functional.normalize(torch.randn(m, d, device="cuda"), dim=1)
     ws_bytes = lib.runia_knn_workspace_bytes(n, m, d, k)
