@@ -77,8 +77,8 @@ __global__ __launch_bounds__(64 * kCholWaves) void cholesky_kernel(T* __restrict
 // between them (ten 2048 x 2048 float32 matrices: 173 ms, and a jitter ladder calls it several times).  Per panel [j0, j1):
 //   chol_update_kernel  rows >= j0, columns of the panel: A[i][c] = (A[i][c] + jitter on the diagonal) - sum_{k < j0} L[i][k] L[c][k]
 //                       as 64 x 64 tiles on the whole chip (one fma chain over k per element, k ascending);
-//   chol_panel_kernel   one workgroup per matrix, column by column inside the panel: the dot products are now over k in [j0, j)
-//                       (< kCholPanel terms, one chain per row), pivot test, scaling.
+//   chol_diag_kernel    the panel's 64 x 64 diagonal block, one wave per matrix in LDS (pivot test here);
+//   chol_trsm_kernel    the rows below it, one thread per row (dot products over k in [j0, j): < kCholPanel terms, one chain each).
 // A failed pivot writes info = j + 1 (LAPACK's convention) and every later launch of that matrix returns at its first instruction.
 // Every sum has one fixed order: same bits from run to run and on every rank (not the bits of the one-workgroup kernel: the
 // sums are grouped by panel).
@@ -131,34 +131,65 @@ __global__ __launch_bounds__(256) void chol_update_kernel(T* __restrict__ a, int
     }
 }
 
+// The panel itself, after the update: (1) its diagonal block is factorised by one wave per matrix in LDS (column by column: dot
+// products over k in [j0, j), pivot test, scaling - the arithmetic of the one-workgroup kernel on a 64 x 64 block); (2) the rows below
+// are independent of each other given that block: L[i][panel] = A[i][panel] L_diag^-T, one thread per row with its 64 panel entries
+// in registers and the block's entries as scalar operands (wave-uniform loads through the constant address space: no LDS, no
+// barrier), on the whole chip.  (A first form did both in one workgroup per matrix, thread per row with the row re-read from
+// memory for every column: 1.07 ms per panel of ten 2048 x 2048 matrices - 8 KB-strided rows thrash the L1; profiles/README.md.)
 template <typename T>
-__global__ __launch_bounds__(1024) void chol_panel_kernel(T* __restrict__ a, int64_t D, int64_t j0, int64_t j1, int* __restrict__ info) {
+__global__ __launch_bounds__(64) void chol_diag_kernel(T* __restrict__ a, int64_t D, int64_t j0, int64_t j1, int* __restrict__ info) {
   const int64_t b = blockIdx.x;
   if (info[b] != 0) return;  // (uniform)
   T* m = a + b * D * D;
-  const int tid = threadIdx.x;
-  __shared__ T rowj[kCholPanel];
-  for (int64_t j = j0; j < j1; ++j) {
-    if (tid < j - j0) rowj[tid] = m[j * D + j0 + tid];  // row j of the panel: final since the steps before
-    __syncthreads();
-    const int len = (int)(j - j0);
-    for (int64_t i = j + tid; i < D; i += 1024) {
-      const T* ri = m + i * D + j0;
-      T acc = (T)0;
-      for (int k = 0; k < len; ++k) acc = fma(ri[k], rowj[k], acc);
-      m[i * D + j] -= acc;
-    }
-    __syncthreads();
-    const T p = m[j * D + j];
-    if (!(p > (T)0)) {  // not positive, or NaN: the leading minor of order j + 1 is not positive definite
-      if (tid == 0) info[b] = (int)(j + 1);
-      return;  // uniform: every thread read the same pivot
+  const int w = (int)(j1 - j0), r = threadIdx.x;
+  __shared__ T ld[kCholPanel][kCholPanel + 1];
+  for (int c = 0; c < w; ++c) ld[r][c] = (r < w) ? m[(j0 + r) * D + j0 + c] : (T)0;
+  __builtin_amdgcn_wave_barrier();
+  for (int c = 0; c < w; ++c) {
+    T acc = (T)0;
+    for (int k = 0; k < c; ++k) acc = fma(ld[r][k], ld[c][k], acc);
+    const T v = ld[r][c] - acc;
+    __builtin_amdgcn_wave_barrier();
+    const T p = __shfl(v, c, 64);  // the pivot: row c's value
+    if (!(p > (T)0)) {             // not positive, or NaN (uniform)
+      if (r == 0) info[b] = (int)(j0 + c + 1);
+      return;
     }
     const T d = sqrt(p);
-    __syncthreads();  // every thread has read the pivot before it is overwritten
-    for (int64_t i = j + tid; i < D; i += 1024) m[i * D + j] = (i == j) ? d : m[i * D + j] / d;
-    __syncthreads();
+    if (r >= c && r < w) ld[r][c] = (r == c) ? d : v / d;
+    __builtin_amdgcn_wave_barrier();
   }
+  if (r < w)
+    for (int c = 0; c <= r; ++c) m[(j0 + r) * D + j0 + c] = ld[r][c];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void chol_trsm_kernel(T* __restrict__ a, int64_t D, int64_t j0, int64_t j1, const int* __restrict__ info) {
+  const int64_t b = blockIdx.y;
+  if (info[b] != 0) return;  // (uniform: the diagonal block of this panel - or an earlier one - had no factor)
+  T* m = a + b * D * D;
+  const int64_t i = j1 + (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int w = (int)(j1 - j0);
+  typedef const __attribute__((address_space(4))) T* cptr;  // wave-uniform reads: scalar loads
+  cptr ld = (cptr)(m + j0 * D + j0);
+  if (i >= D) return;
+  T* ri = m + i * D + j0;
+  T x[kCholPanel];
+#pragma unroll
+  for (int c = 0; c < kCholPanel; ++c) x[c] = (c < w) ? ri[c] : (T)0;
+#pragma unroll
+  for (int c = 0; c < kCholPanel; ++c) {
+    if (c < w) {  // (uniform; the last panel of a ragged matrix is narrower)
+      T acc = (T)0;
+#pragma unroll
+      for (int k = 0; k < c; ++k) acc = fma(x[k], ld[(int64_t)c * D + k], acc);
+      x[c] = (x[c] - acc) / ld[(int64_t)c * D + c];
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < kCholPanel; ++c)
+    if (c < w) ri[c] = x[c];
 }
 
 template <typename T>
@@ -185,7 +216,11 @@ int launch_cholesky(T* a, int* info, int64_t batch, int64_t D, double jitter, ru
     const int64_t j1 = (j0 + kCholPanel < D) ? j0 + kCholPanel : D;
     const dim3 grid((unsigned)((D - j0 + 63) / 64), (unsigned)batch);
     chol_update_kernel<T><<<grid, 256, 0, s>>>(a, D, j0, j1, (T)jitter, info);
-    chol_panel_kernel<T><<<(unsigned)batch, 1024, 0, s>>>(a, D, j0, j1, info);
+    chol_diag_kernel<T><<<(unsigned)batch, 64, 0, s>>>(a, D, j0, j1, info);
+    if (j1 < D) {
+      const dim3 tgrid((unsigned)((D - j1 + 255) / 256), (unsigned)batch);
+      chol_trsm_kernel<T><<<tgrid, 256, 0, s>>>(a, D, j0, j1, info);
+    }
   }
   const dim3 zgrid((unsigned)runia_stream_grid(D * D, 256) < 1024u ? (unsigned)runia_stream_grid(D * D, 256) : 1024u, (unsigned)batch);
   chol_zero_upper_kernel<T><<<zgrid, 256, 0, s>>>(a, D);
