@@ -104,8 +104,18 @@ def _inv_sqrt_spd(t: torch.Tensor) -> torch.Tensor:
 
 
 def _orthonormalise(y: torch.Tensor) -> torch.Tensor:
-    """Orthonormal basis of the column span of ``y`` (symmetric orthogonalisation ``y (y^T y)^(-1/2)``)."""
+    """A well-conditioned basis of the column span of ``y`` for the next step of the subspace iteration (only the span enters the
+    result: see ``pca_fit_randomized_device``).  ``y L^-T`` with the Cholesky factor of the Gram matrix ``y^T y = L L^T`` - one
+    factorisation + one triangular inverse (``runia_cholesky_f64`` / ``runia_tril_inverse_f64``) where the symmetric form
+    ``y (y^T y)^(-1/2)`` takes a Jacobi eigen-decomposition (266 columns: ~1 ms against 5-8 ms, seven times per fit).  Columns
+    orthonormal to ``eps * cond(y)^2``; a Gram matrix without a factor, or with a pivot ratio below 1e-12 (a rank-deficient block:
+    constant features), takes the symmetric form, which drops the directions below the numerical rank."""
     g = _hip.matmul_f64(y.T.contiguous(), y)
+    tril, info = _hip.cholesky(g)
+    if int(info.reshape(-1)[0]) == 0:
+        diag = torch.diagonal(tril)
+        if bool(torch.isfinite(diag).all()) and float(diag.min()) > 1e-6 * float(diag.max()):  # (pivots are square roots)
+            return _hip.matmul_f64(y, _hip.tril_inverse(tril.unsqueeze(0))[0], transpose_b=True)
     return _hip.matmul_f64(y, _inv_sqrt_spd(g))
 
 
