@@ -112,10 +112,10 @@ def _orthonormalise(y: torch.Tensor) -> torch.Tensor:
     constant features), takes the symmetric form, which drops the directions below the numerical rank."""
     g = _hip.matmul_f64(y.T.contiguous(), y)
     tril, info = _hip.cholesky(g)
-    if int(info.reshape(-1)[0]) == 0:
-        diag = torch.diagonal(tril)
-        if bool(torch.isfinite(diag).all()) and float(diag.min()) > 1e-6 * float(diag.max()):  # (pivots are square roots)
-            return _hip.matmul_f64(y, _hip.tril_inverse(tril.unsqueeze(0))[0], transpose_b=True)
+    diag = torch.diagonal(tril)
+    failed, lo, hi = torch.stack([info.reshape(-1)[0].to(torch.float64), diag.min(), diag.max()]).tolist()  # one read-back
+    if failed == 0 and lo > 1e-6 * hi:  # (pivots are square roots; a NaN compares false)
+        return _hip.matmul_f64(y, _hip.tril_inverse(tril.unsqueeze(0))[0], transpose_b=True)
     return _hip.matmul_f64(y, _inv_sqrt_spd(g))
 
 

@@ -1777,3 +1777,24 @@ def test_fused_metrics_launches_equal_the_curve_chain(n_ind, n_ood, kind):
     exp = oracle.auroc_fpr95_aupr(ind, ood)
     assert tuple(fused) == pytest.approx(exp, abs=2e-6, nan_ok=True)
     assert np.array_equal(_hip.ood_metrics(a, b).cpu().numpy(), fused, equal_nan=True)   # same bits from run to run
+
+
+def test_subspace_basis_reconditioning_and_its_fallback():
+    """device_fit._orthonormalise (round 6): y L^-T with the Cholesky factor of y^T y - columns orthonormal, same span; a Gram
+    matrix without a usable factor (duplicated columns: rank-deficient) takes the symmetric inverse square root, which drops the
+    directions below the numerical rank instead of dividing by a rounding-sized pivot."""
+    from runia_core_amd.device_fit import _orthonormalise
+
+    rng = np.random.default_rng(3)
+    y = rng.standard_normal((512, 74)) * np.logspace(0, -4, 74)[None, :]  # columns over four orders of magnitude
+    q = _orthonormalise(torch.from_numpy(y).cuda()).cpu().numpy()
+    assert np.max(np.abs(q.T @ q - np.eye(74))) < 1e-7
+    proj = q @ q.T
+    assert np.max(np.abs(proj @ y - y)) < 1e-9 * np.abs(y).max()  # same column span
+    yd = y.copy()
+    yd[:, 10] = yd[:, 3]          # exact duplicate: y^T y is singular
+    yd[:, 20] = 0.0               # and a zero column
+    qd = _orthonormalise(torch.from_numpy(yd).cuda()).cpu().numpy()
+    assert np.isfinite(qd).all()
+    g = qd.T @ qd                 # a projector of rank 72, not the identity
+    assert np.max(np.abs(g @ g - g)) < 1e-8 and abs(np.trace(g) - 72.0) < 1e-6
