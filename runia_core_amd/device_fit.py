@@ -31,9 +31,28 @@ __all__ = ["empirical_precision_device", "pinvh_device", "pca_fit_device", "pca_
            "vim_null_space_device", "percentile_flat"]
 
 
+_PINVH_CHOLESKY_FROM = 128      # below: the eigen-decomposition is a few launches anyway
+_PINVH_CHOLESKY_MAX_COND = 1e8  # bound on ||A||_F ||A^-1||_F up to which the Cholesky route is taken
+
+
 def pinvh_device(cov: torch.Tensor) -> torch.Tensor:
     """``scipy.linalg.pinvh(cov)``: eigen-decomposition, eigenvalues with ``|s| <= max|s| * max(M,N) * eps``
-    dropped, ``(U / s) @ U^T``."""
+    dropped, ``(U / s) @ U^T``.
+
+    A symmetric positive definite matrix whose smallest eigenvalue is far above that cut-off loses no direction: its pseudo-inverse IS
+    its inverse, ``W^T W`` with ``W = L^-1`` from the Cholesky factor (``runia_cholesky_f64`` + ``runia_tril_inverse_f64`` + one
+    product: 2048 x 2048 in ~5 ms, the Jacobi eigen-decomposition takes 156).  Taken when the factorisation succeeds AND
+    ``||A||_F ||A^-1||_F < 1e8`` - an upper bound of the 2-norm condition number, so ``lambda_min > 1e-8 lambda_max``, eight orders
+    above SciPy's cut-off; everything else (rank-deficient, indefinite to rounding, badly conditioned) takes the eigen route."""
+    n = cov.shape[0]
+    if n >= _PINVH_CHOLESKY_FROM:
+        sym = ((cov + cov.T) * 0.5).contiguous()
+        tril, info = _hip.cholesky(sym)
+        w = _hip.tril_inverse(tril.unsqueeze(0))[0]
+        inv = _hip.matmul_f64(w.T.contiguous(), w)
+        failed, na, ni = torch.stack([info.reshape(-1)[0].to(torch.float64), torch.linalg.norm(sym), torch.linalg.norm(inv)]).tolist()
+        if failed == 0 and na * ni < _PINVH_CHOLESKY_MAX_COND:  # (a NaN compares false)
+            return inv
     s, u = _hip.eigh(cov)
     cutoff = s.abs().max() * (max(cov.shape) * torch.finfo(cov.dtype).eps)
     keep = s.abs() > cutoff

@@ -39,6 +39,7 @@ def mahalanobis_preprocess(ind_data: Dict[str, np.ndarray], num_classes: int) ->
     from sklearn.covariance import EmpiricalCovariance
 
     feats, labels = ind_data["train features"], ind_data["train labels"]
+    on_device = config.use_device_fit() and getattr(feats, "dtype", None) in (np.float32, np.float64)
     class_mean, centered = [], []
     for c in range(num_classes):
         class_samples = feats[labels == c]
@@ -47,8 +48,26 @@ def mahalanobis_preprocess(ind_data: Dict[str, np.ndarray], num_classes: int) ->
         with warnings.catch_warnings():
             warnings.simplefilter("ignore", RuntimeWarning)
             class_mean.append(class_samples.mean(0))
-        centered.append(class_samples - class_mean[c].reshape(1, -1))
+        if not on_device:
+            centered.append(class_samples - class_mean[c].reshape(1, -1))
     class_mean = np.stack(class_mean)
+    if on_device and class_mean.dtype == feats.dtype:
+        # the centred rows are formed on the device from ONE upload of the features (x - mu_label in the features' dtype, then the
+        # reference's cast to float32: the values of `pooled` below, in the rows' own order - the covariance does not care) instead
+        # of a second 410 MB host array and its upload (cfg3 size: 0.2 of the fit's 0.25 s)
+        from ..device_fit import pinvh_device
+
+        dt = torch.float32 if feats.dtype == np.float32 else torch.float64
+        lab = np.asarray(labels).reshape(-1)
+        keep = np.flatnonzero((lab >= 0) & (lab < num_classes))
+        xd = _hip.to_device(feats, dt)
+        idx = _hip.to_device(keep.astype(np.int64), torch.int64)
+        mu = _hip.to_device(np.nan_to_num(class_mean), dt)  # (an empty class's NaN row is never indexed)
+        z = (xd.index_select(0, idx) - mu.index_select(0, _hip.to_device(lab[keep].astype(np.int64), torch.int64))).to(torch.float32)
+        _, cov = _hip.covariance(z)
+        return class_mean, _hip.to_host(pinvh_device(cov))
+    if on_device:  # (a mean of another dtype than the rows: not a case NumPy produces for float rows)
+        centered = [feats[labels == c] - class_mean[c].reshape(1, -1) for c in range(num_classes)]
     pooled = np.concatenate(centered).astype(np.float32)
     if config.use_device_fit():
         return class_mean, empirical_precision_device(pooled)

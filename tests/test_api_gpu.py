@@ -1798,3 +1798,47 @@ def test_subspace_basis_reconditioning_and_its_fallback():
     assert np.isfinite(qd).all()
     g = qd.T @ qd                 # a projector of rank 72, not the identity
     assert np.max(np.abs(g @ g - g)) < 1e-8 and abs(np.trace(g) - 72.0) < 1e-6
+
+
+def test_pinvh_device_routes():
+    """device_fit.pinvh_device (round 6): the Cholesky route for matrices that provably lose no direction to SciPy's cut-off, the
+    eigen route for everything else - both equal scipy.linalg.pinvh."""
+    from scipy.linalg import pinvh
+
+    from runia_core_amd import _hip
+    from runia_core_amd import device_fit
+
+    rng = np.random.default_rng(9)
+    n = 300
+
+    def run(a):
+        calls = {"eigh": 0}
+        real = _hip.eigh
+
+        def counting(*args, **kw):
+            calls["eigh"] += 1
+            return real(*args, **kw)
+
+        _hip.eigh = counting
+        try:
+            out = device_fit.pinvh_device(torch.from_numpy(a).cuda()).cpu().numpy()
+        finally:
+            _hip.eigh = real
+        return out, calls["eigh"]
+
+    x = rng.standard_normal((n, 3 * n))
+    good = x @ x.T / (3 * n) + 0.1 * np.eye(n)                      # condition ~ 30
+    got, used = run(good)
+    assert used == 0 and rel_err(got, pinvh(good)) < 1e-12 and np.array_equal(got, got.T)
+    q, _ = np.linalg.qr(rng.standard_normal((n, n)))
+    stiff = (q * np.logspace(0, -10, n)) @ q.T                       # positive definite, condition 1e10: beyond the bound
+    stiff = (stiff + stiff.T) / 2
+    got, used = run(stiff)
+    assert used == 1 and rel_err(got @ stiff, np.eye(n)) < 1e-4
+    low = x[:, :40] @ x[:, :40].T                                    # rank 40: SciPy drops 260 directions
+    got, used = run(low)
+    ref = pinvh(low)
+    assert used == 1 and np.max(np.abs(got - ref)) < 1e-9 * np.abs(ref).max()
+    small = good[:64, :64].copy()                                    # below the size threshold: the eigen route
+    got, used = run(small)
+    assert used == 1 and rel_err(got, pinvh(small)) < 1e-11
