@@ -656,9 +656,9 @@ class KNN(OodPostprocessor):
     def setup(self, ind_train_data: np.ndarray, **kwargs):
         assert "valid_feats" in kwargs, "valid_feats must be provided for KNN setup"
         train = np.asarray(ind_train_data)
-        bank = _hip.to_host(_hip.l2_normalize(_hip.to_device(train, torch.float32)))
         self.index = FlatL2Bank(train.shape[1])
-        self.index.add(bank)
+        # the normalised bank stays where it was made (the host copy - pickling, a later `add` - is read back when asked for)
+        self.index.add_device(_hip.l2_normalize(_hip.to_device(train, torch.float32)))
         ind_scores = self.postprocess(kwargs["valid_feats"])
         ind_scores = self.flip_sign_fn(ind_scores)
         self.set_threshold(ind_scores)
