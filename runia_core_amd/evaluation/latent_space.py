@@ -119,6 +119,17 @@ def log_evaluate_larex(cfg, baselines_names: List[str], ood_baselines_scores: Di
                        mlflow_run_name: str = "", mlflow_logging: bool = False, visualize_score: Optional[str] = None,
                        postprocessors: Optional[List[str]] = None, save_csv: bool = False, save_plots_to_local: bool = False,
                        device_resident: bool = False, thresholds: bool = True):
+    """See ``_log_evaluate_larex``; the host-array mode runs inside ``_hip.upload_cache()``: a split (full or PCA-reduced) that five
+    postprocessors score in turn is uploaded once, not five times (the arrays are read-only here, as upstream)."""
+    import contextlib
+
+    with (contextlib.nullcontext() if device_resident else _hip.upload_cache()):
+        return _log_evaluate_larex(cfg, baselines_names, ood_baselines_scores, ind_data_dict, ood_data_dict, mlflow_run_name, mlflow_logging,
+                                   visualize_score, postprocessors, save_csv, save_plots_to_local, device_resident, thresholds)
+
+
+def _log_evaluate_larex(cfg, baselines_names, ood_baselines_scores, ind_data_dict, ood_data_dict, mlflow_run_name, mlflow_logging,
+                        visualize_score, postprocessors, save_csv, save_plots_to_local, device_resident, thresholds):
     """``log_evaluate_larex`` of the reference (signature and return value :30-221): returns ``(overall_metrics_df,
     best_postprocessors_dict, postprocessor_thresholds, ood_data_dict)``.  ``cfg`` needs ``ind_dataset``, ``ood_datasets``,
     ``n_pca_components`` (+ what the postprocessors read: ``num_classes``, ``k_neighbors``); a dict works as well.
