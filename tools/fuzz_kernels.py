@@ -433,6 +433,19 @@ for t in range(a.rounds):
         ranks_ = sorted(set(int(r_) for r_ in rng.integers(0, ns_, size=4)) | {0, ns_ - 1})
         got_ = np.array(_hip.kth_smallest_flat(dev(xs_), ranks_), dtype=np.float32)
         check("radix select", (ns_,), 0.0 if np.array_equal(got_, np.sort(xs_)[ranks_]) else 1.0, 0.5)
+        # pinvh on the device (Cholesky route / eigen route) against SciPy; the percentile of a large flat array against NumPy
+        from scipy.linalg import pinvh as _pinvh
+        from runia_core_amd.device_fit import percentile_flat, pinvh_device
+        dp = int(rng.choice([40, 128, 129, 200, 333]))
+        rank_ = dp if rng.random() < 0.6 else int(rng.integers(1, dp))
+        xa_ = rng.standard_normal((dp, rank_ + (3 * dp if rank_ == dp else 0)))
+        spd_ = xa_ @ xa_.T / xa_.shape[1] + (float(rng.choice([0.0, 1e-6, 0.1])) if rank_ == dp else 0.0) * np.eye(dp)
+        got_p, ref_p = pinvh_device(dev(spd_)).cpu().numpy(), _pinvh(spd_)
+        check("pinvh", (dp, rank_), float(np.max(np.abs(got_p - ref_p)) / np.abs(ref_p).max()), 1e-7)
+        if t % 12 == 0:
+            big_ = np.maximum(rng.standard_normal(int(rng.choice([1 << 22, (1 << 22) + 12345]))).astype(np.float32), 0 if rng.random() < 0.5 else -9)
+            qq_ = float(rng.choice([90, 65, 99.5, 12.5]))
+            check("percentile_flat", (big_.size, qq_), 0.0 if np.array_equal(percentile_flat(big_, qq_), np.percentile(big_, qq_)) else 1.0, 0.5)
 
     if (t + 1) % 10 == 0:
         print(f"round {t + 1}/{a.rounds}, mismatches so far: {bad}", flush=True)
