@@ -72,7 +72,7 @@ __global__ __launch_bounds__(64 * kCholWaves) void cholesky_kernel(T* __restrict
   }
 }
 
-// ---- wide matrices (D >= kCholBlockedFrom): the same left-looking factorisation in panels of kCholPanel columns.  The one-workgroup
+// ---- matrices of kCholBlockedFrom columns or more: the same left-looking factorisation in panels of kCholPanel columns.  The one-workgroup
 // kernel above reads D^3 / 3 elements through one compute unit and meets 3 barriers per column with dot products of up to D terms
 // between them (ten 2048 x 2048 float32 matrices: 173 ms, and a jitter ladder calls it several times).  Per panel [j0, j1):
 //   chol_update_kernel  rows >= j0, columns of the panel: A[i][c] = (A[i][c] + jitter on the diagonal) - sum_{k < j0} L[i][k] L[c][k]
@@ -83,7 +83,10 @@ __global__ __launch_bounds__(64 * kCholWaves) void cholesky_kernel(T* __restrict
 // Every sum has one fixed order: same bits from run to run and on every rank (not the bits of the one-workgroup kernel: the
 // sums are grouped by panel).
 constexpr int kCholPanel = 64;
-constexpr int64_t kCholBlockedFrom = 768;
+#ifndef CHOL_BLOCKED_FROM
+#define CHOL_BLOCKED_FROM 128  // (ten matrices of 128 / 256 / 512 / 700 columns: panel forms faster from the first size - tools/ablate/run_gmm_fit.py)
+#endif
+constexpr int64_t kCholBlockedFrom = CHOL_BLOCKED_FROM;
 
 template <typename T>
 __global__ __launch_bounds__(256) void chol_update_kernel(T* __restrict__ a, int64_t D, int64_t j0, int64_t j1, T jitter,

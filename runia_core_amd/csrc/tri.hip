@@ -32,14 +32,17 @@ __global__ __launch_bounds__(64) void tril_inverse_kernel(const double* __restri
   }
 }
 
-// ---- wide factors (D >= kTrilBlockedFrom): block forward substitution in 64 x 64 blocks.  The kernel above walks D rows per wave with a
+// ---- factors of kTrilBlockedFrom columns or more: block forward substitution in 64 x 64 blocks.  The kernel above walks D rows per wave with a
 // dependent inner loop (ten 2048 x 2048 factors: 494 ms of a 0.8 s DDU fit).  With W and L cut into blocks,
 //     W[J][J] = L[J][J]^-1,      W[I][J] = -W[I][I] (sum_{K = J}^{I - 1} L[I][K] W[K][J])   for I > J,
 // so: tril_diag_blocks_kernel inverts every diagonal block (the kernel above on 64 rows, one wave per block), then
 // tril_block_columns_kernel takes one block column J per workgroup and walks down its block rows: the sum as a 64 x 64 tile product
 // over k in [c0, i0) staged through LDS (one fma chain per element, k ascending), then the product with the inverted diagonal block.
 // Block columns are independent of each other; what a workgroup reads of W it wrote itself (behind a barrier).
-constexpr int64_t kTrilBlockedFrom = 768;
+#ifndef TRIL_BLOCKED_FROM
+#define TRIL_BLOCKED_FROM 128  // (ten matrices of 128 / 256 / 512 / 700 columns: panel forms faster from the first size - tools/ablate/run_gmm_fit.py)
+#endif
+constexpr int64_t kTrilBlockedFrom = TRIL_BLOCKED_FROM;
 constexpr int kTB = 64, kTK = 16;
 
 __global__ __launch_bounds__(64) void tril_diag_blocks_kernel(const double* __restrict__ L, double* __restrict__ W, int64_t D) {

@@ -1119,8 +1119,9 @@ def test_get_dl_h_z_single_read_equals_the_two_kernels(hip, n_mc, d, n_img):
         assert torch.equal(torch.nan_to_num(a, nan=-7.0), torch.nan_to_num(hip.kl_entropy_joint(zt, n_mc, 4), nan=-7.0))
 
 
-@pytest.mark.parametrize("d,batch", [(1, 2), (37, 3), (64, 1), (65, 2), (300, 10), (767, 2), (768, 2), (833, 3), (1024, 2), (2048, 2)])
-def test_tril_inverse_of_the_class_factors(hip, d, batch):  # (from 768: block forward substitution)
+@pytest.mark.parametrize("d,batch", [(1, 2), (37, 3), (64, 1), (65, 2), (127, 2), (128, 2), (129, 3), (300, 10), (767, 2), (833, 3), (1024, 2),
+                                     (2048, 2)])
+def test_tril_inverse_of_the_class_factors(hip, d, batch):  # (from 128: block forward substitution)
     """runia_tril_inverse_f64 (round 5; setup of GMMLatentSpace / DDU: the Cholesky factors torch's MultivariateNormal keeps,
     reference inference/postprocessors.py:490, 778): W = L^-1 per class by forward substitution, against the host's triangular
     solve; W L = I; the strict upper triangle is zero; the precision W^T W equals torch.cholesky_inverse."""
@@ -1336,8 +1337,8 @@ def test_gmm_log_prob_triangular_kernel_vs_torch(hip, n, d, c):
 
 
 @pytest.mark.parametrize("dtype", [np.float32, np.float64])
-@pytest.mark.parametrize("d,batch", [(1, 3), (2, 2), (63, 2), (64, 1), (200, 10), (513, 2), (767, 2), (768, 3), (833, 3), (1024, 1),
-                                     (2048, 2)])  # (from 768: the panel form)
+@pytest.mark.parametrize("d,batch", [(1, 3), (2, 2), (63, 2), (64, 1), (127, 2), (128, 3), (129, 2), (200, 10), (513, 2), (767, 2), (768, 3),
+                                     (833, 3), (1024, 1), (2048, 2)])  # (from 128: the panel form)
 def test_cholesky_kernel_vs_lapack(hip, d, batch, dtype):
     """runia_cholesky_* (round 6; gmm_fit's jitter ladder on the device, the triangular factor of MD's precision): L L^T = a + jitter I
     against LAPACK's factor, zeros above the diagonal, info = j + 1 at the first pivot that is not positive (an indefinite and a NaN

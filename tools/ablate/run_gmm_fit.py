@@ -10,6 +10,9 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 from runia_core_amd import _hip  # noqa: E402
+
+if os.environ.get("RUNIA_LIB"):  # a library variant (tools/ablate/build_lib_variant.sh)
+    _hip._LIB_PATH = os.environ["RUNIA_LIB"]
 from runia_core_amd.inference.funcs import GmmState, gmm_fit  # noqa: E402
 
 

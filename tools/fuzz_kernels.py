@@ -404,9 +404,9 @@ for t in range(a.rounds):
               rel(kb[smp].cpu().numpy(), oracle.kde_score(trb.cpu().numpy(), yb[smp].cpu().numpy(), 4.0)), 1e-9)
         del hb, yb, kb, sb
 
-    # ---- round 6: Cholesky / triangular inverse around the panel switch (768), order statistics of a flat array ----
+    # ---- round 6: Cholesky / triangular inverse around the panel switch (128), order statistics of a flat array ----
     if t % 4 == 0:
-        dc = int(rng.choice([1, 5, 63, 64, 65, 300, 767, 768, 769, 831, 896, 1000, 1100]))
+        dc = int(rng.choice([1, 5, 63, 64, 65, 127, 128, 129, 191, 300, 513, 768, 831, 1000, 1100]))
         bc = int(rng.integers(1, 4))
         ac = rng.standard_normal((bc, dc, dc + int(rng.integers(1, 40))))
         cov = ac @ ac.transpose(0, 2, 1) / ac.shape[2] + float(rng.choice([1e-3, 0.05, 1.0])) * np.eye(dc)
