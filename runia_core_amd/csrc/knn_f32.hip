@@ -725,11 +725,13 @@ static bool knn16_bank_ok(int64_t M, int64_t D) {
 // (round 4, with the candidate filter the feature width no longer has to pay for a distance matrix: 65 536 x 50 000 at
 // D = 8 / 16 / 32 / 64 / 128: 5.6 / 5.6 / 5.7 / 6.0 / 6.7 ms against 9.1 / 9.0 / 9.0 / 10.2 / 13.1 for the f32 kernel, same
 // bits, tools/ablate/run_knn_low_d.py; the limit was 256 while the bf16 kernel wrote the matrix too)
-// (round 6: from D = 1 - a call of >= 2^27 pairs on 2 ... 7 features, e.g. KNNLatentSpace behind a PCA to 2 or 4 components in the
+// (round 6: from D = 2 - a call of >= 2^27 pairs on 2 ... 7 features, e.g. KNNLatentSpace behind a PCA to 2 or 4 components in the
 // harness sweep, wrote and re-read its whole chunk x bank matrix through the f32 kernel: 10 000 x 50 000 at D = 4 / 3 / 2:
 // 1.52 / 1.48 / 1.62 -> 1.01 / 1.02 / 1.36 ms, 65 536 x 50 000 at D = 4: 8.79 -> 5.62 ms, same bits)
+// (one feature stays on the f32 kernel: normalised 1-d rows are +-1, every distance is 0 or 4 and half the bank ties at the k-th
+// place - 58.8 ms per 10 000 x 50 000 there, 72.7 ms through the pieces; a degenerate case either way)
 #ifndef KNN16_MIN_D
-#define KNN16_MIN_D 1
+#define KNN16_MIN_D 2
 #endif
   return KNN_BF16 && M >= 4096 && D >= KNN16_MIN_D && D <= runia_knn16_max_width() && runia_knn16_fits(M, D) &&
          runia_knn16_fits(kQueryChunk, D) && 4 * M * 256 <= ((int64_t)1 << 31);  // (chunks of >= 256 queries: whole tiles)

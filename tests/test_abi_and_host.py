@@ -433,12 +433,12 @@ def test_knn_kernel_choice_and_workspace_are_host_decisions():
     # matrix whose cost the width would have to pay for - as long as the call has 2^31 multiply-adds)
     # (round 6: below 16 features the threshold counts 16 - narrow rows cost the f32 kernel its distance matrix, not multiply-adds)
     for n, m, d in ((10, 50000, 2048), (511, 50000, 2048), (4096, 1000, 2048), (4096, 20000, 2), (1024, 4096, 256), (4096, 5000, 64),
-                    (4096, 20000, 15)):
+                    (4096, 20000, 15), (10000, 50000, 1)):
         assert lib.runia_knn_piece_products(n, m, d) == 0
         assert lib.runia_knn_workspace_bytes(n, m, d, 50) == f32_words(n, m) * 4
     pad = lambda r: (r + 255) // 256 * 256
     for n, m, d in ((1024, 4096, 512), (512, 50000, 2048), (100000, 50000, 2048), (3000, 5000, 300), (4096, 50000, 64), (65536, 50000, 9),
-                    (4096, 50000, 4), (10000, 50000, 2), (10000, 50000, 1)):
+                    (4096, 50000, 4), (10000, 50000, 2)):
         assert lib.runia_knn_piece_products(n, m, d) == 3
         dp = (d + 31) // 32 * 32
         pieces = 4 * dp * (pad(m) + pad(min(n, 8192)))  # bank + (at least) 8 192 query rows, h | m

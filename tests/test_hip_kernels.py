@@ -509,7 +509,7 @@ def test_knn_sampled_threshold_path_and_its_fallbacks(hip, m):
 
 @pytest.mark.parametrize("n,m,d", [(2048, 8192, 512), (1500, 8200, 300), (1024, 4096, 2048), (8192, 8300, 64), (4100, 8192, 100),
                                    (8192, 4096, 128), (16400, 8200, 16), (32768, 8192, 9), (16400, 8200, 4), (32768, 8192, 2),
-                                   (20000, 8192, 3), (33000, 8192, 1)])  # (round 6: from one feature)
+                                   (20000, 8192, 3)])  # (round 6: from two features)
 def test_knn_bf16_candidate_distances_equal_the_f32_path(hip, n, m, d):
     """Large problems take their candidate distances from bf16 piece products (csrc/knn_bf16.hip) when the caller's
     workspace holds the planes (runia_knn_workspace_bytes asks for them); with an f32-sized workspace the same entry
