@@ -67,10 +67,16 @@ def fat_record(workload="cfg2", n_stages=40):
         rec["cpu_baseline"] = {"value": None, "unit": "s (bounded subset, see sample)", "cores": 16, "kind": "port", "sample": "q" * 400}
         rec["larex_eval"] = {"table": {f"row {i}": [0.1] * 5 for i in range(90)}}
         del rec["stages"], rec["parity"]
+    if workload == "baselines_eval":
+        rec.update(metric="OOD scores/sec through the baselines harness loop", unit="rows scored/s", roofline=None)
+        rec["cpu_baseline"] = {"value": None, "unit": "s (bounded subset, see sample)", "cores": 16, "kind": "port", "sample": "q" * 400}
+        rec["baselines_eval"] = {"seconds_per_baseline": {f"baseline {i}": 0.1 for i in range(12)}, "notes": "n" * 20000}
+        rec["parity"] = {"max_rel_err": 2.3e-6, **{f"max_rel_err_b{i}": 1e-7 * i for i in range(12)}}
+        del rec["stages"]
     return rec
 
 
-@pytest.mark.parametrize("workload", ["cfg2", "cfg3", "larex_eval"])
+@pytest.mark.parametrize("workload", ["cfg2", "cfg3", "larex_eval", "baselines_eval"])
 @pytest.mark.parametrize("n_stages", [0, 12, 400])
 def test_contract_line_is_small_strict_json_with_the_required_keys(workload, n_stages):
     full = fat_record(workload, n_stages)
@@ -89,7 +95,9 @@ def test_contract_line_is_small_strict_json_with_the_required_keys(workload, n_s
     assert rec["steps"] == 20 and rec["warmup"] == 5 and rec["n_gpus"] == 1 and rec["vs_baseline"] is None
     assert set(rec["config"]) - {"workload"} and len(rec["config"]) <= 9 and "workload" in rec["config"]
     assert all(not isinstance(v, (dict, list)) for v in rec["config"].values())
-    if workload != "larex_eval":
+    if workload == "baselines_eval":
+        assert rec["roofline"] is None and rec["parity"]["max_rel_err"] == pytest.approx(2.3e-6)
+    elif workload != "larex_eval":
         for k in ROOFLINE:
             assert k in rec["roofline"], k
         assert rec["roofline"]["bound"] in ("hbm", "mfma")
